@@ -1,0 +1,150 @@
+/*
+ * snpmatch_hip.h -- C ABI of libsnpmatch_hip.so, the MI355X (gfx950) scoring engine that replaces
+ * the numpy hot path of SNPmatch's Genotyper / CrossIdentifier.
+ *
+ * Plain C, plain pointers and sizes; no C++ or torch types cross this line.  It is what a ctypes
+ * binding inside the reference would call (see INTEGRATION.md for that stub).  Reference
+ * interfaces replaced (paths relative to the SNPmatch v5.0.1 tree):
+ *
+ *   snpm_score_dense_host   <- matchGTsAccs(sampleWei, t1001snps, skip_hets_db)      core/snpmatch.py:74-89
+ *   snpm_query_run          <- the chunk loop of Genotyper.genotyper                 core/snpmatch.py:207-225
+ *                              (gather g.g.snps[idx,:] :222, matchGTsAccs :223, accumulate :224-225)
+ *   snpm_query_run_windows  <- the window loop of CrossIdentifier.window_genotyper   core/csmatch.py:80-90
+ *   snpm_likelihood         <- likeliTest + GenotyperOutput.calculate_likelihoods    core/snpmatch.py:40-55,106-117
+ *   snpm_binom_identity     <- np_test_identity (binom.sf)                           core/snpmatch.py:57-72
+ *   snpm_panel_*            <- HDF5Genotype.snps (int8 [num_snps,num_accessions])    pygwas/genotype.py:534-550
+ *                              as an HBM-resident panel fed by a pinned-host staging path
+ *
+ * Conventions
+ *   - every function returns int: SNPM_OK (0) or a negative SNPM_ERR_*; the message is available
+ *     from snpm_last_error(ctx) (ctx == NULL: last error of a failed snpm_init in this thread).
+ *   - the caller owns every host buffer it passes in (inputs are never modified) and every output
+ *     buffer (pre-allocated, C-contiguous); the library owns device memory and pinned staging
+ *     buffers behind the opaque handles.  No pointer handed out outlives its handle.
+ *   - calls are blocking from the caller's view unless the name says otherwise; one ctx must not
+ *     be used from two threads at once; distinct ctx are independent.  One ctx == one GPU; a
+ *     multi-GPU job is one process (one ctx) per GPU with the accession axis sharded by the host
+ *     layer (snpmatch_amd.dist) and a final all-gather over RCCL.
+ *   - genotype codes: 0 hom-ref, 1 hom-alt, 2 het, negative = missing (stored as -1);
+ *     values > 2 are informative but match nothing (stored as 3).
+ *   - weights `wei` are float64 [n,3]: column 0 scores db==0, column 1 scores db==2 (het),
+ *     column 2 scores db==1, exactly as sampleWei in the reference.
+ */
+#ifndef SNPMATCH_HIP_H
+#define SNPMATCH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNPM_OK            0
+#define SNPM_ERR_BADARG   -1   /* argument violates the contract (the Python layer raises AssertionError) */
+#define SNPM_ERR_HIP      -2   /* a HIP runtime call or kernel launch failed */
+#define SNPM_ERR_OOM      -3   /* device or pinned-host allocation failed */
+#define SNPM_ERR_STATE    -4   /* handle used in the wrong state */
+#define SNPM_ERR_DOMAIN   -5   /* likelihood: a score exceeds its informative count (reference asserts y <= n) */
+
+/* scoring modes of snpm_query_run */
+#define SNPM_MODE_EXACT   0    /* fast streaming pass + strict re-evaluation of every accession whose score could
+                                  truncate differently from the reference: int(score) and ninfo are bit-exact,
+                                  fp64 scores are within the returned error bound of the reference's */
+#define SNPM_MODE_STRICT  1    /* reference summation order for every accession: fp64 scores bit-exact */
+#define SNPM_MODE_FAST    2    /* fast streaming pass only (benchmarks of the dominant kernel) */
+
+typedef struct snpm_ctx   snpm_ctx;
+typedef struct snpm_panel snpm_panel;
+typedef struct snpm_query snpm_query;
+
+/* ---------------------------------------------------------------- lifecycle */
+int         snpm_version(void);
+int         snpm_device_count(int *count);
+int         snpm_init(int device_id, snpm_ctx **out);
+int         snpm_destroy(snpm_ctx *ctx);
+const char *snpm_last_error(const snpm_ctx *ctx);
+/* run the library's kernels on a caller-provided hipStream_t (e.g. torch's current stream);
+   NULL restores the library's own stream */
+int         snpm_set_stream(snpm_ctx *ctx, void *hip_stream);
+int         snpm_synchronize(snpm_ctx *ctx);
+
+/* ---------------------------------------------------------------- panel (DB genotype matrix in HBM) */
+/* SNP-major int8 [n_snp, pitch], pitch = n_acc rounded up to 256 B, pad bytes = -1. */
+int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out);
+int snpm_panel_free(snpm_panel *panel);
+int snpm_panel_info(const snpm_panel *panel, int64_t *n_snp, int64_t *n_acc, int64_t *pitch, void **device_ptr);
+/* Asynchronous upload of rows [row0, row0+nrows) from host memory (row stride host_pitch bytes,
+   >= n_acc): rows are repacked into double-buffered pinned staging slabs and copied with
+   hipMemcpyAsync on a side stream, canonicalised on the device (negative -> -1, >2 -> 3).
+   Returns once the last slab is enqueued; scoring calls wait for it on the device. */
+int snpm_panel_upload_rows(snpm_panel *panel, int64_t row0, int64_t nrows, const int8_t *host, int64_t host_pitch);
+int snpm_panel_upload_wait(snpm_panel *panel);
+int snpm_panel_download_rows(snpm_panel *panel, int64_t row0, int64_t nrows, int8_t *host, int64_t host_pitch);
+/* Device-side synthetic fill (benchmarks; no PCIe): element (snp, acc) is a pure function of
+   (seed, snp0 + row, acc0 + col) with P(-1,0,1,2) = (3277, 39321, 21627, 1311)/65536.
+   snpmatch_amd.synth.panel_values() is the numpy twin used by the tests. */
+int snpm_panel_fill_synthetic(snpm_panel *panel, uint64_t seed, int64_t snp0, int64_t acc0);
+
+/* ---------------------------------------------------------------- query (one sample's matched SNPs, resident) */
+/* row_idx: int64 [n] panel rows matched by the sample (commonSNPs[0]); NULL = the dense range
+   [row0, row0+n).  wei: float64 [n,3] = inputs.wei[commonSNPs[1]].  Both are copied to the device. */
+int snpm_query_create(snpm_panel *panel, const int64_t *row_idx, int64_t row0, int64_t n,
+                      const double *wei, snpm_query **out);
+int snpm_query_free(snpm_query *query);
+
+/* Genotyper.genotyper over the whole matched list with `chunk`-row matchGTsAccs calls (1000 in the
+   reference).  Outputs (host pointers, may be NULL): score float64 [n_acc] (ScoreList before the int
+   truncation), ninfo int64 [n_acc].  info (may be NULL), int64 [4]:
+   [0] accessions re-evaluated in strict order, [1] 1 if all weights are integers (any order exact),
+   and double bound via snpm_query_error_bound.  */
+int snpm_query_run(snpm_query *query, int64_t chunk, int skip_hets, int mode,
+                   double *score, int64_t *ninfo, int64_t *info);
+/* Same, leaving results in device memory (pointers owned by the query, valid until the next run /
+   free): d_score float64 [n_acc], d_ninfo int64 [n_acc].  Work is enqueued on the ctx stream. */
+int snpm_query_run_device(snpm_query *query, int64_t chunk, int skip_hets, int mode,
+                          void **d_score, void **d_ninfo, int64_t *info);
+/* Redirect the results of subsequent runs into caller-owned DEVICE buffers (e.g. torch tensors that
+   feed an RCCL all-gather): d_score float64 [n_acc], d_ninfo int64 [n_acc].  NULL, NULL restores the
+   query's own buffers. */
+int snpm_query_bind_outputs(snpm_query *query, void *d_score, void *d_ninfo);
+/* Rigorous bound on |fast-pass score - reference score| used by SNPM_MODE_EXACT for this query. */
+int snpm_query_error_bound(snpm_query *query, int64_t chunk, double *bound);
+
+/* CrossIdentifier.window_genotyper: one matchGTsAccs call per window w over matched rows
+   [win_off[w], win_off[w+1]) (reference order, fp64 bit-exact).  Outputs (host, may be NULL):
+   score float64 [n_win, n_acc], ninfo int64 [n_win, n_acc], totals accumulated window after
+   window: tot_score float64 [n_acc], tot_ninfo int64 [n_acc]. */
+int snpm_query_run_windows(snpm_query *query, const int64_t *win_off, int64_t n_win, int skip_hets,
+                           double *score, int64_t *ninfo, double *tot_score, int64_t *tot_ninfo);
+
+/* ---------------------------------------------------------------- one-shot forms */
+/* matchGTsAccs on host arrays: db int8 [n, n_acc] (row stride db_pitch), wei float64 [n,3].
+   fp64 bit-exact with the reference (strict order). */
+int snpm_score_dense_host(snpm_ctx *ctx, const int8_t *db, int64_t db_pitch, int64_t n, int64_t n_acc,
+                          const double *wei, int skip_hets, double *score, int64_t *ninfo);
+
+/* likeliTest over rows: y float64 [m, len] (matches; truncated toward zero first when
+   truncate != 0, as GenotyperOutput does for inbred), n int64 [m, len].  Per row r:
+   lik[r,:] = likeliTest, lrt[r,:] = lik / nanmin(lik[r,:]) (amin_or_nan: use this TopHit
+   instead when it is not NaN).  Host pointers.  SNPM_ERR_DOMAIN if some y > n. */
+int snpm_likelihood(snpm_ctx *ctx, const double *y, const int64_t *n, int64_t m, int64_t len,
+                    int truncate, double amin_or_nan, double *lik, double *lrt);
+/* device-pointer form used after snpm_query_run_device (m = 1) */
+int snpm_likelihood_device(snpm_ctx *ctx, const void *d_y, const void *d_n, int64_t m, int64_t len,
+                           int truncate, double amin_or_nan, void *d_lik, void *d_lrt, int *domain_error);
+
+/* np_test_identity: out[i] = (binom.sf((n[i]-x[i]) - 1, n[i], error_rate) >= pthres).  Host pointers;
+   sf (may be NULL) receives the survival function values. */
+int snpm_binom_identity(snpm_ctx *ctx, const double *x, const int64_t *n, int64_t len, double error_rate,
+                        double pthres, int64_t *out, double *sf);
+
+/* ---------------------------------------------------------------- profiling (HIP events on the ctx stream) */
+int snpm_profile_enable(snpm_ctx *ctx, int on);
+int snpm_profile_reset(snpm_ctx *ctx);
+/* kernel: "fast", "strict", "reduce", "scan", "likelihood", "synth", "canon".  Synchronises the stream. */
+int snpm_profile_read(snpm_ctx *ctx, const char *kernel, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNPMATCH_HIP_H */

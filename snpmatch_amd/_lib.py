@@ -1,0 +1,116 @@
+"""
+ctypes binding of libsnpmatch_hip.so (include/snpmatch_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or no MI355X is
+usable, the calls below raise.  (The CPU oracle lives in oracle/ and is test infrastructure.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnpmatch_hip.so")
+
+SNPM_OK = 0
+SNPM_ERR_BADARG = -1
+SNPM_ERR_HIP = -2
+SNPM_ERR_OOM = -3
+SNPM_ERR_STATE = -4
+SNPM_ERR_DOMAIN = -5
+
+MODE_EXACT = 0
+MODE_STRICT = 1
+MODE_FAST = 2
+
+# every symbol include/snpmatch_hip.h declares (tests check that the .so exports all of them)
+SYMBOLS = [
+    "snpm_version", "snpm_device_count", "snpm_init", "snpm_destroy", "snpm_last_error", "snpm_set_stream",
+    "snpm_synchronize", "snpm_panel_create", "snpm_panel_free", "snpm_panel_info", "snpm_panel_upload_rows",
+    "snpm_panel_upload_wait", "snpm_panel_download_rows", "snpm_panel_fill_synthetic", "snpm_query_create",
+    "snpm_query_free", "snpm_query_bind_outputs", "snpm_query_run", "snpm_query_run_device", "snpm_query_error_bound",
+    "snpm_query_run_windows", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
+    "snpm_binom_identity", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
+]
+
+_lib = None
+
+
+class SnpmError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libsnpmatch_hip error %d: %s" % (code, msg))
+        self.code = code
+        self.msg = msg
+
+
+def load():
+    """dlopen the HIP library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with ./build_lib.sh (hipcc --offload-arch=gfx950). "
+            "snpmatch_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    i64, p, dbl, ci = C.c_int64, C.c_void_p, C.c_double, C.c_int
+    pp = C.POINTER(C.c_void_p)
+    lib.snpm_version.restype = ci
+    lib.snpm_device_count.argtypes = [C.POINTER(ci)]
+    lib.snpm_init.argtypes = [ci, pp]
+    lib.snpm_destroy.argtypes = [p]
+    lib.snpm_last_error.argtypes = [p]
+    lib.snpm_last_error.restype = C.c_char_p
+    lib.snpm_set_stream.argtypes = [p, p]
+    lib.snpm_synchronize.argtypes = [p]
+    lib.snpm_panel_create.argtypes = [p, i64, i64, pp]
+    lib.snpm_panel_free.argtypes = [p]
+    lib.snpm_panel_info.argtypes = [p, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), pp]
+    lib.snpm_panel_upload_rows.argtypes = [p, i64, i64, p, i64]
+    lib.snpm_panel_upload_wait.argtypes = [p]
+    lib.snpm_panel_download_rows.argtypes = [p, i64, i64, p, i64]
+    lib.snpm_panel_fill_synthetic.argtypes = [p, C.c_uint64, i64, i64]
+    lib.snpm_query_create.argtypes = [p, p, i64, i64, p, pp]
+    lib.snpm_query_free.argtypes = [p]
+    lib.snpm_query_bind_outputs.argtypes = [p, p, p]
+    lib.snpm_query_run.argtypes = [p, i64, ci, ci, p, p, p]
+    lib.snpm_query_run_device.argtypes = [p, i64, ci, ci, pp, pp, p]
+    lib.snpm_query_error_bound.argtypes = [p, i64, C.POINTER(dbl)]
+    lib.snpm_query_run_windows.argtypes = [p, p, i64, ci, p, p, p, p]
+    lib.snpm_score_dense_host.argtypes = [p, p, i64, i64, i64, p, ci, p, p]
+    lib.snpm_likelihood.argtypes = [p, p, p, i64, i64, ci, dbl, p, p]
+    lib.snpm_likelihood_device.argtypes = [p, p, p, i64, i64, ci, dbl, p, p, C.POINTER(ci)]
+    lib.snpm_binom_identity.argtypes = [p, p, p, i64, dbl, dbl, p, p]
+    lib.snpm_profile_enable.argtypes = [p, ci]
+    lib.snpm_profile_reset.argtypes = [p]
+    lib.snpm_profile_read.argtypes = [p, C.c_char_p, C.POINTER(i64), C.POINTER(dbl)]
+    for name in SYMBOLS:          # fail at load time, not at first use, if the .so is stale
+        getattr(lib, name)
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def check(rc, ctx_handle=None):
+    if rc == SNPM_OK:
+        return
+    msg = load().snpm_last_error(ctx_handle)
+    msg = msg.decode("utf-8", "replace") if msg else ""
+    if rc == SNPM_ERR_BADARG:
+        # the reference validates arguments with `assert` (core/snpmatch.py:75-76)
+        raise AssertionError(msg)
+    if rc == SNPM_ERR_DOMAIN:
+        raise AssertionError(msg or "provided y is greater than n")     # core/snpmatch.py:43
+    if rc == SNPM_ERR_OOM:
+        raise MemoryError(msg)
+    raise SnpmError(rc, msg)
+
+
+def as_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        assert a.shape == shape
+    return a

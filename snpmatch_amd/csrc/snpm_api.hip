@@ -1,0 +1,1042 @@
+// snpm_api.hip -- C ABI of libsnpmatch_hip.so (see include/snpmatch_hip.h for the contract and the
+// reference interfaces each entry point replaces).  gfx950 only; no CPU fallback lives here: every
+// compute entry point launches HIP kernels and fails with SNPM_ERR_HIP when no device is usable.
+#include "snpmatch_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "snpm_kernels.hpp"
+
+using namespace snpm;
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+thread_local std::string g_init_error;
+
+enum ProfKind { PK_FAST = 0, PK_STRICT, PK_REDUCE, PK_SCAN, PK_LIK, PK_SYNTH, PK_CANON, PK_LUT, PK_COUNT };
+const char *kProfNames[PK_COUNT] = {"fast", "strict", "reduce", "scan", "likelihood", "synth", "canon", "lut"};
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct snpm_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;       // stream kernels are launched on (own or caller-provided)
+    hipStream_t copy_stream = nullptr;  // H2D staging side stream
+    std::string err;
+    int n_cu = 256;
+    // pinned staging (double-buffered)
+    static constexpr size_t kStageBytes = 32u << 20;
+    void *stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+    // grow-only device workspaces
+    Buf ws_part_score, ws_part_miss, ws_seg_score, ws_seg_miss, ws_seg_off, ws_cols, ws_tmp_score, ws_tmp_ninfo, ws_flags;
+    Buf ws_lik_y, ws_lik_n, ws_lik_l, ws_lik_r;
+    // profiling
+    bool prof_on = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<std::pair<size_t, size_t>> prof_pairs[PK_COUNT];
+    // tunables (environment)
+    int force_bpl = 0;
+    int parts_mult = 1;
+};
+
+struct snpm_panel {
+    snpm_ctx *ctx = nullptr;
+    int64_t n_snp = 0, n_acc = 0, pitch = 0;
+    int8_t *d = nullptr;
+    hipEvent_t uploaded = nullptr;      // last upload / fill enqueued on copy_stream
+    bool upload_pending = false;
+};
+
+struct snpm_query {
+    snpm_panel *panel = nullptr;
+    int64_t n = 0, row0 = 0;
+    int64_t *d_row_idx = nullptr;       // NULL = dense
+    double *d_w = nullptr;              // [n,3]
+    double *d_lut = nullptr;            // [n,4]
+    int lut_skip = -1;                  // which skip_hets variant d_lut currently holds
+    double *d_score = nullptr;          // results: own buffers [pitch] or caller-bound [n_acc]
+    int64_t *d_ninfo = nullptr;
+    double *own_score = nullptr;
+    int64_t *own_ninfo = nullptr;
+    std::vector<double> wmax;           // host: max_c |W[r,c]| per matched row
+    bool all_integer = false;
+    std::map<int64_t, double> eref_cache;  // chunk -> E_ref
+};
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+int set_err(snpm_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    else
+        g_init_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return set_err((ctx), (e_ == hipErrorOutOfMemory) ? SNPM_ERR_OOM : SNPM_ERR_HIP,           \
+                           "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define CHECK_ARG(ctx, cond, msg)                                   \
+    do {                                                            \
+        if (!(cond)) return set_err((ctx), SNPM_ERR_BADARG, "%s", msg); \
+    } while (0)
+
+int ensure(snpm_ctx *ctx, Buf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return SNPM_OK;
+    if (b.p) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = std::max<size_t>(bytes, 256);
+    HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return SNPM_OK;
+}
+
+struct ProfScope {
+    snpm_ctx *ctx;
+    int kind;
+    size_t a = 0, b = 0;
+    bool on = false;
+    ProfScope(snpm_ctx *c, int k) : ctx(c), kind(k)
+    {
+        if (!ctx->prof_on) return;
+        if (ctx->ev_used + 2 > ctx->ev_pool.size()) {
+            for (int i = 0; i < 64; ++i) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return;
+                ctx->ev_pool.push_back(e);
+            }
+        }
+        a = ctx->ev_used++;
+        b = ctx->ev_used++;
+        on = true;
+        (void)hipEventRecord(ctx->ev_pool[a], ctx->stream);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(ctx->ev_pool[b], ctx->stream);
+        ctx->prof_pairs[kind].push_back({a, b});
+    }
+};
+
+int wait_upload(snpm_panel *p)
+{
+    // make the compute stream wait for any pending staging copies into this panel
+    if (p->upload_pending) {
+        HIPCHK(p->ctx, hipStreamWaitEvent(p->ctx->stream, p->uploaded, 0));
+    }
+    return SNPM_OK;
+}
+
+// ---- launch geometry of the fast pass ---------------------------------------------------------
+struct FastGeom {
+    int bpl, wpb;
+    int64_t n_wc, n_colblocks, n_parts, part_rows;
+};
+
+template <int BPL, bool SKIP, bool GATHER>
+int occupancy_of(int threads)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<BPL, SKIP, GATHER>, threads, 0) != hipSuccess) nb = 0;
+    return nb;
+}
+
+int pick_bpl(snpm_ctx *ctx, int64_t n_acc)
+{
+    if (ctx->force_bpl == 4 || ctx->force_bpl == 8 || ctx->force_bpl == 16) return ctx->force_bpl;
+    const int cand[3] = {16, 8, 4};
+    double util[3], best = 0;
+    for (int i = 0; i < 3; ++i) {
+        int64_t span = (int64_t)WAVE * cand[i];
+        int64_t nwc = (n_acc + span - 1) / span;
+        util[i] = (double)n_acc / (double)(nwc * span);
+        best = std::max(best, util[i]);
+    }
+    for (int i = 0; i < 3; ++i)
+        if (util[i] >= 0.85 * best) return cand[i];
+    return 4;
+}
+
+FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint, int bpl)
+{
+    FastGeom g;
+    g.bpl = bpl;
+    const int64_t span = (int64_t)WAVE * bpl;
+    g.n_wc = std::max<int64_t>(1, (n_acc + span - 1) / span);
+    if (g.n_wc <= 8) {
+        g.wpb = (int)g.n_wc;
+    } else {
+        int best_w = 8;
+        int64_t best_waste = INT64_MAX;
+        for (int w = 8; w >= 4; --w) {
+            int64_t waste = ((g.n_wc + w - 1) / w) * w - g.n_wc;
+            if (waste < best_waste) { best_waste = waste; best_w = w; }
+        }
+        g.wpb = best_w;
+    }
+    g.n_colblocks = (g.n_wc + g.wpb - 1) / g.wpb;
+    int occ = occ_blocks_hint > 0 ? occ_blocks_hint : 2;
+    int64_t resident = (int64_t)ctx->n_cu * occ * std::max(1, ctx->parts_mult);
+    int64_t n_parts = std::max<int64_t>(1, resident / g.n_colblocks);
+    int64_t min_parts = (n + 65279) / 65280;                 // u16 SWAR counters per part
+    n_parts = std::max(n_parts, min_parts);
+    int64_t part_rows = (n + n_parts - 1) / std::max<int64_t>(n_parts, 1);
+    part_rows = std::max<int64_t>(TILE_ROWS, ((part_rows + TILE_ROWS - 1) / TILE_ROWS) * TILE_ROWS);
+    part_rows = std::min<int64_t>(part_rows, 65280 / TILE_ROWS * TILE_ROWS);
+    g.part_rows = part_rows;
+    g.n_parts = std::max<int64_t>(1, (n + part_rows - 1) / part_rows);
+    return g;
+}
+
+template <int BPL, bool SKIP, bool GATHER>
+int launch_fast_t(snpm_query *q, const FastGeom &g)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    dim3 grid((unsigned)g.n_colblocks, (unsigned)g.n_parts);
+    dim3 block(WAVE * g.wpb);
+    ProfScope ps(ctx, PK_FAST);
+    hipLaunchKernelGGL((k_fast<BPL, SKIP, GATHER>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0,
+                       q->n, q->d_lut, g.part_rows, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p,
+                       p->pitch);
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+template <int BPL>
+int launch_fast_b(snpm_query *q, const FastGeom &g, bool skip, bool gather)
+{
+    if (skip)
+        return gather ? launch_fast_t<BPL, true, true>(q, g) : launch_fast_t<BPL, true, false>(q, g);
+    return gather ? launch_fast_t<BPL, false, true>(q, g) : launch_fast_t<BPL, false, false>(q, g);
+}
+
+template <int BPL>
+int occ_b(bool skip, bool gather, int threads)
+{
+    if (skip) return gather ? occupancy_of<BPL, true, true>(threads) : occupancy_of<BPL, true, false>(threads);
+    return gather ? occupancy_of<BPL, false, true>(threads) : occupancy_of<BPL, false, false>(threads);
+}
+
+int ensure_lut(snpm_query *q, int skip)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    if (q->lut_skip == skip) return SNPM_OK;
+    if (q->n > 0) {
+        ProfScope ps(ctx, PK_LUT);
+        const int thr = 256;
+        hipLaunchKernelGGL(k_build_lut, dim3((unsigned)((q->n + thr - 1) / thr)), dim3(thr), 0, ctx->stream, q->d_w,
+                           q->d_lut, q->n, skip);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    q->lut_skip = skip;
+    return SNPM_OK;
+}
+
+// fast pass + ordered reduce -> q->d_score / q->d_ninfo; returns geometry used (for the error bound)
+int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    int rc = ensure_lut(q, skip);
+    if (rc) return rc;
+    const bool gather = q->d_row_idx != nullptr;
+    const int bpl = pick_bpl(ctx, p->n_acc);
+    FastGeom g0 = fast_geom(ctx, p->n_acc, q->n, 2, bpl);   // wpb does not depend on occupancy
+    int occ = 0;
+    if (bpl == 16) occ = occ_b<16>(skip, gather, WAVE * g0.wpb);
+    else if (bpl == 8) occ = occ_b<8>(skip, gather, WAVE * g0.wpb);
+    else occ = occ_b<4>(skip, gather, WAVE * g0.wpb);
+    FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl);
+    if (geom_out) *geom_out = g;
+    rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_parts * p->pitch * sizeof(double));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->ws_part_miss, (size_t)g.n_parts * p->pitch * sizeof(uint32_t));
+    if (rc) return rc;
+    if (q->n > 0) {
+        if (bpl == 16) rc = launch_fast_b<16>(q, g, skip, gather);
+        else if (bpl == 8) rc = launch_fast_b<8>(q, g, skip, gather);
+        else rc = launch_fast_b<4>(q, g, skip, gather);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(ctx, PK_REDUCE);
+        const int thr = 256;
+        hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                           (const double *)ctx->ws_part_score.p, (const uint32_t *)ctx->ws_part_miss.p,
+                           q->n > 0 ? g.n_parts : 0, p->pitch, p->n_acc, q->n, q->d_score, q->d_ninfo);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    return SNPM_OK;
+}
+
+// strict segment sums for `ncols` columns (d_cols NULL = all accessions) over segments d_seg_off[n_seg+1]
+int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64_t n_seg, const int32_t *d_cols,
+                        int64_t ncols, int64_t ld)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    int rc = ensure(ctx, ctx->ws_seg_score, (size_t)std::max<int64_t>(n_seg, 1) * ld * sizeof(double));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->ws_seg_miss, (size_t)std::max<int64_t>(n_seg, 1) * ld * sizeof(uint32_t));
+    if (rc) return rc;
+    if (n_seg == 0 || ncols == 0) return SNPM_OK;
+    const int thr = ncols >= 256 ? 256 : (ncols > 128 ? 256 : (ncols > 64 ? 128 : 64));
+    const bool gather = q->d_row_idx != nullptr;
+    // grid.x = segments (can be large), grid.y = column blocks
+    dim3 grid((unsigned)n_seg, (unsigned)((ncols + thr - 1) / thr));
+    ProfScope ps(ctx, PK_STRICT);
+#define LAUNCH_STRICT(S, G)                                                                                       \
+    hipLaunchKernelGGL((k_strict<S, G>), grid, dim3(thr), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0,  \
+                       q->d_w, d_seg_off, d_cols, ncols, (double *)ctx->ws_seg_score.p,                           \
+                       (uint32_t *)ctx->ws_seg_miss.p, ld)
+    if (skip) {
+        if (gather) LAUNCH_STRICT(true, true); else LAUNCH_STRICT(true, false);
+    } else {
+        if (gather) LAUNCH_STRICT(false, true); else LAUNCH_STRICT(false, false);
+    }
+#undef LAUNCH_STRICT
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+int upload_seg_off(snpm_ctx *ctx, const std::vector<int64_t> &off)
+{
+    int rc = ensure(ctx, ctx->ws_seg_off, off.size() * sizeof(int64_t));
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_seg_off.p, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // `off` is a host temporary
+    return SNPM_OK;
+}
+
+std::vector<int64_t> chunk_offsets(int64_t n, int64_t chunk)
+{
+    std::vector<int64_t> off;
+    for (int64_t j = 0; j < n; j += chunk) off.push_back(j);
+    off.push_back(n);
+    if (n == 0) off.assign(1, 0);
+    return off;
+}
+
+// ---- rigorous error bounds (see DESIGN.md "Exactness") -----------------------------------------
+// For sums of terms x_i with |x_i| <= wmax_i, a computed sum differs from the exact one by at most
+// sum_i wmax_i * gamma(m_i), gamma(m) = m*u/(1-m*u), u = 2^-53, m_i = number of fp64 additions the
+// term passes through.  Reference order: m_i <= (rows left in its chunk) + 3 + (chunks left).
+double eref_bound(const snpm_query *q, int64_t chunk)
+{
+    const double u = 1.1102230246251565e-16;
+    const int64_t n = q->n;
+    const int64_t K = (n + chunk - 1) / chunk;
+    long double acc = 0;
+    for (int64_t k = 0; k < K; ++k) {
+        int64_t r0 = k * chunk, r1 = std::min(n, r0 + chunk);
+        long double s = 0;
+        for (int64_t r = r0; r < r1; ++r) s += q->wmax[r];
+        acc += s * (long double)((r1 - r0) + 3 + (K - k));
+    }
+    const double mmax = (double)(chunk + 3 + K);
+    return (double)(acc * u / (1.0 - mmax * u)) * 1.0000001;
+}
+
+double efast_bound(const snpm_query *q, const FastGeom &g)
+{
+    const double u = 1.1102230246251565e-16;
+    long double s = 0;
+    for (double w : q->wmax) s += w;
+    const double m = (double)(g.part_rows + g.n_parts + 1);
+    return (double)(s * (m * u / (1.0 - m * u))) * 1.0000001;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int snpm_version(void) { return 100; }
+
+int snpm_device_count(int *count)
+{
+    if (!count) return set_err(nullptr, SNPM_ERR_BADARG, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return set_err(nullptr, SNPM_ERR_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return SNPM_OK;
+}
+
+const char *snpm_last_error(const snpm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int snpm_init(int device_id, snpm_ctx **out)
+{
+    if (!out) return set_err(nullptr, SNPM_ERR_BADARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return set_err(nullptr, SNPM_ERR_HIP, "no usable HIP device (hipGetDeviceCount: %s, count %d)",
+                       hipGetErrorString(e), n);
+    if (device_id < 0 || device_id >= n)
+        return set_err(nullptr, SNPM_ERR_BADARG, "device_id %d out of range (0..%d)", device_id, n - 1);
+    HIPCHK(nullptr, hipSetDevice(device_id));
+    snpm_ctx *ctx = new snpm_ctx();
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return set_err(nullptr, SNPM_ERR_HIP, "hipStreamCreate failed");
+    }
+    ctx->stream = ctx->own_stream;
+    if (const char *s = getenv("SNPM_FORCE_BPL")) ctx->force_bpl = atoi(s);
+    if (const char *s = getenv("SNPM_PARTS_MULT")) ctx->parts_mult = std::max(1, atoi(s));
+    *out = ctx;
+    return SNPM_OK;
+}
+
+int snpm_destroy(snpm_ctx *ctx)
+{
+    if (!ctx) return SNPM_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    Buf *bufs[] = {&ctx->ws_part_score, &ctx->ws_part_miss, &ctx->ws_seg_score, &ctx->ws_seg_miss, &ctx->ws_seg_off,
+                   &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
+                   &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r};
+    for (Buf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
+        if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
+    }
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    delete ctx;
+    return SNPM_OK;
+}
+
+int snpm_set_stream(snpm_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SNPM_OK;
+}
+
+int snpm_synchronize(snpm_ctx *ctx)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SNPM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- panel
+int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    CHECK_ARG(ctx, out != nullptr, "out is NULL");
+    CHECK_ARG(ctx, n_snp >= 0 && n_acc >= 1, "panel needs n_snp >= 0 and n_acc >= 1");
+    CHECK_ARG(ctx, n_acc <= (int64_t)1 << 30, "n_acc too large");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    snpm_panel *p = new snpm_panel();
+    p->ctx = ctx;
+    p->n_snp = n_snp;
+    p->n_acc = n_acc;
+    p->pitch = ((n_acc + 255) / 256) * 256;
+    size_t bytes = (size_t)std::max<int64_t>(n_snp, 1) * (size_t)p->pitch;
+    hipError_t e = hipMalloc((void **)&p->d, bytes);
+    if (e != hipSuccess) {
+        delete p;
+        return set_err(ctx, SNPM_ERR_OOM, "hipMalloc of %zu panel bytes failed: %s", bytes, hipGetErrorString(e));
+    }
+    if (hipEventCreateWithFlags(&p->uploaded, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(p->d);
+        delete p;
+        return set_err(ctx, SNPM_ERR_HIP, "hipEventCreate failed");
+    }
+    *out = p;
+    return SNPM_OK;
+}
+
+int snpm_panel_free(snpm_panel *p)
+{
+    if (!p) return SNPM_OK;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->copy_stream);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->d) (void)hipFree(p->d);
+    if (p->uploaded) (void)hipEventDestroy(p->uploaded);
+    delete p;
+    return SNPM_OK;
+}
+
+int snpm_panel_info(const snpm_panel *p, int64_t *n_snp, int64_t *n_acc, int64_t *pitch, void **device_ptr)
+{
+    if (!p) return SNPM_ERR_BADARG;
+    if (n_snp) *n_snp = p->n_snp;
+    if (n_acc) *n_acc = p->n_acc;
+    if (pitch) *pitch = p->pitch;
+    if (device_ptr) *device_ptr = p->d;
+    return SNPM_OK;
+}
+
+int snpm_panel_upload_rows(snpm_panel *p, int64_t row0, int64_t nrows, const int8_t *host, int64_t host_pitch)
+{
+    if (!p) return SNPM_ERR_BADARG;
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "upload rows outside the panel");
+    CHECK_ARG(ctx, nrows == 0 || host != nullptr, "host pointer is NULL");
+    CHECK_ARG(ctx, host_pitch >= p->n_acc, "host_pitch smaller than n_acc");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->stage[i]) {
+            hipError_t e = hipHostMalloc(&ctx->stage[i], snpm_ctx::kStageBytes, hipHostMallocDefault);
+            if (e != hipSuccess) return set_err(ctx, SNPM_ERR_OOM, "hipHostMalloc staging failed: %s", hipGetErrorString(e));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+        }
+    }
+    const int64_t slab_rows = std::max<int64_t>(1, (int64_t)(snpm_ctx::kStageBytes / (size_t)p->pitch));
+    int which = 0;
+    for (int64_t r = 0; r < nrows; r += slab_rows, which ^= 1) {
+        const int64_t nr = std::min(slab_rows, nrows - r);
+        if (ctx->stage_busy[which]) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->stage_done[which]));
+            ctx->stage_busy[which] = false;
+        }
+        int8_t *st = (int8_t *)ctx->stage[which];
+        const int64_t pad = p->pitch - p->n_acc;
+        for (int64_t k = 0; k < nr; ++k) {
+            memcpy(st + k * p->pitch, host + (r + k) * host_pitch, (size_t)p->n_acc);
+            if (pad) memset(st + k * p->pitch + p->n_acc, 0xff, (size_t)pad);
+        }
+        int8_t *dst = p->d + (row0 + r) * p->pitch;
+        HIPCHK(ctx, hipMemcpyAsync(dst, st, (size_t)nr * p->pitch, hipMemcpyHostToDevice, ctx->copy_stream));
+        {
+            const int64_t n16 = nr * p->pitch / 16;
+            const int thr = 256;
+            const unsigned blocks = (unsigned)std::min<int64_t>((n16 + thr - 1) / thr, 4096);
+            hipLaunchKernelGGL(k_canon, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->copy_stream, (uint4 *)dst, n16);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->stage_done[which], ctx->copy_stream));
+        ctx->stage_busy[which] = true;
+    }
+    HIPCHK(ctx, hipEventRecord(p->uploaded, ctx->copy_stream));
+    p->upload_pending = true;
+    return SNPM_OK;
+}
+
+int snpm_panel_upload_wait(snpm_panel *p)
+{
+    if (!p) return SNPM_ERR_BADARG;
+    HIPCHK(p->ctx, hipStreamSynchronize(p->ctx->copy_stream));
+    p->upload_pending = false;
+    p->ctx->stage_busy[0] = p->ctx->stage_busy[1] = false;
+    return SNPM_OK;
+}
+
+int snpm_panel_download_rows(snpm_panel *p, int64_t row0, int64_t nrows, int8_t *host, int64_t host_pitch)
+{
+    if (!p) return SNPM_ERR_BADARG;
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "download rows outside the panel");
+    CHECK_ARG(ctx, host_pitch >= p->n_acc, "host_pitch smaller than n_acc");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (nrows == 0) return SNPM_OK;
+    HIPCHK(ctx, hipMemcpy2D(host, (size_t)host_pitch, p->d + row0 * p->pitch, (size_t)p->pitch, (size_t)p->n_acc,
+                            (size_t)nrows, hipMemcpyDeviceToHost));
+    return SNPM_OK;
+}
+
+int snpm_panel_fill_synthetic(snpm_panel *p, uint64_t seed, int64_t snp0, int64_t acc0)
+{
+    if (!p) return SNPM_ERR_BADARG;
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, (acc0 & 3) == 0 && acc0 >= 0 && snp0 >= 0, "acc0 must be a non-negative multiple of 4");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (p->n_snp == 0) return SNPM_OK;
+    ProfScope ps(ctx, PK_SYNTH);
+    const int thr = 256;
+    const int64_t total = p->n_snp * (p->pitch / 4);
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + thr - 1) / thr, (int64_t)ctx->n_cu * 32);
+    hipLaunchKernelGGL(k_synth, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->stream, (uint32_t *)p->d, p->pitch,
+                       p->n_snp, p->n_acc, seed, snp0, acc0);
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- query
+int snpm_query_create(snpm_panel *p, const int64_t *row_idx, int64_t row0, int64_t n, const double *wei,
+                      snpm_query **out)
+{
+    if (!p) return SNPM_ERR_BADARG;
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, out != nullptr, "out is NULL");
+    CHECK_ARG(ctx, n >= 0, "n must be >= 0");
+    CHECK_ARG(ctx, n == 0 || wei != nullptr, "SNP weights should be a np.array with  shape == n,3");
+    if (row_idx) {
+        for (int64_t i = 0; i < n; ++i)
+            if (row_idx[i] < 0 || row_idx[i] >= p->n_snp)
+                return set_err(ctx, SNPM_ERR_BADARG, "row index %lld at %lld outside the panel (n_snp %lld)",
+                               (long long)row_idx[i], (long long)i, (long long)p->n_snp);
+    } else {
+        CHECK_ARG(ctx, row0 >= 0 && row0 + n <= p->n_snp, "dense row range outside the panel");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    snpm_query *q = new snpm_query();
+    q->panel = p;
+    q->n = n;
+    q->row0 = row_idx ? 0 : row0;
+    const size_t nn = (size_t)std::max<int64_t>(n, 1);
+    hipError_t e = hipSuccess;
+    if (row_idx && e == hipSuccess) e = hipMalloc((void **)&q->d_row_idx, nn * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&q->d_w, nn * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&q->d_lut, nn * 4 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&q->own_score, (size_t)p->pitch * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&q->own_ninfo, (size_t)p->pitch * sizeof(int64_t));
+    q->d_score = q->own_score;
+    q->d_ninfo = q->own_ninfo;
+    if (e != hipSuccess) {
+        snpm_query_free(q);
+        return set_err(ctx, SNPM_ERR_OOM, "query allocation failed: %s", hipGetErrorString(e));
+    }
+    if (n > 0) {
+        if (row_idx)
+            HIPCHK(ctx, hipMemcpyAsync(q->d_row_idx, row_idx, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(q->d_w, wei, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    q->wmax.resize((size_t)n);
+    bool all_int = true;
+    for (int64_t i = 0; i < n; ++i) {
+        const double a = std::fabs(wei[3 * i]), b = std::fabs(wei[3 * i + 1]), c = std::fabs(wei[3 * i + 2]);
+        q->wmax[(size_t)i] = std::max(a, std::max(b, c));
+        if (all_int && !(a == std::floor(a) && b == std::floor(b) && c == std::floor(c))) all_int = false;
+        if (!std::isfinite(a) || !std::isfinite(b) || !std::isfinite(c)) all_int = false;
+    }
+    long double tot = 0;
+    for (double w : q->wmax) tot += w;
+    q->all_integer = all_int && tot < 9.0e15L;     // every partial sum exactly representable
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host buffers may be released by the caller
+    *out = q;
+    return SNPM_OK;
+}
+
+int snpm_query_free(snpm_query *q)
+{
+    if (!q) return SNPM_OK;
+    snpm_ctx *ctx = q->panel->ctx;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (q->d_row_idx) (void)hipFree(q->d_row_idx);
+    if (q->d_w) (void)hipFree(q->d_w);
+    if (q->d_lut) (void)hipFree(q->d_lut);
+    if (q->own_score) (void)hipFree(q->own_score);
+    if (q->own_ninfo) (void)hipFree(q->own_ninfo);
+    delete q;
+    return SNPM_OK;
+}
+
+int snpm_query_bind_outputs(snpm_query *q, void *d_score, void *d_ninfo)
+{
+    if (!q) return SNPM_ERR_BADARG;
+    snpm_ctx *ctx = q->panel->ctx;
+    CHECK_ARG(ctx, (d_score == nullptr) == (d_ninfo == nullptr), "bind both outputs or neither");
+    q->d_score = d_score ? (double *)d_score : q->own_score;
+    q->d_ninfo = d_ninfo ? (int64_t *)d_ninfo : q->own_ninfo;
+    return SNPM_OK;
+}
+
+int snpm_query_error_bound(snpm_query *q, int64_t chunk, double *bound)
+{
+    if (!q || !bound) return SNPM_ERR_BADARG;
+    snpm_ctx *ctx = q->panel->ctx;
+    CHECK_ARG(ctx, chunk >= 1, "chunk must be >= 1");
+    if (q->all_integer) { *bound = 0.0; return SNPM_OK; }
+    auto it = q->eref_cache.find(chunk);
+    double eref = (it != q->eref_cache.end()) ? it->second : (q->eref_cache[chunk] = eref_bound(q, chunk));
+    const int bpl = pick_bpl(ctx, q->panel->n_acc);
+    FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl);   // occ 1 -> longest parts -> largest bound
+    *bound = eref + efast_bound(q, g);
+    return SNPM_OK;
+}
+
+int snpm_query_run_device(snpm_query *q, int64_t chunk, int skip_hets, int mode, void **d_score, void **d_ninfo,
+                          int64_t *info)
+{
+    if (!q) return SNPM_ERR_BADARG;
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    CHECK_ARG(ctx, chunk >= 1, "chunk must be >= 1");
+    CHECK_ARG(ctx, mode == SNPM_MODE_EXACT || mode == SNPM_MODE_STRICT || mode == SNPM_MODE_FAST, "unknown mode");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = wait_upload(p);
+    if (rc) return rc;
+    const int skip = skip_hets ? 1 : 0;
+    int64_t n_flag = 0;
+
+    if (mode == SNPM_MODE_STRICT) {
+        std::vector<int64_t> off = chunk_offsets(q->n, chunk);
+        const int64_t n_seg = (int64_t)off.size() - 1;
+        rc = upload_seg_off(ctx, off);
+        if (rc) return rc;
+        rc = run_strict_segments(q, skip, (const int64_t *)ctx->ws_seg_off.p, n_seg, nullptr, p->n_acc, p->pitch);
+        if (rc) return rc;
+        ProfScope ps(ctx, PK_SCAN);
+        const int thr = 256;
+        hipLaunchKernelGGL(k_scan, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                           (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
+                           (const int64_t *)ctx->ws_seg_off.p, n_seg, p->pitch, p->n_acc, q->d_score, q->d_ninfo);
+        HIPCHK(ctx, hipGetLastError());
+    } else {
+        FastGeom g;
+        rc = run_fast(q, skip, &g);
+        if (rc) return rc;
+        if (mode == SNPM_MODE_EXACT && !q->all_integer && q->n > 0) {
+            auto it = q->eref_cache.find(chunk);
+            const double eref = (it != q->eref_cache.end()) ? it->second : (q->eref_cache[chunk] = eref_bound(q, chunk));
+            const double E = eref + efast_bound(q, g);
+            std::vector<double> h((size_t)p->n_acc);
+            HIPCHK(ctx, hipMemcpyAsync(h.data(), q->d_score, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            std::vector<int32_t> cols;
+            for (int64_t a = 0; a < p->n_acc; ++a) {
+                const double f = h[(size_t)a];
+                const double lo = f - E, hi = f + E;
+                if (!(lo >= 0.0) || std::floor(lo) != std::floor(hi)) cols.push_back((int32_t)a);
+            }
+            n_flag = (int64_t)cols.size();
+            if (n_flag > 0) {
+                std::vector<int64_t> off = chunk_offsets(q->n, chunk);
+                const int64_t n_seg = (int64_t)off.size() - 1;
+                rc = upload_seg_off(ctx, off);
+                if (rc) return rc;
+                rc = ensure(ctx, ctx->ws_cols, cols.size() * sizeof(int32_t));
+                if (rc) return rc;
+                HIPCHK(ctx, hipMemcpyAsync(ctx->ws_cols.p, cols.data(), cols.size() * sizeof(int32_t),
+                                           hipMemcpyHostToDevice, ctx->stream));
+                const int64_t ld = ((n_flag + 63) / 64) * 64;
+                rc = run_strict_segments(q, skip, (const int64_t *)ctx->ws_seg_off.p, n_seg, (const int32_t *)ctx->ws_cols.p,
+                                         n_flag, ld);
+                if (rc) return rc;
+                rc = ensure(ctx, ctx->ws_tmp_score, (size_t)ld * sizeof(double));
+                if (rc) return rc;
+                const int thr = 256;
+                {
+                    ProfScope ps(ctx, PK_SCAN);
+                    hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_flag + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                                       (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
+                                       (const int64_t *)ctx->ws_seg_off.p, n_seg, ld, n_flag, (double *)ctx->ws_tmp_score.p,
+                                       (int64_t *)nullptr);
+                    HIPCHK(ctx, hipGetLastError());
+                }
+                hipLaunchKernelGGL(k_patch, dim3((unsigned)((n_flag + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                                   (const double *)ctx->ws_tmp_score.p, (const int32_t *)ctx->ws_cols.p, n_flag, q->d_score);
+                HIPCHK(ctx, hipGetLastError());
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // `cols` is a host temporary
+            }
+        }
+    }
+    if (d_score) *d_score = q->d_score;
+    if (d_ninfo) *d_ninfo = q->d_ninfo;
+    if (info) {
+        info[0] = n_flag;
+        info[1] = q->all_integer ? 1 : 0;
+        info[2] = 0;
+        info[3] = 0;
+    }
+    return SNPM_OK;
+}
+
+int snpm_query_run(snpm_query *q, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo, int64_t *info)
+{
+    int rc = snpm_query_run_device(q, chunk, skip_hets, mode, nullptr, nullptr, info);
+    if (rc) return rc;
+    snpm_ctx *ctx = q->panel->ctx;
+    const size_t na = (size_t)q->panel->n_acc;
+    if (score) HIPCHK(ctx, hipMemcpyAsync(score, q->d_score, na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (ninfo) HIPCHK(ctx, hipMemcpyAsync(ninfo, q->d_ninfo, na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SNPM_OK;
+}
+
+int snpm_query_run_windows(snpm_query *q, const int64_t *win_off, int64_t n_win, int skip_hets, double *score,
+                           int64_t *ninfo, double *tot_score, int64_t *tot_ninfo)
+{
+    if (!q) return SNPM_ERR_BADARG;
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    CHECK_ARG(ctx, n_win >= 0 && win_off != nullptr, "window offsets missing");
+    for (int64_t w = 0; w < n_win; ++w)
+        CHECK_ARG(ctx, win_off[w] <= win_off[w + 1], "window offsets must be non-decreasing");
+    CHECK_ARG(ctx, win_off[0] >= 0 && win_off[n_win] <= q->n, "window offsets outside the matched list");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = wait_upload(p);
+    if (rc) return rc;
+    const int skip = skip_hets ? 1 : 0;
+    std::vector<int64_t> off(win_off, win_off + n_win + 1);
+    rc = upload_seg_off(ctx, off);
+    if (rc) return rc;
+    rc = run_strict_segments(q, skip, (const int64_t *)ctx->ws_seg_off.p, n_win, nullptr, p->n_acc, p->pitch);
+    if (rc) return rc;
+    const int thr = 256;
+    const size_t na = (size_t)p->n_acc;
+    if (tot_score || tot_ninfo) {
+        {
+            ProfScope ps(ctx, PK_SCAN);
+            hipLaunchKernelGGL(k_scan, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                               (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
+                               (const int64_t *)ctx->ws_seg_off.p, n_win, p->pitch, p->n_acc, q->d_score, q->d_ninfo);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        if (tot_score) HIPCHK(ctx, hipMemcpyAsync(tot_score, q->d_score, na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (tot_ninfo) {
+            HIPCHK(ctx, hipMemcpyAsync(tot_ninfo, q->d_ninfo, na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        }
+    }
+    if ((score || ninfo) && n_win > 0) {
+        rc = ensure(ctx, ctx->ws_tmp_score, (size_t)n_win * na * sizeof(double));
+        if (rc) return rc;
+        rc = ensure(ctx, ctx->ws_tmp_ninfo, (size_t)n_win * na * sizeof(int64_t));
+        if (rc) return rc;
+        // grid.y is limited to 65535: loop in slabs of windows
+        for (int64_t w0 = 0; w0 < n_win; w0 += 32768) {
+            const int64_t nw = std::min<int64_t>(32768, n_win - w0);
+            hipLaunchKernelGGL(k_seg_pack, dim3((unsigned)((p->n_acc + thr - 1) / thr), (unsigned)nw), dim3(thr), 0,
+                               ctx->stream, (const double *)ctx->ws_seg_score.p + w0 * p->pitch,
+                               (const uint32_t *)ctx->ws_seg_miss.p + w0 * p->pitch,
+                               (const int64_t *)ctx->ws_seg_off.p + w0, nw, p->pitch, p->n_acc,
+                               (double *)ctx->ws_tmp_score.p + w0 * p->n_acc, (int64_t *)ctx->ws_tmp_ninfo.p + w0 * p->n_acc);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        if (score)
+            HIPCHK(ctx, hipMemcpyAsync(score, ctx->ws_tmp_score.p, (size_t)n_win * na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        if (ninfo)
+            HIPCHK(ctx, hipMemcpyAsync(ninfo, ctx->ws_tmp_ninfo.p, (size_t)n_win * na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SNPM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- one-shot
+int snpm_score_dense_host(snpm_ctx *ctx, const int8_t *db, int64_t db_pitch, int64_t n, int64_t n_acc,
+                          const double *wei, int skip_hets, double *score, int64_t *ninfo)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    CHECK_ARG(ctx, n >= 0 && n_acc >= 1, "please provide same number of positions for both sample and db");
+    CHECK_ARG(ctx, n == 0 || (db != nullptr && wei != nullptr), "NULL input");
+    CHECK_ARG(ctx, db_pitch >= n_acc, "db_pitch smaller than n_acc");
+    snpm_panel *p = nullptr;
+    snpm_query *q = nullptr;
+    int rc = snpm_panel_create(ctx, n, n_acc, &p);
+    if (rc) return rc;
+    rc = snpm_panel_upload_rows(p, 0, n, db, db_pitch);
+    if (!rc) rc = snpm_query_create(p, nullptr, 0, n, wei, &q);
+    if (!rc) {
+        // one matchGTsAccs call == one segment over all n rows, reference order
+        rc = snpm_query_run(q, std::max<int64_t>(n, 1), skip_hets, SNPM_MODE_STRICT, score, ninfo, nullptr);
+    }
+    std::string keep = ctx->err;
+    if (q) snpm_query_free(q);
+    (void)snpm_panel_upload_wait(p);
+    snpm_panel_free(p);
+    if (rc) ctx->err = keep;
+    return rc;
+}
+
+int snpm_likelihood_device(snpm_ctx *ctx, const void *d_y, const void *d_n, int64_t m, int64_t len, int truncate,
+                           double amin_or_nan, void *d_lik, void *d_lrt, int *domain_error)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    CHECK_ARG(ctx, m >= 0 && len >= 0, "negative size");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (domain_error) *domain_error = 0;
+    if (m == 0 || len == 0) return SNPM_OK;
+    int rc = ensure(ctx, ctx->ws_flags, sizeof(int));
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->ws_flags.p, 0, sizeof(int), ctx->stream));
+    {
+        ProfScope ps(ctx, PK_LIK);
+        const int thr = len >= 1024 ? 1024 : (len > 256 ? 512 : 256);
+        for (int64_t r0 = 0; r0 < m; r0 += 1 << 30) {
+            const int64_t mr = std::min<int64_t>(m - r0, 1 << 30);
+            hipLaunchKernelGGL(k_likelihood, dim3((unsigned)mr), dim3(thr), 0, ctx->stream, (const double *)d_y + r0 * len,
+                               (const int64_t *)d_n + r0 * len, len, truncate, amin_or_nan, (double *)d_lik + r0 * len,
+                               (double *)d_lrt + r0 * len, (int *)ctx->ws_flags.p);
+            HIPCHK(ctx, hipGetLastError());
+        }
+    }
+    if (domain_error) {
+        int flag = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&flag, ctx->ws_flags.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        *domain_error = flag & 1;
+    }
+    return SNPM_OK;
+}
+
+int snpm_likelihood(snpm_ctx *ctx, const double *y, const int64_t *n, int64_t m, int64_t len, int truncate,
+                    double amin_or_nan, double *lik, double *lrt)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    CHECK_ARG(ctx, m >= 0 && len >= 0, "negative size");
+    const size_t tot = (size_t)m * (size_t)len;
+    if (tot == 0) return SNPM_OK;
+    CHECK_ARG(ctx, y && n && lik && lrt, "NULL pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ensure(ctx, ctx->ws_lik_y, tot * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_lik_n, tot * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_lik_l, tot * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_lik_r, tot * sizeof(double)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_lik_y.p, y, tot * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_lik_n.p, n, tot * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    int dom = 0;
+    rc = snpm_likelihood_device(ctx, ctx->ws_lik_y.p, ctx->ws_lik_n.p, m, len, truncate, amin_or_nan, ctx->ws_lik_l.p,
+                                ctx->ws_lik_r.p, &dom);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(lik, ctx->ws_lik_l.p, tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(lrt, ctx->ws_lik_r.p, tot * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (dom) return set_err(ctx, SNPM_ERR_DOMAIN, "provided y is greater than n");
+    return SNPM_OK;
+}
+
+// binom.sf(k, n, p) = P(X > floor(k)), X ~ Binomial(n, p); host implementation (cold path: one value per
+// accession per window), summed in log space from the mode of the tail outward.
+static double binom_sf(double k, double n, double p)
+{
+    if (!(n >= 0) || !(p >= 0.0 && p <= 1.0) || std::isnan(k)) return NAN;
+    const double kf = std::floor(k);
+    if (kf < 0) return 1.0;
+    if (kf >= n) return 0.0;
+    if (p == 0.0) return 0.0;
+    if (p == 1.0) return 1.0;
+    const double lp = std::log(p), lq = std::log1p(-p);
+    const double lg_n1 = std::lgamma(n + 1.0);
+    auto logpmf = [&](double j) { return lg_n1 - std::lgamma(j + 1.0) - std::lgamma(n - j + 1.0) + j * lp + (n - j) * lq; };
+    // sum the smaller tail
+    const double mean = n * p;
+    if (kf + 1 > mean) {
+        // upper tail j = kf+1 .. n : terms decrease
+        double j = kf + 1;
+        double t = std::exp(logpmf(j));
+        double s = 0;
+        while (j <= n && t > 0) {
+            s += t;
+            if (t < s * 1e-18) break;
+            t *= (n - j) / (j + 1.0) * (p / (1.0 - p));
+            j += 1;
+        }
+        return s > 1.0 ? 1.0 : s;
+    }
+    // lower tail cdf = sum_{j=0..kf}, terms increase toward kf: go downward from kf
+    double j = kf;
+    double t = std::exp(logpmf(j));
+    double s = 0;
+    while (j >= 0 && t > 0) {
+        s += t;
+        if (t < s * 1e-18) break;
+        t *= j / (n - j + 1.0) * ((1.0 - p) / p);
+        j -= 1;
+    }
+    double sf = 1.0 - s;
+    return sf < 0 ? 0.0 : sf;
+}
+
+int snpm_binom_identity(snpm_ctx *ctx, const double *x, const int64_t *n, int64_t len, double error_rate,
+                        double pthres, int64_t *out, double *sf)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    CHECK_ARG(ctx, len >= 0, "negative size");
+    CHECK_ARG(ctx, len == 0 || (x && n && out), "NULL pointer");
+    for (int64_t i = 0; i < len; ++i) {
+        const double nn = (double)n[i];
+        const double v = binom_sf(nn - x[i] - 1.0, nn, error_rate);
+        if (sf) sf[i] = v;
+        out[i] = (v >= pthres) ? 1 : 0;      // NaN compares false -> 0, as numpy's (nan >= p)
+    }
+    return SNPM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- profiling
+int snpm_profile_enable(snpm_ctx *ctx, int on)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    ctx->prof_on = on != 0;
+    return SNPM_OK;
+}
+
+int snpm_profile_reset(snpm_ctx *ctx)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < PK_COUNT; ++k) ctx->prof_pairs[k].clear();
+    ctx->ev_used = 0;
+    return SNPM_OK;
+}
+
+int snpm_profile_read(snpm_ctx *ctx, const char *kernel, int64_t *launches, double *total_ms)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    CHECK_ARG(ctx, kernel != nullptr, "kernel name is NULL");
+    int kind = -1;
+    for (int k = 0; k < PK_COUNT; ++k)
+        if (strcmp(kernel, kProfNames[k]) == 0) kind = k;
+    CHECK_ARG(ctx, kind >= 0, "unknown kernel name");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    for (auto &pr : ctx->prof_pairs[kind]) {
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[pr.first], ctx->ev_pool[pr.second]));
+        tot += ms;
+    }
+    if (launches) *launches = (int64_t)ctx->prof_pairs[kind].size();
+    if (total_ms) *total_ms = tot;
+    return SNPM_OK;
+}
+
+}  // extern "C"

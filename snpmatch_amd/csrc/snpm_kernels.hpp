@@ -1,0 +1,465 @@
+// snpm_kernels.hpp -- hand-written HIP kernels for gfx950 (MI355X, wave64) behind libsnpmatch_hip.so.
+//
+// The work is compare-and-count over an int8 SNP x accession panel: HBM-bound byte streaming,
+// no MFMA.  Layout: panel is SNP-major [n_snp, pitch] (pitch = n_acc rounded up to 256 B), so one
+// SNP row is a coalesced run of accession bytes and the three weights of a row are wave-uniform.
+//
+// Kernels
+//   k_fast     dominant kernel.  Each lane owns BPL adjacent accessions (one 4/8/16-byte load per
+//              row), each wave 64*BPL adjacent accession bytes, each workgroup a run of rows (a "part").
+//              Per-row weights live in LDS as a 4-entry fp64 LUT {ref, alt, het, 0} indexed by
+//              (byte & 3); every element costs one ds_read_b64 + one v_add_f64 instead of three
+//              compare/select pairs.  Missing counts are SWAR (packed u8 lanes).  Partials per part
+//              are written once; k_reduce adds them in part order (deterministic, no atomics).
+//   k_strict   reference summation order (three per-category sequential fp64 sums per segment,
+//              core/snpmatch.py:85-87): one lane per accession column, one wave per (segment, 64
+//              columns).  Used for cross windows, for SNPM_MODE_STRICT and to re-evaluate the few
+//              accessions the fast pass cannot certify.
+//   k_scan     sequential accumulation of segment sums (ScoreList += chunk, core/snpmatch.py:224).
+//   k_likelihood  likeliTest + nanmin + ratio on device (core/snpmatch.py:40-55,106-117).
+//   k_build_lut, k_canon, k_synth, k_patch: small helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace snpm {
+
+constexpr int WAVE = 64;
+constexpr int TILE_ROWS = 128;          // rows per LDS LUT tile (4 KiB); also the SWAR counter flush period (<= 255)
+constexpr int LUT_ROW_BYTES = 32;       // 4 x fp64
+constexpr int MAX_WAVES_PER_BLOCK = 8;
+
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+
+// ------------------------------------------------------------------------------------------------
+// LUT build: W [n,3] (ref, het, alt) -> LUT [n,4] = {ref, alt, het (0 if skip_hets), 0}, entry index = db byte & 3
+// (0 -> ref, 1 -> alt, 2 -> het, 3 and 0xFF -> nothing).
+__global__ void k_build_lut(const double *__restrict__ w, double *__restrict__ lut, int64_t n, int skip_hets)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double w0 = w[3 * i + 0], w1 = w[3 * i + 1], w2 = w[3 * i + 2];
+    double4 e;
+    e.x = w0;
+    e.y = w2;
+    e.z = skip_hets ? 0.0 : w1;
+    e.w = 0.0;
+    reinterpret_cast<double4 *>(lut)[i] = e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast pass.
+//   grid.x = column blocks (each WPB waves * 64 lanes * BPL bytes), grid.y = parts
+//   part p covers matched rows [p*part_rows, min(n, (p+1)*part_rows))
+//   out_score [n_parts, ld] fp64, out_miss [n_parts, ld] u32 (ld = pitch)
+template <int BPL>
+struct LoadT;
+template <>
+struct LoadT<4> { typedef uint32_t type; };
+template <>
+struct LoadT<8> { typedef uint2 type; };
+template <>
+struct LoadT<16> { typedef uint4 type; };
+
+__device__ __forceinline__ uint32_t dword_of(const uint32_t &v, int) { return v; }
+__device__ __forceinline__ uint32_t dword_of(const uint2 &v, int k) { return k == 0 ? v.x : v.y; }
+__device__ __forceinline__ uint32_t dword_of(const uint4 &v, int k)
+{
+    return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+}
+
+// One SNP row for one lane: NDW dwords of accession bytes.
+//   address of element j of dword x = group_base | byte,  byte = (code & 3) * 8 + roff, built by ONE
+//   v_perm_b32 (group_base is 256-B aligned and wave-uniform; roff in {0,128} selects the half of the
+//   256-B block, the row's offset inside its 4-row group, U*32, goes into the ds_read immediate);
+//   then one ds_read_b64 and one v_add_f64 per element.
+template <int NDW, bool SKIP, int U>
+__device__ __forceinline__ void fast_row(const uint32_t (&x)[NDW], uint32_t group_base, uint32_t roff4,
+                                         double (&acc)[NDW * 4], uint32_t (&miss8)[NDW])
+{
+    double w[NDW * 4];
+#pragma unroll
+    for (int k = 0; k < NDW; ++k) {
+        const uint32_t tix = ((x[k] << 3) & 0x18181818u) | roff4;   // byte j = (code & 3) * 8 + roff
+        if (SKIP)
+            miss8[k] += ((x[k] >> 7) | (x[k] >> 1)) & 0x01010101u;   // negative or het
+        else
+            miss8[k] += (x[k] >> 7) & 0x01010101u;                   // negative
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // v_perm_b32: D.b0 = tix.b[j] (selector 4+j: src0 bytes), D.b1 = group_base.b1, D.b2 = D.b3 = 0
+            const uint32_t addr = __builtin_amdgcn_perm(tix, group_base, 0x0c0c0100u | (uint32_t)(4 + j));
+            lds_cdouble *ptr = (lds_cdouble *)(uintptr_t)addr;
+            w[4 * k + j] = ptr[U * 4];                               // + U*32 bytes: immediate offset
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NDW * 4; ++e) acc[e] += w[e];
+}
+
+template <int BPL, bool SKIP, bool GATHER>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
+       const double *__restrict__ lut, int64_t part_rows, double *__restrict__ out_score,
+       uint32_t *__restrict__ out_miss, int64_t ld)
+{
+    constexpr int NDW = BPL / 4;
+    constexpr int G = 4;                    // rows per unrolled group (G*32 B = 128 B of LUT = half a 256-B block)
+    typedef typename LoadT<BPL>::type load_t;
+    __shared__ __attribute__((aligned(256))) double s_lut[2][TILE_ROWS * 4];
+
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int64_t col0 = ((int64_t)blockIdx.x * nthr + tid) * BPL;
+    const bool lane_on = col0 < pitch;      // pitch is a multiple of 256 >= n_acc: loads stay in the row
+    const int64_t p = blockIdx.y;
+    const int64_t r_begin = p * part_rows;
+    const int64_t r_end = (r_begin + part_rows < n) ? r_begin + part_rows : n;
+    const int64_t n_tiles = (r_end - r_begin + TILE_ROWS - 1) / TILE_ROWS;
+
+    double acc[BPL];
+    uint32_t miss16[NDW * 2];               // packed 2 x u16 per register, flushed from packed u8 every tile
+#pragma unroll
+    for (int i = 0; i < BPL; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < NDW * 2; ++i) miss16[i] = 0;
+
+    // tile 0 of the LUT -> LDS
+    {
+        const int rows2 = 2 * (int)((r_end - r_begin < TILE_ROWS) ? (r_end - r_begin) : TILE_ROWS);
+        const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * r_begin);
+        double2 *dst = reinterpret_cast<double2 *>(&s_lut[0][0]);
+        for (int i = tid; i < rows2; i += nthr) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    const int8_t *colp = db + col0;
+
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        const int64_t tr0 = r_begin + t * TILE_ROWS;
+        const int rows = (int)((r_end - tr0 < TILE_ROWS) ? (r_end - tr0) : TILE_ROWS);
+        // prefetch the next LUT tile into registers (256 double2 over nthr >= 64 threads: <= 4 each)
+        double2 pre0 = make_double2(0.0, 0.0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
+        const bool more = (t + 1 < n_tiles);
+        if (more) {
+            const int64_t nr0 = tr0 + TILE_ROWS;
+            const int nrows2 = 2 * (int)((r_end - nr0 < TILE_ROWS) ? (r_end - nr0) : TILE_ROWS);
+            const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * nr0);
+            if (tid < nrows2) pre0 = src[tid];
+            if (tid + nthr < nrows2) pre1 = src[tid + nthr];
+            if (tid + 2 * nthr < nrows2) pre2 = src[tid + 2 * nthr];
+            if (tid + 3 * nthr < nrows2) pre3 = src[tid + 3 * nthr];
+        }
+
+        if (lane_on) {
+            const uint32_t lds_base =
+                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)(&s_lut[t & 1][0]);
+            uint32_t miss8[NDW];
+#pragma unroll
+            for (int i = 0; i < NDW; ++i) miss8[i] = 0;
+
+            const int full_groups = rows / G;
+            for (int g = 0; g < full_groups; ++g) {
+                uint32_t x[G][NDW];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int64_t rr = tr0 + g * G + u;
+                    const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
+                    const load_t v = *reinterpret_cast<const load_t *>(colp + prow * pitch);
+#pragma unroll
+                    for (int k = 0; k < NDW; ++k) x[u][k] = dword_of(v, k);
+                }
+                const uint32_t group_base = lds_base + (uint32_t)(g >> 1) * 256u;   // 256-B aligned, wave-uniform
+                const uint32_t roff4 = (g & 1) ? 0x80808080u : 0u;
+                fast_row<NDW, SKIP, 0>(x[0], group_base, roff4, acc, miss8);
+                fast_row<NDW, SKIP, 1>(x[1], group_base, roff4, acc, miss8);
+                fast_row<NDW, SKIP, 2>(x[2], group_base, roff4, acc, miss8);
+                fast_row<NDW, SKIP, 3>(x[3], group_base, roff4, acc, miss8);
+            }
+            for (int r = full_groups * G; r < rows; ++r) {          // at most G-1 rows, last tile of the last part
+                const int64_t rr = tr0 + r;
+                const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
+                const load_t v = *reinterpret_cast<const load_t *>(colp + prow * pitch);
+                uint32_t x[NDW];
+#pragma unroll
+                for (int k = 0; k < NDW; ++k) x[k] = dword_of(v, k);
+                const uint32_t group_base = lds_base + (uint32_t)(r >> 3) * 256u;
+                const uint32_t roff4 = (uint32_t)(r & 7) * 0x20202020u;            // (r & 7) * 32 in every byte
+                fast_row<NDW, SKIP, 0>(x, group_base, roff4, acc, miss8);
+            }
+            // flush packed u8 counters (<= TILE_ROWS <= 255 per byte) into packed u16 pairs
+#pragma unroll
+            for (int k = 0; k < NDW; ++k) {
+                miss16[2 * k + 0] += miss8[k] & 0x00ff00ffu;          // bytes 0 and 2
+                miss16[2 * k + 1] += (miss8[k] >> 8) & 0x00ff00ffu;   // bytes 1 and 3
+            }
+        }
+
+        if (more) {
+            double2 *dst = reinterpret_cast<double2 *>(&s_lut[(t + 1) & 1][0]);
+            if (tid < TILE_ROWS * 2) dst[tid] = pre0;
+            if (tid + nthr < TILE_ROWS * 2) dst[tid + nthr] = pre1;
+            if (tid + 2 * nthr < TILE_ROWS * 2) dst[tid + 2 * nthr] = pre2;
+            if (tid + 3 * nthr < TILE_ROWS * 2) dst[tid + 3 * nthr] = pre3;
+        }
+        __syncthreads();
+    }
+
+    if (lane_on) {
+        double *os = out_score + p * ld + col0;
+        uint32_t *om = out_miss + p * ld + col0;
+#pragma unroll
+        for (int i = 0; i < BPL; i += 2) *reinterpret_cast<double2 *>(os + i) = make_double2(acc[i], acc[i + 1]);
+#pragma unroll
+        for (int k = 0; k < NDW; ++k) {
+            uint4 m;
+            m.x = miss16[2 * k + 0] & 0xffffu;
+            m.y = miss16[2 * k + 1] & 0xffffu;
+            m.z = miss16[2 * k + 0] >> 16;
+            m.w = miss16[2 * k + 1] >> 16;
+            *reinterpret_cast<uint4 *>(om + 4 * k) = m;
+        }
+    }
+}
+
+// Ordered sum of the per-part partials: score[a] = ((p0 + p1) + p2) + ..., ninfo[a] = n - sum(miss).
+__global__ void k_reduce(const double *__restrict__ part_score, const uint32_t *__restrict__ part_miss,
+                         int64_t n_parts, int64_t ld, int64_t n_acc, int64_t n_rows, double *__restrict__ score,
+                         int64_t *__restrict__ ninfo)
+{
+    int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_acc) return;
+    double s = 0.0;
+    int64_t m = 0;
+    for (int64_t p = 0; p < n_parts; ++p) {
+        s = s + part_score[p * ld + a];
+        m += part_miss[p * ld + a];
+    }
+    score[a] = s;
+    ninfo[a] = n_rows - m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Strict (reference-order) segment sums.
+//   grid.x = segment, grid.y = column blocks of blockDim.x lanes
+//   cols: optional list of accession indices (NULL = dense 0..ncols-1)
+//   out_score [n_seg, ld] fp64 = ((0 + A_ref) + A_het) + A_alt, out_miss [n_seg, ld] u32
+template <bool SKIP, bool GATHER>
+__global__ void __launch_bounds__(256)
+k_strict(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
+         const double *__restrict__ w, const int64_t *__restrict__ seg_off, const int32_t *__restrict__ cols,
+         int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
+{
+    const int64_t seg = blockIdx.x;
+    const int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
+    if (i >= ncols) return;
+    const int64_t col = cols ? (int64_t)cols[i] : i;
+    const int64_t r0 = seg_off[seg], r1 = seg_off[seg + 1];
+    const int8_t *colp = db + col;
+    double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
+    uint32_t miss = 0;
+    int64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        int b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t prow = GATHER ? row_idx[r + u] : (row0 + r + u);
+            b[u] = colp[prow * pitch];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double w0 = w[3 * (r + u) + 0], w1 = w[3 * (r + u) + 1], w2 = w[3 * (r + u) + 2];
+            a_ref = a_ref + (b[u] == 0 ? w0 : 0.0);
+            if (!SKIP) a_het = a_het + (b[u] == 2 ? w1 : 0.0);
+            a_alt = a_alt + (b[u] == 1 ? w2 : 0.0);
+            miss += SKIP ? (b[u] < 0 || b[u] == 2) : (b[u] < 0);
+        }
+    }
+    for (; r < r1; ++r) {
+        const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
+        const int b = colp[prow * pitch];
+        const double w0 = w[3 * r + 0], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
+        a_ref = a_ref + (b == 0 ? w0 : 0.0);
+        if (!SKIP) a_het = a_het + (b == 2 ? w1 : 0.0);
+        a_alt = a_alt + (b == 1 ? w2 : 0.0);
+        miss += SKIP ? (b < 0 || b == 2) : (b < 0);
+    }
+    out_score[seg * ld + i] = ((0.0 + a_ref) + a_het) + a_alt;
+    out_miss[seg * ld + i] = miss;
+}
+
+// total[i] = (((0 + s0) + s1) + ...) over non-empty segments; ninfo[i] = n_rows - sum(miss)
+__global__ void k_scan(const double *__restrict__ seg_score, const uint32_t *__restrict__ seg_miss,
+                       const int64_t *__restrict__ seg_off, int64_t n_seg, int64_t ld, int64_t ncols,
+                       double *__restrict__ tot_score, int64_t *__restrict__ tot_ninfo)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncols) return;
+    double s = 0.0;
+    int64_t m = 0;
+    for (int64_t k = 0; k < n_seg; ++k) {
+        s = s + seg_score[k * ld + i];
+        m += seg_miss[k * ld + i];
+    }
+    tot_score[i] = s;
+    if (tot_ninfo) tot_ninfo[i] = (seg_off[n_seg] - seg_off[0]) - m;
+}
+
+// per-segment ninfo [n_seg, n_acc] i64 and score copy-out into a dense [n_seg, n_acc] host-shaped layout
+__global__ void k_seg_pack(const double *__restrict__ seg_score, const uint32_t *__restrict__ seg_miss,
+                           const int64_t *__restrict__ seg_off, int64_t n_seg, int64_t ld, int64_t n_acc,
+                           double *__restrict__ score, int64_t *__restrict__ ninfo)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t k = blockIdx.y;
+    if (i >= n_acc || k >= n_seg) return;
+    int64_t len = seg_off[k + 1] - seg_off[k];
+    score[k * n_acc + i] = seg_score[k * ld + i];
+    ninfo[k * n_acc + i] = len - (int64_t)seg_miss[k * ld + i];
+}
+
+// score[cols[i]] = strict_total[i]
+__global__ void k_patch(const double *__restrict__ strict_total, const int32_t *__restrict__ cols, int64_t ncols,
+                        double *__restrict__ score)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ncols) score[cols[i]] = strict_total[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// likeliTest (core/snpmatch.py:40-55) row-wise, nanmin per row, ratio (core/snpmatch.py:106-117).
+// grid.x = row; one block per row.  flags[0] |= 1 when some y > n (the reference asserts).
+__device__ __forceinline__ double likeli_one(double y, double n, int *bad)
+{
+    const double p = 0.99999999;
+    if (y > n) { *bad = 1; return __builtin_nan(""); }
+    if (n == 0.0) return __builtin_nan("");
+    if (y == n) return 1.0;
+    if (y > 0.0) {
+        const double ps = y / n;
+        const double a = y * log(ps / p);
+        const double b = (n - y) * log((1.0 - ps) / (1.0 - p));
+        return a + b;
+    }
+    return __builtin_nan("");
+}
+
+__global__ void __launch_bounds__(1024)
+k_likelihood(const double *__restrict__ y, const int64_t *__restrict__ n, int64_t len, int truncate,
+             double amin_or_nan, double *__restrict__ lik, double *__restrict__ lrt, int *__restrict__ flags)
+{
+    __shared__ double s_min[16];
+    __shared__ double s_top;
+    const int64_t row = blockIdx.x;
+    const double *yr = y + row * len;
+    const int64_t *nr = n + row * len;
+    double *lr = lik + row * len;
+    double *rr = lrt + row * len;
+    double mn = __builtin_inf();
+    int bad = 0;
+    for (int64_t i = threadIdx.x; i < len; i += blockDim.x) {
+        double yy = yr[i];
+        if (truncate) yy = trunc(yy);
+        const double l = likeli_one(yy, (double)nr[i], &bad);
+        lr[i] = l;
+        if (l == l && l < mn) mn = l;
+    }
+    if (bad) atomicOr(flags, 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        double other = __shfl_xor(mn, o);
+        mn = other < mn ? other : mn;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_min[wave] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = __builtin_inf();
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int k = 0; k < nw; ++k) m = s_min[k] < m ? s_min[k] : m;
+        if (m == __builtin_inf()) m = __builtin_nan("");      // all-NaN row: np.nanmin -> nan
+        if (amin_or_nan == amin_or_nan) m = amin_or_nan;
+        s_top = m;
+    }
+    __syncthreads();
+    const double top = s_top;
+    for (int64_t i = threadIdx.x; i < len; i += blockDim.x) {
+        // get_fraction(x, y): nan when y <= 0 (core/snpmatch.py:25-28); y = nan falls through to x / nan
+        rr[i] = (top <= 0.0) ? __builtin_nan("") : lr[i] / top;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// canonicalise uploaded bytes in place: negative -> 0xFF, > 2 -> 3 (16 bytes per thread)
+__device__ __forceinline__ uint32_t canon_dword(uint32_t x)
+{
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int b = (int8_t)((x >> (8 * j)) & 0xff);
+        uint32_t c = b < 0 ? 0xffu : (b > 2 ? 3u : (uint32_t)b);
+        out |= c << (8 * j);
+    }
+    return out;
+}
+
+__global__ void k_canon(uint4 *__restrict__ p, int64_t n16)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n16; i += stride) {
+        uint4 v = p[i];
+        v.x = canon_dword(v.x);
+        v.y = canon_dword(v.y);
+        v.z = canon_dword(v.z);
+        v.w = canon_dword(v.w);
+        p[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic panel fill: counter-based, element (snp, acc) depends only on (seed, snp, acc).
+// One splitmix64 hash per 4 adjacent accessions (16 random bits each).
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__host__ __device__ __forceinline__ uint32_t synth_quad(uint64_t seed, uint64_t snp, uint64_t acc_quad)
+{
+    // thresholds on 16-bit uniforms: P(-1)=3277/65536, P(0)=39321/65536, P(1)=21627/65536, P(2)=1311/65536
+    const uint64_t h = splitmix64(splitmix64(seed ^ (snp * 0xD6E8FEB86659FD93ull)) + acc_quad);
+    uint32_t out = 0;
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t u = (uint32_t)(h >> (16 * j)) & 0xffffu;
+        const uint32_t c = u < 3277u ? 0xffu : (u < 42598u ? 0u : (u < 64225u ? 1u : 2u));
+        out |= c << (8 * j);
+    }
+    return out;
+}
+
+__global__ void k_synth(uint32_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n_acc, uint64_t seed,
+                        int64_t snp0, int64_t acc0)
+{
+    // acc0 must be a multiple of 4 so that a shard sees the same quads as the full panel
+    const int64_t quads_per_row = pitch / 4;
+    const int64_t total = n_snp * quads_per_row;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int64_t row = i / quads_per_row;
+        const int64_t q = i - row * quads_per_row;
+        uint32_t v = synth_quad(seed, (uint64_t)(snp0 + row), (uint64_t)((acc0 >> 2) + q));
+        const int64_t c = q * 4;
+        if (c + 4 > n_acc) {       // pad bytes are "missing"
+            for (int j = 0; j < 4; ++j)
+                if (c + j >= n_acc) v |= 0xffu << (8 * j);
+        }
+        db[i] = v;
+    }
+}
+
+}  // namespace snpm

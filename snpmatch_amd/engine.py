@@ -1,0 +1,249 @@
+"""
+Thin object layer over the C ABI: Context (one GPU), Panel (DB genotype matrix resident in HBM),
+Query (one sample's matched SNPs resident in HBM).  All compute happens in libsnpmatch_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MODE_EXACT, MODE_FAST, MODE_STRICT, check, ptr  # noqa: F401
+
+_default_ctx = None
+
+
+class Context(object):
+    def __init__(self, device_id=0):
+        lib = _lib.load()
+        h = C.c_void_p()
+        rc = lib.snpm_init(int(device_id), C.byref(h))
+        check(rc, None)
+        self.lib = lib
+        self.h = h
+        self.device_id = int(device_id)
+
+    def close(self):
+        if self.h:
+            self.lib.snpm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        check(self.lib.snpm_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None), self.h)
+
+    def synchronize(self):
+        check(self.lib.snpm_synchronize(self.h), self.h)
+
+    # ---- profiling (HIP events on the stream the kernels run on)
+    def profile(self, on=True):
+        check(self.lib.snpm_profile_enable(self.h, 1 if on else 0), self.h)
+
+    def profile_reset(self):
+        check(self.lib.snpm_profile_reset(self.h), self.h)
+
+    def profile_read(self, kernel):
+        n = C.c_int64(0)
+        ms = C.c_double(0)
+        check(self.lib.snpm_profile_read(self.h, kernel.encode(), C.byref(n), C.byref(ms)), self.h)
+        return n.value, ms.value
+
+    # ---- one-shot forms
+    def score_dense(self, wei, db, skip_hets=False):
+        """matchGTsAccs on host arrays (fp64 bit-exact with the reference)."""
+        db = np.asarray(db)
+        wei = np.asarray(wei)
+        assert wei.shape[0] == db.shape[0], "please provide same number of positions for both sample and db"
+        assert wei.ndim == 2 and wei.shape[1] == 3, "SNP weights should be a np.array with  shape == n,3"
+        db = np.ascontiguousarray(db, dtype=np.int8)
+        wei = np.ascontiguousarray(wei, dtype=np.float64)
+        n, n_acc = db.shape
+        score = np.zeros(n_acc, dtype=np.float64)
+        ninfo = np.zeros(n_acc, dtype=np.int64)
+        if n_acc == 0:
+            return score, ninfo
+        check(self.lib.snpm_score_dense_host(self.h, ptr(db), n_acc, n, n_acc, ptr(wei), int(bool(skip_hets)),
+                                             ptr(score), ptr(ninfo)), self.h)
+        return score, ninfo
+
+    def likelihood_device(self, d_y, d_n, m, length, d_lik, d_lrt, truncate=False, amin=None, check_domain=False):
+        """likeliTest rows on device pointers (no host round trip unless check_domain)."""
+        a = float("nan") if amin is None else float(amin)
+        dom = C.c_int(0)
+        check(self.lib.snpm_likelihood_device(self.h, C.c_void_p(d_y), C.c_void_p(d_n), int(m), int(length),
+                                              int(bool(truncate)), a, C.c_void_p(d_lik), C.c_void_p(d_lrt),
+                                              C.byref(dom) if check_domain else None), self.h)
+        if check_domain and dom.value:
+            raise AssertionError("provided y is greater than n")
+
+    def likelihood(self, y, n, truncate=False, amin=None):
+        """Rows of (matches y, informative n) -> (likelihood, ratio to the row minimum)."""
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        n = np.ascontiguousarray(n, dtype=np.int64)
+        assert y.shape == n.shape
+        shape = y.shape
+        if y.ndim == 1:
+            m, ln = 1, y.shape[0]
+        else:
+            m, ln = y.shape
+        lik = np.empty(shape, dtype=np.float64)
+        lrt = np.empty(shape, dtype=np.float64)
+        if y.size == 0:
+            return lik, lrt
+        a = float("nan") if amin is None else float(amin)
+        check(self.lib.snpm_likelihood(self.h, ptr(y), ptr(n), m, ln, int(bool(truncate)), a, ptr(lik), ptr(lrt)), self.h)
+        return lik, lrt
+
+    def binom_identity(self, x, n, error_rate=0.0005, pthres=0.05, return_sf=False):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        n = np.ascontiguousarray(n, dtype=np.int64)
+        out = np.empty(len(x), dtype=np.int64)
+        sf = np.empty(len(x), dtype=np.float64)
+        check(self.lib.snpm_binom_identity(self.h, ptr(x), ptr(n), len(x), float(error_rate), float(pthres), ptr(out),
+                                           ptr(sf)), self.h)
+        return (out, sf) if return_sf else out
+
+
+def default_context():
+    """Process-wide context on the device named by SNPMATCH_DEVICE / LOCAL_RANK (default 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        import os
+        dev = int(os.environ.get("SNPMATCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _default_ctx = Context(dev)
+    return _default_ctx
+
+
+class Panel(object):
+    """int8 [n_snp, n_acc] genotype matrix in HBM (SNP-major, row pitch padded to 256 B)."""
+
+    def __init__(self, ctx, n_snp, n_acc):
+        self.ctx = ctx
+        self.n_snp = int(n_snp)
+        self.n_acc = int(n_acc)
+        h = C.c_void_p()
+        check(ctx.lib.snpm_panel_create(ctx.h, self.n_snp, self.n_acc, C.byref(h)), ctx.h)
+        self.h = h
+        pitch = C.c_int64(0)
+        dptr = C.c_void_p()
+        check(ctx.lib.snpm_panel_info(h, None, None, C.byref(pitch), C.byref(dptr)), ctx.h)
+        self.pitch = pitch.value
+        self.device_ptr = dptr.value
+
+    @classmethod
+    def from_host(cls, ctx, snps, slab_rows=1 << 16):
+        """Upload an array-like [n_snp, n_acc] (numpy array, memmap or h5py dataset) slab by slab."""
+        n_snp, n_acc = snps.shape
+        p = cls(ctx, n_snp, n_acc)
+        for r0 in range(0, n_snp, slab_rows):
+            slab = np.ascontiguousarray(snps[r0:r0 + slab_rows], dtype=np.int8)
+            p.upload_rows(r0, slab)
+            p.upload_wait()          # `slab` is repacked into pinned memory before the call returns,
+        return p                     # the wait only bounds the number of slabs in flight
+
+    def upload_rows(self, row0, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int8)
+        assert rows.ndim == 2 and rows.shape[1] == self.n_acc
+        check(self.ctx.lib.snpm_panel_upload_rows(self.h, int(row0), rows.shape[0], ptr(rows), rows.shape[1]), self.ctx.h)
+
+    def upload_wait(self):
+        check(self.ctx.lib.snpm_panel_upload_wait(self.h), self.ctx.h)
+
+    def download_rows(self, row0, nrows):
+        out = np.empty((int(nrows), self.n_acc), dtype=np.int8)
+        check(self.ctx.lib.snpm_panel_download_rows(self.h, int(row0), int(nrows), ptr(out), self.n_acc), self.ctx.h)
+        return out
+
+    def fill_synthetic(self, seed, snp0=0, acc0=0):
+        check(self.ctx.lib.snpm_panel_fill_synthetic(self.h, C.c_uint64(int(seed)), int(snp0), int(acc0)), self.ctx.h)
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.snpm_panel_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Query(object):
+    """A sample's matched SNPs (panel rows + weights) resident on the device."""
+
+    def __init__(self, panel, row_idx, wei, row0=0):
+        self.panel = panel
+        ctx = panel.ctx
+        wei = np.asarray(wei)
+        assert wei.ndim == 2 and wei.shape[1] == 3, "SNP weights should be a np.array with  shape == n,3"
+        wei = np.ascontiguousarray(wei, dtype=np.float64)
+        n = wei.shape[0]
+        if row_idx is not None:
+            row_idx = np.ascontiguousarray(row_idx, dtype=np.int64)
+            assert row_idx.shape == (n,), "please provide same number of positions for both sample and db"
+        self.n = n
+        h = C.c_void_p()
+        check(ctx.lib.snpm_query_create(panel.h, ptr(row_idx), int(row0), n, ptr(wei), C.byref(h)), ctx.h)
+        self.h = h
+
+    def run(self, chunk=1000, skip_hets=False, mode=MODE_EXACT, return_info=False):
+        """Genotyper.genotyper accumulators: (ScoreList float64 [n_acc], NumInfoSites int64 [n_acc])."""
+        ctx = self.panel.ctx
+        score = np.empty(self.panel.n_acc, dtype=np.float64)
+        ninfo = np.empty(self.panel.n_acc, dtype=np.int64)
+        info = np.zeros(4, dtype=np.int64)
+        check(ctx.lib.snpm_query_run(self.h, int(chunk), int(bool(skip_hets)), int(mode), ptr(score), ptr(ninfo), ptr(info)),
+              ctx.h)
+        if return_info:
+            return score, ninfo, {"n_strict_reeval": int(info[0]), "all_integer_weights": bool(info[1])}
+        return score, ninfo
+
+    def run_device(self, chunk=1000, skip_hets=False, mode=MODE_EXACT):
+        """Enqueue the scoring; returns raw device pointers (d_score f64[n_acc], d_ninfo i64[n_acc])."""
+        ctx = self.panel.ctx
+        ds, dn = C.c_void_p(), C.c_void_p()
+        info = np.zeros(4, dtype=np.int64)
+        check(ctx.lib.snpm_query_run_device(self.h, int(chunk), int(bool(skip_hets)), int(mode), C.byref(ds), C.byref(dn),
+                                            ptr(info)), ctx.h)
+        return ds.value, dn.value, int(info[0])
+
+    def bind_outputs(self, d_score, d_ninfo):
+        """Write results of later runs into caller-owned device buffers (raw pointers, e.g. tensor.data_ptr())."""
+        ctx = self.panel.ctx
+        check(ctx.lib.snpm_query_bind_outputs(self.h, C.c_void_p(d_score) if d_score else None,
+                                              C.c_void_p(d_ninfo) if d_ninfo else None), ctx.h)
+
+    def error_bound(self, chunk=1000):
+        b = C.c_double(0)
+        check(self.panel.ctx.lib.snpm_query_error_bound(self.h, int(chunk), C.byref(b)), self.panel.ctx.h)
+        return b.value
+
+    def run_windows(self, win_off, skip_hets=False, totals=True):
+        """Per-window matchGTsAccs: (score [n_win,n_acc], ninfo [n_win,n_acc], tot_score, tot_ninfo)."""
+        ctx = self.panel.ctx
+        win_off = np.ascontiguousarray(win_off, dtype=np.int64)
+        n_win = len(win_off) - 1
+        na = self.panel.n_acc
+        score = np.empty((n_win, na), dtype=np.float64)
+        ninfo = np.empty((n_win, na), dtype=np.int64)
+        ts = np.empty(na, dtype=np.float64)
+        tn = np.empty(na, dtype=np.int64)
+        check(ctx.lib.snpm_query_run_windows(self.h, ptr(win_off), n_win, int(bool(skip_hets)), ptr(score), ptr(ninfo),
+                                             ptr(ts) if totals else None, ptr(tn) if totals else None), ctx.h)
+        return score, ninfo, ts, tn
+
+    def free(self):
+        if self.h:
+            self.panel.ctx.lib.snpm_query_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -1,0 +1,333 @@
+"""
+Parity tests proper (-m gpu): the HIP path, called through the C ABI (ctypes), against
+ (a) the golden vectors generated from the reference, and
+ (b) the CPU oracle on the same seeded inputs,
+bit-exact for counts / informative sites / strict-order fp64 scores, <= 1e-6 relative for
+likelihoods (tolerance from BASELINE.json north_star; we assert 1e-12).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import snpmatch_oracle as orc
+from snpmatch_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+LIK_RTOL = 1e-12      # north_star allows 1e-6
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context(0)
+    yield c
+    c.close()
+
+
+def rand_db(rng, n, n_acc):
+    return rng.choice(np.array([-1, 0, 1, 2], dtype=np.int8), size=(n, n_acc), p=[0.05, 0.60, 0.33, 0.02])
+
+
+def rand_wei(rng, n, frac_pl=0.8):
+    codes = rng.choice(np.array([0, 1, 2], dtype=np.int8), size=n, p=[0.6, 0.35, 0.05])
+    return synth.sample_weights(rng, codes, frac_pl)
+
+
+# ------------------------------------------------------------------ matchGTsAccs (a1)
+def test_match_golden_bitexact(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g1_match.npz"))
+    for name in g["names"]:
+        skip = name.endswith("_1")
+        s, n = ctx.score_dense(g[name + "_wei"], g[name + "_db"], skip)
+        assert np.array_equal(bits(s), bits(g[name + "_score"])), name
+        assert np.array_equal(n, g[name + "_ninfo"]), name
+
+
+def test_match_asserts_like_reference(ctx):
+    with pytest.raises(AssertionError, match="same number of positions"):
+        ctx.score_dense(np.ones((3, 3)), np.zeros((4, 2), dtype=np.int8))
+    with pytest.raises(AssertionError, match="shape == n,3"):
+        ctx.score_dense(np.ones((4, 2)), np.zeros((4, 2), dtype=np.int8))
+
+
+def test_match_does_not_modify_inputs(ctx):
+    rng = np.random.default_rng(3)
+    db = rand_db(rng, 100, 33)
+    wei = rand_wei(rng, 100)
+    db0, wei0 = db.copy(), wei.copy()
+    ctx.score_dense(wei, db, True)
+    assert np.array_equal(db, db0) and np.array_equal(wei, wei0)
+
+
+# ------------------------------------------------------------------ Genotyper chunk loop (a2)
+CASES = [
+    # n_snp_panel, n_acc, n_matched (None = dense all rows), chunk
+    (4000, 1, 1000, 1000),
+    (4000, 3, 2500, 1000),
+    (6000, 64, 3001, 1000),
+    (20000, 257, 5000, 1000),
+    (20000, 1135, 7545, 1000),
+    (3000, 1250, None, 1000),
+    (1500, 4097, None, 500),
+    (2100, 10000, None, 1000),
+    (130, 17, 129, 7),
+]
+
+
+@pytest.mark.parametrize("n_snp,n_acc,n_match,chunk", CASES)
+@pytest.mark.parametrize("skip", [False, True])
+def test_query_modes_vs_oracle(ctx, n_snp, n_acc, n_match, chunk, skip):
+    rng = np.random.default_rng(n_snp * 31 + n_acc)
+    db = rand_db(rng, n_snp, n_acc)
+    if n_acc > 5:
+        db[:, 2] = -1                      # an accession with no informative site at all
+        db[:, 3] = 3                       # out-of-range codes: informative, never matching
+    panel = engine.Panel.from_host(ctx, db)
+    if n_match is None:
+        row_idx, n = None, n_snp
+    else:
+        row_idx = np.sort(rng.choice(n_snp, size=n_match, replace=False)).astype(np.int64)
+        n = n_match
+    wei = rand_wei(rng, n)
+    want_s, want_n = c_oracle.genotyper(db, row_idx, wei, chunk, skip)
+    q = engine.Query(panel, row_idx, wei)
+    bound = q.error_bound(chunk)
+    assert 0 < bound < 1e-6
+    # strict: the reference's fp64 bits
+    s, ni = q.run(chunk, skip, engine.MODE_STRICT)
+    assert np.array_equal(bits(s), bits(want_s))
+    assert np.array_equal(ni, want_n)
+    # exact (default): counts bit-exact, fp64 within the certified bound
+    s, ni, info = q.run(chunk, skip, engine.MODE_EXACT, return_info=True)
+    assert np.array_equal(ni, want_n)
+    assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int))
+    assert np.max(np.abs(s - want_s)) <= bound
+    # fast pass alone stays inside the bound too
+    s, ni = q.run(chunk, skip, engine.MODE_FAST)
+    assert np.array_equal(ni, want_n)
+    assert np.max(np.abs(s - want_s)) <= bound
+    q.free()
+    panel.free()
+
+
+def test_hard_weights_are_exact_in_every_mode(ctx):
+    """0/1 weights (BED input, VCF without PL): every order is exact -> all modes bit-identical."""
+    rng = np.random.default_rng(77)
+    db = rand_db(rng, 9000, 300)
+    wei = rand_wei(rng, 9000, frac_pl=0.0)
+    want_s, want_n = c_oracle.genotyper(db, None, wei, 1000, False)
+    panel = engine.Panel.from_host(ctx, db)
+    q = engine.Query(panel, None, wei)
+    assert q.error_bound(1000) == 0.0
+    for mode in (engine.MODE_EXACT, engine.MODE_STRICT, engine.MODE_FAST):
+        s, ni, info = q.run(1000, False, mode, return_info=True)
+        assert np.array_equal(bits(s), bits(want_s)) and np.array_equal(ni, want_n)
+        assert info["n_strict_reeval"] == 0
+
+
+def test_exact_mode_reevaluates_boundary_cases(ctx):
+    """Scores that sit on an integer boundary must be re-evaluated in strict order: a perfect-match
+    accession under PL weights sums exact 1.0s, an integer the fast pass cannot certify."""
+    rng = np.random.default_rng(5)
+    n, n_acc = 5000, 40
+    db = rand_db(rng, n, n_acc)
+    codes = db[:, 7].copy()
+    codes[codes < 0] = 0
+    wei = synth.sample_weights(rng, codes, frac_pl=1.0)
+    want_s, want_n = c_oracle.genotyper(db, None, wei, 1000, False)
+    panel = engine.Panel.from_host(ctx, db)
+    q = engine.Query(panel, None, wei)
+    s, ni, info = q.run(1000, False, engine.MODE_EXACT, return_info=True)
+    assert info["n_strict_reeval"] >= 1
+    assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int))
+    assert bits(s)[7] == bits(want_s)[7]
+
+
+def test_golden_inbred_accumulators(ctx, golden_dir):
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    g = np.load(os.path.join(golden_dir, "g2_inbred.npz"))
+    panel = engine.Panel.from_host(ctx, toy["snps"])
+    q = engine.Query(panel, g["common_db"], toy["s_wei"][g["common_sample"]])
+    for skip in (0, 1):
+        s, ni = q.run(1000, bool(skip), engine.MODE_STRICT)
+        assert np.array_equal(bits(s), bits(g["score_skip%d" % skip]))
+        assert np.array_equal(ni, g["ninfo_skip%d" % skip])
+        s, ni = q.run(1000, bool(skip), engine.MODE_EXACT)
+        assert np.array_equal(np.array(s, dtype=int), np.array(g["score_skip%d" % skip], dtype=int))
+        assert np.array_equal(ni, g["ninfo_skip%d" % skip])
+
+
+def test_empty_and_ragged(ctx):
+    rng = np.random.default_rng(9)
+    db = rand_db(rng, 50, 5)
+    panel = engine.Panel.from_host(ctx, db)
+    q = engine.Query(panel, np.zeros(0, dtype=np.int64), np.zeros((0, 3)))
+    for mode in (engine.MODE_EXACT, engine.MODE_STRICT, engine.MODE_FAST):
+        s, ni = q.run(1000, False, mode)
+        assert np.array_equal(s, np.zeros(5)) and np.array_equal(ni, np.zeros(5, dtype=np.int64))
+    with pytest.raises(AssertionError):
+        engine.Query(panel, np.array([50], dtype=np.int64), np.ones((1, 3)))       # row outside the panel
+    with pytest.raises(AssertionError, match="shape == n,3"):
+        engine.Query(panel, np.array([1], dtype=np.int64), np.ones((1, 2)))
+    # repeated rows are allowed (the reference would gather them twice as well)
+    idx = np.array([3, 3, 4, 10, 10, 10], dtype=np.int64)
+    wei = rand_wei(rng, 6)
+    want_s, want_n = c_oracle.genotyper(db, idx, wei, 1000, False)
+    s, ni = engine.Query(panel, idx, wei).run(1000, False, engine.MODE_STRICT)
+    assert np.array_equal(bits(s), bits(want_s)) and np.array_equal(ni, want_n)
+
+
+# ------------------------------------------------------------------ windows (a7)
+def test_windows_golden(ctx, golden_dir):
+    toy = np.load(os.path.join(golden_dir, "toy_db_cross.npz"))
+    g = np.load(os.path.join(golden_dir, "g5_cross.npz"))
+    panel = engine.Panel.from_host(ctx, toy["snps"])
+    for skip in (0, 1):
+        rows_db = g["win_rows_db_skip%d" % skip]
+        wei = toy["s_wei"][g["win_rows_sample_skip%d" % skip]]
+        off = g["win_off_skip%d" % skip]
+        q = engine.Query(panel, rows_db, wei)
+        s, ni, ts, tn = q.run_windows(off, bool(skip))
+        assert np.array_equal(bits(s), bits(g["win_score_skip%d" % skip]))
+        assert np.array_equal(ni, g["win_ninfo_skip%d" % skip])
+        _, _, ots, otn = c_oracle.windows(toy["snps"], rows_db, wei, off, bool(skip))
+        assert np.array_equal(bits(ts), bits(ots)) and np.array_equal(tn, otn)
+
+
+def test_windows_random_vs_oracle(ctx):
+    rng = np.random.default_rng(21)
+    db = rand_db(rng, 30000, 1135)
+    panel = engine.Panel.from_host(ctx, db)
+    rows = np.sort(rng.choice(30000, size=12000, replace=False)).astype(np.int64)
+    wei = rand_wei(rng, 12000)
+    cuts = np.sort(rng.choice(12001, size=398, replace=True))
+    off = np.concatenate([[0], cuts, [12000]]).astype(np.int64)        # includes empty windows
+    want = c_oracle.windows(db, rows, wei, off, False)
+    got = engine.Query(panel, rows, wei).run_windows(off, False)
+    assert np.array_equal(bits(got[0]), bits(want[0])) and np.array_equal(got[1], want[1])
+    assert np.array_equal(bits(got[2]), bits(want[2])) and np.array_equal(got[3], want[3])
+
+
+# ------------------------------------------------------------------ likelihood (a3/a4) and identity (a8)
+def test_likelihood_golden(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_likelihood.npz"))
+    # pointwise: one row per point so that the ratio column is irrelevant
+    lik, _ = ctx.likelihood(g["y"].reshape(-1, 1), g["n"].reshape(-1, 1))
+    lik = lik.ravel()
+    assert np.array_equal(np.isnan(lik), np.isnan(g["lik"]))
+    ok = ~np.isnan(lik)
+    np.testing.assert_allclose(lik[ok], g["lik"][ok], rtol=LIK_RTOL, atol=0)
+    assert lik[(g["n"] == 10) & (g["y"] == 3)][0] == pytest.approx(122.8361221819443, rel=LIK_RTOL)
+    for s, n, l, r, amin in (("sc_i", "ni_i", "l_i", "r_i", None), ("sc_f", "ni_f", "l_f", "r_f", None),
+                             ("sc_i", "ni_i", "l_a", "r_a", 517.0)):
+        lik, lrt = ctx.likelihood(g[s], g[n], amin=amin)
+        np.testing.assert_allclose(lik, g[l], rtol=LIK_RTOL, equal_nan=True)
+        np.testing.assert_allclose(lrt, g[r], rtol=LIK_RTOL, equal_nan=True)
+
+
+def test_likelihood_truncates_and_asserts(ctx):
+    lik, lrt = ctx.likelihood(np.array([4946.9, 4861.2]), np.array([4987, 5194]), truncate=True)
+    assert lik[0] == pytest.approx(orc.likeli_test(4987, 4946), rel=LIK_RTOL)
+    assert lrt[1] == pytest.approx(orc.likeli_test(5194, 4861) / orc.likeli_test(4987, 4946), rel=LIK_RTOL)
+    with pytest.raises(AssertionError, match="greater than n"):
+        ctx.likelihood(np.array([11.0]), np.array([10]))
+    lik, lrt = ctx.likelihood(np.array([0.0, 0.0]), np.array([5, 0]))      # all-NaN row
+    assert np.isnan(lik).all() and np.isnan(lrt).all()
+
+
+def test_identity_golden(ctx, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5_cross.npz"))
+    out, sf = ctx.binom_identity(g["ident_x"], g["ident_n"], 0.02, return_sf=True)
+    np.testing.assert_allclose(sf, g["ident_sf"], rtol=1e-9, atol=1e-300)
+    assert np.array_equal(out, g["ident_out"])
+    out, sf = ctx.binom_identity(g["ident_xfrac"], g["ident_n"], 0.02, return_sf=True)
+    np.testing.assert_allclose(sf, g["ident_sf_frac"], rtol=1e-9, atol=1e-300)
+    assert np.array_equal(out, g["ident_out_frac"])
+
+
+# ------------------------------------------------------------------ panel plumbing
+def test_synthetic_fill_matches_numpy_twin(ctx):
+    panel = engine.Panel(ctx, 777, 1135)
+    panel.fill_synthetic(1001, snp0=5000, acc0=8)
+    got = panel.download_rows(0, 777)
+    want = synth.panel_values(1001, 5000, 777, 8, 1135)
+    assert np.array_equal(got, want)
+
+
+def test_upload_roundtrip_and_canonical_codes(ctx):
+    rng = np.random.default_rng(4)
+    db = rng.integers(-128, 128, size=(300, 77)).astype(np.int8)
+    panel = engine.Panel.from_host(ctx, db)
+    back = panel.download_rows(0, 300)
+    want = np.where(db < 0, -1, np.where(db > 2, 3, db)).astype(np.int8)
+    assert np.array_equal(back, want)
+    wei = rand_wei(rng, 300)
+    s, ni = engine.Query(panel, None, wei).run(1000, False, engine.MODE_STRICT)
+    ws, wn = c_oracle.genotyper(db, None, wei, 1000, False)
+    assert np.array_equal(bits(s), bits(ws)) and np.array_equal(ni, wn)
+
+
+# ------------------------------------------------------------------ size-independent properties at scale
+def test_large_panel_properties(ctx):
+    """10k accessions x 1M SNPs (10 GB) generated on the device: every informative element matches
+    exactly one category under all-ones weights (score == ninfo), ninfo agrees with the numpy twin on
+    sampled columns, a planted sample matches its accession perfectly, and the score is additive over
+    row ranges for integer weights."""
+    n_snp, n_acc = 1_000_000, 10_000
+    panel = engine.Panel(ctx, n_snp, n_acc)
+    panel.fill_synthetic(10050)
+    ones = np.ones((n_snp, 3))
+    q = engine.Query(panel, None, ones)
+    s, ni, info = q.run(1000, False, engine.MODE_EXACT, return_info=True)
+    assert info["all_integer_weights"] and info["n_strict_reeval"] == 0
+    assert np.array_equal(s, ni.astype(np.float64))
+    cols = [0, 1, 4999, 9996]                       # whole quads around these columns from the twin
+    for c in cols:
+        c4 = (c // 4) * 4
+        tw = synth.panel_values(10050, 0, n_snp, c4, 4)
+        assert np.array_equal(ni[c4:c4 + 4], n_snp - (tw < 0).sum(axis=0))
+    s_skip, ni_skip = q.run(1000, True, engine.MODE_EXACT)
+    tw = synth.panel_values(10050, 0, n_snp, 416, 4)
+    assert np.array_equal(ni_skip[416:420], n_snp - ((tw < 0) | (tw == 2)).sum(axis=0))
+    q.free()
+    # planted accession 417, hard weights: perfect match, nobody else above it
+    col = tw[:, 1].copy()
+    codes = col.copy()
+    codes[codes < 0] = 0
+    wei = orc.weights_from_gt_codes(codes)
+    q = engine.Query(panel, None, wei)
+    s, ni = q.run(1000, False, engine.MODE_EXACT)
+    assert s[417] == ni[417] and np.argmax(s / np.maximum(ni, 1)) == 417
+    # additivity over row ranges (integer weights: exact)
+    h = n_snp // 2 + 77
+    s1, n1 = engine.Query(panel, None, wei[:h], row0=0).run(1000, False, engine.MODE_EXACT)
+    s2, n2 = engine.Query(panel, None, wei[h:], row0=h).run(1000, False, engine.MODE_EXACT)
+    assert np.array_equal(s1 + s2, s) and np.array_equal(n1 + n2, ni)
+
+
+def test_medium_dense_vs_oracle_counts(ctx):
+    """100k SNPs x 10k accessions against the C oracle: counts bit-exact in the default mode."""
+    n_snp, n_acc = 100_000, 10_000
+    panel = engine.Panel(ctx, n_snp, n_acc)
+    panel.fill_synthetic(424242)
+    db = panel.download_rows(0, n_snp)
+    assert np.array_equal(db[:1000], synth.panel_values(424242, 0, 1000, 0, n_acc))
+    rng = np.random.default_rng(8)
+    codes, wei = synth.planted_sample(rng, db[:, 4321], err=0.02)
+    want_s, want_n = c_oracle.genotyper(db, None, wei, 1000, False)
+    q = engine.Query(panel, None, wei)
+    s, ni, info = q.run(1000, False, engine.MODE_EXACT, return_info=True)
+    assert np.array_equal(ni, want_n)
+    assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int))
+    assert np.max(np.abs(s - want_s)) <= q.error_bound(1000)
+    lik, lrt = ctx.likelihood(s, ni, truncate=True)
+    wl, wr = orc.calculate_likelihoods(np.array(want_s, dtype=int), want_n)
+    np.testing.assert_allclose(lik, wl, rtol=LIK_RTOL, equal_nan=True)
+    np.testing.assert_allclose(lrt, wr, rtol=LIK_RTOL, equal_nan=True)
+    assert np.nanargmin(lik) == 4321
