@@ -82,7 +82,7 @@ __device__ __forceinline__ void fast_row(const uint32_t (&x)[NDW], uint32_t grou
     for (int k = 0; k < NDW; ++k) {
         const uint32_t tix = ((x[k] << 3) & 0x18181818u) | roff4;   // byte j = (code & 3) * 8 + roff
         if (SKIP)
-            miss8[k] += ((x[k] >> 7) | (x[k] >> 1)) & 0x01010101u;   // negative or het
+            miss8[k] += ((x[k] >> 7) | ((x[k] >> 1) & ~x[k])) & 0x01010101u;   // negative, or het (code 2 = 0b10; 3 is not)
         else
             miss8[k] += (x[k] >> 7) & 0x01010101u;                   // negative
 #pragma unroll

@@ -3,6 +3,7 @@ Thin object layer over the C ABI: Context (one GPU), Panel (DB genotype matrix r
 Query (one sample's matched SNPs resident in HBM).  All compute happens in libsnpmatch_hip.so.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -21,9 +22,17 @@ class Context(object):
         self.lib = lib
         self.h = h
         self.device_id = int(device_id)
+        self._children = weakref.WeakSet()      # panels and queries: freed before the context
 
     def close(self):
         if self.h:
+            kids = list(self._children)
+            for k in kids:
+                if isinstance(k, Query):
+                    k.free()
+            for k in kids:
+                if isinstance(k, Panel):
+                    k.free()
             self.lib.snpm_destroy(self.h)
             self.h = None
 
@@ -115,6 +124,8 @@ def default_context():
         import os
         dev = int(os.environ.get("SNPMATCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         _default_ctx = Context(dev)
+        import atexit
+        atexit.register(_default_ctx.close)     # free device objects before the HIP runtime unloads
     return _default_ctx
 
 
@@ -133,6 +144,8 @@ class Panel(object):
         check(ctx.lib.snpm_panel_info(h, None, None, C.byref(pitch), C.byref(dptr)), ctx.h)
         self.pitch = pitch.value
         self.device_ptr = dptr.value
+        self._queries = weakref.WeakSet()
+        ctx._children.add(self)
 
     @classmethod
     def from_host(cls, ctx, snps, slab_rows=1 << 16):
@@ -163,7 +176,10 @@ class Panel(object):
 
     def free(self):
         if self.h:
-            self.ctx.lib.snpm_panel_free(self.h)
+            for q in list(self._queries):
+                q.free()
+            if self.ctx.h:
+                self.ctx.lib.snpm_panel_free(self.h)
             self.h = None
 
     def __del__(self):
@@ -190,6 +206,8 @@ class Query(object):
         h = C.c_void_p()
         check(ctx.lib.snpm_query_create(panel.h, ptr(row_idx), int(row0), n, ptr(wei), C.byref(h)), ctx.h)
         self.h = h
+        panel._queries.add(self)
+        ctx._children.add(self)
 
     def run(self, chunk=1000, skip_hets=False, mode=MODE_EXACT, return_info=False):
         """Genotyper.genotyper accumulators: (ScoreList float64 [n_acc], NumInfoSites int64 [n_acc])."""
@@ -239,7 +257,8 @@ class Query(object):
 
     def free(self):
         if self.h:
-            self.panel.ctx.lib.snpm_query_free(self.h)
+            if self.panel.ctx.h and self.panel.h:
+                self.panel.ctx.lib.snpm_query_free(self.h)
             self.h = None
 
     def __del__(self):
