@@ -56,7 +56,9 @@ struct snpm_ctx {
     std::vector<std::pair<size_t, size_t>> prof_pairs[PK_COUNT];
     // tunables (environment)
     int force_bpl = 0;
+    int force_wpb = 0;
     int parts_mult = 1;
+    int nt_loads = 0;
 };
 
 struct snpm_panel {
@@ -171,17 +173,22 @@ struct FastGeom {
     int64_t n_wc, n_colblocks, n_parts, part_rows;
 };
 
-template <int BPL, bool SKIP, bool GATHER>
+template <int BPL, bool SKIP, bool GATHER, bool NT>
 int occupancy_of(int threads)
 {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<BPL, SKIP, GATHER>, threads, 0) != hipSuccess) nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast<BPL, SKIP, GATHER, NT>, threads, 0) != hipSuccess) nb = 0;
     return nb;
 }
 
 int pick_bpl(snpm_ctx *ctx, int64_t n_acc)
 {
     if (ctx->force_bpl == 4 || ctx->force_bpl == 8 || ctx->force_bpl == 16) return ctx->force_bpl;
+    // Measured on MI355X (10k x 6.25M panel): 4 B per lane (6 waves/SIMD) streams at 5.8 TB/s, 8 B at
+    // 4.0, 16 B at 3.8 -- the kernel is latency-bound and the narrow layout keeps the most waves
+    // resident; it also has the best lane utilisation for every n_acc.
+    (void)n_acc;
+    return 4;
     const int cand[3] = {16, 8, 4};
     double util[3], best = 0;
     for (int i = 0; i < 3; ++i) {
@@ -201,7 +208,9 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     g.bpl = bpl;
     const int64_t span = (int64_t)WAVE * bpl;
     g.n_wc = std::max<int64_t>(1, (n_acc + span - 1) / span);
-    if (g.n_wc <= 8) {
+    if (ctx->force_wpb >= 1 && ctx->force_wpb <= MAX_WAVES_PER_BLOCK) {
+        g.wpb = (int)std::min<int64_t>(ctx->force_wpb, g.n_wc);
+    } else if (g.n_wc <= 8) {
         g.wpb = (int)g.n_wc;
     } else {
         int best_w = 8;
@@ -226,7 +235,7 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     return g;
 }
 
-template <int BPL, bool SKIP, bool GATHER>
+template <int BPL, bool SKIP, bool GATHER, bool NT>
 int launch_fast_t(snpm_query *q, const FastGeom &g)
 {
     snpm_ctx *ctx = q->panel->ctx;
@@ -234,26 +243,26 @@ int launch_fast_t(snpm_query *q, const FastGeom &g)
     dim3 grid((unsigned)g.n_colblocks, (unsigned)g.n_parts);
     dim3 block(WAVE * g.wpb);
     ProfScope ps(ctx, PK_FAST);
-    hipLaunchKernelGGL((k_fast<BPL, SKIP, GATHER>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0,
+    hipLaunchKernelGGL((k_fast<BPL, SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0,
                        q->n, q->d_lut, g.part_rows, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p,
                        p->pitch);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }
 
-template <int BPL>
+template <int BPL, bool NT>
 int launch_fast_b(snpm_query *q, const FastGeom &g, bool skip, bool gather)
 {
     if (skip)
-        return gather ? launch_fast_t<BPL, true, true>(q, g) : launch_fast_t<BPL, true, false>(q, g);
-    return gather ? launch_fast_t<BPL, false, true>(q, g) : launch_fast_t<BPL, false, false>(q, g);
+        return gather ? launch_fast_t<BPL, true, true, NT>(q, g) : launch_fast_t<BPL, true, false, NT>(q, g);
+    return gather ? launch_fast_t<BPL, false, true, NT>(q, g) : launch_fast_t<BPL, false, false, NT>(q, g);
 }
 
-template <int BPL>
+template <int BPL, bool NT>
 int occ_b(bool skip, bool gather, int threads)
 {
-    if (skip) return gather ? occupancy_of<BPL, true, true>(threads) : occupancy_of<BPL, true, false>(threads);
-    return gather ? occupancy_of<BPL, false, true>(threads) : occupancy_of<BPL, false, false>(threads);
+    if (skip) return gather ? occupancy_of<BPL, true, true, NT>(threads) : occupancy_of<BPL, true, false, NT>(threads);
+    return gather ? occupancy_of<BPL, false, true, NT>(threads) : occupancy_of<BPL, false, false, NT>(threads);
 }
 
 int ensure_lut(snpm_query *q, int skip)
@@ -282,9 +291,11 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
     const int bpl = pick_bpl(ctx, p->n_acc);
     FastGeom g0 = fast_geom(ctx, p->n_acc, q->n, 2, bpl);   // wpb does not depend on occupancy
     int occ = 0;
-    if (bpl == 16) occ = occ_b<16>(skip, gather, WAVE * g0.wpb);
-    else if (bpl == 8) occ = occ_b<8>(skip, gather, WAVE * g0.wpb);
-    else occ = occ_b<4>(skip, gather, WAVE * g0.wpb);
+    const bool nt = ctx->nt_loads != 0;
+    const int thr = WAVE * g0.wpb;
+    if (bpl == 16) occ = nt ? occ_b<16, true>(skip, gather, thr) : occ_b<16, false>(skip, gather, thr);
+    else if (bpl == 8) occ = nt ? occ_b<8, true>(skip, gather, thr) : occ_b<8, false>(skip, gather, thr);
+    else occ = nt ? occ_b<4, true>(skip, gather, thr) : occ_b<4, false>(skip, gather, thr);
     FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl);
     if (geom_out) *geom_out = g;
     rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_parts * p->pitch * sizeof(double));
@@ -292,9 +303,9 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
     rc = ensure(ctx, ctx->ws_part_miss, (size_t)g.n_parts * p->pitch * sizeof(uint32_t));
     if (rc) return rc;
     if (q->n > 0) {
-        if (bpl == 16) rc = launch_fast_b<16>(q, g, skip, gather);
-        else if (bpl == 8) rc = launch_fast_b<8>(q, g, skip, gather);
-        else rc = launch_fast_b<4>(q, g, skip, gather);
+        if (bpl == 16) rc = nt ? launch_fast_b<16, true>(q, g, skip, gather) : launch_fast_b<16, false>(q, g, skip, gather);
+        else if (bpl == 8) rc = nt ? launch_fast_b<8, true>(q, g, skip, gather) : launch_fast_b<8, false>(q, g, skip, gather);
+        else rc = nt ? launch_fast_b<4, true>(q, g, skip, gather) : launch_fast_b<4, false>(q, g, skip, gather);
         if (rc) return rc;
     }
     {
@@ -432,6 +443,8 @@ int snpm_init(int device_id, snpm_ctx **out)
     ctx->stream = ctx->own_stream;
     if (const char *s = getenv("SNPM_FORCE_BPL")) ctx->force_bpl = atoi(s);
     if (const char *s = getenv("SNPM_PARTS_MULT")) ctx->parts_mult = std::max(1, atoi(s));
+    if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
+    if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
     *out = ctx;
     return SNPM_OK;
 }
@@ -485,7 +498,8 @@ int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **
     p->n_snp = n_snp;
     p->n_acc = n_acc;
     p->pitch = ((n_acc + 255) / 256) * 256;
-    size_t bytes = (size_t)std::max<int64_t>(n_snp, 1) * (size_t)p->pitch;
+    // PREFETCH_PAD_ROWS extra rows: the fast pass prefetches (and never scores) a few rows past a part
+    size_t bytes = (size_t)(n_snp + PREFETCH_PAD_ROWS) * (size_t)p->pitch;
     hipError_t e = hipMalloc((void **)&p->d, bytes);
     if (e != hipSuccess) {
         delete p;
@@ -633,7 +647,7 @@ int snpm_query_create(snpm_panel *p, const int64_t *row_idx, int64_t row0, int64
     q->row0 = row_idx ? 0 : row0;
     const size_t nn = (size_t)std::max<int64_t>(n, 1);
     hipError_t e = hipSuccess;
-    if (row_idx && e == hipSuccess) e = hipMalloc((void **)&q->d_row_idx, nn * sizeof(int64_t));
+    if (row_idx && e == hipSuccess) e = hipMalloc((void **)&q->d_row_idx, (nn + PREFETCH_PAD_ROWS) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_w, nn * 3 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_lut, nn * 4 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&q->own_score, (size_t)p->pitch * sizeof(double));
@@ -647,6 +661,11 @@ int snpm_query_create(snpm_panel *p, const int64_t *row_idx, int64_t row0, int64
     if (n > 0) {
         if (row_idx)
             HIPCHK(ctx, hipMemcpyAsync(q->d_row_idx, row_idx, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (row_idx) {      // pad entries: a valid row (0), only ever prefetched
+        HIPCHK(ctx, hipMemsetAsync(q->d_row_idx + n, 0, PREFETCH_PAD_ROWS * sizeof(int64_t), ctx->stream));
+    }
+    if (n > 0) {
         HIPCHK(ctx, hipMemcpyAsync(q->d_w, wei, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     }
     q->wmax.resize((size_t)n);

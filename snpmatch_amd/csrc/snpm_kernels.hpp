@@ -28,6 +28,7 @@ constexpr int WAVE = 64;
 constexpr int TILE_ROWS = 128;          // rows per LDS LUT tile (4 KiB); also the SWAR counter flush period (<= 255)
 constexpr int LUT_ROW_BYTES = 32;       // 4 x fp64
 constexpr int MAX_WAVES_PER_BLOCK = 8;
+constexpr int PREFETCH_PAD_ROWS = 16;   // rows the fast pass may read (never score) past the last row of a part
 
 typedef __attribute__((address_space(3))) const double lds_cdouble;
 
@@ -52,18 +53,21 @@ __global__ void k_build_lut(const double *__restrict__ w, double *__restrict__ l
 //   grid.x = column blocks (each WPB waves * 64 lanes * BPL bytes), grid.y = parts
 //   part p covers matched rows [p*part_rows, min(n, (p+1)*part_rows))
 //   out_score [n_parts, ld] fp64, out_miss [n_parts, ld] u32 (ld = pitch)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 template <int BPL>
 struct LoadT;
 template <>
 struct LoadT<4> { typedef uint32_t type; };
 template <>
-struct LoadT<8> { typedef uint2 type; };
+struct LoadT<8> { typedef u32x2 type; };
 template <>
-struct LoadT<16> { typedef uint4 type; };
+struct LoadT<16> { typedef u32x4 type; };
 
 __device__ __forceinline__ uint32_t dword_of(const uint32_t &v, int) { return v; }
-__device__ __forceinline__ uint32_t dword_of(const uint2 &v, int k) { return k == 0 ? v.x : v.y; }
-__device__ __forceinline__ uint32_t dword_of(const uint4 &v, int k)
+__device__ __forceinline__ uint32_t dword_of(const u32x2 &v, int k) { return k == 0 ? v.x : v.y; }
+__device__ __forceinline__ uint32_t dword_of(const u32x4 &v, int k)
 {
     return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
 }
@@ -97,15 +101,30 @@ __device__ __forceinline__ void fast_row(const uint32_t (&x)[NDW], uint32_t grou
     for (int e = 0; e < NDW * 4; ++e) acc[e] += w[e];
 }
 
-template <int BPL, bool SKIP, bool GATHER>
+template <int BPL, bool NT>
+__device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[BPL / 4])
+{
+    typedef typename LoadT<BPL>::type load_t;
+    load_t v;
+    if (NT)
+        v = __builtin_nontemporal_load(reinterpret_cast<const load_t *>(p));
+    else
+        v = *reinterpret_cast<const load_t *>(p);
+#pragma unroll
+    for (int k = 0; k < BPL / 4; ++k) x[k] = dword_of(v, k);
+}
+
+// Fast pass.  The row loop is software-pipelined: the G rows of group g+1 are requested from HBM
+// before the G rows of group g are scored, so every wave keeps 2*G row loads in flight.
+template <int BPL, bool SKIP, bool GATHER, bool NT>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
        const double *__restrict__ lut, int64_t part_rows, double *__restrict__ out_score,
        uint32_t *__restrict__ out_miss, int64_t ld)
 {
     constexpr int NDW = BPL / 4;
-    constexpr int G = 4;                    // rows per unrolled group (G*32 B = 128 B of LUT = half a 256-B block)
-    typedef typename LoadT<BPL>::type load_t;
+    constexpr int G = 4;                    // rows per group (G*32 B = 128 B of LUT = half a 256-B block)
+    constexpr int GROUPS_PER_TILE = TILE_ROWS / G;
     __shared__ __attribute__((aligned(256))) double s_lut[2][TILE_ROWS * 4];
 
     const int tid = threadIdx.x;
@@ -115,30 +134,46 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     const int64_t p = blockIdx.y;
     const int64_t r_begin = p * part_rows;
     const int64_t r_end = (r_begin + part_rows < n) ? r_begin + part_rows : n;
-    const int64_t n_tiles = (r_end - r_begin + TILE_ROWS - 1) / TILE_ROWS;
+    const int64_t n_rows = r_end - r_begin;
+    const int64_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
 
     double acc[BPL];
     uint32_t miss16[NDW * 2];               // packed 2 x u16 per register, flushed from packed u8 every tile
+    uint32_t miss8[NDW];
 #pragma unroll
     for (int i = 0; i < BPL; ++i) acc[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < NDW * 2; ++i) miss16[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NDW; ++i) miss8[i] = 0;
 
     // tile 0 of the LUT -> LDS
     {
-        const int rows2 = 2 * (int)((r_end - r_begin < TILE_ROWS) ? (r_end - r_begin) : TILE_ROWS);
+        const int rows2 = 2 * (int)((n_rows < TILE_ROWS) ? n_rows : TILE_ROWS);
         const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * r_begin);
         double2 *dst = reinterpret_cast<double2 *>(&s_lut[0][0]);
         for (int i = tid; i < rows2; i += nthr) dst[i] = src[i];
     }
-    __syncthreads();
 
-    const int8_t *colp = db + col0;
+    const int8_t *colp = db + (lane_on ? col0 : 0);
+    // Prefetches are unconditional (straight-line code lets the compiler count vmcnt exactly) and may
+    // run up to 2*G rows past the end of the part: the panel and the row-index list are allocated with
+    // PREFETCH_PAD_ROWS extra rows/entries, and rows past the end are never scored.
+    auto row_ptr = [&](int64_t rr) -> const int8_t * {
+        const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
+        return colp + prow * pitch;
+    };
+
+    // prologue of the pipeline: group 0 in flight
+    uint32_t xa[G][NDW], xb[G][NDW];
+#pragma unroll
+    for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(r_begin + u), xa[u]);
+    __syncthreads();
 
     for (int64_t t = 0; t < n_tiles; ++t) {
         const int64_t tr0 = r_begin + t * TILE_ROWS;
         const int rows = (int)((r_end - tr0 < TILE_ROWS) ? (r_end - tr0) : TILE_ROWS);
-        // prefetch the next LUT tile into registers (256 double2 over nthr >= 64 threads: <= 4 each)
+        // stage the next LUT tile in registers (256 double2 over nthr >= 64 threads: <= 4 each)
         double2 pre0 = make_double2(0.0, 0.0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
         const bool more = (t + 1 < n_tiles);
         if (more) {
@@ -151,48 +186,48 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
             if (tid + 3 * nthr < nrows2) pre3 = src[tid + 3 * nthr];
         }
 
-        if (lane_on) {
-            const uint32_t lds_base =
-                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)(&s_lut[t & 1][0]);
-            uint32_t miss8[NDW];
+        const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)(&s_lut[t & 1][0]);
+        const int full_groups = rows / G;
+        // two groups per iteration so that the xa/xb roles are static (no register copies)
+        int g = 0;
+        for (; g + 2 <= full_groups; g += 2) {
+            const int64_t rnext = tr0 + (int64_t)(g + 1) * G;
+            const uint32_t group_base = lds_base + (uint32_t)(g >> 1) * 256u;   // 256-B aligned, wave-uniform
+            // ---- group g (data in xa); request group g+1 into xb
 #pragma unroll
-            for (int i = 0; i < NDW; ++i) miss8[i] = 0;
-
-            const int full_groups = rows / G;
-            for (int g = 0; g < full_groups; ++g) {
-                uint32_t x[G][NDW];
+            for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rnext + u), xb[u]);
+            fast_row<NDW, SKIP, 0>(xa[0], group_base, 0u, acc, miss8);
+            fast_row<NDW, SKIP, 1>(xa[1], group_base, 0u, acc, miss8);
+            fast_row<NDW, SKIP, 2>(xa[2], group_base, 0u, acc, miss8);
+            fast_row<NDW, SKIP, 3>(xa[3], group_base, 0u, acc, miss8);
+            // ---- group g+1 (data in xb); request group g+2 into xa (first group of the next tile at the end)
 #pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const int64_t rr = tr0 + g * G + u;
-                    const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
-                    const load_t v = *reinterpret_cast<const load_t *>(colp + prow * pitch);
+            for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rnext + G + u), xa[u]);
+            fast_row<NDW, SKIP, 0>(xb[0], group_base, 0x80808080u, acc, miss8);
+            fast_row<NDW, SKIP, 1>(xb[1], group_base, 0x80808080u, acc, miss8);
+            fast_row<NDW, SKIP, 2>(xb[2], group_base, 0x80808080u, acc, miss8);
+            fast_row<NDW, SKIP, 3>(xb[3], group_base, 0x80808080u, acc, miss8);
+        }
+        if (g < full_groups) {                                   // odd group count: only in the last tile of a part
+            const uint32_t group_base = lds_base + (uint32_t)(g >> 1) * 256u;
+            fast_row<NDW, SKIP, 0>(xa[0], group_base, 0u, acc, miss8);
+            fast_row<NDW, SKIP, 1>(xa[1], group_base, 0u, acc, miss8);
+            fast_row<NDW, SKIP, 2>(xa[2], group_base, 0u, acc, miss8);
+            fast_row<NDW, SKIP, 3>(xa[3], group_base, 0u, acc, miss8);
+        }
+        for (int r = full_groups * G; r < rows; ++r) {          // at most G-1 rows: last tile of the last part
+            uint32_t x[NDW];
+            load_row<BPL, NT>(row_ptr(tr0 + r), x);
+            const uint32_t group_base = lds_base + (uint32_t)(r >> 3) * 256u;
+            const uint32_t roff4 = (uint32_t)(r & 7) * 0x20202020u;            // (r & 7) * 32 in every byte
+            fast_row<NDW, SKIP, 0>(x, group_base, roff4, acc, miss8);
+        }
+        // flush packed u8 counters (<= TILE_ROWS <= 255 per byte) into packed u16 pairs
 #pragma unroll
-                    for (int k = 0; k < NDW; ++k) x[u][k] = dword_of(v, k);
-                }
-                const uint32_t group_base = lds_base + (uint32_t)(g >> 1) * 256u;   // 256-B aligned, wave-uniform
-                const uint32_t roff4 = (g & 1) ? 0x80808080u : 0u;
-                fast_row<NDW, SKIP, 0>(x[0], group_base, roff4, acc, miss8);
-                fast_row<NDW, SKIP, 1>(x[1], group_base, roff4, acc, miss8);
-                fast_row<NDW, SKIP, 2>(x[2], group_base, roff4, acc, miss8);
-                fast_row<NDW, SKIP, 3>(x[3], group_base, roff4, acc, miss8);
-            }
-            for (int r = full_groups * G; r < rows; ++r) {          // at most G-1 rows, last tile of the last part
-                const int64_t rr = tr0 + r;
-                const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
-                const load_t v = *reinterpret_cast<const load_t *>(colp + prow * pitch);
-                uint32_t x[NDW];
-#pragma unroll
-                for (int k = 0; k < NDW; ++k) x[k] = dword_of(v, k);
-                const uint32_t group_base = lds_base + (uint32_t)(r >> 3) * 256u;
-                const uint32_t roff4 = (uint32_t)(r & 7) * 0x20202020u;            // (r & 7) * 32 in every byte
-                fast_row<NDW, SKIP, 0>(x, group_base, roff4, acc, miss8);
-            }
-            // flush packed u8 counters (<= TILE_ROWS <= 255 per byte) into packed u16 pairs
-#pragma unroll
-            for (int k = 0; k < NDW; ++k) {
-                miss16[2 * k + 0] += miss8[k] & 0x00ff00ffu;          // bytes 0 and 2
-                miss16[2 * k + 1] += (miss8[k] >> 8) & 0x00ff00ffu;   // bytes 1 and 3
-            }
+        for (int k = 0; k < NDW; ++k) {
+            miss16[2 * k + 0] += miss8[k] & 0x00ff00ffu;          // bytes 0 and 2
+            miss16[2 * k + 1] += (miss8[k] >> 8) & 0x00ff00ffu;   // bytes 1 and 3
+            miss8[k] = 0;
         }
 
         if (more) {
