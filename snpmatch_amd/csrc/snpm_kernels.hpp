@@ -49,10 +49,6 @@ __global__ void k_build_lut(const double *__restrict__ w, double *__restrict__ l
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fast pass.
-//   grid.x = column blocks (each WPB waves * 64 lanes * BPL bytes), grid.y = parts
-//   part p covers matched rows [p*part_rows, min(n, (p+1)*part_rows))
-//   out_score [n_parts, ld] fp64, out_miss [n_parts, ld] u32 (ld = pitch)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -114,17 +110,23 @@ __device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[BPL / 4]
     for (int k = 0; k < BPL / 4; ++k) x[k] = dword_of(v, k);
 }
 
-// Fast pass.  The row loop is software-pipelined: the G rows of group g+1 are requested from HBM
-// before the G rows of group g are scored, so every wave keeps 2*G row loads in flight.
+// Fast pass.
+//   grid.x = column blocks (blockDim.x/64 waves x 64 lanes x BPL bytes), grid.y = P parts.
+//   Rows are cut into tiles of TILE_ROWS; part p scores tiles p, p+P, p+2P, ... so that at any time the
+//   resident workgroups sweep ONE contiguous window of the panel (DRAM-page friendly, like a streaming
+//   copy) and every part gets the same number of tiles (+-1).
+//   The row loop is software-pipelined: the G rows of the next group are requested from HBM before the
+//   G rows of the current group are scored, so every wave keeps 2*G row loads in flight; prefetches are
+//   unconditional (straight-line code lets the compiler count vmcnt exactly) and may run up to 2*G rows
+//   past the last row: the panel and the row-index list carry PREFETCH_PAD_ROWS extra rows/entries.
+//   out_score [P, ld] fp64, out_miss [P, ld] u32 (ld = pitch).
 template <int BPL, bool SKIP, bool GATHER, bool NT>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
 k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
-       const double *__restrict__ lut, int64_t part_rows, double *__restrict__ out_score,
-       uint32_t *__restrict__ out_miss, int64_t ld)
+       const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
 {
     constexpr int NDW = BPL / 4;
     constexpr int G = 4;                    // rows per group (G*32 B = 128 B of LUT = half a 256-B block)
-    constexpr int GROUPS_PER_TILE = TILE_ROWS / G;
     __shared__ __attribute__((aligned(256))) double s_lut[2][TILE_ROWS * 4];
 
     const int tid = threadIdx.x;
@@ -132,10 +134,8 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     const int64_t col0 = ((int64_t)blockIdx.x * nthr + tid) * BPL;
     const bool lane_on = col0 < pitch;      // pitch is a multiple of 256 >= n_acc: loads stay in the row
     const int64_t p = blockIdx.y;
-    const int64_t r_begin = p * part_rows;
-    const int64_t r_end = (r_begin + part_rows < n) ? r_begin + part_rows : n;
-    const int64_t n_rows = r_end - r_begin;
-    const int64_t n_tiles = (n_rows + TILE_ROWS - 1) / TILE_ROWS;
+    const int64_t P = gridDim.y;
+    const int64_t n_tiles_total = (n + TILE_ROWS - 1) / TILE_ROWS;
 
     double acc[BPL];
     uint32_t miss16[NDW * 2];               // packed 2 x u16 per register, flushed from packed u8 every tile
@@ -147,97 +147,104 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
 #pragma unroll
     for (int i = 0; i < NDW; ++i) miss8[i] = 0;
 
-    // tile 0 of the LUT -> LDS
-    {
-        const int rows2 = 2 * (int)((n_rows < TILE_ROWS) ? n_rows : TILE_ROWS);
-        const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * r_begin);
-        double2 *dst = reinterpret_cast<double2 *>(&s_lut[0][0]);
-        for (int i = tid; i < rows2; i += nthr) dst[i] = src[i];
-    }
-
-    const int8_t *colp = db + (lane_on ? col0 : 0);
-    // Prefetches are unconditional (straight-line code lets the compiler count vmcnt exactly) and may
-    // run up to 2*G rows past the end of the part: the panel and the row-index list are allocated with
-    // PREFETCH_PAD_ROWS extra rows/entries, and rows past the end are never scored.
+    // address = wave-uniform row base (scalar registers) + 32-bit lane offset: global_load saddr form,
+    // no per-lane 64-bit address arithmetic
+    const uint32_t lane_off = lane_on ? (uint32_t)col0 : 0u;
     auto row_ptr = [&](int64_t rr) -> const int8_t * {
         const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
-        return colp + prow * pitch;
+        const int8_t *rowbase = db + prow * pitch;                 // wave-uniform: scalar registers
+        // The empty asm keeps the zero-extension of the lane offset inside the loop body, where the
+        // instruction selector can fold it: global_load_dword v, v_off, s[base:base+1] (saddr form), no
+        // per-lane 64-bit address arithmetic and no address VGPR pairs.
+        uint32_t off = lane_off;
+        asm volatile("" : "+v"(off));
+        return rowbase + off;
     };
 
-    // prologue of the pipeline: group 0 in flight
-    uint32_t xa[G][NDW], xb[G][NDW];
+    if (p < n_tiles_total) {
+        // first LUT tile -> LDS; first group in flight
+        {
+            const int64_t tr0 = p * TILE_ROWS;
+            const int rows2 = 2 * (int)((n - tr0 < TILE_ROWS) ? (n - tr0) : TILE_ROWS);
+            const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * tr0);
+            double2 *dst = reinterpret_cast<double2 *>(&s_lut[0][0]);
+            for (int i = tid; i < rows2; i += nthr) dst[i] = src[i];
+        }
+        uint32_t xa[G][NDW], xb[G][NDW];
 #pragma unroll
-    for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(r_begin + u), xa[u]);
-    __syncthreads();
-
-    for (int64_t t = 0; t < n_tiles; ++t) {
-        const int64_t tr0 = r_begin + t * TILE_ROWS;
-        const int rows = (int)((r_end - tr0 < TILE_ROWS) ? (r_end - tr0) : TILE_ROWS);
-        // stage the next LUT tile in registers (256 double2 over nthr >= 64 threads: <= 4 each)
-        double2 pre0 = make_double2(0.0, 0.0), pre1 = pre0, pre2 = pre0, pre3 = pre0;
-        const bool more = (t + 1 < n_tiles);
-        if (more) {
-            const int64_t nr0 = tr0 + TILE_ROWS;
-            const int nrows2 = 2 * (int)((r_end - nr0 < TILE_ROWS) ? (r_end - nr0) : TILE_ROWS);
-            const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * nr0);
-            if (tid < nrows2) pre0 = src[tid];
-            if (tid + nthr < nrows2) pre1 = src[tid + nthr];
-            if (tid + 2 * nthr < nrows2) pre2 = src[tid + 2 * nthr];
-            if (tid + 3 * nthr < nrows2) pre3 = src[tid + 3 * nthr];
-        }
-
-        const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)(&s_lut[t & 1][0]);
-        const int full_groups = rows / G;
-        // two groups per iteration so that the xa/xb roles are static (no register copies)
-        int g = 0;
-        for (; g + 2 <= full_groups; g += 2) {
-            const int64_t rnext = tr0 + (int64_t)(g + 1) * G;
-            const uint32_t group_base = lds_base + (uint32_t)(g >> 1) * 256u;   // 256-B aligned, wave-uniform
-            // ---- group g (data in xa); request group g+1 into xb
-#pragma unroll
-            for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rnext + u), xb[u]);
-            fast_row<NDW, SKIP, 0>(xa[0], group_base, 0u, acc, miss8);
-            fast_row<NDW, SKIP, 1>(xa[1], group_base, 0u, acc, miss8);
-            fast_row<NDW, SKIP, 2>(xa[2], group_base, 0u, acc, miss8);
-            fast_row<NDW, SKIP, 3>(xa[3], group_base, 0u, acc, miss8);
-            // ---- group g+1 (data in xb); request group g+2 into xa (first group of the next tile at the end)
-#pragma unroll
-            for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rnext + G + u), xa[u]);
-            fast_row<NDW, SKIP, 0>(xb[0], group_base, 0x80808080u, acc, miss8);
-            fast_row<NDW, SKIP, 1>(xb[1], group_base, 0x80808080u, acc, miss8);
-            fast_row<NDW, SKIP, 2>(xb[2], group_base, 0x80808080u, acc, miss8);
-            fast_row<NDW, SKIP, 3>(xb[3], group_base, 0x80808080u, acc, miss8);
-        }
-        if (g < full_groups) {                                   // odd group count: only in the last tile of a part
-            const uint32_t group_base = lds_base + (uint32_t)(g >> 1) * 256u;
-            fast_row<NDW, SKIP, 0>(xa[0], group_base, 0u, acc, miss8);
-            fast_row<NDW, SKIP, 1>(xa[1], group_base, 0u, acc, miss8);
-            fast_row<NDW, SKIP, 2>(xa[2], group_base, 0u, acc, miss8);
-            fast_row<NDW, SKIP, 3>(xa[3], group_base, 0u, acc, miss8);
-        }
-        for (int r = full_groups * G; r < rows; ++r) {          // at most G-1 rows: last tile of the last part
-            uint32_t x[NDW];
-            load_row<BPL, NT>(row_ptr(tr0 + r), x);
-            const uint32_t group_base = lds_base + (uint32_t)(r >> 3) * 256u;
-            const uint32_t roff4 = (uint32_t)(r & 7) * 0x20202020u;            // (r & 7) * 32 in every byte
-            fast_row<NDW, SKIP, 0>(x, group_base, roff4, acc, miss8);
-        }
-        // flush packed u8 counters (<= TILE_ROWS <= 255 per byte) into packed u16 pairs
-#pragma unroll
-        for (int k = 0; k < NDW; ++k) {
-            miss16[2 * k + 0] += miss8[k] & 0x00ff00ffu;          // bytes 0 and 2
-            miss16[2 * k + 1] += (miss8[k] >> 8) & 0x00ff00ffu;   // bytes 1 and 3
-            miss8[k] = 0;
-        }
-
-        if (more) {
-            double2 *dst = reinterpret_cast<double2 *>(&s_lut[(t + 1) & 1][0]);
-            if (tid < TILE_ROWS * 2) dst[tid] = pre0;
-            if (tid + nthr < TILE_ROWS * 2) dst[tid + nthr] = pre1;
-            if (tid + 2 * nthr < TILE_ROWS * 2) dst[tid + 2 * nthr] = pre2;
-            if (tid + 3 * nthr < TILE_ROWS * 2) dst[tid + 3 * nthr] = pre3;
-        }
+        for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(p * TILE_ROWS + u), xa[u]);
         __syncthreads();
+
+        int buf = 0;
+        for (int64_t T = p; T < n_tiles_total; T += P, buf ^= 1) {
+            const int64_t tr0 = T * TILE_ROWS;
+            const int rows = (int)((n - tr0 < TILE_ROWS) ? (n - tr0) : TILE_ROWS);
+            const bool more = (T + P < n_tiles_total);
+            const int64_t ntr0 = more ? (T + P) * TILE_ROWS : tr0;      // my next tile (or a harmless re-read)
+            // stage the next LUT tile (256 double2) in ONE register pair per thread when the block has
+            // >= 256 threads; narrower blocks copy it synchronously at the end of the tile instead
+            double2 pre0 = make_double2(0.0, 0.0);
+            const bool staged = more && nthr >= TILE_ROWS * 2;
+            const int nrows2 = more ? 2 * (int)((n - ntr0 < TILE_ROWS) ? (n - ntr0) : TILE_ROWS) : 0;
+            if (staged && tid < nrows2) pre0 = reinterpret_cast<const double2 *>(lut + 4 * ntr0)[tid];
+
+            const uint32_t lds_base =
+                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)(&s_lut[buf][0]);
+            const int full_groups = rows / G;
+            // two groups per iteration so that the xa/xb roles are static (no register copies)
+            int g = 0;
+            for (; g + 2 <= full_groups; g += 2) {
+                const int64_t rnext = tr0 + (int64_t)(g + 1) * G;
+                // the group after the pair: inside this tile, or the first group of my next tile
+                const int64_t rafter = (g + 2 < TILE_ROWS / G) ? rnext + G : ntr0;
+                const uint32_t group_base = lds_base + (uint32_t)(g >> 1) * 256u;   // 256-B aligned, wave-uniform
+                // ---- group g (data in xa); request group g+1 into xb
+#pragma unroll
+                for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rnext + u), xb[u]);
+                fast_row<NDW, SKIP, 0>(xa[0], group_base, 0u, acc, miss8);
+                fast_row<NDW, SKIP, 1>(xa[1], group_base, 0u, acc, miss8);
+                fast_row<NDW, SKIP, 2>(xa[2], group_base, 0u, acc, miss8);
+                fast_row<NDW, SKIP, 3>(xa[3], group_base, 0u, acc, miss8);
+                // ---- group g+1 (data in xb); request the following group into xa
+#pragma unroll
+                for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rafter + u), xa[u]);
+                fast_row<NDW, SKIP, 0>(xb[0], group_base, 0x80808080u, acc, miss8);
+                fast_row<NDW, SKIP, 1>(xb[1], group_base, 0x80808080u, acc, miss8);
+                fast_row<NDW, SKIP, 2>(xb[2], group_base, 0x80808080u, acc, miss8);
+                fast_row<NDW, SKIP, 3>(xb[3], group_base, 0x80808080u, acc, miss8);
+            }
+            if (g < full_groups) {                               // odd group count: only in the last tile of all
+                const uint32_t group_base = lds_base + (uint32_t)(g >> 1) * 256u;
+                fast_row<NDW, SKIP, 0>(xa[0], group_base, 0u, acc, miss8);
+                fast_row<NDW, SKIP, 1>(xa[1], group_base, 0u, acc, miss8);
+                fast_row<NDW, SKIP, 2>(xa[2], group_base, 0u, acc, miss8);
+                fast_row<NDW, SKIP, 3>(xa[3], group_base, 0u, acc, miss8);
+            }
+            for (int r = full_groups * G; r < rows; ++r) {      // at most G-1 rows: last tile of all
+                uint32_t x[NDW];
+                load_row<BPL, NT>(row_ptr(tr0 + r), x);
+                const uint32_t group_base = lds_base + (uint32_t)(r >> 3) * 256u;
+                const uint32_t roff4 = (uint32_t)(r & 7) * 0x20202020u;        // (r & 7) * 32 in every byte
+                fast_row<NDW, SKIP, 0>(x, group_base, roff4, acc, miss8);
+            }
+            // flush packed u8 counters (<= TILE_ROWS <= 255 per byte) into packed u16 pairs
+#pragma unroll
+            for (int k = 0; k < NDW; ++k) {
+                miss16[2 * k + 0] += miss8[k] & 0x00ff00ffu;          // bytes 0 and 2
+                miss16[2 * k + 1] += (miss8[k] >> 8) & 0x00ff00ffu;   // bytes 1 and 3
+                miss8[k] = 0;
+            }
+            if (more) {
+                double2 *dst = reinterpret_cast<double2 *>(&s_lut[buf ^ 1][0]);
+                if (staged) {
+                    if (tid < TILE_ROWS * 2) dst[tid] = pre0;
+                } else {
+                    const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * ntr0);
+                    for (int i = tid; i < nrows2; i += nthr) dst[i] = src[i];
+                }
+            }
+            __syncthreads();
+        }
     }
 
     if (lane_on) {
