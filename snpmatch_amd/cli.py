@@ -1,0 +1,111 @@
+"""
+Command line: ``snpmatch inbred`` and ``snpmatch cross`` with the reference's flags
+(snpmatch/__init__.py:44-63), logging setup (:23-34) and exit codes (:155-183), plus ``makedb-native``
+to write the flat panel format this engine streams to the GPU.  The other reference subcommands
+(genotype_cross, parser, pairsnp, makedb, simulate) are outside the accelerated path.
+"""
+import argparse
+import logging
+import os
+import sys
+
+__version__ = "0.1.0 (SNPmatch 5.0.1 inbred/cross interface)"
+
+
+def setLog(logDebug):
+    log = logging.getLogger()
+    numeric_level = logging.DEBUG if logDebug else logging.ERROR
+    log_format = logging.Formatter("%(asctime)s - %(name)s - %(levelname)s - %(message)s")
+    lch = logging.StreamHandler()
+    lch.setLevel(numeric_level)
+    lch.setFormatter(log_format)
+    log.setLevel(numeric_level)
+    log.addHandler(lch)
+
+
+def die(msg):
+    sys.stderr.write('Error: ' + msg + '\n')
+    sys.exit(1)
+
+
+def check_file(inFile):
+    if not inFile:
+        die("file: %s not specified" % inFile)
+    if not os.path.exists(inFile):
+        die("input file does not exist: " + inFile)
+
+
+def snpmatch_inbred(args):
+    from .core import snpmatch
+    check_file(args['inFile'])
+    snpmatch.potatoGenotyper(args)
+
+
+def snpmatch_cross(args):
+    from .core import csmatch
+    check_file(args['inFile'])
+    csmatch.potatoCrossIdentifier(args)
+
+
+def makedb_native(args):
+    """<db>.npz (snps, accessions, positions, chrs, chr_regions) or HDF5 -> <out>.snpm flat panel"""
+    from .core import snp_genotype
+    g = snp_genotype._load_any(args['inFile'])
+    snp_genotype.save_native(args['outFile'], g.snps, g.accessions, g.positions, g.chrs, g.chr_regions)
+
+
+def get_options(description, version_message):
+    p = argparse.ArgumentParser(description=description)
+    p.add_argument('-V', '--version', action='version', version=version_message)
+    sub = p.add_subparsers(title='subcommands', description='Choose a command to run', help='Following commands are supported')
+
+    def common(sp, default_out):
+        sp.add_argument("-i", "--input_file", dest="inFile", help="VCF/BED file for the variants in the sample")
+        sp.add_argument("-d", "--hdf5_file", default=None, dest="hdf5File",
+                        help="Path to SNP matrix: native flat panel directory (.snpm), .npz, or HDF5 chunked row-wise")
+        sp.add_argument("-e", "--hdf5_acc_file", default=None, dest="hdf5accFile",
+                        help="Path to SNP matrix chunked column-wise (optional for flat panels)")
+        sp.add_argument("--skip_db_hets", action="store_true", dest="skip_db_hets", default=False,
+                        help="Replace heterozygous calls in DB with nan during the analysis.")
+        sp.add_argument("-v", "--verbose", action="store_true", dest="logDebug", default=False, help="Show verbose debugging output")
+        sp.add_argument("-o", "--output", dest="outFile", default=default_out, help="Output file prefix")
+
+    inbred = sub.add_parser('inbred', help="SNPmatch on the inbred samples")
+    common(inbred, "identify_inbred")
+    inbred.add_argument("--refine", action="store_true", dest="refine", default=False, help="Refine scores for indistinguishable lines")
+    inbred.set_defaults(func=snpmatch_inbred)
+
+    cross = sub.add_parser('cross', help="SNPmatch on the crosses (F2s and F3s) of A. thaliana")
+    common(cross, "identify_cross")
+    cross.add_argument("-b", "--binLength", dest="binLen", help="Length of bins to calculate the likelihoods", default=300000, type=int)
+    cross.add_argument("--genome", dest="genome", default="athaliana_tair10",
+                       help="Genome id or path to a reference JSON file (ref_chrs, ref_chrlen)")
+    cross.set_defaults(func=snpmatch_cross)
+
+    mk = sub.add_parser('makedb-native', help="Convert a DB (.npz / HDF5) to the native flat panel format")
+    mk.add_argument("-i", "--input", dest="inFile")
+    mk.add_argument("-o", "--output", dest="outFile")
+    mk.add_argument("-v", "--verbose", action="store_true", dest="logDebug", default=False)
+    mk.set_defaults(func=makedb_native)
+    return p
+
+
+def main(argv=None):
+    parser = get_options("SNPmatch inbred / cross scoring on MI355X (snpmatch_amd)", '%(prog)s ' + __version__)
+    args = vars(parser.parse_args(argv))
+    setLog(args.get('logDebug', False))
+    if 'func' not in args:
+        parser.print_help()
+        return 0
+    try:
+        args['func'](args)
+        return 0
+    except KeyboardInterrupt:
+        return 0
+    except Exception as e:
+        logging.exception(e)
+        return 2
+
+
+if __name__ == '__main__':
+    sys.exit(main())

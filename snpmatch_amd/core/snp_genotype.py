@@ -1,0 +1,222 @@
+"""
+DB genotype container (reference: core/snp_genotype.py:24-68,188-211 and the HDF5Genotype duck type of
+pygwas/genotype.py:534-673).
+
+``Genotype(hdf5_file, hdf5_acc_file)`` keeps the reference's constructor and the attributes the hot
+path uses -- ``g.g.snps[idx, :]``, ``g.g.accessions``, ``g.g.positions``, ``g.g.chrs``,
+``g.g.chr_regions``, ``g.g.chromosomes``, ``g.g_acc.snps[:, i]``, ``g.accessions``, ``g.chrs`` -- and
+adds ``g.panel(ctx)``: the int8 matrix resident in HBM (uploaded once through the pinned-host staging
+path of libsnpmatch_hip), which is what ``Genotyper`` / ``CrossIdentifier`` score against.
+
+On-disk formats
+  * native flat panel ``<name>.snpm/``: ``snps.i8`` = raw int8 [num_snps, num_accessions] C-order
+    (memory-mapped, streamed to the GPU slab by slab) + ``meta.npz`` (accessions, positions, chrs,
+    chr_regions).  ``save_native`` / ``Genotype.from_arrays`` create it.
+  * ``.npz`` with the same keys plus ``snps`` (small DBs, tests).
+  * the reference's HDF5 layout (pygwas/genotype.py:310-326) when ``h5py`` is importable.
+"""
+import logging
+import os
+import re
+from glob import glob
+
+import numpy as np
+
+from . import parsers
+
+log = logging.getLogger(__name__)
+chunk_size = 1000
+
+
+class MemGenotype(object):
+    """Array-backed stand-in for pygwas HDF5Genotype (attributes used by inbred / cross only)."""
+
+    def __init__(self, snps, accessions, positions, chrs, chr_regions):
+        self.snps = snps
+        acc = np.asarray(accessions)
+        self.accessions = acc if acc.dtype.kind == "S" else np.char.encode(acc.astype("U"), "utf-8")
+        self.positions = np.asarray(positions, dtype="i4")
+        self.chrs = np.asarray(chrs).astype("U")
+        self.chr_regions = np.asarray(chr_regions, dtype=np.int64).reshape(-1, 2)
+
+    @property
+    def chromosomes(self):
+        """one chromosome name per SNP row (pygwas/genotype.py:156-161), as an array"""
+        reps = (self.chr_regions[:, 1] - self.chr_regions[:, 0]).astype(int)
+        return np.repeat(self.chrs, reps)
+
+    @property
+    def num_snps(self):
+        return self.snps.shape[0]
+
+
+def save_native(path, snps, accessions, positions, chrs, chr_regions):
+    """Write the native flat panel directory ``path`` (conventionally ``*.snpm``)."""
+    os.makedirs(path, exist_ok=True)
+    snps = np.asarray(snps)
+    mm = np.lib.format.open_memmap(os.path.join(path, "snps.npy"), mode="w+", dtype=np.int8, shape=snps.shape)
+    for r0 in range(0, snps.shape[0], 1 << 16):
+        mm[r0:r0 + (1 << 16)] = snps[r0:r0 + (1 << 16)]
+    mm.flush()
+    del mm
+    np.savez(os.path.join(path, "meta.npz"), accessions=np.asarray(accessions).astype("S"),
+             positions=np.asarray(positions, dtype="i4"), chrs=np.asarray(chrs).astype("S"),
+             chr_regions=np.asarray(chr_regions, dtype=np.int64))
+
+
+def _load_any(path):
+    if os.path.isdir(path):
+        meta = np.load(os.path.join(path, "meta.npz"))
+        snps = np.load(os.path.join(path, "snps.npy"), mmap_mode="r")
+        return MemGenotype(snps, meta["accessions"], meta["positions"], meta["chrs"].astype("U"), meta["chr_regions"])
+    if path.endswith(".npz"):
+        d = np.load(path)
+        return MemGenotype(d["snps"], d["accessions"], d["positions"], np.asarray(d["chrs"]).astype("U"), d["chr_regions"])
+    try:
+        import h5py
+    except ImportError:
+        raise ImportError("%s looks like an HDF5 database but h5py is not installed; convert it to the native "
+                          "flat panel format (snpmatch_amd.core.snp_genotype.save_native)" % path)
+    h5 = h5py.File(path, "r")
+    return MemGenotype(h5["snps"], h5["accessions"][:], h5["positions"][:],
+                       h5["positions"].attrs["chrs"].astype("U"), h5["positions"].attrs["chr_regions"])
+
+
+def load_genotype_files(h5file, hdf5_acc_file=None):
+    return Genotype(h5file, hdf5_acc_file)
+
+
+class Genotype(object):
+
+    def __init__(self, hdf5_file, hdf5_acc_file):
+        assert hdf5_file is not None or hdf5_acc_file is not None, "Provide atleast one hdf5 genotype file"
+        self._panel = None
+        if hdf5_file is None:
+            assert os.path.exists(hdf5_acc_file), "Path to %s seems to be broken" % hdf5_acc_file
+            self.g_acc = _load_any(hdf5_acc_file)
+            return None
+        assert os.path.exists(hdf5_file), "Path to %s seems to be broken" % hdf5_file
+        self.g = _load_any(hdf5_file)
+        if hdf5_acc_file is None:
+            hdf5_acc_file = re.sub(r'\.hdf5$', '', hdf5_file) + '.acc.hdf5'
+            if len(glob(hdf5_acc_file)) > 0:
+                self.g_acc = _load_any(hdf5_acc_file)
+            else:
+                self.g_acc = self.g        # flat panels serve rows and columns from the same matrix
+        else:
+            self.g_acc = _load_any(hdf5_acc_file)
+        self.accessions = self.g.accessions.astype('U')
+        self.chrs = self.g.chrs.astype('U')
+
+    @classmethod
+    def from_arrays(cls, snps, accessions, positions, chrs, chr_regions):
+        self = cls.__new__(cls)
+        self._panel = None
+        self.g = MemGenotype(snps, accessions, positions, chrs, chr_regions)
+        self.g_acc = self.g
+        self.accessions = self.g.accessions.astype('U')
+        self.chrs = self.g.chrs.astype('U')
+        return self
+
+    # ------------------------------------------------------------------ device residency
+    def panel(self, ctx=None):
+        """The DB matrix resident in HBM (created on first use; slabs go through pinned staging)."""
+        from .. import engine
+        if self._panel is None or self._panel.h is None:
+            ctx = ctx or engine.default_context()
+            self._panel = engine.Panel.from_host(ctx, self.g.snps)
+        return self._panel
+
+    # ------------------------------------------------------------------ position intersection (a5)
+    def get_positions_idxs(self, commonSNPsCHR, commonSNPsPOS):
+        """(db_row_idx, sample_idx) of the positions present in both; core/snp_genotype.py:43-44.
+        Same result as ``get_common_positions(chromosomes, positions, ...)`` without materialising one
+        chromosome string per DB row: the DB side is walked region by region (pygwas chr_regions)."""
+        ins = parsers.ParseInputs("")
+        ins.load_snp_info(snpCHR=commonSNPsCHR, snpPOS=commonSNPsPOS, snpGT="", snpWEI=np.nan, DPmean=0)
+        ins.filter_chr_names()
+        db_ids = np.array([re.sub("chr", "", c, flags=re.IGNORECASE) for c in self.g.chrs.astype("U").tolist()], dtype="str")
+        positions = np.asarray(self.g.positions)
+        regions = np.asarray(self.g.chr_regions)
+        idx1 = [np.zeros(0, dtype=int)]
+        idx2 = [np.zeros(0, dtype=int)]
+        seen = set()
+        for ci, cid in enumerate(db_ids):
+            if cid in seen:             # a chromosome id listed twice: fall back to the generic path
+                return self.get_common_positions(self.g.chromosomes, positions, commonSNPsCHR, commonSNPsPOS)
+            seen.add(cid)
+            if regions[ci][1] <= regions[ci][0] or cid not in ins.g_chrs_ids:
+                continue
+            s, e = int(regions[ci][0]), int(regions[ci][1])
+            ix2 = np.where(ins.g_chrs == cid)[0]
+            p1 = np.array(positions[s:e], dtype=int)
+            p2 = np.array(ins.pos[ix2], dtype=int)
+            idx1.append(s + np.where(np.isin(p1, p2, assume_unique=True))[0])
+            idx2.append(ix2[np.where(np.isin(p2, p1, assume_unique=True))[0]])
+        return (np.concatenate(idx1), np.concatenate(idx2))
+
+    @staticmethod
+    def get_common_positions(input_1_chr, input_1_pos, input_2_chr, input_2_pos):
+        """core/snp_genotype.py:46-68: chromosomes in the order of input 1, per chromosome the
+        positions present in both inputs (inputs sorted and unique per chromosome)."""
+        assert len(input_1_chr) == len(input_1_pos), "Both chromosome and position array provided should be of same length"
+        assert len(input_2_chr) == len(input_2_pos), "Both chromosome and position array provided should be of same length"
+        in1 = parsers.ParseInputs("")
+        in1.load_snp_info(snpCHR=input_1_chr, snpPOS=input_1_pos, snpGT="", snpWEI=np.nan, DPmean=0)
+        in1.filter_chr_names()
+        in2 = parsers.ParseInputs("")
+        in2.load_snp_info(snpCHR=input_2_chr, snpPOS=input_2_pos, snpGT="", snpWEI=np.nan, DPmean=0)
+        in2.filter_chr_names()
+        common = np.intersect1d(in1.g_chrs_ids, in2.g_chrs_ids)
+        common = in1.g_chrs_ids[np.where(np.isin(in1.g_chrs_ids, common))[0]]
+        idx1 = np.zeros(0, dtype=int)
+        idx2 = np.zeros(0, dtype=int)
+        for cid in common:
+            ix1 = np.where(in1.g_chrs == cid)[0]
+            ix2 = np.where(in2.g_chrs == cid)[0]
+            p1 = np.array(in1.pos[ix1], dtype=int)
+            p2 = np.array(in2.pos[ix2], dtype=int)
+            idx1 = np.append(idx1, ix1[np.where(np.isin(p1, p2, assume_unique=True))[0]])
+            idx2 = np.append(idx2, ix2[np.where(np.isin(p2, p1, assume_unique=True))[0]])
+        return (idx1, idx2)
+
+    def get_matching_accs_ix(self, accs, return_np=False):
+        acc_ix = []
+        for ea in accs:
+            t_ix = np.where(self.accessions == ea)[0]
+            acc_ix.append(None if len(t_ix) == 0 else t_ix[0])
+        if return_np:
+            acc_ix = np.array([a for a in acc_ix if a is not None], dtype="int")
+        return acc_ix
+
+    # ------------------------------------------------------------------ --refine support
+    def identify_segregating_snps(self, accs_ix):
+        """DB rows where the given accessions do not all carry the same informative call
+        (core/snp_genotype.py:188-211, segregting_snps :378-383)."""
+        assert type(accs_ix) is np.ndarray, "provide an np array for list of indices to be considered"
+        assert len(accs_ix) > 1, "polymorphism happens in more than 1 line"
+        if len(accs_ix) > (len(self.accessions) / 2):
+            return None
+        n_snps = self.g.positions.shape[0]
+        seg_counts = np.zeros(0, dtype=int)
+        total_counts = np.zeros(0, dtype=int)
+        snps = self.g.snps
+        for j in range(0, n_snps, 1 << 16):
+            t = np.array(snps[j:j + (1 << 16), :][:, accs_ix], dtype=float)
+            s, r = segregting_snps(t)
+            seg_counts = np.append(seg_counts, s)
+            total_counts = np.append(total_counts, r)
+        div_counts = np.divide(seg_counts, total_counts, out=np.zeros(len(seg_counts)), where=total_counts != 0)
+        seg_ix = np.setdiff1d(np.where(div_counts < 1)[0], np.where(total_counts == 0)[0])
+        return seg_ix
+
+
+def segregting_snps(t):
+    """per row: (size of the longest run after sorting = #equal-neighbour pairs + 1, #informative);
+    core/snp_genotype.py:378-383."""
+    t = np.array(t, dtype=float)
+    t[t < 0] = np.nan
+    t = np.sort(t, axis=1)
+    t_r_sum = np.sum(~np.isnan(t), axis=1)
+    t_sum = np.nansum(t[:, 1:] == t[:, :-1], axis=1) + 1
+    return (t_sum, t_r_sum)

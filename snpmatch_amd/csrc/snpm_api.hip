@@ -332,6 +332,24 @@ int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64
     if (n_seg == 0 || ncols == 0) return SNPM_OK;
     const int thr = ncols >= 256 ? 256 : (ncols > 128 ? 256 : (ncols > 64 ? 128 : 64));
     const bool gather = q->d_row_idx != nullptr;
+    if (d_cols && ncols <= 64) {
+        // short column list: one lane per (segment, column), see k_strict_sparse
+        const int64_t total = n_seg * ncols;
+        dim3 sgrid((unsigned)((total + 255) / 256));
+        ProfScope ps(ctx, PK_STRICT);
+#define LAUNCH_SPARSE(S, G)                                                                                        \
+    hipLaunchKernelGGL((k_strict_sparse<S, G>), sgrid, dim3(256), 0, ctx->stream, p->d, p->pitch, q->d_row_idx,     \
+                       q->row0, q->d_w, d_seg_off, n_seg, d_cols, ncols, (double *)ctx->ws_seg_score.p,            \
+                       (uint32_t *)ctx->ws_seg_miss.p, ld)
+        if (skip) {
+            if (gather) LAUNCH_SPARSE(true, true); else LAUNCH_SPARSE(true, false);
+        } else {
+            if (gather) LAUNCH_SPARSE(false, true); else LAUNCH_SPARSE(false, false);
+        }
+#undef LAUNCH_SPARSE
+        HIPCHK(ctx, hipGetLastError());
+        return SNPM_OK;
+    }
     // grid.x = segments (can be large), grid.y = column blocks
     dim3 grid((unsigned)n_seg, (unsigned)((ncols + thr - 1) / thr));
     ProfScope ps(ctx, PK_STRICT);

@@ -330,6 +330,56 @@ k_strict(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict
     out_miss[seg * ld + i] = miss;
 }
 
+// Strict segment sums for a SHORT list of columns (the accessions SNPM_MODE_EXACT has to re-evaluate):
+// one lane per (segment, column) pair so that every lane of a wave is busy and 8 independent byte
+// loads per lane are in flight (each is its own cache line: this path is latency-bound).
+// Same arithmetic and order as k_strict.  out_* [n_seg, ld].
+template <bool SKIP, bool GATHER>
+__global__ void __launch_bounds__(256)
+k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
+                const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t n_seg,
+                const int32_t *__restrict__ cols, int64_t ncols, double *__restrict__ out_score,
+                uint32_t *__restrict__ out_miss, int64_t ld)
+{
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_seg * ncols) return;
+    const int64_t seg = id / ncols;
+    const int64_t i = id - seg * ncols;
+    const int8_t *colp = db + cols[i];
+    const int64_t r0 = seg_off[seg], r1 = seg_off[seg + 1];
+    double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
+    uint32_t miss = 0;
+    constexpr int U = 8;
+    int64_t r = r0;
+    for (; r + U <= r1; r += U) {
+        int b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t prow = GATHER ? row_idx[r + u] : (row0 + r + u);
+            b[u] = colp[prow * pitch];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double w0 = w[3 * (r + u) + 0], w1 = w[3 * (r + u) + 1], w2 = w[3 * (r + u) + 2];
+            a_ref = a_ref + (b[u] == 0 ? w0 : 0.0);
+            if (!SKIP) a_het = a_het + (b[u] == 2 ? w1 : 0.0);
+            a_alt = a_alt + (b[u] == 1 ? w2 : 0.0);
+            miss += SKIP ? (b[u] < 0 || b[u] == 2) : (b[u] < 0);
+        }
+    }
+    for (; r < r1; ++r) {
+        const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
+        const int b = colp[prow * pitch];
+        const double w0 = w[3 * r + 0], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
+        a_ref = a_ref + (b == 0 ? w0 : 0.0);
+        if (!SKIP) a_het = a_het + (b == 2 ? w1 : 0.0);
+        a_alt = a_alt + (b == 1 ? w2 : 0.0);
+        miss += SKIP ? (b < 0 || b == 2) : (b < 0);
+    }
+    out_score[seg * ld + i] = ((0.0 + a_ref) + a_het) + a_alt;
+    out_miss[seg * ld + i] = miss;
+}
+
 // total[i] = (((0 + s0) + s1) + ...) over non-empty segments; ninfo[i] = n_rows - sum(miss)
 __global__ void k_scan(const double *__restrict__ seg_score, const uint32_t *__restrict__ seg_miss,
                        const int64_t *__restrict__ seg_off, int64_t n_seg, int64_t ld, int64_t ncols,

@@ -1,0 +1,153 @@
+"""
+End-to-end drop-in tests (-m gpu): the host-side mirror classes (Genotyper, GenotyperOutput,
+CrossIdentifier) and the CLI, driven like the reference, against the files the UNMODIFIED reference
+wrote for the same inputs (tests/golden/g2_inbred.json, g3_refine.json, g5_cross.json).
+Integer columns, probabilities and JSON must be identical; likelihood columns within 1e-12 relative
+(north_star allows 1e-6).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from snpmatch_amd.core import csmatch, parsers, snp_genotype, snpmatch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL = 1e-12
+
+
+def make_inputs(toy):
+    inp = parsers.ParseInputs("")
+    inp.load_snp_info(toy["s_chrs"], toy["s_pos"], toy["s_gt"], toy["s_wei"], toy["s_dp"])
+    return inp
+
+
+def make_g(toy):
+    return snp_genotype.Genotype.from_arrays(toy["snps"], toy["accs"], toy["positions"], toy["chrs"], toy["regions"])
+
+
+def cmp_scores_table(got_text, want_text, float_cols=(4, 5)):
+    got = [l.split("\t") for l in got_text.strip().split("\n")]
+    want = [l.split("\t") for l in want_text.strip().split("\n")]
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert len(g) == len(w)
+        for c in range(len(w)):
+            if c in float_cols:
+                a, b = float(g[c]), float(w[c])
+                assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= RTOL * abs(b), (g, w)
+            else:
+                assert g[c] == w[c], (c, g, w)
+
+
+def test_inbred_end_to_end_matches_reference_files(golden_dir, tmp_path):
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    gold = json.load(open(os.path.join(golden_dir, "g2_inbred.json")))
+    for skip in (False, True):
+        out = str(tmp_path / ("inbred%d" % skip))
+        gt = snpmatch.Genotyper(make_inputs(toy), make_g(toy), out, run_genotyper=True, skip_db_hets=skip)
+        want = gold["inbred_skip%d" % int(skip)]
+        cmp_scores_table(open(out + ".scores.txt").read(), want["scores.txt"])
+        assert json.load(open(out + ".matches.json")) == json.loads(want["matches.json"])
+        assert open(out + ".matches.json").read() == want["matches.json"]          # byte-identical JSON
+        assert gt.result.scores.dtype.kind == "i" and len(gt.commonSNPs[0]) == 2400
+
+
+def test_refine_matches_reference_files(golden_dir, tmp_path):
+    toy = np.load(os.path.join(golden_dir, "toy_db_refine.npz"))
+    gold = json.load(open(os.path.join(golden_dir, "g3_refine.json")))
+    out = str(tmp_path / "refine")
+    gt = snpmatch.Genotyper(make_inputs(toy), make_g(toy), out, run_genotyper=False)
+    gt.filter_tophits()
+    assert hasattr(gt, "result_fine") == gold["has_result_fine"]
+    cmp_scores_table(open(out + ".scores.txt").read(), gold["scores.txt"])
+    cmp_scores_table(open(out + ".refined.scores.txt").read(), gold["refined.scores.txt"])
+    assert open(out + ".matches.json").read() == gold["matches.json"]
+
+
+def cmp_window_table(got_text, want_text):
+    got = [l.split("\t") for l in got_text.strip().split("\n")]
+    want = [l.split("\t") for l in want_text.strip().split("\n")]
+    assert got[0] == want[0]
+    assert len(got) == len(want)
+    for g, w in zip(got[1:], want[1:]):
+        for c in range(8):
+            if c == 4:        # likelihood
+                assert abs(float(g[c]) - float(w[c])) <= RTOL * abs(float(w[c])), (g, w)
+            else:
+                assert g[c] == w[c], (c, g, w)
+
+
+def test_cross_end_to_end_matches_reference_files(golden_dir, tmp_path):
+    toy = np.load(os.path.join(golden_dir, "toy_db_cross.npz"))
+    gold = json.load(open(os.path.join(golden_dir, "g5_cross.json")))
+    for skip in (False, True):
+        out = str(tmp_path / ("cross%d" % skip))
+        ci = csmatch.CrossIdentifier(make_inputs(toy), make_g(toy), "athaliana_tair10", 300000, out,
+                                     run_identifier=True, skip_db_hets=skip)
+        want = gold["cross_skip%d" % int(skip)]
+        cmp_window_table(open(out + ".windowscore.txt").read(), want[".windowscore.txt"])
+        cmp_scores_table(open(out + ".scores.txt").read(), want[".scores.txt"])
+        assert open(out + ".scores.txt.matches.json").read() == want[".scores.txt.matches.json"]
+        assert os.path.exists(out + ".matches.json") == (".matches.json" in want)
+        if ".matches.json" in want:
+            assert json.load(open(out + ".matches.json")) == json.loads(want[".matches.json"])
+        assert len(ci.result.accs) == 30 + 45
+
+
+def test_get_window_data_api(golden_dir):
+    """CrossIdentifier.get_window_data (static, one window) keeps the reference's semantics."""
+    accs = np.array(["a", "b", "c", "d"])
+    f = csmatch.CrossIdentifier.get_window_data(7, accs, np.array([11.0, 10.25, 3.5, 11.0]), np.array([11, 11, 11, 11]))
+    assert list(f.columns) == ["acc", "snps_match", "snps_info", "score", "likelihood", "identical", "num_amb", "window_index"]
+    # likeliTest(11, 10.25) / 1.0 is far above lr_thres: only the two perfect matches are ambiguous
+    assert f["acc"].tolist() == ["a", "d"] and f["snps_match"].tolist() == [11, 11]
+    assert f["num_amb"].tolist() == [2, 2] and f["window_index"].tolist() == [7, 7]
+    assert f["likelihood"].tolist() == ["1.0", "1.0"] and f["score"].tolist() == ["1.0", "1.0"]
+    f = csmatch.CrossIdentifier.get_window_data(3, accs, np.array([10.9, 10.25, 3.5, 10.8]), np.array([11, 11, 11, 11]))
+    assert f["acc"].tolist() == ["a", "d"] and f["snps_match"].tolist() == [10, 10] and f["identical"].tolist() == [1.0, 1.0]
+    # every accession ambiguous -> empty frame (core/csmatch.py:57-60)
+    f = csmatch.CrossIdentifier.get_window_data(1, accs, np.array([5.0, 5.0, 5.0, 5.0]), np.array([5, 5, 5, 5]))
+    assert len(f) == 0
+
+
+def test_scalar_api_known_answers():
+    # /root/reference/tests/test_inbred.py:22-24
+    assert snpmatch.likeliTest(10, 3) == pytest.approx(122.8361221819443, rel=RTOL)
+    assert snpmatch.likeliTest(10, 0) is np.nan
+    with pytest.raises(AssertionError):
+        snpmatch.likeliTest(0, 10)
+    assert snpmatch.likeliTest(11, 11) == 1
+    s, n = snpmatch.matchGTsAccs(np.array([[1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]), np.array([[0, 1, -1], [1, 1, 2]], dtype=np.int8))
+    assert s.tolist() == [2.0, 1.0, 0.0] and n.tolist() == [2, 2, 1]
+    assert snpmatch.np_test_identity(np.array([98.0, 50.0]), np.array([100, 100]), error_rate=0.02).tolist() == [1, 0]
+
+
+def test_cli_inbred_and_cross(golden_dir, tmp_path):
+    """`python -m snpmatch_amd inbred|cross` on a native flat panel + .npz sample."""
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    gold = json.load(open(os.path.join(golden_dir, "g2_inbred.json")))
+    db = str(tmp_path / "toy.snpm")
+    snp_genotype.save_native(db, toy["snps"], toy["accs"], toy["positions"], toy["chrs"], toy["regions"])
+    sample = str(tmp_path / "sample.npz")
+    np.savez(sample, chr=toy["s_chrs"], pos=toy["s_pos"], gt=toy["s_gt"], wei=toy["s_wei"], dp=toy["s_dp"])
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = str(tmp_path / "cli_inbred")
+    r = subprocess.run([sys.executable, "-m", "snpmatch_amd", "inbred", "-i", sample, "-d", db, "-o", out],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    cmp_scores_table(open(out + ".scores.txt").read(), gold["inbred_skip0"]["scores.txt"])
+    assert open(out + ".matches.json").read() == gold["inbred_skip0"]["matches.json"]
+    out = str(tmp_path / "cli_cross")
+    r = subprocess.run([sys.executable, "-m", "snpmatch_amd", "cross", "-i", sample, "-d", db, "-b", "300000", "-o", out],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(out + ".windowscore.txt") and os.path.exists(out + ".scores.txt")
+    # missing input file -> exit code 1 with the reference's message (snpmatch/__init__.py:114-118)
+    r = subprocess.run([sys.executable, "-m", "snpmatch_amd", "inbred", "-i", str(tmp_path / "nope.vcf"), "-d", db],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "input file does not exist" in r.stderr

@@ -1,0 +1,97 @@
+"""Host logic that needs no GPU: position intersection, window segmentation, segregating SNPs,
+native panel format, drop-in import path."""
+import os
+
+import numpy as np
+
+from oracle import snpmatch_oracle as orc
+from snpmatch_amd.core import genomes, parsers, snp_genotype
+
+
+def toy_genotype(toy):
+    return snp_genotype.Genotype.from_arrays(toy["snps"], toy["accs"], toy["positions"], toy["chrs"], toy["regions"])
+
+
+def test_common_positions_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g6_common.npz"))
+    for name in g["names"]:
+        i1, i2 = snp_genotype.Genotype.get_common_positions(g[name + "_c1"], g[name + "_p1"], g[name + "_c2"], g[name + "_p2"])
+        assert np.array_equal(i1, g[name + "_i1"]), name
+        assert np.array_equal(i2, g[name + "_i2"]), name
+
+
+def test_positions_idxs_matches_reference_on_toy_db(golden_dir):
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    gold = np.load(os.path.join(golden_dir, "g2_inbred.npz"))
+    g = toy_genotype(toy)
+    c0, c1 = g.get_positions_idxs(toy["s_chrs"], toy["s_pos"])
+    assert np.array_equal(c0, gold["common_db"]) and np.array_equal(c1, gold["common_sample"])
+    # the region walk equals the generic path on awkward chromosome sets as well
+    rng = np.random.default_rng(0)
+    sc = np.array(["Chr3"] * 40 + ["chr1"] * 30 + ["Mt"] * 5)
+    sp = np.concatenate([np.sort(rng.choice(toy["positions"][4000:6000], 40, replace=False)),
+                         np.sort(rng.choice(toy["positions"][0:2000], 30, replace=False)), np.arange(1, 6)])
+    a = g.get_positions_idxs(sc, sp)
+    b = snp_genotype.Genotype.get_common_positions(g.g.chromosomes, g.g.positions, sc, sp)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and len(a[0]) == 70
+
+
+def test_windows_match_reference(golden_dir):
+    toy = np.load(os.path.join(golden_dir, "toy_db_cross.npz"))
+    gold = np.load(os.path.join(golden_dir, "g5_cross.npz"))
+    g = toy_genotype(toy)
+    genome = genomes.Genome("athaliana_tair10")
+    wg = list(genome.get_bins_genome(g.g, 300000))
+    ws = list(genome.get_bins_arrays(toy["s_chrs"], toy["s_pos"], 300000))
+    assert len(wg) == len(ws) == 399 == len(genome.window_table(300000))
+    assert np.array_equal([w[0] for w in wg], gold["win_chr_skip0"])
+    rows_db, rows_s, off = [], [], [0]
+    for e_g, e_s in zip(wg, ws):
+        gp = toy["positions"][e_g[2]]
+        sp = toy["s_pos"][e_s[2]]
+        rows_db += np.array(e_g[2], dtype=int)[np.isin(gp, sp)].tolist()
+        rows_s += np.array(e_s[2], dtype=int)[np.isin(sp, gp)].tolist()
+        off.append(len(rows_db))
+    assert np.array_equal(off, gold["win_off_skip0"])
+    assert np.array_equal(rows_db, gold["win_rows_db_skip0"]) and np.array_equal(rows_s, gold["win_rows_sample_skip0"])
+    assert genome.get_chr_ind("Chr3") == 2 and genome.get_chr_ind("7") is None
+
+
+def test_segregating_snps():
+    snps = np.array([[0, 0, 0, 1], [0, 1, -1, 0], [-1, -1, -1, 0], [1, 1, 1, 1], [2, 1, 1, 0], [0, -1, 0, 1]], dtype=np.int8)
+    g = snp_genotype.Genotype.from_arrays(np.repeat(snps, 3, axis=1), ["a%d" % i for i in range(12)],
+                                          np.arange(1, 7), ["1"], [(0, 6)])
+    # accessions 0,1,2 are copies of column 0; 3,4,5 of column 1 -> rows where col0 != col1 (both informative)
+    seg = g.identify_segregating_snps(np.array([0, 3]))
+    assert seg.tolist() == [1, 4]
+    assert g.identify_segregating_snps(np.arange(7)) is None          # more than half of the lines
+
+
+def test_native_panel_roundtrip(golden_dir, tmp_path):
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    path = str(tmp_path / "toy.snpm")
+    snp_genotype.save_native(path, toy["snps"], toy["accs"], toy["positions"], toy["chrs"], toy["regions"])
+    g = snp_genotype.Genotype(path, None)
+    assert g.g.snps.shape == toy["snps"].shape and np.array_equal(g.g.snps[[5, 77, 9999], :], toy["snps"][[5, 77, 9999], :])
+    assert g.accessions.tolist() == toy["accs"].tolist() and g.chrs.tolist() == ["1", "2", "3", "4", "5"]
+    assert np.array_equal(np.asarray(g.g_acc.snps[:, 3]), toy["snps"][:, 3])
+    assert len(g.g.chromosomes) == len(toy["positions"]) and g.g.chromosomes[2000] == "2"
+    npz = str(tmp_path / "toy.npz")
+    np.savez(npz, snps=toy["snps"], accessions=toy["accs"], positions=toy["positions"], chrs=toy["chrs"], chr_regions=toy["regions"])
+    g2 = snp_genotype.Genotype(npz, None)
+    assert np.array_equal(g2.g.positions, g.g.positions)
+
+
+def test_dropin_import_path():
+    from snpmatch.core import snpmatch as a
+    from snpmatch.core import csmatch as c
+    import snpmatch_amd.core.snpmatch as b
+    assert a is b and a.lr_thres == 3.841 and a.snp_thres == 4000 and a.prob_thres == 0.98 and c.chunk_size == 1000
+    for name in ("matchGTsAccs", "likeliTest", "get_fraction", "np_get_fraction", "np_binom_test", "np_test_identity",
+                 "GenotyperOutput", "Genotyper", "getHeterozygosity", "potatoGenotyper"):
+        assert hasattr(a, name), name
+    for name in ("CrossIdentifier", "convert_int64", "potatoCrossIdentifier"):
+        assert hasattr(c, name), name
+    import snpmatch
+    assert callable(snpmatch.main)
+    assert orc.get_fraction(1, 0) is np.nan and a.get_fraction(1, 0) is np.nan

@@ -1,0 +1,76 @@
+"""
+Input parsing (boundary producer of the hot path), pinned by the reference's own parse tests
+(/root/reference/tests/test_inbred.py:9-18) on the reference's sample files (tests/conftest.py:27-35;
+copied as data fixtures: tests/golden/701_501.filter.vcf.gz, 701_502.filter.bed).
+"""
+import gzip
+import json
+import os
+import shutil
+
+import numpy as np
+
+from snpmatch_amd.core import parsers
+
+
+def test_vcf_parse_reference_pins(golden_dir, tmp_path):
+    src = os.path.join(golden_dir, "701_501.filter.vcf.gz")
+    vcf = tmp_path / "701_501.filter.vcf"
+    with gzip.open(src, "rb") as fi, open(vcf, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    snps = parsers.ParseInputs(inFile=str(vcf), logDebug=True)
+    assert len(snps.chrs) == 7545                       # test_inbred.py:10
+    assert snps.chrs[0] == 'Chr1'                       # :11
+    assert snps.gt[0] == '0/0'                          # :12
+    vals, counts = np.unique(snps.gt, return_counts=True)
+    assert dict(zip(vals.tolist(), counts.tolist())) == {'0/0': 6579, '0/1': 110, '1/1': 856}
+    assert snps.pos[0] == 13226
+    # PL 0,9,87 -> exp(-PL/10) (core/parsers.py:147-150); depth from INFO/DP
+    np.testing.assert_array_equal(snps.wei[0], np.exp(np.array([0.0, 9.0, 87.0]) / (-10)))
+    assert snps.wei.shape == (7545, 3) and snps.dp[0] == 3
+    assert np.all((snps.wei > 0) & (snps.wei <= 1))
+    # cache + stats files, as the reference writes them (core/parsers.py:85-86, 96-116)
+    assert os.path.isfile(str(vcf) + ".snpmatch.npz")
+    stats = json.load(open(str(vcf) + ".snpmatch.stats.json"))
+    assert stats["num_of_snps"] == 7545 and stats["interpretation"]["case"] == 0
+    assert stats["percent_heterozygosity"] == 110 / 7545.0
+    again = parsers.ParseInputs(inFile=str(vcf), logDebug=False)          # served from the .npz cache
+    assert np.array_equal(again.pos, snps.pos) and np.array_equal(again.wei, snps.wei)
+    assert np.array_equal(again.gt, snps.gt) and np.array_equal(again.chrs, snps.chrs)
+    # gz input goes through the same reader
+    gz = tmp_path / "copy.vcf.gz"
+    shutil.copyfile(src, gz)
+    z = parsers.ParseInputs(inFile=str(gz), logDebug=False)
+    assert len(z.chrs) == 7545 and np.array_equal(z.wei, snps.wei)
+
+
+def test_bed_parse_reference_pins(golden_dir, tmp_path):
+    bed = tmp_path / "701_502.filter.bed"
+    shutil.copyfile(os.path.join(golden_dir, "701_502.filter.bed"), bed)
+    snps = parsers.ParseInputs(inFile=str(bed), logDebug=True)
+    assert len(snps.chrs) == 10000                      # test_inbred.py:15
+    assert snps.chrs[0] == '1'                          # :16
+    assert snps.gt[0] == '0/0'                          # :17
+    assert snps.pos[1] == 51103                         # :18
+    # hard weights: one-hot on the called genotype (core/parsers.py:126-129)
+    assert set(np.unique(snps.wei).tolist()) <= {0.0, 1.0}
+    assert np.all(snps.wei.sum(axis=1) <= 1.0)
+    codes = parsers.parseGT(snps.gt)
+    assert np.all(snps.wei[codes == 0, 0] == 1) and np.all(snps.wei[codes == 1, 2] == 1)
+    # the reference crashes on BED depth "NA" (np.nanmean("NA")); here the stats file reports NaN
+    stats = json.load(open(str(bed) + ".snpmatch.stats.json"))
+    assert stats["num_of_snps"] == 10000 and np.isnan(stats["depth"])
+
+
+def test_parse_gt_and_chr_names():
+    gt = np.array(["0/0", "1/1", "0/1", "1/0", "./.", "1/2"])
+    assert parsers.parseGT(gt).tolist() == [0, 1, 2, 2, -1, 0]
+    assert parsers.parseGT(np.array(["0|0", "1|1", "0|1", ".|."])).tolist() == [0, 1, 2, -1]
+    assert parsers.parseGT(np.array(["0", "1", "2"])).tolist() == [0, 1, 2]
+    assert parsers.parseGT(np.array([])).tolist() == []
+    assert parsers.snp_binary_to_gt([-1, 0, 1, 2]).tolist() == [b"./.", b"0/0", b"1/1", b"0/1"]
+    ins = parsers.ParseInputs("")
+    ins.load_snp_info(["Chr2", "chr2", "CHR1", "1", "M"], [1, 2, 3, 4, 5], "", np.nan, 0)
+    ins.filter_chr_names()
+    assert ins.g_chrs.tolist() == ["2", "2", "1", "1", "M"]
+    assert ins.g_chrs_ids.tolist() == ["2", "1", "M"]           # order of first appearance
