@@ -32,12 +32,6 @@ N_ACC_TOTAL = 10000
 SNPS_PER_GPU_UNIT = 6_250_000    # x N ranks
 
 
-def shard_bounds(n_acc, world):
-    """accession shards with boundaries on multiples of 4 (the synthetic generator hashes quads)."""
-    per = ((n_acc + world - 1) // world + 3) // 4 * 4
-    return [(min(r * per, n_acc), min((r + 1) * per, n_acc)) for r in range(world)], per
-
-
 def make_sample(n_snp, seed, planted, err=0.02, frac_pl=0.8, block=2_000_000):
     """weights [n_snp,3] of a sample planted on accession `planted` (numpy twin of the device panel)."""
     from snpmatch_amd import synth
@@ -52,7 +46,7 @@ def make_sample(n_snp, seed, planted, err=0.02, frac_pl=0.8, block=2_000_000):
     return wei
 
 
-def cpu_baseline(panel, wei, n_acc, seconds_target=15.0):
+def cpu_baseline(panel, wei, n_acc, seconds_target=20.0):
     """Reference CPU path (numpy, same expression graph as matchGTsAccs) on a bounded sample of the
     same workload: 1000-row chunks of the resident panel, single thread as the reference runs."""
     from oracle import snpmatch_oracle as orc
@@ -61,7 +55,7 @@ def cpu_baseline(panel, wei, n_acc, seconds_target=15.0):
     t0 = time.perf_counter()
     orc.match_gts_accs_graph(wei[:chunk], db)
     t1 = time.perf_counter() - t0
-    n_chunks = int(max(2, min(40, seconds_target / max(t1, 1e-3))))
+    n_chunks = int(max(2, min(100, seconds_target / max(t1, 1e-3))))
     db = panel.download_rows(0, chunk * n_chunks)
     t0 = time.perf_counter()
     s, n = orc.genotyper_scores(wei[:chunk * n_chunks], db, chunk, False, match=orc.match_gts_accs_graph)
@@ -94,6 +88,7 @@ def main():
     import torch
     import torch.distributed as dist
     from snpmatch_amd import engine
+    from snpmatch_amd.dist import AccessionShards
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
@@ -109,9 +104,8 @@ def main():
 
     n_acc = args.n_acc
     n_snp = args.snps_per_gpu_unit * world
-    bounds, per = shard_bounds(n_acc, world)
-    a0, a1 = bounds[rank]
-    n_loc = a1 - a0
+    shards = AccessionShards(n_acc, world, rank, dev)
+    a0, n_loc, per = shards.a0, shards.n_local, shards.per
     mode = {"exact": engine.MODE_EXACT, "strict": engine.MODE_STRICT, "fast": engine.MODE_FAST}[args.mode]
 
     t_setup = time.perf_counter()
@@ -120,11 +114,7 @@ def main():
     wei = make_sample(n_snp, SEED, PLANTED)
     query = engine.Query(panel, None, wei)
     # results land in torch tensors (plumbing for the all-gather); padded to the common shard size
-    score_loc = torch.zeros(per, dtype=torch.float64, device=dev)
-    ninfo_loc = torch.zeros(per, dtype=torch.int64, device=dev)
-    query.bind_outputs(score_loc.data_ptr(), ninfo_loc.data_ptr())
-    score_all = torch.zeros(per * world, dtype=torch.float64, device=dev)
-    ninfo_all = torch.zeros(per * world, dtype=torch.int64, device=dev)
+    query.bind_outputs(shards.score_loc.data_ptr(), shards.ninfo_loc.data_ptr())
     lik = torch.zeros(per * world, dtype=torch.float64, device=dev)
     lrt = torch.zeros(per * world, dtype=torch.float64, device=dev)
     torch.cuda.synchronize()
@@ -135,12 +125,7 @@ def main():
     def step():
         _, _, nre = query.run_device(args.chunk, False, mode)
         n_reeval[0] += nre
-        if world > 1:
-            dist.all_gather_into_tensor(score_all, score_loc)
-            dist.all_gather_into_tensor(ninfo_all, ninfo_loc)
-            src_s, src_n = score_all, ninfo_all
-        else:
-            src_s, src_n = score_loc, ninfo_loc
+        src_s, src_n = shards.gather()          # the one collective of the path (no-op at N=1)
         # padded tail entries are (0, 0) -> NaN likelihood, ignored by nanmin
         ctx.likelihood_device(src_s.data_ptr(), src_n.data_ptr(), 1, per * world, lik.data_ptr(), lrt.data_ptr(),
                               truncate=True)
@@ -182,8 +167,7 @@ def main():
 
     # correctness of what was timed: top hit is the planted accession, counts agree with the CPU path
     top = int(np.nanargmin(lik.cpu().numpy()))
-    r_of, off = divmod(top, per)
-    result_ok = (bounds[r_of][0] + off == PLANTED)
+    result_ok = (shards.to_global(top) == PLANTED)
 
     cpu = None
     parity = None

@@ -139,6 +139,10 @@ int snpm_binom_identity(snpm_ctx *ctx, const double *x, const int64_t *n, int64_
                         double pthres, int64_t *out, double *sf);
 
 /* ---------------------------------------------------------------- profiling (HIP events on the ctx stream) */
+/* PMC calibration: reads the whole panel once with the access shape of the scoring kernel (4 B per
+   lane, non-temporal); *bytes_read = n_snp * pitch.  Used by tools/pmc_traffic.py to calibrate
+   FETCH_SIZE on a known byte count. */
+int snpm_debug_stream_read(snpm_panel *panel, int64_t *bytes_read);
 int snpm_profile_enable(snpm_ctx *ctx, int on);
 int snpm_profile_reset(snpm_ctx *ctx);
 /* kernel: "fast", "strict", "reduce", "scan", "likelihood", "synth", "canon".  Synchronises the stream. */

@@ -30,7 +30,7 @@ SYMBOLS = [
     "snpm_panel_upload_wait", "snpm_panel_download_rows", "snpm_panel_fill_synthetic", "snpm_query_create",
     "snpm_query_free", "snpm_query_bind_outputs", "snpm_query_run", "snpm_query_run_device", "snpm_query_error_bound",
     "snpm_query_run_windows", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
-    "snpm_binom_identity", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
+    "snpm_binom_identity", "snpm_debug_stream_read", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
 ]
 
 _lib = None
@@ -81,6 +81,7 @@ def load():
     lib.snpm_likelihood.argtypes = [p, p, p, i64, i64, ci, dbl, p, p]
     lib.snpm_likelihood_device.argtypes = [p, p, p, i64, i64, ci, dbl, p, p, C.POINTER(ci)]
     lib.snpm_binom_identity.argtypes = [p, p, p, i64, dbl, dbl, p, p]
+    lib.snpm_debug_stream_read.argtypes = [p, C.POINTER(i64)]
     lib.snpm_profile_enable.argtypes = [p, ci]
     lib.snpm_profile_reset.argtypes = [p]
     lib.snpm_profile_read.argtypes = [p, C.c_char_p, C.POINTER(i64), C.POINTER(dbl)]

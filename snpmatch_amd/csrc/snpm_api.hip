@@ -1038,6 +1038,24 @@ int snpm_binom_identity(snpm_ctx *ctx, const double *x, const int64_t *n, int64_
     return SNPM_OK;
 }
 
+// PMC calibration helper: stream the whole panel once (known byte count = n_snp * pitch)
+int snpm_debug_stream_read(snpm_panel *p, int64_t *bytes_read)
+{
+    if (!p) return SNPM_ERR_BADARG;
+    snpm_ctx *ctx = p->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->ws_flags, sizeof(int));
+    if (rc) return rc;
+    const int64_t n_dwords = p->n_snp * p->pitch / 4;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_dwords + 1023) / 1024, (int64_t)ctx->n_cu * 8));
+    hipLaunchKernelGGL(k_calib_read, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t *)p->d, n_dwords,
+                       (uint32_t *)ctx->ws_flags.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (bytes_read) *bytes_read = n_dwords * 4;
+    return SNPM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- profiling
 int snpm_profile_enable(snpm_ctx *ctx, int on)
 {

@@ -554,4 +554,25 @@ __global__ void k_synth(uint32_t *__restrict__ db, int64_t pitch, int64_t n_snp,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PMC calibration: reads `n_dwords` dwords exactly once with the access shape of k_fast (one dword
+// per lane, 256 contiguous bytes per wave instruction, non-temporal), so that FETCH_SIZE can be
+// calibrated on a known byte count (MI355X_MICROARCH.md, HBM section).  The xor keeps the loads live.
+__global__ void __launch_bounds__(256)
+k_calib_read(const uint32_t *__restrict__ p, int64_t n_dwords, uint32_t *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t acc = 0;
+    for (; i + 3 * stride < n_dwords; i += 4 * stride) {
+        const uint32_t a = __builtin_nontemporal_load(p + i);
+        const uint32_t b = __builtin_nontemporal_load(p + i + stride);
+        const uint32_t c = __builtin_nontemporal_load(p + i + 2 * stride);
+        const uint32_t d = __builtin_nontemporal_load(p + i + 3 * stride);
+        acc ^= a ^ b ^ c ^ d;
+    }
+    for (; i < n_dwords; i += stride) acc ^= __builtin_nontemporal_load(p + i);
+    if (acc == 0x9e3779b9u) out[0] = acc;       // practically never true; prevents dead-code elimination
+}
+
 }  // namespace snpm

@@ -1,0 +1,80 @@
+"""
+Accession-axis sharding over the GPUs of one node (one process per GPU, torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" for CPU rehearsals).
+
+Every reduction of the hot path runs over the SNP axis (core/snpmatch.py:84-88), so accession columns
+never interact: rank r owns columns [a0, a1) of every SNP row, scores them locally with no data-path
+collective, and ONE all-gather of the per-accession results (score fp64, ninfo int64: 16 B per
+accession, latency-bound) makes the full vectors available everywhere for the likelihood step, which
+needs the global minimum (core/snpmatch.py:112).  Shard boundaries are multiples of 4 accessions (the
+synthetic generator hashes accession quads); shards are padded to a common length for the collective.
+"""
+import numpy as np
+
+
+def shard_bounds(n_acc, world, align=4):
+    """[(a0, a1)] per rank and the common padded shard length."""
+    per = ((n_acc + world - 1) // world + align - 1) // align * align
+    return [(min(r * per, n_acc), min((r + 1) * per, n_acc)) for r in range(world)], per
+
+
+class AccessionShards(object):
+    """Buffers and the collective for one rank of an accession-sharded job."""
+
+    def __init__(self, n_acc, world=1, rank=0, device="cpu", group=None):
+        import torch
+        self.torch = torch
+        self.n_acc, self.world, self.rank, self.group = int(n_acc), int(world), int(rank), group
+        self.bounds, self.per = shard_bounds(n_acc, world)
+        self.a0, self.a1 = self.bounds[rank]
+        self.n_local = self.a1 - self.a0
+        self.device = device
+        # padded tail entries stay (score 0, ninfo 0): NaN likelihood, ignored by nanmin
+        self.score_loc = torch.zeros(self.per, dtype=torch.float64, device=device)
+        self.ninfo_loc = torch.zeros(self.per, dtype=torch.int64, device=device)
+        if world > 1:
+            self.score_all = torch.zeros(self.per * world, dtype=torch.float64, device=device)
+            self.ninfo_all = torch.zeros(self.per * world, dtype=torch.int64, device=device)
+        else:
+            self.score_all, self.ninfo_all = self.score_loc, self.ninfo_loc
+
+    @property
+    def padded_len(self):
+        return self.per * self.world
+
+    def set_local(self, score, ninfo):
+        """host results of this rank's shard -> the local buffers (CPU rehearsals / host API)."""
+        t = self.torch
+        self.score_loc[:self.n_local] = t.as_tensor(np.asarray(score, dtype=np.float64), device=self.device)
+        self.ninfo_loc[:self.n_local] = t.as_tensor(np.asarray(ninfo, dtype=np.int64), device=self.device)
+
+    def gather(self):
+        """the single collective of the path: all-gather of (score, ninfo) along the accession axis"""
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(self.score_all, self.score_loc, group=self.group)
+            dist.all_gather_into_tensor(self.ninfo_all, self.ninfo_loc, group=self.group)
+        return self.score_all, self.ninfo_all
+
+    def padded_index(self):
+        """positions of accessions 0..n_acc-1 inside the padded gathered vectors"""
+        idx = [np.arange(a0, a1) - a0 + r * self.per for r, (a0, a1) in enumerate(self.bounds)]
+        return np.concatenate(idx) if idx else np.zeros(0, dtype=int)
+
+    def unpad(self, full):
+        """gathered padded tensor -> numpy array of length n_acc in accession order"""
+        return full.detach().cpu().numpy()[self.padded_index()]
+
+    def to_global(self, padded_pos):
+        r, off = divmod(int(padded_pos), self.per)
+        return self.bounds[r][0] + off
+
+
+def sharded_genotyper_scores(score_local_fn, n_acc, world, rank, device="cpu", group=None):
+    """Run `score_local_fn(a0, a1) -> (score, ninfo)` on this rank's accession shard and return the
+    full-length (score, ninfo) numpy vectors on every rank."""
+    sh = AccessionShards(n_acc, world, rank, device, group)
+    s, n = score_local_fn(sh.a0, sh.a1)
+    sh.set_local(s, n)
+    fs, fn = sh.gather()
+    return sh.unpad(fs), sh.unpad(fn)

@@ -174,6 +174,12 @@ class Panel(object):
     def fill_synthetic(self, seed, snp0=0, acc0=0):
         check(self.ctx.lib.snpm_panel_fill_synthetic(self.h, C.c_uint64(int(seed)), int(snp0), int(acc0)), self.ctx.h)
 
+    def stream_read(self):
+        """PMC calibration: read every panel byte once; returns the byte count."""
+        n = C.c_int64(0)
+        check(self.ctx.lib.snpm_debug_stream_read(self.h, C.byref(n)), self.ctx.h)
+        return n.value
+
     def free(self):
         if self.h:
             for q in list(self._queries):

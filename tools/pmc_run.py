@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Workload for the PMC passes (run under `rocprofv3 --pmc ...`): the bench panel shard, one calibration
+read of known size (k_calib_read) and a few launches of the scoring kernel (k_fast)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from snpmatch_amd import engine  # noqa: E402
+
+n_acc = int(os.environ.get("PMC_N_ACC", "10000"))
+n_snp = int(os.environ.get("PMC_N_SNP", "6250000"))
+ctx = engine.Context(0)
+panel = engine.Panel(ctx, n_snp, n_acc)
+panel.fill_synthetic(bench.SEED)
+wei = bench.make_sample(n_snp, bench.SEED, bench.PLANTED)
+q = engine.Query(panel, None, wei)
+for _ in range(2):
+    print("calib bytes", panel.stream_read())
+for _ in range(3):
+    q.run(1000, False, engine.MODE_FAST)
+print("alg bytes per k_fast launch", n_snp * (n_acc + 24))

@@ -2,6 +2,6 @@
 # usage: tools_bench_shape.sh N_ACC SNPS "ENV=.." ...
 nacc=$1; snps=$2; shift 2
 for v in "$@"; do
-  out=$(env $v timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --mode fast --n-acc $nacc --snps-per-gpu-unit $snps 2>/dev/null)
+  out=$(env $v timeout -k 10 300 python "$(dirname $0)/../bench.py" --steps 5 --warmup 2 --no-cpu-baseline --mode fast --n-acc $nacc --snps-per-gpu-unit $snps 2>/dev/null)
   echo "$out" | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%6d x %9d %-28s k_fast %.0f GB/s (%.3f)  avg %.3f ms  step %.3f ms' % ($nacc, $snps, '$v', d['roofline']['achieved'], d['roofline']['frac'], d['roofline']['avg_ms'], d['ms_per_step']))"
 done
