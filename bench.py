@@ -75,6 +75,10 @@ def main():
     ap.add_argument("--mode", default="exact", choices=["exact", "strict", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=1000)
+    # rehearsal of the N>1 code path on a one-GPU box (never used by the driver): gloo instead of
+    # RCCL and every rank on device 0
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--all-ranks-on-device0", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,11 +96,16 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
+    if args.all_ranks_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     ctx = engine.Context(local_rank)
     stream = torch.cuda.current_stream()
@@ -199,7 +208,7 @@ def main():
                             % (n_loc, n_snp, n_snp * panel.pitch / 1e9, n_acc, n_snp),
                 "n_acc": n_acc, "n_snp": n_snp, "acc_per_gpu": n_loc, "mode": args.mode, "chunk": args.chunk,
                 "sample": "planted accession %d, 2%% error, 80%% PL weights" % PLANTED,
-                "parallelism": "acc-shard x%d + all-gather" % world,
+                "parallelism": "acc-shard x%d + all-gather (%s)" % (world, args.backend if world > 1 else "none"),
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

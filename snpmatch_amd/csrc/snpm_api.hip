@@ -84,6 +84,8 @@ struct snpm_query {
     long double wsum = 0;               // sum of wmax
     bool all_integer = false;
     std::map<int64_t, double> eref_cache;  // chunk -> E_ref
+    int64_t *d_chunk_off = nullptr;        // device copy of the chunk offsets for `chunk_off_chunk`
+    int64_t chunk_off_chunk = -1, chunk_off_nseg = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -310,7 +312,7 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
     }
     {
         ProfScope ps(ctx, PK_REDUCE);
-        const int thr = 256;
+        const int thr = 64;       // one wave per block: narrow panels still spread over many CUs
         hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
                            (const double *)ctx->ws_part_score.p, (const uint32_t *)ctx->ws_part_miss.p,
                            q->n > 0 ? g.n_parts : 0, p->pitch, p->n_acc, q->n, q->d_score, q->d_ninfo);
@@ -377,6 +379,8 @@ int upload_seg_off(snpm_ctx *ctx, const std::vector<int64_t> &off)
     return SNPM_OK;
 }
 
+int ensure_chunk_offsets(snpm_query *q, int64_t chunk);
+
 std::vector<int64_t> chunk_offsets(int64_t n, int64_t chunk)
 {
     std::vector<int64_t> off;
@@ -384,6 +388,25 @@ std::vector<int64_t> chunk_offsets(int64_t n, int64_t chunk)
     off.push_back(n);
     if (n == 0) off.assign(1, 0);
     return off;
+}
+
+// device-resident chunk offsets of a query, rebuilt only when `chunk` changes
+int ensure_chunk_offsets(snpm_query *q, int64_t chunk)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    if (q->d_chunk_off && q->chunk_off_chunk == chunk) return SNPM_OK;
+    std::vector<int64_t> off = chunk_offsets(q->n, chunk);
+    if (q->d_chunk_off) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(q->d_chunk_off));
+        q->d_chunk_off = nullptr;
+    }
+    HIPCHK(ctx, hipMalloc((void **)&q->d_chunk_off, off.size() * sizeof(int64_t)));
+    HIPCHK(ctx, hipMemcpyAsync(q->d_chunk_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    q->chunk_off_chunk = chunk;
+    q->chunk_off_nseg = (int64_t)off.size() - 1;
+    return SNPM_OK;
 }
 
 // ---- rigorous error bounds (see DESIGN.md "Exactness") -----------------------------------------
@@ -710,6 +733,7 @@ int snpm_query_free(snpm_query *q)
     if (q->d_row_idx) (void)hipFree(q->d_row_idx);
     if (q->d_w) (void)hipFree(q->d_w);
     if (q->d_lut) (void)hipFree(q->d_lut);
+    if (q->d_chunk_off) (void)hipFree(q->d_chunk_off);
     if (q->own_score) (void)hipFree(q->own_score);
     if (q->own_ninfo) (void)hipFree(q->own_ninfo);
     delete q;
@@ -755,17 +779,16 @@ int snpm_query_run_device(snpm_query *q, int64_t chunk, int skip_hets, int mode,
     int64_t n_flag = 0;
 
     if (mode == SNPM_MODE_STRICT) {
-        std::vector<int64_t> off = chunk_offsets(q->n, chunk);
-        const int64_t n_seg = (int64_t)off.size() - 1;
-        rc = upload_seg_off(ctx, off);
+        rc = ensure_chunk_offsets(q, chunk);
         if (rc) return rc;
-        rc = run_strict_segments(q, skip, (const int64_t *)ctx->ws_seg_off.p, n_seg, nullptr, p->n_acc, p->pitch);
+        const int64_t n_seg = q->chunk_off_nseg;
+        rc = run_strict_segments(q, skip, q->d_chunk_off, n_seg, nullptr, p->n_acc, p->pitch);
         if (rc) return rc;
         ProfScope ps(ctx, PK_SCAN);
         const int thr = 256;
         hipLaunchKernelGGL(k_scan, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
                            (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
-                           (const int64_t *)ctx->ws_seg_off.p, n_seg, p->pitch, p->n_acc, q->d_score, q->d_ninfo);
+                           q->d_chunk_off, n_seg, p->pitch, p->n_acc, q->d_score, q->d_ninfo);
         HIPCHK(ctx, hipGetLastError());
     } else {
         FastGeom g;
@@ -786,27 +809,31 @@ int snpm_query_run_device(snpm_query *q, int64_t chunk, int skip_hets, int mode,
             }
             n_flag = (int64_t)cols.size();
             if (n_flag > 0) {
-                std::vector<int64_t> off = chunk_offsets(q->n, chunk);
-                const int64_t n_seg = (int64_t)off.size() - 1;
-                rc = upload_seg_off(ctx, off);
+                rc = ensure_chunk_offsets(q, chunk);
                 if (rc) return rc;
+                const int64_t n_seg = q->chunk_off_nseg;
                 rc = ensure(ctx, ctx->ws_cols, cols.size() * sizeof(int32_t));
                 if (rc) return rc;
                 HIPCHK(ctx, hipMemcpyAsync(ctx->ws_cols.p, cols.data(), cols.size() * sizeof(int32_t),
                                            hipMemcpyHostToDevice, ctx->stream));
                 const int64_t ld = ((n_flag + 63) / 64) * 64;
-                rc = run_strict_segments(q, skip, (const int64_t *)ctx->ws_seg_off.p, n_seg, (const int32_t *)ctx->ws_cols.p,
-                                         n_flag, ld);
+                rc = run_strict_segments(q, skip, q->d_chunk_off, n_seg, (const int32_t *)ctx->ws_cols.p, n_flag, ld);
                 if (rc) return rc;
                 rc = ensure(ctx, ctx->ws_tmp_score, (size_t)ld * sizeof(double));
                 if (rc) return rc;
                 const int thr = 256;
                 {
                     ProfScope ps(ctx, PK_SCAN);
-                    hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_flag + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
-                                       (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
-                                       (const int64_t *)ctx->ws_seg_off.p, n_seg, ld, n_flag, (double *)ctx->ws_tmp_score.p,
-                                       (int64_t *)nullptr);
+                    if (n_flag <= 64) {
+                        hipLaunchKernelGGL(k_scan_few, dim3(1), dim3(256), 0, ctx->stream,
+                                           (const double *)ctx->ws_seg_score.p, n_seg, ld, (int)n_flag,
+                                           (double *)ctx->ws_tmp_score.p);
+                    } else {
+                        hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_flag + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                                           (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
+                                           q->d_chunk_off, n_seg, ld, n_flag,
+                                           (double *)ctx->ws_tmp_score.p, (int64_t *)nullptr);
+                    }
                     HIPCHK(ctx, hipGetLastError());
                 }
                 hipLaunchKernelGGL(k_patch, dim3((unsigned)((n_flag + thr - 1) / thr)), dim3(thr), 0, ctx->stream,

@@ -265,6 +265,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
 }
 
 // Ordered sum of the per-part partials: score[a] = ((p0 + p1) + p2) + ..., ninfo[a] = n - sum(miss).
+// Loads are issued 8 ahead of the (ordered) adds.
 __global__ void k_reduce(const double *__restrict__ part_score, const uint32_t *__restrict__ part_miss,
                          int64_t n_parts, int64_t ld, int64_t n_acc, int64_t n_rows, double *__restrict__ score,
                          int64_t *__restrict__ ninfo)
@@ -273,7 +274,22 @@ __global__ void k_reduce(const double *__restrict__ part_score, const uint32_t *
     if (a >= n_acc) return;
     double s = 0.0;
     int64_t m = 0;
-    for (int64_t p = 0; p < n_parts; ++p) {
+    int64_t p = 0;
+    for (; p + 8 <= n_parts; p += 8) {
+        double v[8];
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u] = part_score[(p + u) * ld + a];
+            c[u] = part_miss[(p + u) * ld + a];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s = s + v[u];
+            m += c[u];
+        }
+    }
+    for (; p < n_parts; ++p) {
         s = s + part_score[p * ld + a];
         m += part_miss[p * ld + a];
     }
@@ -349,7 +365,7 @@ k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__r
     const int64_t r0 = seg_off[seg], r1 = seg_off[seg + 1];
     double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
     uint32_t miss = 0;
-    constexpr int U = 8;
+    constexpr int U = 32;                 // byte loads in flight per lane (each its own cache line)
     int64_t r = r0;
     for (; r + U <= r1; r += U) {
         int b[U];
@@ -380,7 +396,9 @@ k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__r
     out_miss[seg * ld + i] = miss;
 }
 
-// total[i] = (((0 + s0) + s1) + ...) over non-empty segments; ninfo[i] = n_rows - sum(miss)
+// total[i] = (((0 + s0) + s1) + ...) over the segments in order; ninfo[i] = n_rows - sum(miss).
+// The adds are sequential by contract (ScoreList += chunk, core/snpmatch.py:224); the loads are not:
+// 8 are issued ahead of the adds that consume them.
 __global__ void k_scan(const double *__restrict__ seg_score, const uint32_t *__restrict__ seg_miss,
                        const int64_t *__restrict__ seg_off, int64_t n_seg, int64_t ld, int64_t ncols,
                        double *__restrict__ tot_score, int64_t *__restrict__ tot_ninfo)
@@ -389,12 +407,59 @@ __global__ void k_scan(const double *__restrict__ seg_score, const uint32_t *__r
     if (i >= ncols) return;
     double s = 0.0;
     int64_t m = 0;
-    for (int64_t k = 0; k < n_seg; ++k) {
+    int64_t k = 0;
+    for (; k + 8 <= n_seg; k += 8) {
+        double v[8];
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u] = seg_score[(k + u) * ld + i];
+            c[u] = seg_miss[(k + u) * ld + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s = s + v[u];
+            m += c[u];
+        }
+    }
+    for (; k < n_seg; ++k) {
         s = s + seg_score[k * ld + i];
         m += seg_miss[k * ld + i];
     }
     tot_score[i] = s;
     if (tot_ninfo) tot_ninfo[i] = (seg_off[n_seg] - seg_off[0]) - m;
+}
+
+// Same result for a SHORT column list (ncols <= 64, one block): the segment sums of a tile are
+// fetched by all 256 threads in parallel into LDS, then one thread per column adds them in order.
+constexpr int SCAN_TILE_ELEMS = 4096;
+__global__ void __launch_bounds__(256)
+k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, int ncols, double *__restrict__ tot_score)
+{
+    __shared__ double tile[SCAN_TILE_ELEMS];
+    const int ts = SCAN_TILE_ELEMS / ncols;          // segments per tile
+    double s = 0.0;
+    for (int64_t base = 0; base < n_seg; base += ts) {
+        const int nseg = (int)((n_seg - base < ts) ? (n_seg - base) : ts);
+        for (int e = threadIdx.x; e < nseg * ncols; e += blockDim.x) {
+            const int sg = e / ncols, c = e - sg * ncols;
+            tile[e] = seg_score[(base + sg) * ld + c];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < ncols) {
+            int sg = 0;
+            for (; sg + 16 <= nseg; sg += 16) {          // LDS reads batched ahead of the dependent adds
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = tile[(sg + u) * ncols + threadIdx.x];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s = s + v[u];
+            }
+            for (; sg < nseg; ++sg) s = s + tile[sg * ncols + threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x < ncols) tot_score[threadIdx.x] = s;
 }
 
 // per-segment ninfo [n_seg, n_acc] i64 and score copy-out into a dense [n_seg, n_acc] host-shaped layout
