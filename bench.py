@@ -108,8 +108,12 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     ctx = engine.Context(local_rank)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)           # library kernels and torch collectives share one stream
+    # One dedicated (non-default) stream for everything: the library's kernels are launched on it and
+    # torch.distributed orders its collectives against torch's CURRENT stream, so the all-gather
+    # cannot start before the scores it gathers are written, with no host synchronisation.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
 
     n_acc = args.n_acc
     n_snp = args.snps_per_gpu_unit * world

@@ -43,7 +43,15 @@ class Context(object):
             pass
 
     def set_stream(self, hip_stream):
-        check(self.lib.snpm_set_stream(self.h, C.c_void_p(hip_stream) if hip_stream else None), self.h)
+        """Launch the library's kernels on the given hipStream_t handle (e.g. torch.cuda.Stream().cuda_stream).
+        None restores the library's own stream.  Handle 0 (the legacy default stream) is refused: pass a
+        real stream so that ordering with the caller's other work is explicit."""
+        if hip_stream is None:
+            check(self.lib.snpm_set_stream(self.h, None), self.h)
+            return
+        if int(hip_stream) == 0:
+            raise ValueError("set_stream needs a non-default stream handle (got 0); use torch.cuda.Stream()")
+        check(self.lib.snpm_set_stream(self.h, C.c_void_p(int(hip_stream))), self.h)
 
     def synchronize(self):
         check(self.lib.snpm_synchronize(self.h), self.h)

@@ -33,6 +33,21 @@ def panel_values(seed, snp0, n_snp, acc0, n_acc):
     return out[:, :n_acc]
 
 
+def panel_rows(seed, rows, acc0, n_acc):
+    """panel_values for an arbitrary list of SNP rows (int8 [len(rows), n_acc])."""
+    assert acc0 % 4 == 0
+    rows = np.asarray(rows, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        nq = (n_acc + 3) // 4
+        quad = (np.arange(nq, dtype=np.uint64) + np.uint64(acc0 // 4))[None, :]
+        h = _splitmix64(_splitmix64(np.uint64(seed) ^ (rows[:, None] * np.uint64(0xD6E8FEB86659FD93))) + quad)
+        out = np.empty((len(rows), nq * 4), dtype=np.int8)
+        for j in range(4):
+            u = ((h >> np.uint64(16 * j)) & np.uint64(0xFFFF)).astype(np.int64)
+            out[:, j::4] = np.where(u < 3277, -1, np.where(u < 42598, 0, np.where(u < 64225, 1, 2))).astype(np.int8)
+    return out[:, :n_acc]
+
+
 def sample_weights(rng, codes, frac_pl=0.8):
     """[n,3] weights: frac_pl of the rows PL-derived exp(-PL/10) (integer PL in 1..255, 0 for the
     called genotype), the rest hard one-hot (core/parsers.py:132-150)."""

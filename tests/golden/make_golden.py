@@ -25,6 +25,7 @@ Outputs (all under tests/golden/):
   g4_likelihood.npz  likeliTest / calculate_likelihoods grid
   g5_cross.npz/json  per-window scores, get_window_data rows, np_test_identity, cross files' text
   g6_common.npz      get_common_positions edge cases
+  g7_cross_*         F1-like and F2-like samples through the whole cross pipeline (interpreter cases >= 3)
 """
 import io
 import json
@@ -411,11 +412,92 @@ def g6_common():
     print("g6: %d cases" % len(names))
 
 
+# ----------------------------------------------------------------------------- G7: cross interpreter cases
+def cross_sample(rng, toy, kind):
+    """samples that drive cross_interpreter (core/csmatch.py:131-186) into its F1 / F2 branches"""
+    snps, positions, regions = toy["snps"], toy["positions"], toy["regions"]
+    n_db = len(positions)
+    hit = np.sort(rng.choice(n_db, size=4000, replace=False))
+    chr_of_row = np.zeros(n_db, dtype=int)
+    for i, (a, b) in enumerate(regions):
+        chr_of_row[a:b] = i
+    p1, p2 = 3, 9
+    codes = np.zeros(len(hit), dtype=np.int8)
+    for i, r in enumerate(hit):
+        a, b = snps[r, p1], snps[r, p2]
+        if kind == "f1":
+            if a >= 0 and b >= 0 and a != b:
+                c = 2
+            elif a >= 0:
+                c = a
+            else:
+                c = b if b >= 0 else 0
+        elif kind == "f2hom":   # homozygous mosaic: 3 Mb blocks alternate parent1 / parent2 (no het blocks)
+            blk = (int(positions[r]) // 3000000) % 2
+            src = a if blk == 0 else b
+            c = src if src >= 0 else 0
+        else:   # f2: 3 Mb blocks alternate parent1 / het / parent2
+            blk = (int(positions[r]) // 3000000 + chr_of_row[r]) % 3
+            if blk == 0:
+                c = a if a >= 0 else 0
+            elif blk == 1:
+                c = b if b >= 0 else 0
+            else:
+                c = 2 if (a >= 0 and b >= 0 and a != b) else (a if a >= 0 else (b if b >= 0 else 0))
+        if c == 2 and rng.random() < 0.0:
+            c = 0
+        codes[i] = c
+    wei, _ = make_weights(rng, len(hit), codes=codes)
+    gt_of = {0: "0/0", 1: "1/1", 2: "0/1"}
+    chrs = np.array(["Chr%d" % (chr_of_row[r] + 1) for r in hit])
+    pos = positions[hit].astype(int)
+    gt = np.array([gt_of[int(k)] for k in codes])
+    dp = rng.integers(1, 40, size=len(hit))
+    return chrs, pos, gt, wei, dp
+
+
+def g7_cross_cases():
+    def _append(self, other, ignore_index=False):
+        return pd.concat([self, other], ignore_index=ignore_index)
+    pd.DataFrame.append = _append
+    toy = dict(np.load(os.path.join(OUT, "toy_db_cross.npz")))
+    rng = np.random.default_rng(77)
+    res = {"note": "pandas2-append-shim"}
+    samples = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for kind in ("f1", "f2", "f2hom"):
+            chrs, pos, gt, wei, dp = cross_sample(rng, toy, kind)
+            samples[kind + "_chrs"], samples[kind + "_pos"], samples[kind + "_gt"] = chrs, pos, gt
+            samples[kind + "_wei"], samples[kind + "_dp"] = wei, dp
+            g = make_genotype(toy["snps"].copy(), toy["accs"], toy["positions"], toy["chrs"], toy["regions"])
+            inputs = make_inputs(chrs, pos, gt, wei, dp)
+            outp = os.path.join(tmp, "cross_" + kind)
+            stderr = sys.stderr
+            sys.stderr = io.StringIO()
+            try:
+                ref_cs.CrossIdentifier(inputs, g, "athaliana_tair10", 300000, outp, run_identifier=True)
+            finally:
+                sys.stderr = stderr
+            files = {}
+            for suf in (".windowscore.txt", ".scores.txt", ".scores.txt.matches.json", ".matches.json"):
+                if os.path.exists(outp + suf):
+                    files[suf] = read_text(outp + suf)
+            res[kind] = files
+            if ".matches.json" in files:
+                print("g7 %s: case %s" % (kind, json.loads(files[".matches.json"])["interpretation"]))
+            else:
+                print("g7 %s: no cross interpretation (case < 3)" % kind)
+    np.savez_compressed(os.path.join(OUT, "g7_cross_samples.npz"), **samples)
+    with open(os.path.join(OUT, "g7_cross_cases.json"), "w") as fh:
+        json.dump(res, fh, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     g1_match()
     g2_g3()
     g4_likelihood()
     g5_cross()
     g6_common()
+    g7_cross_cases()
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith((".npz", ".json"))}
     print(json.dumps(sizes, indent=1))

@@ -331,3 +331,68 @@ def test_medium_dense_vs_oracle_counts(ctx):
     np.testing.assert_allclose(lik, wl, rtol=LIK_RTOL, equal_nan=True)
     np.testing.assert_allclose(lrt, wr, rtol=LIK_RTOL, equal_nan=True)
     assert np.nanargmin(lik) == 4321
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[1] / configs[2] at full shape
+def test_config2_and_config3_full_shape(ctx):
+    """1001-Genomes-shaped panel (1135 accessions x 11M SNPs, 12.7 GB resident), 200k-SNP sample:
+    inbred (row-gather mode, config 2) and 300 kb windows (399 windows, config 3) against the C oracle
+    run on the same 200k rows regenerated by the numpy twin of the device generator."""
+    from snpmatch_amd.core import genomes
+    n_snp, n_acc, n_match = 11_000_000, 1135, 200_000
+    panel = engine.Panel(ctx, n_snp, n_acc)
+    panel.fill_synthetic(1001)
+    rng = np.random.default_rng(1001)
+    rows = np.sort(rng.choice(n_snp, size=n_match, replace=False)).astype(np.int64)
+    db = synth.panel_rows(1001, rows, 0, n_acc)
+    assert np.array_equal(db[:500], np.vstack([panel.download_rows(int(r), 1) for r in rows[:500]]))
+    codes, wei = synth.planted_sample(rng, db[:, 417], err=0.02)
+    want_s, want_n = c_oracle.genotyper(db, None, wei, 1000, False)
+    q = engine.Query(panel, rows, wei)
+    s, ni, info = q.run(1000, False, engine.MODE_EXACT, return_info=True)
+    assert np.array_equal(ni, want_n)
+    assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int))
+    s2, ni2 = q.run(1000, False, engine.MODE_STRICT)
+    assert np.array_equal(bits(s2), bits(want_s)) and np.array_equal(ni2, want_n)
+    lik, lrt = ctx.likelihood(s, ni, truncate=True)
+    wl, wr = orc.calculate_likelihoods(np.array(want_s, dtype=int), want_n)
+    np.testing.assert_allclose(lik, wl, rtol=LIK_RTOL, equal_nan=True)
+    np.testing.assert_allclose(lrt, wr, rtol=LIK_RTOL, equal_nan=True)
+    assert int(np.nanargmin(lik)) == 417 and (lrt < 3.841).sum() == 1
+    # config 3: TAIR10 chromosomes proportional to their lengths, 300 kb windows over the matched rows
+    g = genomes.Genome("athaliana_tair10")
+    frac = np.cumsum(g.chrlen) / g.chrlen.sum()
+    bounds = np.concatenate([[0], np.round(frac * n_snp).astype(np.int64)])
+    off = [0]
+    for c in range(5):
+        in_chr = rows[(rows >= bounds[c]) & (rows < bounds[c + 1])]
+        pos = 1 + (in_chr - bounds[c]) * int(g.chrlen[c] - 1) // int(bounds[c + 1] - bounds[c])   # pseudo-positions
+        for t in range(1, int(g.chrlen[c]), 300000):
+            off.append(off[-1] + int(((pos >= t) & (pos <= t + 299999)).sum()))
+    off = np.array(off, dtype=np.int64)
+    assert len(off) - 1 == 399 and off[-1] == n_match
+    got = q.run_windows(off, False)
+    want = c_oracle.windows(db, None, wei, off, False)
+    assert np.array_equal(bits(got[0]), bits(want[0])) and np.array_equal(got[1], want[1])
+    assert np.array_equal(bits(got[2]), bits(want[2])) and np.array_equal(got[3], want[3])
+    wlik, wlrt = ctx.likelihood(got[0], got[1])
+    k = 200
+    ol, orr = orc.calculate_likelihoods(want[0][k], want[1][k])
+    np.testing.assert_allclose(wlik[k], ol, rtol=LIK_RTOL, equal_nan=True)
+    np.testing.assert_allclose(wlrt[k], orr, rtol=LIK_RTOL, equal_nan=True)
+
+
+def test_upload_staging_throughput(ctx):
+    """pinned-host staging path: a 2 GiB host panel goes through the double-buffered slabs intact."""
+    import time
+    n_snp, n_acc = 1 << 21, 1000
+    rng = np.random.default_rng(12)
+    host = rng.integers(-1, 3, size=(n_snp, n_acc), dtype=np.int8)
+    t0 = time.perf_counter()
+    panel = engine.Panel(ctx, n_snp, n_acc)
+    panel.upload_rows(0, host)
+    panel.upload_wait()
+    dt = time.perf_counter() - t0
+    print("staging upload: %.2f GB in %.2f s = %.2f GB/s" % (host.nbytes / 1e9, dt, host.nbytes / 1e9 / dt))
+    for r0 in (0, 12345, n_snp - 777):
+        assert np.array_equal(panel.download_rows(r0, 777), host[r0:r0 + 777])
