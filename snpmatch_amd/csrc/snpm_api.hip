@@ -47,6 +47,7 @@ struct snpm_ctx {
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     bool stage_busy[2] = {false, false};
     // grow-only device workspaces
+    Buf ws_grp_score, ws_grp_miss;
     Buf ws_part_score, ws_part_miss, ws_seg_score, ws_seg_miss, ws_seg_off, ws_cols, ws_tmp_score, ws_tmp_ninfo, ws_flags;
     Buf ws_lik_y, ws_lik_n, ws_lik_l, ws_lik_r;
     // profiling
@@ -174,6 +175,7 @@ int wait_upload(snpm_panel *p)
 struct FastGeom {
     int bpl, wpb;
     int64_t n_wc, n_colblocks, n_parts, part_rows;
+    int64_t n_epochs, n_slots, n_groups;      // partial slots = n_epochs * n_parts, reduced in groups
 };
 
 template <int BPL, bool SKIP, bool GATHER, bool NT>
@@ -229,12 +231,14 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     int64_t resident = (int64_t)ctx->n_cu * occ * std::max(1, ctx->parts_mult);
     int64_t n_parts = std::max<int64_t>(1, resident / g.n_colblocks);
     const int64_t n_tiles = std::max<int64_t>(1, (n + TILE_ROWS - 1) / TILE_ROWS);
-    const int64_t max_tiles_per_part = 65280 / TILE_ROWS;    // u16 SWAR counters per part
-    n_parts = std::max(n_parts, (n_tiles + max_tiles_per_part - 1) / max_tiles_per_part);
     n_parts = std::min(n_parts, n_tiles);                    // part p scores tiles p, p+P, p+2P, ...
     n_parts = std::min<int64_t>(n_parts, 65535);             // grid.y
     g.n_parts = n_parts;
-    g.part_rows = ((n_tiles + n_parts - 1) / n_parts) * TILE_ROWS;   // rows per part (upper bound)
+    const int64_t tiles_per_part = (n_tiles + n_parts - 1) / n_parts;
+    g.part_rows = tiles_per_part * TILE_ROWS;                // rows per part (upper bound)
+    g.n_epochs = std::max<int64_t>(1, (tiles_per_part + EPOCH_TILES - 1) / EPOCH_TILES);
+    g.n_slots = g.n_epochs * g.n_parts;
+    g.n_groups = (g.n_slots + REDUCE_GROUP - 1) / REDUCE_GROUP;
     return g;
 }
 
@@ -300,11 +304,21 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
     else occ = nt ? occ_b<4, true>(skip, gather, thr) : occ_b<4, false>(skip, gather, thr);
     FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl);
     if (geom_out) *geom_out = g;
-    rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_parts * p->pitch * sizeof(double));
+    rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_slots * p->pitch * sizeof(double));
     if (rc) return rc;
-    rc = ensure(ctx, ctx->ws_part_miss, (size_t)g.n_parts * p->pitch * sizeof(uint32_t));
+    rc = ensure(ctx, ctx->ws_part_miss, (size_t)g.n_slots * p->pitch * sizeof(uint32_t));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->ws_grp_score, (size_t)g.n_groups * p->pitch * sizeof(double));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->ws_grp_miss, (size_t)g.n_groups * p->pitch * sizeof(uint32_t));
     if (rc) return rc;
     if (q->n > 0) {
+        if (g.n_epochs > 1) {
+            // parts with fewer tiles never reach the last epoch slot: those slots must read as zero
+            const size_t off = (size_t)(g.n_epochs - 1) * g.n_parts * p->pitch;
+            HIPCHK(ctx, hipMemsetAsync((double *)ctx->ws_part_score.p + off, 0, (size_t)g.n_parts * p->pitch * sizeof(double), ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync((uint32_t *)ctx->ws_part_miss.p + off, 0, (size_t)g.n_parts * p->pitch * sizeof(uint32_t), ctx->stream));
+        }
         if (bpl == 16) rc = nt ? launch_fast_b<16, true>(q, g, skip, gather) : launch_fast_b<16, false>(q, g, skip, gather);
         else if (bpl == 8) rc = nt ? launch_fast_b<8, true>(q, g, skip, gather) : launch_fast_b<8, false>(q, g, skip, gather);
         else rc = nt ? launch_fast_b<4, true>(q, g, skip, gather) : launch_fast_b<4, false>(q, g, skip, gather);
@@ -313,9 +327,17 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
     {
         ProfScope ps(ctx, PK_REDUCE);
         const int thr = 64;       // one wave per block: narrow panels still spread over many CUs
-        hipLaunchKernelGGL(k_reduce, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
-                           (const double *)ctx->ws_part_score.p, (const uint32_t *)ctx->ws_part_miss.p,
-                           q->n > 0 ? g.n_parts : 0, p->pitch, p->n_acc, q->n, q->d_score, q->d_ninfo);
+        const unsigned cb = (unsigned)((p->n_acc + thr - 1) / thr);
+        const int64_t n_groups = q->n > 0 ? g.n_groups : 0;
+        if (n_groups > 0) {
+            hipLaunchKernelGGL(k_reduce_groups, dim3(cb, (unsigned)n_groups), dim3(thr), 0, ctx->stream,
+                               (const double *)ctx->ws_part_score.p, (const uint32_t *)ctx->ws_part_miss.p, g.n_slots,
+                               p->pitch, p->n_acc, (double *)ctx->ws_grp_score.p, (uint32_t *)ctx->ws_grp_miss.p);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_reduce, dim3(cb), dim3(thr), 0, ctx->stream, (const double *)ctx->ws_grp_score.p,
+                           (const uint32_t *)ctx->ws_grp_miss.p, n_groups, p->pitch, p->n_acc, q->n, q->d_score,
+                           q->d_ninfo);
         HIPCHK(ctx, hipGetLastError());
     }
     return SNPM_OK;
@@ -432,7 +454,8 @@ double eref_bound(const snpm_query *q, int64_t chunk)
 double efast_bound(const snpm_query *q, const FastGeom &g)
 {
     const double u = 1.1102230246251565e-16;
-    const double m = (double)(g.part_rows + g.n_parts + 1);
+    // a term passes through <= EPOCH_TILES*TILE_ROWS adds inside k_fast, REDUCE_GROUP in its group, n_groups after
+    const double m = (double)(std::min<int64_t>(g.part_rows, (int64_t)EPOCH_TILES * TILE_ROWS) + REDUCE_GROUP + g.n_groups + 2);
     return (double)(q->wsum * (m * u / (1.0 - m * u))) * 1.0000001;
 }
 
@@ -493,7 +516,7 @@ int snpm_destroy(snpm_ctx *ctx)
     if (!ctx) return SNPM_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    Buf *bufs[] = {&ctx->ws_part_score, &ctx->ws_part_miss, &ctx->ws_seg_score, &ctx->ws_seg_miss, &ctx->ws_seg_off,
+    Buf *bufs[] = {&ctx->ws_grp_score, &ctx->ws_grp_miss, &ctx->ws_part_score, &ctx->ws_part_miss, &ctx->ws_seg_score, &ctx->ws_seg_miss, &ctx->ws_seg_off,
                    &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
                    &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r};
     for (Buf *b : bufs)

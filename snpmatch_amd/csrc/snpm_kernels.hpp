@@ -28,6 +28,8 @@ constexpr int WAVE = 64;
 constexpr int TILE_ROWS = 128;          // rows per LDS LUT tile (4 KiB); also the SWAR counter flush period (<= 255)
 constexpr int LUT_ROW_BYTES = 32;       // 4 x fp64
 constexpr int MAX_WAVES_PER_BLOCK = 8;
+constexpr int EPOCH_TILES = 64;         // k_fast writes its partial sums out (and restarts them) every 64 of its tiles
+constexpr int REDUCE_GROUP = 64;        // k_reduce_groups adds this many partials sequentially per group
 constexpr int PREFETCH_PAD_ROWS = 16;   // rows the fast pass may read (never score) past the last row of a part
 
 typedef __attribute__((address_space(3))) const double lds_cdouble;
@@ -119,9 +121,14 @@ __device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[BPL / 4]
 //   G rows of the current group are scored, so every wave keeps 2*G row loads in flight; prefetches are
 //   unconditional (straight-line code lets the compiler count vmcnt exactly) and may run up to 2*G rows
 //   past the last row: the panel and the row-index list carry PREFETCH_PAD_ROWS extra rows/entries.
-//   out_score [P, ld] fp64, out_miss [P, ld] u32 (ld = pitch).
+//   Partial sums are written out and restarted every EPOCH_TILES tiles of a part (epoch e of part p goes
+//   to slot e*P + p): accumulation chains stay short (tight rounding bound, u16 counters never overflow).
+//   out_score [n_epochs*P, ld] fp64, out_miss [n_epochs*P, ld] u32 (ld = pitch).
+// launch bound: <= 512 threads and (for the 4 B/lane layout) >= 6 waves per SIMD, i.e. <= 80 VGPRs: the
+// kernel is latency-bound and 5-wave blocks only fit 4 per CU with 6 wave slots per SIMD (measured:
+// 79-82 % of HBM peak at 80 VGPRs vs 67-70 % at 88)
 template <int BPL, bool SKIP, bool GATHER, bool NT>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK)
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (BPL == 4 ? 6 : 1))
 k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
        const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
 {
@@ -161,6 +168,30 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
         return rowbase + off;
     };
 
+    // write this lane's partial sums to slot (epoch, part) and restart them
+    auto store_partials = [&](int64_t epoch) {
+        if (lane_on) {
+            double *os = out_score + (epoch * P + p) * ld + col0;
+            uint32_t *om = out_miss + (epoch * P + p) * ld + col0;
+#pragma unroll
+            for (int i = 0; i < BPL; i += 2) *reinterpret_cast<double2 *>(os + i) = make_double2(acc[i], acc[i + 1]);
+#pragma unroll
+            for (int k = 0; k < NDW; ++k) {
+                uint4 m;
+                m.x = miss16[2 * k + 0] & 0xffffu;
+                m.y = miss16[2 * k + 1] & 0xffffu;
+                m.z = miss16[2 * k + 0] >> 16;
+                m.w = miss16[2 * k + 1] >> 16;
+                *reinterpret_cast<uint4 *>(om + 4 * k) = m;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPL; ++i) acc[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NDW * 2; ++i) miss16[i] = 0;
+    };
+    int64_t last_epoch = 0;
+
     if (p < n_tiles_total) {
         // first LUT tile -> LDS; first group in flight
         {
@@ -176,7 +207,15 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
         __syncthreads();
 
         int buf = 0;
+        int tiles_in_epoch = 0;
+        int64_t epoch = 0;
         for (int64_t T = p; T < n_tiles_total; T += P, buf ^= 1) {
+            if (tiles_in_epoch == EPOCH_TILES) {
+                store_partials(epoch);
+                ++epoch;
+                tiles_in_epoch = 0;
+            }
+            ++tiles_in_epoch;
             const int64_t tr0 = T * TILE_ROWS;
             const int rows = (int)((n - tr0 < TILE_ROWS) ? (n - tr0) : TILE_ROWS);
             const bool more = (T + P < n_tiles_total);
@@ -245,27 +284,50 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
             }
             __syncthreads();
         }
+        last_epoch = epoch;
     }
-
-    if (lane_on) {
-        double *os = out_score + p * ld + col0;
-        uint32_t *om = out_miss + p * ld + col0;
-#pragma unroll
-        for (int i = 0; i < BPL; i += 2) *reinterpret_cast<double2 *>(os + i) = make_double2(acc[i], acc[i + 1]);
-#pragma unroll
-        for (int k = 0; k < NDW; ++k) {
-            uint4 m;
-            m.x = miss16[2 * k + 0] & 0xffffu;
-            m.y = miss16[2 * k + 1] & 0xffffu;
-            m.z = miss16[2 * k + 0] >> 16;
-            m.w = miss16[2 * k + 1] >> 16;
-            *reinterpret_cast<uint4 *>(om + 4 * k) = m;
-        }
-    }
+    // the last (possibly only, possibly empty) epoch; epochs a short part never reaches are zeroed by the host
+    store_partials(last_epoch);
 }
 
-// Ordered sum of the per-part partials: score[a] = ((p0 + p1) + p2) + ..., ninfo[a] = n - sum(miss).
-// Loads are issued 8 ahead of the (ordered) adds.
+// Blocked summation of the M = n_epochs*P partial slots (deterministic, no atomics):
+//   k_reduce_groups: group g = slots [g*REDUCE_GROUP, ...) added sequentially   -> grp [n_groups, ld]
+//   k_reduce       : groups added sequentially                                  -> score, ninfo = n - miss
+// Every term passes through at most REDUCE_GROUP + n_groups additions here.
+__global__ void k_reduce_groups(const double *__restrict__ part_score, const uint32_t *__restrict__ part_miss,
+                                int64_t n_slots, int64_t ld, int64_t n_acc, double *__restrict__ grp_score,
+                                uint32_t *__restrict__ grp_miss)
+{
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g = blockIdx.y;
+    if (a >= n_acc) return;
+    const int64_t s0 = g * REDUCE_GROUP;
+    const int64_t s1 = (s0 + REDUCE_GROUP < n_slots) ? s0 + REDUCE_GROUP : n_slots;
+    double s = 0.0;
+    uint32_t m = 0;
+    int64_t k = s0;
+    for (; k + 8 <= s1; k += 8) {
+        double v[8];
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            v[u] = part_score[(k + u) * ld + a];
+            c[u] = part_miss[(k + u) * ld + a];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s = s + v[u];
+            m += c[u];
+        }
+    }
+    for (; k < s1; ++k) {
+        s = s + part_score[k * ld + a];
+        m += part_miss[k * ld + a];
+    }
+    grp_score[g * ld + a] = s;
+    grp_miss[g * ld + a] = m;
+}
+
 __global__ void k_reduce(const double *__restrict__ part_score, const uint32_t *__restrict__ part_miss,
                          int64_t n_parts, int64_t ld, int64_t n_acc, int64_t n_rows, double *__restrict__ score,
                          int64_t *__restrict__ ninfo)
