@@ -133,10 +133,24 @@ int snpm_likelihood(snpm_ctx *ctx, const double *y, const int64_t *n, int64_t m,
 int snpm_likelihood_device(snpm_ctx *ctx, const void *d_y, const void *d_n, int64_t m, int64_t len,
                            int truncate, double amin_or_nan, void *d_lik, void *d_lrt, int *domain_error);
 
-/* np_test_identity: out[i] = (binom.sf((n[i]-x[i]) - 1, n[i], error_rate) >= pthres).  Host pointers;
-   sf (may be NULL) receives the survival function values. */
+/* np_test_identity on the device: out[i] = (binom.sf((n[i]-x[i]) - 1, n[i], error_rate) >= pthres).  Host
+   pointers; sf (may be NULL) receives the survival function values. */
 int snpm_binom_identity(snpm_ctx *ctx, const double *x, const int64_t *n, int64_t len, double error_rate,
                         double pthres, int64_t *out, double *sf);
+/* host twin of the device arithmetic of snpm_binom_identity: sf[i] = binom.sf(k[i], n[i], p) (no ctx, no GPU) */
+int snpm_binom_sf_host(const double *k, const double *n, int64_t len, double p, double *sf);
+
+/* ---------------------------------------------------------------- caller-side index preparation */
+/* Sorted-merge intersection of two strictly increasing int64 arrays (the positions of one chromosome in the
+   DB and in the sample): ia / ib receive the indices of the common values (capacity min(na, nb)), *n_out
+   their number.  Replaces the two np.in1d calls per chromosome of Genotype.get_common_positions
+   (core/snp_genotype.py:66-67).  Pure host code, needs no ctx / GPU.  SNPM_ERR_STATE when an input is not
+   strictly increasing (the caller then takes its generic path). */
+int snpm_intersect_sorted(const int64_t *a, int64_t na, const int64_t *b, int64_t nb, int64_t *ia, int64_t *ib,
+                          int64_t *n_out);
+/* Genotype.identify_segregating_snps on the resident panel (core/snp_genotype.py:188-211, used by --refine):
+   mask [n_snp] (host, uint8) = 1 where the informative calls of accessions cols[0..ncols) are not all equal. */
+int snpm_panel_segregating(snpm_panel *panel, const int32_t *cols, int64_t ncols, uint8_t *mask);
 
 /* ---------------------------------------------------------------- profiling (HIP events on the ctx stream) */
 /* PMC calibration: reads the whole panel once with the access shape of the scoring kernel (4 B per

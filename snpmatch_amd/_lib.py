@@ -30,7 +30,8 @@ SYMBOLS = [
     "snpm_panel_upload_wait", "snpm_panel_download_rows", "snpm_panel_fill_synthetic", "snpm_query_create",
     "snpm_query_free", "snpm_query_bind_outputs", "snpm_query_run", "snpm_query_run_device", "snpm_query_error_bound",
     "snpm_query_run_windows", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
-    "snpm_binom_identity", "snpm_debug_stream_read", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
+    "snpm_binom_identity", "snpm_binom_sf_host", "snpm_intersect_sorted", "snpm_panel_segregating",
+    "snpm_debug_stream_read", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
 ]
 
 _lib = None
@@ -81,6 +82,9 @@ def load():
     lib.snpm_likelihood.argtypes = [p, p, p, i64, i64, ci, dbl, p, p]
     lib.snpm_likelihood_device.argtypes = [p, p, p, i64, i64, ci, dbl, p, p, C.POINTER(ci)]
     lib.snpm_binom_identity.argtypes = [p, p, p, i64, dbl, dbl, p, p]
+    lib.snpm_binom_sf_host.argtypes = [p, p, i64, dbl, p]
+    lib.snpm_intersect_sorted.argtypes = [p, i64, p, i64, p, p, C.POINTER(i64)]
+    lib.snpm_panel_segregating.argtypes = [p, p, i64, p]
     lib.snpm_debug_stream_read.argtypes = [p, C.POINTER(i64)]
     lib.snpm_profile_enable.argtypes = [p, ci]
     lib.snpm_profile_reset.argtypes = [p]
@@ -108,6 +112,32 @@ def check(rc, ctx_handle=None):
     if rc == SNPM_ERR_OOM:
         raise MemoryError(msg)
     raise SnpmError(rc, msg)
+
+
+def intersect_sorted(a, b):
+    """indices (ia, ib) of the common values of two strictly increasing integer arrays (native sorted merge);
+    None when an input is not strictly increasing."""
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    b = np.ascontiguousarray(b, dtype=np.int64)
+    m = min(len(a), len(b))
+    ia = np.empty(m, dtype=np.int64)
+    ib = np.empty(m, dtype=np.int64)
+    n = C.c_int64(0)
+    rc = load().snpm_intersect_sorted(ptr(a), len(a), ptr(b), len(b), ptr(ia), ptr(ib), C.byref(n))
+    if rc == SNPM_ERR_STATE:
+        return None
+    if rc != SNPM_OK:
+        raise AssertionError("snpm_intersect_sorted: bad arguments")
+    return ia[:n.value], ib[:n.value]
+
+
+def binom_sf_host(k, n, p):
+    k = np.ascontiguousarray(k, dtype=np.float64)
+    n = np.ascontiguousarray(n, dtype=np.float64)
+    out = np.empty(len(k), dtype=np.float64)
+    rc = load().snpm_binom_sf_host(ptr(k), ptr(n), len(k), float(p), ptr(out))
+    assert rc == SNPM_OK
+    return out
 
 
 def as_f64(a, shape=None):

@@ -23,6 +23,7 @@ from glob import glob
 import numpy as np
 
 from . import parsers
+from .. import _lib
 
 log = logging.getLogger(__name__)
 chunk_size = 1000
@@ -151,9 +152,14 @@ class Genotype(object):
             ix2 = np.where(ins.g_chrs == cid)[0]
             p1 = np.array(positions[s:e], dtype=int)
             p2 = np.array(ins.pos[ix2], dtype=int)
-            idx1.append(s + np.where(np.isin(p1, p2, assume_unique=True))[0])
-            idx2.append(ix2[np.where(np.isin(p2, p1, assume_unique=True))[0]])
-        return (np.concatenate(idx1), np.concatenate(idx2))
+            merged = _lib.intersect_sorted(p1, p2)          # native sorted merge (strictly increasing inputs)
+            if merged is not None:
+                idx1.append(s + merged[0])
+                idx2.append(ix2[merged[1]])
+            else:                                           # the reference's np.in1d pair, quirks included
+                idx1.append(s + np.where(np.isin(p1, p2, assume_unique=True))[0])
+                idx2.append(ix2[np.where(np.isin(p2, p1, assume_unique=True))[0]])
+        return (np.concatenate(idx1).astype(int), np.concatenate(idx2).astype(int))
 
     @staticmethod
     def get_common_positions(input_1_chr, input_1_pos, input_2_chr, input_2_pos):
@@ -197,6 +203,9 @@ class Genotype(object):
         assert len(accs_ix) > 1, "polymorphism happens in more than 1 line"
         if len(accs_ix) > (len(self.accessions) / 2):
             return None
+        if self._panel is not None and self._panel.h is not None:
+            # the DB is resident in HBM: one device scan over the listed columns
+            return np.where(self._panel.segregating_rows(accs_ix))[0]
         n_snps = self.g.positions.shape[0]
         seg_counts = np.zeros(0, dtype=int)
         total_counts = np.zeros(0, dtype=int)

@@ -46,6 +46,9 @@ struct snpm_ctx {
     void *stage[2] = {nullptr, nullptr};
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     bool stage_busy[2] = {false, false};
+    // pinned host buffer for small result readbacks (exactness check)
+    void *h_pinned = nullptr;
+    size_t h_pinned_cap = 0;
     // grow-only device workspaces
     Buf ws_grp_score, ws_grp_miss;
     Buf ws_part_score, ws_part_miss, ws_seg_score, ws_seg_miss, ws_seg_off, ws_cols, ws_tmp_score, ws_tmp_ninfo, ws_flags;
@@ -521,6 +524,7 @@ int snpm_destroy(snpm_ctx *ctx)
                    &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r};
     for (Buf *b : bufs)
         if (b->p) (void)hipFree(b->p);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     for (int i = 0; i < 2; ++i) {
         if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
         if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
@@ -821,12 +825,20 @@ int snpm_query_run_device(snpm_query *q, int64_t chunk, int skip_hets, int mode,
             auto it = q->eref_cache.find(chunk);
             const double eref = (it != q->eref_cache.end()) ? it->second : (q->eref_cache[chunk] = eref_bound(q, chunk));
             const double E = eref + efast_bound(q, g);
-            std::vector<double> h((size_t)p->n_acc);
-            HIPCHK(ctx, hipMemcpyAsync(h.data(), q->d_score, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            const size_t hbytes = (size_t)p->n_acc * sizeof(double);
+            if (ctx->h_pinned_cap < hbytes) {
+                if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+                ctx->h_pinned = nullptr;
+                ctx->h_pinned_cap = 0;
+                HIPCHK(ctx, hipHostMalloc(&ctx->h_pinned, hbytes, hipHostMallocDefault));
+                ctx->h_pinned_cap = hbytes;
+            }
+            const double *h = (const double *)ctx->h_pinned;
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, q->d_score, hbytes, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
             std::vector<int32_t> cols;
             for (int64_t a = 0; a < p->n_acc; ++a) {
-                const double f = h[(size_t)a];
+                const double f = h[a];
                 const double lo = f - E, hi = f + E;
                 if (!(lo >= 0.0) || std::floor(lo) != std::floor(hi)) cols.push_back((int32_t)a);
             }
@@ -1031,60 +1043,81 @@ int snpm_likelihood(snpm_ctx *ctx, const double *y, const int64_t *n, int64_t m,
     return SNPM_OK;
 }
 
-// binom.sf(k, n, p) = P(X > floor(k)), X ~ Binomial(n, p); host implementation (cold path: one value per
-// accession per window), summed in log space from the mode of the tail outward.
-static double binom_sf(double k, double n, double p)
-{
-    if (!(n >= 0) || !(p >= 0.0 && p <= 1.0) || std::isnan(k)) return NAN;
-    const double kf = std::floor(k);
-    if (kf < 0) return 1.0;
-    if (kf >= n) return 0.0;
-    if (p == 0.0) return 0.0;
-    if (p == 1.0) return 1.0;
-    const double lp = std::log(p), lq = std::log1p(-p);
-    const double lg_n1 = std::lgamma(n + 1.0);
-    auto logpmf = [&](double j) { return lg_n1 - std::lgamma(j + 1.0) - std::lgamma(n - j + 1.0) + j * lp + (n - j) * lq; };
-    // sum the smaller tail
-    const double mean = n * p;
-    if (kf + 1 > mean) {
-        // upper tail j = kf+1 .. n : terms decrease
-        double j = kf + 1;
-        double t = std::exp(logpmf(j));
-        double s = 0;
-        while (j <= n && t > 0) {
-            s += t;
-            if (t < s * 1e-18) break;
-            t *= (n - j) / (j + 1.0) * (p / (1.0 - p));
-            j += 1;
-        }
-        return s > 1.0 ? 1.0 : s;
-    }
-    // lower tail cdf = sum_{j=0..kf}, terms increase toward kf: go downward from kf
-    double j = kf;
-    double t = std::exp(logpmf(j));
-    double s = 0;
-    while (j >= 0 && t > 0) {
-        s += t;
-        if (t < s * 1e-18) break;
-        t *= j / (n - j + 1.0) * ((1.0 - p) / p);
-        j -= 1;
-    }
-    double sf = 1.0 - s;
-    return sf < 0 ? 0.0 : sf;
-}
-
+// np_test_identity on the device (k_binom_identity); host pointers in and out.
 int snpm_binom_identity(snpm_ctx *ctx, const double *x, const int64_t *n, int64_t len, double error_rate,
                         double pthres, int64_t *out, double *sf)
 {
     if (!ctx) return SNPM_ERR_BADARG;
     CHECK_ARG(ctx, len >= 0, "negative size");
-    CHECK_ARG(ctx, len == 0 || (x && n && out), "NULL pointer");
-    for (int64_t i = 0; i < len; ++i) {
-        const double nn = (double)n[i];
-        const double v = binom_sf(nn - x[i] - 1.0, nn, error_rate);
-        if (sf) sf[i] = v;
-        out[i] = (v >= pthres) ? 1 : 0;      // NaN compares false -> 0, as numpy's (nan >= p)
+    if (len == 0) return SNPM_OK;
+    CHECK_ARG(ctx, x && n && out, "NULL pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc;
+    const size_t L = (size_t)len;
+    if ((rc = ensure(ctx, ctx->ws_lik_y, L * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_lik_n, L * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_lik_l, L * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_lik_r, L * sizeof(int64_t)))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_lik_y.p, x, L * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_lik_n.p, n, L * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_binom_identity, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double *)ctx->ws_lik_y.p, (const int64_t *)ctx->ws_lik_n.p, len, error_rate, pthres,
+                       (int64_t *)ctx->ws_lik_r.p, (double *)ctx->ws_lik_l.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->ws_lik_r.p, L * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (sf) HIPCHK(ctx, hipMemcpyAsync(sf, ctx->ws_lik_l.p, L * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SNPM_OK;
+}
+
+// host twin of k_binom_identity's arithmetic (no device needed): lets the CPU test-suite pin the algorithm
+int snpm_binom_sf_host(const double *k, const double *n, int64_t len, double p, double *sf)
+{
+    if (len < 0 || (len > 0 && (!k || !n || !sf))) return SNPM_ERR_BADARG;
+    for (int64_t i = 0; i < len; ++i) sf[i] = binom_sf_eval(k[i], n[i], p);
+    return SNPM_OK;
+}
+
+// Sorted-merge intersection of two strictly increasing int64 arrays (position lists of one chromosome):
+// ia/ib receive the indices of the common values, *n_out their number.  Pure host code (no ctx).
+// Replaces the two np.in1d calls per chromosome of get_common_positions (core/snp_genotype.py:66-67).
+int snpm_intersect_sorted(const int64_t *a, int64_t na, const int64_t *b, int64_t nb, int64_t *ia, int64_t *ib,
+                          int64_t *n_out)
+{
+    if (na < 0 || nb < 0 || !n_out || ((na > 0 && nb > 0) && (!a || !b || !ia || !ib))) return SNPM_ERR_BADARG;
+    for (int64_t i = 1; i < na; ++i)
+        if (a[i] <= a[i - 1]) return SNPM_ERR_STATE;       // not strictly increasing: caller uses its generic path
+    for (int64_t j = 1; j < nb; ++j)
+        if (b[j] <= b[j - 1]) return SNPM_ERR_STATE;
+    int64_t i = 0, j = 0, k = 0;
+    while (i < na && j < nb) {
+        if (a[i] < b[j]) ++i;
+        else if (a[i] > b[j]) ++j;
+        else { ia[k] = i; ib[k] = j; ++k; ++i; ++j; }
     }
+    *n_out = k;
+    return SNPM_OK;
+}
+
+// identify_segregating_snps on the resident panel: mask [n_snp] (host, uint8)
+int snpm_panel_segregating(snpm_panel *p, const int32_t *cols, int64_t ncols, uint8_t *mask)
+{
+    if (!p) return SNPM_ERR_BADARG;
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, ncols >= 1 && cols && mask, "provide an np array for list of indices to be considered");
+    for (int64_t i = 0; i < ncols; ++i) CHECK_ARG(ctx, cols[i] >= 0 && cols[i] < p->n_acc, "accession index outside the panel");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = wait_upload(p);
+    if (rc) return rc;
+    if (p->n_snp == 0) return SNPM_OK;
+    if ((rc = ensure(ctx, ctx->ws_cols, (size_t)ncols * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_tmp_ninfo, (size_t)p->n_snp))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_cols.p, cols, (size_t)ncols * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_segregating, dim3((unsigned)((p->n_snp + 255) / 256)), dim3(256), 0, ctx->stream, p->d, p->pitch,
+                       p->n_snp, (const int32_t *)ctx->ws_cols.p, (int)ncols, (uint8_t *)ctx->ws_tmp_ninfo.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(mask, ctx->ws_tmp_ninfo.p, (size_t)p->n_snp, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SNPM_OK;
 }
 

@@ -682,6 +682,78 @@ __global__ void k_synth(uint32_t *__restrict__ db, int64_t pitch, int64_t n_snp,
 }
 
 // ------------------------------------------------------------------------------------------------
+// binom.sf(k, n, p) = P(X > floor(k)), X ~ Binomial(n, p) (np_test_identity, core/snpmatch.py:57-72):
+// the smaller tail is summed term by term from its largest term outward (same algorithm as the host
+// reference implementation in snpm_api.hip, used by the tests to cross-check).
+__host__ __device__ inline double binom_sf_eval(double k, double n, double p)
+{
+    if (!(n >= 0) || !(p >= 0.0 && p <= 1.0) || k != k) return __builtin_nan("");
+    const double kf = floor(k);
+    if (kf < 0) return 1.0;
+    if (kf >= n) return 0.0;
+    if (p == 0.0) return 0.0;
+    if (p == 1.0) return 1.0;
+    const double lp = log(p), lq = log1p(-p);
+    const double lg_n1 = lgamma(n + 1.0);
+    const double mean = n * p;
+    if (kf + 1 > mean) {                 // upper tail j = kf+1 .. n, terms decrease
+        double j = kf + 1;
+        double t = exp(lg_n1 - lgamma(j + 1.0) - lgamma(n - j + 1.0) + j * lp + (n - j) * lq);
+        double s = 0;
+        while (j <= n && t > 0) {
+            s += t;
+            if (t < s * 1e-18) break;
+            t *= (n - j) / (j + 1.0) * (p / (1.0 - p));
+            j += 1;
+        }
+        return s > 1.0 ? 1.0 : s;
+    }
+    double j = kf;                       // lower tail j = kf .. 0, terms decrease going down
+    double t = exp(lg_n1 - lgamma(j + 1.0) - lgamma(n - j + 1.0) + j * lp + (n - j) * lq);
+    double s = 0;
+    while (j >= 0 && t > 0) {
+        s += t;
+        if (t < s * 1e-18) break;
+        t *= j / (n - j + 1.0) * ((1.0 - p) / p);
+        j -= 1;
+    }
+    const double sf = 1.0 - s;
+    return sf < 0 ? 0.0 : sf;
+}
+
+// out[i] = (sf((n[i] - x[i]) - 1, n[i], error_rate) >= pthres); sf[i] optional
+__global__ void k_binom_identity(const double *__restrict__ x, const int64_t *__restrict__ n, int64_t len,
+                                 double error_rate, double pthres, int64_t *__restrict__ out, double *__restrict__ sf)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const double nn = (double)n[i];
+    const double v = binom_sf_eval(nn - x[i] - 1.0, nn, error_rate);
+    if (sf) sf[i] = v;
+    out[i] = (v >= pthres) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// --refine support (identify_segregating_snps, core/snp_genotype.py:188-211): mask[row] = 1 when the
+// informative (non-negative) calls of the listed accessions in that SNP row are not all identical.
+__global__ void k_segregating(const int8_t *__restrict__ db, int64_t pitch, int64_t n_snp,
+                              const int32_t *__restrict__ cols, int ncols, uint8_t *__restrict__ mask)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_snp) return;
+    const int8_t *row = db + r * pitch;
+    int first = -1;
+    int seg = 0;
+    for (int i = 0; i < ncols; ++i) {
+        const int b = row[cols[i]];
+        if (b < 0) continue;
+        if (first < 0) first = b;
+        else if (b != first) seg = 1;
+    }
+    mask[r] = (uint8_t)seg;
+}
+
+// ------------------------------------------------------------------------------------------------
 // PMC calibration: reads `n_dwords` dwords exactly once with the access shape of k_fast (one dword
 // per lane, 256 contiguous bytes per wave instruction, non-temporal), so that FETCH_SIZE can be
 // calibrated on a known byte count (MI355X_MICROARCH.md, HBM section).  The xor keeps the loads live.

@@ -182,6 +182,13 @@ class Panel(object):
     def fill_synthetic(self, seed, snp0=0, acc0=0):
         check(self.ctx.lib.snpm_panel_fill_synthetic(self.h, C.c_uint64(int(seed)), int(snp0), int(acc0)), self.ctx.h)
 
+    def segregating_rows(self, cols):
+        """uint8 mask [n_snp]: 1 where the informative calls of accessions `cols` differ (device scan)."""
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        mask = np.zeros(self.n_snp, dtype=np.uint8)
+        check(self.ctx.lib.snpm_panel_segregating(self.h, ptr(cols), len(cols), ptr(mask)), self.ctx.h)
+        return mask
+
     def stream_read(self):
         """PMC calibration: read every panel byte once; returns the byte count."""
         n = C.c_int64(0)

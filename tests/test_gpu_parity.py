@@ -396,3 +396,18 @@ def test_upload_staging_throughput(ctx):
     print("staging upload: %.2f GB in %.2f s = %.2f GB/s" % (host.nbytes / 1e9, dt, host.nbytes / 1e9 / dt))
     for r0 in (0, 12345, n_snp - 777):
         assert np.array_equal(panel.download_rows(r0, 777), host[r0:r0 + 777])
+
+
+def test_segregating_rows_on_device(ctx):
+    from snpmatch_amd.core import snp_genotype
+    rng = np.random.default_rng(31)
+    db = rand_db(rng, 70000, 40)
+    db[:, 5] = db[:, 4]                       # identical pair: segregating only where one of them is missing? no: never
+    g = snp_genotype.Genotype.from_arrays(db, ["a%d" % i for i in range(40)], np.arange(1, 70001), ["1"], [(0, 70000)])
+    want = g.identify_segregating_snps(np.array([4, 5]))            # host path (panel not resident yet)
+    assert len(want) == 0
+    want = g.identify_segregating_snps(np.array([1, 4, 9, 17]))
+    panel = g.panel(ctx)
+    got = np.where(panel.segregating_rows(np.array([1, 4, 9, 17])))[0]
+    assert np.array_equal(got, want) and len(got) > 1000
+    assert np.array_equal(g.identify_segregating_snps(np.array([1, 4, 9, 17])), want)      # device path now

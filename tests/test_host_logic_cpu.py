@@ -95,3 +95,34 @@ def test_dropin_import_path():
     import snpmatch
     assert callable(snpmatch.main)
     assert orc.get_fraction(1, 0) is np.nan and a.get_fraction(1, 0) is np.nan
+
+
+def test_native_sorted_merge_equals_numpy_isin():
+    from snpmatch_amd import _lib
+    rng = np.random.default_rng(3)
+    for trial in range(30):
+        a = np.sort(rng.choice(5000, size=int(rng.integers(0, 800)), replace=False))
+        b = np.sort(rng.choice(5000, size=int(rng.integers(0, 800)), replace=False))
+        ia, ib = _lib.intersect_sorted(a, b)
+        assert np.array_equal(ia, np.where(np.isin(a, b, assume_unique=True))[0])
+        assert np.array_equal(ib, np.where(np.isin(b, a, assume_unique=True))[0])
+    assert _lib.intersect_sorted(np.array([1, 3, 3, 4]), np.array([3, 4])) is None         # duplicates -> generic path
+    assert _lib.intersect_sorted(np.array([5, 1]), np.array([1])) is None                  # unsorted -> generic path
+    ia, ib = _lib.intersect_sorted(np.zeros(0, dtype=int), np.array([1, 2]))
+    assert len(ia) == 0 and len(ib) == 0
+
+
+def test_binom_sf_algorithm_matches_scipy(golden_dir):
+    """host twin of the device arithmetic (k_binom_identity) against scipy values stored in the goldens"""
+    from snpmatch_amd import _lib
+    g = np.load(os.path.join(golden_dir, "g5_cross.npz"))
+    n = g["ident_n"].astype(float)
+    for x, sf in ((g["ident_x"], g["ident_sf"]), (g["ident_xfrac"], g["ident_sf_frac"])):
+        got = _lib.binom_sf_host(n - x - 1.0, n, 0.02)
+        np.testing.assert_allclose(got, sf, rtol=1e-9, atol=1e-300)
+    from scipy import stats
+    rng = np.random.default_rng(2)
+    n = rng.integers(1, 20000, size=500).astype(float)
+    k = np.floor(rng.random(500) * (n + 2)) - 1
+    for p in (0.0005, 0.02, 0.3, 0.9):
+        np.testing.assert_allclose(_lib.binom_sf_host(k, n, p), stats.binom.sf(k, n, p), rtol=1e-9, atol=1e-280)
