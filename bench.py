@@ -79,6 +79,7 @@ def main():
     # RCCL and every rank on device 0
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--all-ranks-on-device0", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="init the process group and all-gather even at N=1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,8 +101,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -117,7 +120,7 @@ def main():
 
     n_acc = args.n_acc
     n_snp = args.snps_per_gpu_unit * world
-    shards = AccessionShards(n_acc, world, rank, dev)
+    shards = AccessionShards(n_acc, world, rank, dev, force_collective=args.force_dist)
     a0, n_loc, per = shards.a0, shards.n_local, shards.per
     mode = {"exact": engine.MODE_EXACT, "strict": engine.MODE_STRICT, "fast": engine.MODE_FAST}[args.mode]
 
@@ -144,7 +147,7 @@ def main():
                               truncate=True)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -160,7 +163,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ctx.profile(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -224,7 +227,7 @@ def main():
             "setup_s": t_setup,
         }
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

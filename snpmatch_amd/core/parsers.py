@@ -178,14 +178,22 @@ class ParseInputs(object):
         return (snpCHR, snpPOS, snpGT, snpWEI, snpDP)
 
     def filter_chr_names(self):
-        """strip 'chr' case-insensitively; ids in order of first appearance (core/parsers.py:159-163)."""
-        self.g_chrs = np.array([re.sub("chr", "", c, flags=re.IGNORECASE) for c in self.chrs.tolist()], dtype="str")
-        if len(self.g_chrs) == 0:
+        """strip 'chr' case-insensitively; ids in order of first appearance (core/parsers.py:159-163).
+        Chromosome names take few distinct values: the regex runs on the unique names only."""
+        if len(self.chrs) == 0:
             self.g_chrs = np.zeros(0, dtype="U1")
             self.g_chrs_ids = self.g_chrs
             return
-        _, idx = np.unique(self.g_chrs, return_index=True)
-        self.g_chrs_ids = self.g_chrs[np.sort(idx)]
+        uniq, first, inv = np.unique(self.chrs, return_index=True, return_inverse=True)
+        stripped = np.array([re.sub("chr", "", c, flags=re.IGNORECASE) for c in uniq.tolist()], dtype="str")
+        self.g_chrs = stripped[inv]
+        # order of first appearance of the STRIPPED ids ('Chr1' and 'chr1' are the same chromosome)
+        order = np.argsort(first, kind="stable")
+        ids = []
+        for k in order:
+            if stripped[k] not in ids:
+                ids.append(stripped[k])
+        self.g_chrs_ids = np.array(ids, dtype=self.g_chrs.dtype)
 
     def save_to_bed(self, outFile):
         input_df = pd.DataFrame(np.column_stack((self.chrs, self.pos, self.gt)), columns=["chr", 'pos', 'gt'])

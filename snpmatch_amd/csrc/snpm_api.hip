@@ -191,22 +191,12 @@ int occupancy_of(int threads)
 
 int pick_bpl(snpm_ctx *ctx, int64_t n_acc)
 {
-    if (ctx->force_bpl == 4 || ctx->force_bpl == 8 || ctx->force_bpl == 16) return ctx->force_bpl;
-    // Measured on MI355X (10k x 6.25M panel): 4 B per lane (6 waves/SIMD) streams at 5.8 TB/s, 8 B at
-    // 4.0, 16 B at 3.8 -- the kernel is latency-bound and the narrow layout keeps the most waves
-    // resident; it also has the best lane utilisation for every n_acc.
+    // Bytes per lane of the fast pass.  Measured on MI355X (10k x 6.25M panel, round 1): 4 B per lane
+    // streams at 6.5 TB/s, 8 B at 4.4, 16 B at 5.3 -- the kernel is latency-bound and the narrow layout
+    // keeps the most waves resident; it also has the best lane utilisation for every n_acc.  The wider
+    // instantiations stay selectable (SNPM_FORCE_BPL) for experiments.
     (void)n_acc;
-    return 4;
-    const int cand[3] = {16, 8, 4};
-    double util[3], best = 0;
-    for (int i = 0; i < 3; ++i) {
-        int64_t span = (int64_t)WAVE * cand[i];
-        int64_t nwc = (n_acc + span - 1) / span;
-        util[i] = (double)n_acc / (double)(nwc * span);
-        best = std::max(best, util[i]);
-    }
-    for (int i = 0; i < 3; ++i)
-        if (util[i] >= 0.85 * best) return cand[i];
+    if (ctx->force_bpl == 8 || ctx->force_bpl == 16) return ctx->force_bpl;
     return 4;
 }
 

@@ -21,7 +21,7 @@ def shard_bounds(n_acc, world, align=4):
 class AccessionShards(object):
     """Buffers and the collective for one rank of an accession-sharded job."""
 
-    def __init__(self, n_acc, world=1, rank=0, device="cpu", group=None):
+    def __init__(self, n_acc, world=1, rank=0, device="cpu", group=None, force_collective=False):
         import torch
         self.torch = torch
         self.n_acc, self.world, self.rank, self.group = int(n_acc), int(world), int(rank), group
@@ -32,7 +32,8 @@ class AccessionShards(object):
         # padded tail entries stay (score 0, ninfo 0): NaN likelihood, ignored by nanmin
         self.score_loc = torch.zeros(self.per, dtype=torch.float64, device=device)
         self.ninfo_loc = torch.zeros(self.per, dtype=torch.int64, device=device)
-        if world > 1:
+        self.collective = world > 1 or force_collective
+        if self.collective:
             self.score_all = torch.zeros(self.per * world, dtype=torch.float64, device=device)
             self.ninfo_all = torch.zeros(self.per * world, dtype=torch.int64, device=device)
         else:
@@ -50,7 +51,7 @@ class AccessionShards(object):
 
     def gather(self):
         """the single collective of the path: all-gather of (score, ninfo) along the accession axis"""
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             dist.all_gather_into_tensor(self.score_all, self.score_loc, group=self.group)
             dist.all_gather_into_tensor(self.ninfo_all, self.ninfo_loc, group=self.group)
