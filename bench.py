@@ -173,11 +173,13 @@ def main():
     k_avg_ms = k_ms / max(launches, 1)
     alg_bytes = float(n_snp) * (n_loc + 24.0)          # 1 B per element + 24 B of fp64 weights per SNP row
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
-    traffic = None
+    traffic = None           # PMC-measured HBM bytes per launch, only for the shape they were collected on
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and kernel == "fast":
         try:
-            traffic = json.load(open(pmc)).get("%d" % world, {}).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc)).get("%d" % world, {})
+            if rec.get("n_acc") == n_loc and rec.get("n_snp") == n_snp:
+                traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 

@@ -162,9 +162,8 @@ class Panel(object):
         p = cls(ctx, n_snp, n_acc)
         for r0 in range(0, n_snp, slab_rows):
             slab = np.ascontiguousarray(snps[r0:r0 + slab_rows], dtype=np.int8)
-            p.upload_rows(r0, slab)
-            p.upload_wait()          # `slab` is repacked into pinned memory before the call returns,
-        return p                     # the wait only bounds the number of slabs in flight
+            p.upload_rows(r0, slab)  # returns once `slab` is repacked into the pinned staging buffers and the
+        return p                     # copies are enqueued; scoring calls wait for them on the device
 
     def upload_rows(self, row0, rows):
         rows = np.ascontiguousarray(rows, dtype=np.int8)
