@@ -63,6 +63,9 @@ struct snpm_ctx {
     int force_bpl = 0;
     int force_wpb = 0;
     int parts_mult = 1;
+    int use_acc_major = 1;  // keep an accession-major packed copy (+25 % memory) for contiguous re-evaluation reads
+    int64_t acc_major_min_rows = 1000000;   // ... once a query is long enough for the strided path to hurt
+    int debug_reeval = 0;   // SNPM_DEBUG_REEVAL=k: also re-evaluate accessions 0..k-1 (to time that path)
     int stage_threads = 4;  // host threads repacking rows into the pinned staging slabs
     int nt_loads = 1;      // panel bytes are read once: non-temporal loads (+5-8% measured)
 };
@@ -73,6 +76,10 @@ struct snpm_panel {
     int8_t *d = nullptr;
     hipEvent_t uploaded = nullptr;      // last upload / fill enqueued on copy_stream
     bool upload_pending = false;
+    // accession-major packed copy (2 bits per call), built on first use by the exactness re-evaluation
+    uint8_t *dT = nullptr;
+    int64_t pitchT = 0;
+    int dT_state = 0;                   // 0 = not built / stale, 1 = valid, -1 = unusable (code 3 present or no memory)
 };
 
 struct snpm_query {
@@ -338,6 +345,39 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
     return SNPM_OK;
 }
 
+// Build (or reuse) the accession-major packed copy; returns true when it can be used.
+bool ensure_acc_major(snpm_panel *p)
+{
+    snpm_ctx *ctx = p->ctx;
+    if (!ctx->use_acc_major) return false;
+    if (p->dT_state == 1) return true;
+    if (p->dT_state == -1 || p->n_snp == 0) return false;
+    const int64_t pitchT = (((p->n_snp + 3) / 4 + 255) / 256) * 256 + 256;    // + one tile of slack for the last block
+    if (!p->dT) {
+        if (hipMalloc((void **)&p->dT, (size_t)p->n_acc * (size_t)pitchT) != hipSuccess) {
+            (void)hipGetLastError();
+            p->dT = nullptr;
+            p->dT_state = -1;           // not enough memory: keep the strided path
+            return false;
+        }
+        p->pitchT = pitchT;
+    }
+    if (ensure(ctx, ctx->ws_flags, sizeof(int)) != SNPM_OK) return false;
+    if (hipMemsetAsync(ctx->ws_flags.p, 0, sizeof(int), ctx->stream) != hipSuccess) return false;
+    dim3 grid((unsigned)((p->n_snp + PT_ROWS - 1) / PT_ROWS), (unsigned)((p->n_acc + PT_COLS - 1) / PT_COLS));
+    hipLaunchKernelGGL(k_pack_transpose, grid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->n_snp, p->n_acc, p->dT,
+                       p->pitchT, (int *)ctx->ws_flags.p);
+    int bad = 0;
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(&bad, ctx->ws_flags.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        p->dT_state = -1;
+        return false;
+    }
+    p->dT_state = bad ? -1 : 1;
+    return p->dT_state == 1;
+}
+
 // strict segment sums for `ncols` columns (d_cols NULL = all accessions) over segments d_seg_off[n_seg+1]
 int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64_t n_seg, const int32_t *d_cols,
                         int64_t ncols, int64_t ld)
@@ -352,9 +392,25 @@ int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64
     const int thr = ncols >= 256 ? 256 : (ncols > 128 ? 256 : (ncols > 64 ? 128 : 64));
     const bool gather = q->d_row_idx != nullptr;
     if (d_cols && ncols <= 64) {
-        // short column list: one lane per (segment, column), see k_strict_sparse
+        // short column list: one lane per (segment, column), see k_strict_sparse; on the accession-major
+        // packed copy when there is one (contiguous column reads), else strided over the SNP-major panel
         const int64_t total = n_seg * ncols;
         dim3 sgrid((unsigned)((total + 255) / 256));
+        if (q->n >= ctx->acc_major_min_rows && ensure_acc_major(p)) {
+            ProfScope ps(ctx, PK_STRICT);
+#define LAUNCH_SPARSE_T(S, G)                                                                                      \
+    hipLaunchKernelGGL((k_strict_sparse_T<S, G>), sgrid, dim3(256), 0, ctx->stream, p->dT, p->pitchT, q->d_row_idx, \
+                       q->row0, q->d_w, d_seg_off, n_seg, d_cols, ncols, (double *)ctx->ws_seg_score.p,            \
+                       (uint32_t *)ctx->ws_seg_miss.p, ld)
+            if (skip) {
+                if (gather) LAUNCH_SPARSE_T(true, true); else LAUNCH_SPARSE_T(true, false);
+            } else {
+                if (gather) LAUNCH_SPARSE_T(false, true); else LAUNCH_SPARSE_T(false, false);
+            }
+#undef LAUNCH_SPARSE_T
+            HIPCHK(ctx, hipGetLastError());
+            return SNPM_OK;
+        }
         ProfScope ps(ctx, PK_STRICT);
 #define LAUNCH_SPARSE(S, G)                                                                                        \
     hipLaunchKernelGGL((k_strict_sparse<S, G>), sgrid, dim3(256), 0, ctx->stream, p->d, p->pitch, q->d_row_idx,     \
@@ -502,6 +558,9 @@ int snpm_init(int device_id, snpm_ctx **out)
     if (const char *s = getenv("SNPM_PARTS_MULT")) ctx->parts_mult = std::max(1, atoi(s));
     if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
     if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
+    if (const char *s = getenv("SNPM_ACC_MAJOR")) ctx->use_acc_major = atoi(s);
+    if (const char *s = getenv("SNPM_ACC_MAJOR_MIN_ROWS")) ctx->acc_major_min_rows = atoll(s);
+    if (const char *s = getenv("SNPM_DEBUG_REEVAL")) ctx->debug_reeval = atoi(s);
     if (const char *s = getenv("SNPM_STAGE_THREADS")) ctx->stage_threads = std::max(1, atoi(s));
     *out = ctx;
     return SNPM_OK;
@@ -580,6 +639,7 @@ int snpm_panel_free(snpm_panel *p)
     (void)hipStreamSynchronize(p->ctx->copy_stream);
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->d) (void)hipFree(p->d);
+    if (p->dT) (void)hipFree(p->dT);
     if (p->uploaded) (void)hipEventDestroy(p->uploaded);
     delete p;
     return SNPM_OK;
@@ -654,6 +714,7 @@ int snpm_panel_upload_rows(snpm_panel *p, int64_t row0, int64_t nrows, const int
     }
     HIPCHK(ctx, hipEventRecord(p->uploaded, ctx->copy_stream));
     p->upload_pending = true;
+    p->dT_state = 0;                    // the accession-major copy is stale
     return SNPM_OK;
 }
 
@@ -695,6 +756,7 @@ int snpm_panel_fill_synthetic(snpm_panel *p, uint64_t seed, int64_t snp0, int64_
     hipLaunchKernelGGL(k_synth, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->stream, (uint32_t *)p->d, p->pitch,
                        p->n_snp, p->n_acc, seed, snp0, acc0);
     HIPCHK(ctx, hipGetLastError());
+    p->dT_state = 0;
     return SNPM_OK;
 }
 
@@ -849,7 +911,7 @@ int snpm_query_run_device(snpm_query *q, int64_t chunk, int skip_hets, int mode,
             for (int64_t a = 0; a < p->n_acc; ++a) {
                 const double f = h[a];
                 const double lo = f - E, hi = f + E;
-                if (!(lo >= 0.0) || std::floor(lo) != std::floor(hi)) cols.push_back((int32_t)a);
+                if (!(lo >= 0.0) || std::floor(lo) != std::floor(hi) || a < ctx->debug_reeval) cols.push_back((int32_t)a);
             }
             n_flag = (int64_t)cols.size();
             if (n_flag > 0) {
@@ -860,7 +922,7 @@ int snpm_query_run_device(snpm_query *q, int64_t chunk, int skip_hets, int mode,
                 if (rc) return rc;
                 HIPCHK(ctx, hipMemcpyAsync(ctx->ws_cols.p, cols.data(), cols.size() * sizeof(int32_t),
                                            hipMemcpyHostToDevice, ctx->stream));
-                const int64_t ld = ((n_flag + 63) / 64) * 64;
+                const int64_t ld = n_flag;       // compact [n_seg, n_flag]: the scan reads it contiguously
                 rc = run_strict_segments(q, skip, q->d_chunk_off, n_seg, (const int32_t *)ctx->ws_cols.p, n_flag, ld);
                 if (rc) return rc;
                 rc = ensure(ctx, ctx->ws_tmp_score, (size_t)ld * sizeof(double));

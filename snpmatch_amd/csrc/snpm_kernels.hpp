@@ -458,6 +458,99 @@ k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__r
     out_miss[seg * ld + i] = miss;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Accession-major packed copy of the panel (the reference keeps a column-chunked second HDF5 file for
+// the same purpose, core/makedb.py:64-81): dT [n_acc, pitchT] bytes, 4 SNPs per byte, 2 bits per call
+// (0 ref, 1 alt, 2 het, 3 missing).  A column of the panel becomes one contiguous run (n_snp/4 bytes), so
+// re-evaluating an accession in reference order no longer fetches a cache line per SNP.  Code 3 of the
+// SNP-major panel ("informative, matches nothing") has no 2-bit encoding: *bad is set and the copy is not
+// used.  Tile: 256 SNPs x 64 accessions through LDS.
+constexpr int PT_ROWS = 256;
+constexpr int PT_COLS = 64;
+__global__ void __launch_bounds__(256)
+k_pack_transpose(const int8_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n_acc,
+                 uint8_t *__restrict__ dT, int64_t pitchT, int *__restrict__ bad)
+{
+    __shared__ uint32_t tile[PT_ROWS][PT_COLS / 4 + 1];       // +1 dword per row: conflict-free column reads
+    const int64_t snp0 = (int64_t)blockIdx.x * PT_ROWS;
+    const int64_t acc0 = (int64_t)blockIdx.y * PT_COLS;
+    const int t = threadIdx.x;
+    // load: 16 lanes x 4 B cover the 64 accession bytes of one SNP row; 16 rows per pass
+    for (int pass = 0; pass < PT_ROWS / 16; ++pass) {
+        const int r = pass * 16 + (t >> 4);
+        const int64_t row = snp0 + r;
+        uint32_t v = 0xffffffffu;                               // rows past the end: missing
+        if (row < n_snp) v = *reinterpret_cast<const uint32_t *>(db + row * pitch + acc0 + (t & 15) * 4);
+        tile[r][t & 15] = v;
+    }
+    __syncthreads();
+    // pack: thread = (accession c, quarter q of the 256 SNPs): 64 calls -> 16 bytes
+    const int c = t & 63, q = t >> 6;
+    if (acc0 + c < n_acc) {
+        uint32_t out[4] = {0, 0, 0, 0};
+        int saw3 = 0;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            const uint32_t w = tile[q * 64 + k][c >> 2];
+            const uint32_t b = (w >> (8 * (c & 3))) & 0xffu;
+            saw3 |= (b == 3u);
+            const uint32_t code = (b & 0x80u) ? 3u : (b & 3u);
+            out[k >> 4] |= code << (2 * (k & 15));
+        }
+        if (saw3) atomicOr(bad, 1);
+        uint4 o;
+        o.x = out[0]; o.y = out[1]; o.z = out[2]; o.w = out[3];
+        *reinterpret_cast<uint4 *>(dT + (acc0 + c) * pitchT + snp0 / 4 + q * 16) = o;
+    }
+}
+
+// k_strict_sparse on the accession-major packed copy: same arithmetic and order.
+template <bool SKIP, bool GATHER>
+__global__ void __launch_bounds__(256)
+k_strict_sparse_T(const uint8_t *__restrict__ dT, int64_t pitchT, const int64_t *__restrict__ row_idx, int64_t row0,
+                  const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t n_seg,
+                  const int32_t *__restrict__ cols, int64_t ncols, double *__restrict__ out_score,
+                  uint32_t *__restrict__ out_miss, int64_t ld)
+{
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_seg * ncols) return;
+    const int64_t seg = id / ncols;
+    const int64_t i = id - seg * ncols;
+    const uint8_t *colp = dT + (int64_t)cols[i] * pitchT;
+    const int64_t r0 = seg_off[seg], r1 = seg_off[seg + 1];
+    double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
+    uint32_t miss = 0;
+    constexpr int U = 8;
+    int64_t r = r0;
+    for (; r + U <= r1; r += U) {
+        int b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t prow = GATHER ? row_idx[r + u] : (row0 + r + u);
+            b[u] = (colp[prow >> 2] >> (2 * (int)(prow & 3))) & 3;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double w0 = w[3 * (r + u) + 0], w1 = w[3 * (r + u) + 1], w2 = w[3 * (r + u) + 2];
+            a_ref = a_ref + (b[u] == 0 ? w0 : 0.0);
+            if (!SKIP) a_het = a_het + (b[u] == 2 ? w1 : 0.0);
+            a_alt = a_alt + (b[u] == 1 ? w2 : 0.0);
+            miss += SKIP ? (b[u] >= 2) : (b[u] == 3);
+        }
+    }
+    for (; r < r1; ++r) {
+        const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
+        const int b = (colp[prow >> 2] >> (2 * (int)(prow & 3))) & 3;
+        const double w0 = w[3 * r + 0], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
+        a_ref = a_ref + (b == 0 ? w0 : 0.0);
+        if (!SKIP) a_het = a_het + (b == 2 ? w1 : 0.0);
+        a_alt = a_alt + (b == 1 ? w2 : 0.0);
+        miss += SKIP ? (b >= 2) : (b == 3);
+    }
+    out_score[seg * ld + i] = ((0.0 + a_ref) + a_het) + a_alt;
+    out_miss[seg * ld + i] = miss;
+}
+
 // total[i] = (((0 + s0) + s1) + ...) over the segments in order; ninfo[i] = n_rows - sum(miss).
 // The adds are sequential by contract (ScoreList += chunk, core/snpmatch.py:224); the loads are not:
 // 8 are issued ahead of the adds that consume them.
@@ -503,19 +596,50 @@ k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, int 
     double s = 0.0;
     for (int64_t base = 0; base < n_seg; base += ts) {
         const int nseg = (int)((n_seg - base < ts) ? (n_seg - base) : ts);
-        for (int e = threadIdx.x; e < nseg * ncols; e += blockDim.x) {
-            const int sg = e / ncols, c = e - sg * ncols;
-            tile[e] = seg_score[(base + sg) * ld + c];
+        const int n_elem = nseg * ncols;
+        for (int e0 = threadIdx.x; e0 < n_elem; e0 += 8 * blockDim.x) {     // 8 independent loads in flight per thread
+            double v8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * blockDim.x;
+                if (e < n_elem) {
+                    const int sg = e / ncols, c = e - sg * ncols;
+                    v8[u] = seg_score[(base + sg) * ld + c];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * blockDim.x;
+                if (e < n_elem) tile[e] = v8[u];
+            }
         }
         __syncthreads();
         if ((int)threadIdx.x < ncols) {
+            // the adds form one dependent chain; the LDS reads of the next 16 values are issued before the
+            // 16 adds of the current ones
             int sg = 0;
-            for (; sg + 16 <= nseg; sg += 16) {          // LDS reads batched ahead of the dependent adds
-                double v[16];
+            double va[16], vb[16];
+            const double *tp = tile + threadIdx.x;
+            if (nseg >= 16) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = tile[(sg + u) * ncols + threadIdx.x];
+                for (int u = 0; u < 16; ++u) va[u] = tp[u * ncols];
+            }
+            // two register sets with static roles (no copies): while one set is added, the other is read
+            while (sg + 48 <= nseg) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) s = s + v[u];
+                for (int u = 0; u < 16; ++u) vb[u] = tp[(sg + 16 + u) * ncols];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s = s + va[u];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) va[u] = tp[(sg + 32 + u) * ncols];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s = s + vb[u];
+                sg += 32;
+            }
+            if (sg + 16 <= nseg) {          // va holds [sg, sg+16)
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s = s + va[u];
+                sg += 16;
             }
             for (; sg < nseg; ++sg) s = s + tile[sg * ncols + threadIdx.x];
         }

@@ -411,3 +411,49 @@ def test_segregating_rows_on_device(ctx):
     got = np.where(panel.segregating_rows(np.array([1, 4, 9, 17])))[0]
     assert np.array_equal(got, want) and len(got) > 1000
     assert np.array_equal(g.identify_segregating_snps(np.array([1, 4, 9, 17])), want)      # device path now
+
+
+def test_exact_mode_on_accession_major_copy():
+    """The strict re-evaluation of flagged accessions through the accession-major packed copy (forced for
+    short queries here) gives the reference's fp64 bits, dense and gathered, with and without skip_hets;
+    a panel holding the unencodable code 3 falls back to the SNP-major path and is still exact."""
+    os.environ["SNPM_ACC_MAJOR_MIN_ROWS"] = "0"
+    try:
+        c = engine.Context(0)
+    finally:
+        del os.environ["SNPM_ACC_MAJOR_MIN_ROWS"]
+    rng = np.random.default_rng(55)
+    n, n_acc = 9000, 300
+    for has3 in (False, True):
+        db = rand_db(rng, n, n_acc)
+        if has3:
+            db[::7, 11] = 3
+        panel = engine.Panel.from_host(c, db)
+        for rows in (None, np.sort(rng.choice(n, size=5003, replace=False)).astype(np.int64)):
+            sub = db if rows is None else db[rows]
+            codes = sub[:, 7].copy()
+            codes[codes < 0] = 0
+            codes[codes > 2] = 0
+            wei = synth.sample_weights(rng, codes, frac_pl=1.0)       # column 7 sums exact 1.0s: must be re-evaluated
+            q = engine.Query(panel, rows, wei)
+            for skip in (False, True):
+                want_s, want_n = c_oracle.genotyper(db, rows, wei, 1000, skip)
+                s, ni, info = q.run(1000, skip, engine.MODE_EXACT, return_info=True)
+                assert info["n_strict_reeval"] >= 1
+                assert np.array_equal(ni, want_n)
+                assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int))
+                if not skip:
+                    assert bits(s)[7] == bits(want_s)[7]
+        # new rows invalidate the copy: the next run rebuilds it
+        db2 = db.copy()
+        db2[:100] = rand_db(rng, 100, n_acc)
+        panel.upload_rows(0, db2[:100])
+        codes = db2[:, 9].copy()
+        codes[codes < 0] = 0
+        codes[codes > 2] = 0
+        wei = synth.sample_weights(rng, codes, frac_pl=1.0)
+        want_s, want_n = c_oracle.genotyper(db2, None, wei, 1000, False)
+        s, ni, info = engine.Query(panel, None, wei).run(1000, False, engine.MODE_EXACT, return_info=True)
+        assert info["n_strict_reeval"] >= 1 and bits(s)[9] == bits(want_s)[9]
+        assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int)) and np.array_equal(ni, want_n)
+    c.close()
