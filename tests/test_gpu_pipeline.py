@@ -171,3 +171,68 @@ def test_cross_interpreter_cases_match_reference(golden_dir, tmp_path, kind):
     want = json.loads(gold[".matches.json"])
     assert got == want
     assert got["interpretation"]["case"] == (6 if kind == "f2hom" else 5)
+
+
+def test_config1_sample_vcf_through_cli(golden_dir, tmp_path):
+    """BASELINE configs[0]: `snpmatch inbred` on the reference's sample VCF (701_501.filter.vcf).  The real
+    all_chromosomes_binary.hdf5 is not available, so a TAIR10-shaped DB is synthesised as SURVEY.md 8d
+    prescribes: positions = the VCF's and the BED's positions plus random fill to 100k SNPs, 64 accessions,
+    seed 701501, accession 40 planted from the VCF's hard calls with 1 % flips.  CLI outputs are checked
+    against the oracle run on the same parsed sample."""
+    import gzip
+    import shutil
+    from oracle import c_oracle
+    from oracle import snpmatch_oracle as orc
+    vcf = str(tmp_path / "701_501.filter.vcf")
+    with gzip.open(os.path.join(golden_dir, "701_501.filter.vcf.gz"), "rb") as fi, open(vcf, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    smp = parsers.ParseInputs(vcf, logDebug=False)
+    bed = np.loadtxt(os.path.join(golden_dir, "701_502.filter.bed"), dtype=str)
+    rng = np.random.default_rng(701501)
+    chrlen = [30427671, 19698289, 23459830, 18585056, 26975502]
+    s_chr = np.array([int(c.replace("Chr", "")) for c in smp.chrs])
+    b_chr, b_pos = bed[:, 0].astype(int), bed[:, 1].astype(int)
+    pos_by_chr = []
+    for c in range(1, 6):
+        have = np.union1d(smp.pos[s_chr == c], b_pos[b_chr == c])
+        fill = rng.choice(np.arange(1, chrlen[c - 1] + 1), size=20000, replace=False)
+        pos_by_chr.append(np.union1d(have, fill))
+    positions = np.concatenate(pos_by_chr)
+    regions, start = [], 0
+    for p in pos_by_chr:
+        regions.append((start, start + len(p)))
+        start += len(p)
+    n_snp, n_acc, planted = len(positions), 64, 40
+    snps = rng.choice(np.array([-1, 0, 1, 2], dtype=np.int8), size=(n_snp, n_acc), p=[0.05, 0.60, 0.33, 0.02])
+    codes = parsers.parseGT(smp.gt)
+    for c in range(1, 6):
+        a, b = regions[c - 1]
+        ix = a + np.searchsorted(positions[a:b], smp.pos[s_chr == c])
+        col = codes[s_chr == c].copy()
+        flip = rng.random(len(col)) < 0.01
+        col[flip] = rng.choice(np.array([0, 1], dtype=np.int8), size=int(flip.sum()))
+        snps[ix, planted] = col
+    accs = np.array([str(9000 + i) for i in range(n_acc)])
+    db = str(tmp_path / "tair10_like.snpm")
+    snp_genotype.save_native(db, snps, accs, positions, ["1", "2", "3", "4", "5"], regions)
+    out = str(tmp_path / "config1")
+    r = subprocess.run([sys.executable, "-m", "snpmatch_amd", "inbred", "-v", "-i", vcf, "-d", db, "-o", out],
+                       env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    # oracle on the same inputs
+    chrom = np.repeat(np.array(["1", "2", "3", "4", "5"]), [b - a for a, b in regions])
+    c0, c1 = orc.get_common_positions(chrom, positions, smp.chrs, smp.pos)
+    assert len(c0) == 7545
+    want_s, want_n = c_oracle.genotyper(snps, c0, smp.wei[c1], 1000, False)
+    lik, lrt = orc.calculate_likelihoods(np.array(want_s, dtype=int), want_n)
+    rows = [l.split("\t") for l in open(out + ".scores.txt").read().strip().split("\n")]
+    assert [x[0] for x in rows] == accs.tolist()
+    assert [int(x[1]) for x in rows] == np.array(want_s, dtype=int).tolist()
+    assert [int(x[2]) for x in rows] == want_n.tolist()
+    np.testing.assert_allclose([float(x[4]) for x in rows], lik, rtol=RTOL)
+    np.testing.assert_allclose([float(x[5]) for x in rows], lrt, rtol=RTOL)
+    assert all(x[6] == "7545" for x in rows)
+    js = json.load(open(out + ".matches.json"))
+    assert js["interpretation"]["case"] == 0 and js["matches"][0][0] == accs[planted]
+    assert js["overlap"] == [1.0, 7545] and js["percent_heterozygosity"] == 110 / 7545.0
+    assert os.path.exists(vcf + ".snpmatch.npz") and os.path.exists(vcf + ".snpmatch.stats.json")
