@@ -1,114 +1,167 @@
 """
-Sample input parsing: the boundary producer of the hot path (chrs, pos, gt, wei, dp).
+Sample input parsing: the boundary producer of the hot path.
 
-Mirrors the interface of the reference's ``snpmatch.core.parsers`` (core/parsers.py:12-218):
-``parseGT``, ``snp_binary_to_gt``, ``ParseInputs`` (same attributes, same ``.npz`` cache keys
-``chr, pos, gt, wei, dp``, same ``.stats.json``), ``import_vcf_file``, ``potatoParser``.
+Interface of the reference's ``snpmatch.core.parsers`` (core/parsers.py:12-218): ``parseGT``,
+``snp_binary_to_gt``, ``ParseInputs`` (attributes ``chrs, pos, gt, wei, dp``; ``filter_chr_names`` ->
+``g_chrs, g_chrs_ids``; the ``<input>.snpmatch.npz`` cache with keys ``chr, pos, gt, wei, dp`` and the
+``<input>.snpmatch.stats.json`` summary), ``import_vcf_file``, ``potatoParser``.
 
-The reference reads VCF through scikit-allel, which is not a dependency here: ``import_vcf_file``
-is a plain text reader that returns the same fields with the same conventions
-(core/parsers.py:178-213): GT of the first sample as ``'0/0'``-style strings, PL as float with -1
-for missing (three values, Number=G of a diploid call), INFO/DP as ``variants/DP`` (-1 when absent).
-This is CPU work on a few thousand lines; the scoring itself never runs here.
+VCF text is read by ``_vcf.read_calls`` (no scikit-allel); weights are ``exp(-PL/10)`` where PL is
+present and one-hot on the called genotype otherwise (core/parsers.py:132-157).
 
-Deliberate fix: BED inputs carry ``dp = "NA"``; the reference then crashes in ``np.nanmean("NA")``
-(core/parsers.py:113, core/snpmatch.py:133).  Here "NA" depth is reported as NaN.
+Deliberate fix: BED inputs carry ``dp = "NA"``, on which the reference crashes (``np.nanmean("NA")``,
+core/parsers.py:113 and core/snpmatch.py:133); here an unknown depth is reported as NaN.
 """
-import gzip
 import json
 import logging
 import os
 import re
+import sys
 
 import numpy as np
 import pandas as pd
 
+from . import _report
+from . import _vcf
+
 log = logging.getLogger(__name__)
 
-snp_thres = 4000          # core/snpmatch.py:18 (kept here as well to avoid an import cycle)
+_CODE_TO_GT = {-1: "./.", 0: "0/0", 1: "1/1", 2: "0/1"}
 
 
 def die(msg):
-    import sys
     sys.stderr.write('Error: ' + msg + '\n')
     sys.exit(1)
 
 
 def parseGT(snpGT):
-    """GT strings -> int8 codes (0 ref, 1 alt, 2 het, -1 no call); core/parsers.py:12-35."""
+    """genotype text -> int8 codes: 0 hom-ref, 1 hom-alt, 2 het, -1 no call (anything else stays 0).
+    The separator ('/' or '|') is taken from the first entry; purely numeric input is returned as codes."""
     snpGT = np.asarray(snpGT)
-    snpBinary = np.zeros(len(snpGT), dtype="int8")
-    if len(snpBinary) == 0:
-        return snpBinary
-    first = str(snpGT[0])
-    if first.find('|') != -1:
+    codes = np.zeros(len(snpGT), dtype="int8")
+    if len(codes) == 0:
+        return codes
+    head = str(snpGT[0])
+    if "|" in head:
         sep = "|"
-    elif first.find('/') != -1:
+    elif "/" in head:
         sep = "/"
-    elif first.isdigit():
+    elif head.isdigit():
         return np.array(np.copy(snpGT), dtype="int8")
     else:
         die("unable to parse the format of GT in vcf!")
-    gt = snpGT.astype("U")
-    snpBinary[gt == "1" + sep + "1"] = 1
-    snpBinary[(gt == "0" + sep + "1") | (gt == "1" + sep + "0")] = 2
-    snpBinary[gt == "." + sep + "."] = -1
-    return snpBinary
+    text = snpGT.astype("U")
+    for pattern, code in ((("1", "1"), 1), (("0", "1"), 2), (("1", "0"), 2), ((".", "."), -1)):
+        codes[text == sep.join(pattern)] = code
+    return codes
 
 
 def snp_binary_to_gt(snpBinary):
-    """core/parsers.py:37-44."""
-    snpBinary = np.array(snpBinary, dtype="int8")
-    snpGT = np.zeros(len(snpBinary), dtype="S8")
-    snpGT[snpBinary == -1] = "./."
-    snpGT[snpBinary == 0] = "0/0"
-    snpGT[snpBinary == 1] = "1/1"
-    snpGT[snpBinary == 2] = "0/1"
-    return snpGT
+    codes = np.array(snpBinary, dtype="int8")
+    out = np.zeros(len(codes), dtype="S8")
+    for code, text in _CODE_TO_GT.items():
+        out[codes == code] = text
+    return out
 
 
-def _nanmean_depth(dp):
-    """np.nanmean(dp) that tolerates the "NA" depth of BED inputs (see module docstring)."""
-    try:
-        arr = np.asarray(dp, dtype=float)
-    except (TypeError, ValueError):
-        return float("nan")
-    if arr.size == 0:
-        return float("nan")
-    if np.all(np.isnan(arr)):
-        return float("nan")
-    return float(np.nanmean(arr))
+def _one_hot_weights(gt_text):
+    """[n,3] weights (ref, het, alt): 1 in the column of the called genotype, 0 elsewhere"""
+    codes = parseGT(gt_text)
+    wei = np.zeros((len(codes), 3))
+    for code, column in ((0, 0), (2, 1), (1, 2)):
+        wei[codes == code, column] = 1.0
+    return wei
 
 
 class ParseInputs(object):
-    """core/parsers.py:59-175."""
 
     def __init__(self, inFile, logDebug=True, outFile="parser"):
-        if outFile == "parser" or not outFile:
-            outFile = inFile + ".snpmatch"
-        if os.path.isfile(inFile + ".snpmatch.npz"):
-            log.info("snpmatch parser dump found! loading %s", inFile + ".snpmatch.npz")
-            snps = np.load(inFile + ".snpmatch.npz")
-            self.load_snp_info(snps['chr'], snps['pos'], snps['gt'], snps['wei'], snps['dp'])
-            log.info("done!")
+        prefix = inFile + ".snpmatch" if (outFile == "parser" or not outFile) else outFile
+        cache = inFile + ".snpmatch.npz"
+        if os.path.isfile(cache):
+            log.info("using cached parse %s", cache)
+            self._load_npz(cache)
         elif os.path.isfile(inFile):
-            _, inType = os.path.splitext(inFile)
-            if inType == '.npz':
-                log.info("loading snpmatch parser file! %s", inFile)
-                snps = np.load(inFile)
-                self.load_snp_info(snps['chr'], snps['pos'], snps['gt'], snps['wei'], snps['dp'])
+            base = os.path.basename(inFile)
+            if base.endswith(".npz"):
+                log.info("reading parsed sample %s", inFile)
+                self._load_npz(inFile)
+                return
+            log.info('parsing %s', inFile)
+            if base.endswith(".vcf") or base.endswith(".vcf.gz"):
+                fields = self.read_vcf(inFile, logDebug)
+            elif base.endswith(".bed"):
+                fields = self.read_bed(inFile, logDebug)
             else:
-                log.info('running snpmatch parser!')
-                if inType == '.vcf' or os.path.basename(inFile).endswith(".vcf.gz"):
-                    (snpCHR, snpPOS, snpGT, snpWEI, DPmean) = self.read_vcf(inFile, logDebug)
-                elif inType == '.bed':
-                    (snpCHR, snpPOS, snpGT, snpWEI, DPmean) = self.read_bed(inFile, logDebug)
-                else:
-                    die("input file type %s not supported" % inType)
-                self.load_snp_info(snpCHR, snpPOS, snpGT, snpWEI, DPmean)
-                self.save_snp_info(outFile)
-                self.case_interpret_inputs(outFile + ".stats.json")
-            log.info("done!")
+                die("input file type %s not supported" % os.path.splitext(inFile)[1])
+            self.load_snp_info(*fields)
+            self.save_snp_info(prefix)
+            self.case_interpret_inputs(prefix + ".stats.json")
+            log.info("parsed %d SNP calls", len(self.chrs))
+        # anything else (e.g. ParseInputs("")) leaves an empty object to be filled with load_snp_info
+
+    def _load_npz(self, path):
+        z = np.load(path)
+        self.load_snp_info(z['chr'], z['pos'], z['gt'], z['wei'], z['dp'])
+
+    def case_interpret_inputs(self, outFile):
+        """``<prefix>.stats.json``: SNPs per chromosome, depth, heterozygosity, low-SNP warning"""
+        from . import snpmatch
+        n = len(self.chrs)
+        few = n < snpmatch.snp_thres
+        names, counts = np.unique(self.chrs, return_counts=True)
+        stats = {
+            "snps": dict((str(k), int(v)) for k, v in zip(names, counts)),
+            "interpretation": {"case": int(few),
+                               "text": "Attention: low number of SNPs provided" if few else "Sufficient number of SNPs"},
+            "num_of_snps": n,
+            "depth": _report.mean_depth(self.dp),
+            "percent_heterozygosity": snpmatch.getHeterozygosity(self.gt),
+        }
+        with open(outFile, "w") as fh:
+            fh.write(json.dumps(stats))
+
+    @staticmethod
+    def get_wei_from_GT(snpGT):
+        return _one_hot_weights(snpGT)
+
+    @staticmethod
+    def read_bed(inFile, logDebug):
+        """three columns: chromosome, position, genotype (any whitespace / comma separator)"""
+        log.info("reading BED-like table %s", inFile)
+        table = pd.read_csv(inFile, header=None, sep=None, engine='python', usecols=[0, 1, 2])
+        gt = np.array(table[2])
+        return (np.array(table[0], dtype="str"), np.array(table[1], dtype=int), gt, _one_hot_weights(gt), "NA")
+
+    def read_vcf(self, inFile, logDebug):
+        """called sites of the first sample: (chr, pos, gt, weights, depth)"""
+        calls = import_vcf_file(inFile, logDebug, samples_to_load=[0])
+        gt = calls['gt'][:, 0]
+        called = np.flatnonzero((gt != './.') & (gt != '.|.'))
+        gt = gt[called]
+        if 'wei' in calls:
+            pl = calls['wei'][called, 0]
+            no_pl = np.all(pl == -1, axis=1)
+            wei = np.exp(pl / (-10))
+            wei[no_pl] = _one_hot_weights(gt[no_pl])
+        else:
+            wei = _one_hot_weights(gt)
+        return (calls['chr'][called], calls['pos'][called], gt, wei, calls['dp'][called])
+
+    def filter_chr_names(self):
+        """``g_chrs``: chromosome names without a (case-insensitive) 'chr'; ``g_chrs_ids``: their distinct
+        values in order of first appearance.  The regex runs on the distinct names only."""
+        if len(self.chrs) == 0:
+            self.g_chrs = self.g_chrs_ids = np.zeros(0, dtype="U1")
+            return
+        uniq, first, inv = np.unique(self.chrs, return_index=True, return_inverse=True)
+        bare = np.array([re.sub("chr", "", c, flags=re.IGNORECASE) for c in uniq.tolist()], dtype="str")
+        self.g_chrs = bare[inv]
+        ids = []
+        for k in np.argsort(first, kind="stable"):        # 'Chr1' and 'chr1' are the same chromosome
+            if bare[k] not in ids:
+                ids.append(bare[k])
+        self.g_chrs_ids = np.array(ids, dtype=self.g_chrs.dtype)
 
     def load_snp_info(self, snpCHR, snpPOS, snpGT, snpWEI, DPmean):
         self.chrs = np.array(snpCHR, dtype="str")
@@ -118,177 +171,29 @@ class ParseInputs(object):
         self.dp = DPmean
 
     def save_snp_info(self, outFile):
-        log.info("creating snpmatch parser file: %s", outFile + '.npz')
+        log.info("caching the parse as %s.npz", outFile)
         np.savez(outFile, chr=self.chrs, pos=self.pos, gt=self.gt, wei=self.wei, dp=self.dp)
 
-    def case_interpret_inputs(self, outFile):
-        from . import snpmatch
-        NumSNPs = len(self.chrs)
-        case, note = 0, "Sufficient number of SNPs"
-        if NumSNPs < snpmatch.snp_thres:
-            note, case = "Attention: low number of SNPs provided", 1
-        ids, counts = np.unique(self.chrs, return_counts=True)
-        statdict = {
-            "snps": dict(('%s' % ids[i], int(counts[i])) for i in range(len(ids))),
-            "interpretation": {"case": case, "text": note},
-            "num_of_snps": NumSNPs,
-            "depth": _nanmean_depth(self.dp),
-            "percent_heterozygosity": snpmatch.getHeterozygosity(self.gt),
-        }
-        with open(outFile, "w") as out_stats:
-            out_stats.write(json.dumps(statdict))
-
-    @staticmethod
-    def read_bed(inFile, logDebug):
-        log.info("reading the position file")
-        targetSNPs = pd.read_csv(inFile, header=None, sep=None, engine='python', usecols=[0, 1, 2])
-        snpCHR = np.array(targetSNPs[0], dtype="str")
-        snpPOS = np.array(targetSNPs[1], dtype=int)
-        snpGT = np.array(targetSNPs[2])
-        snpWEI = ParseInputs.get_wei_from_GT(snpGT)
-        return (snpCHR, snpPOS, snpGT, snpWEI, "NA")
-
-    @staticmethod
-    def get_wei_from_GT(snpGT):
-        """hard 0/1 weights from the called genotype (core/parsers.py:132-139)."""
-        snpBinary = parseGT(snpGT)
-        snpWEI = np.ones((len(snpGT), 3))
-        snpWEI[snpBinary != 0, 0] = 0
-        snpWEI[snpBinary != 1, 2] = 0
-        snpWEI[snpBinary != 2, 1] = 0
-        return snpWEI
-
-    def read_vcf(self, inFile, logDebug):
-        """core/parsers.py:141-157."""
-        snp_inputs = import_vcf_file(inFile, logDebug, samples_to_load=[0])
-        gt = snp_inputs['gt'][:, 0]
-        snpsREQ = np.where((gt != './.') & (gt != '.|.'))[0]
-        snpGT = gt[snpsREQ]
-        if 'wei' in snp_inputs:
-            snpWEI = snp_inputs['wei'][snpsREQ, 0]
-            missing_pls = np.all(snpWEI == -1, axis=1)
-            snpWEI = np.exp(snpWEI / (-10))
-            if missing_pls.any():
-                snpWEI[missing_pls, ] = self.get_wei_from_GT(snpGT[missing_pls])
-        else:
-            snpWEI = self.get_wei_from_GT(snpGT)
-        snpCHR = snp_inputs['chr'][snpsREQ]
-        snpPOS = snp_inputs['pos'][snpsREQ]
-        snpDP = snp_inputs['dp'][snpsREQ]
-        return (snpCHR, snpPOS, snpGT, snpWEI, snpDP)
-
-    def filter_chr_names(self):
-        """strip 'chr' case-insensitively; ids in order of first appearance (core/parsers.py:159-163).
-        Chromosome names take few distinct values: the regex runs on the unique names only."""
-        if len(self.chrs) == 0:
-            self.g_chrs = np.zeros(0, dtype="U1")
-            self.g_chrs_ids = self.g_chrs
-            return
-        uniq, first, inv = np.unique(self.chrs, return_index=True, return_inverse=True)
-        stripped = np.array([re.sub("chr", "", c, flags=re.IGNORECASE) for c in uniq.tolist()], dtype="str")
-        self.g_chrs = stripped[inv]
-        # order of first appearance of the STRIPPED ids ('Chr1' and 'chr1' are the same chromosome)
-        order = np.argsort(first, kind="stable")
-        ids = []
-        for k in order:
-            if stripped[k] not in ids:
-                ids.append(stripped[k])
-        self.g_chrs_ids = np.array(ids, dtype=self.g_chrs.dtype)
-
     def save_to_bed(self, outFile):
-        input_df = pd.DataFrame(np.column_stack((self.chrs, self.pos, self.gt)), columns=["chr", 'pos', 'gt'])
-        input_df.to_csv(outFile, sep="\t", index=None, header=False)
-
-
-def _open_text(path):
-    if path.endswith(".gz"):
-        return gzip.open(path, "rt")
-    return open(path, "r")
+        pd.DataFrame({"chr": self.chrs, "pos": self.pos, "gt": self.gt}).to_csv(outFile, sep="\t", index=None, header=False)
 
 
 def import_vcf_file(inFile, logDebug=False, samples_to_load=[0], add_fields=None):
-    """Text VCF reader returning what the reference extracts from scikit-allel
-    (core/parsers.py:178-213): dict with 'samples', 'gt' [n, s] str, 'wei' [n, s, 3] float (PL, -1 =
-    missing; only when some record carries PL), 'chr', 'pos', 'dp' (INFO/DP, -1 = missing)."""
-    chroms, poss, gts, pls, dps = [], [], [], [], []
-    samples = []
-    have_pl = False
-    have_gt = False
-    have_info_dp = False
-    sel = list(samples_to_load)
-    with _open_text(inFile) as fh:
-        for line in fh:
-            if line.startswith("##"):
-                if line.startswith("##INFO=<ID=DP,"):
-                    have_info_dp = True
-                continue
-            if line.startswith("#"):
-                cols = line.rstrip("\n").split("\t")
-                samples = cols[9:]
-                continue
-            f = line.rstrip("\n").split("\t")
-            if len(f) < 8:
-                continue
-            chroms.append(f[0])
-            poss.append(int(f[1]))
-            dp = -1
-            if f[7] != ".":
-                for kv in f[7].split(";"):
-                    if kv.startswith("DP="):
-                        try:
-                            dp = int(kv[3:])
-                            have_info_dp = True
-                        except ValueError:
-                            dp = -1
-                        break
-            dps.append(dp)
-            fmt = f[8].split(":") if len(f) > 8 else []
-            row_gt, row_pl = [], []
-            for si in sel:
-                col = 9 + si
-                val = f[col].split(":") if len(f) > col else []
-                gt = "./."
-                pl = (-1.0, -1.0, -1.0)
-                for k, key in enumerate(fmt):
-                    if k >= len(val):
-                        break
-                    if key == "GT":
-                        have_gt = True
-                        gt = val[k]
-                        if gt == ".":
-                            gt = "./."
-                    elif key == "PL" and val[k] != ".":
-                        parts = val[k].split(",")
-                        vals = []
-                        for x in parts[:3]:
-                            vals.append(-1.0 if x == "." else float(x))
-                        while len(vals) < 3:
-                            vals.append(-1.0)
-                        pl = tuple(vals)
-                        have_pl = True
-                row_gt.append(gt)
-                row_pl.append(pl)
-            gts.append(row_gt)
-            pls.append(row_pl)
-    if not have_gt and len(chroms) > 0:
+    """dict with 'samples', 'gt' [n, s], 'wei' (the PL triples, -1 = missing; only when PL occurs), 'chr',
+    'pos', 'dp' (INFO/DP, or "NA" entries when the file has none) -- the keys the reference builds from
+    scikit-allel's output"""
+    calls = _vcf.read_calls(inFile, tuple(samples_to_load))
+    if not calls["has_gt"]:
         die("input VCF file doesnt have required GT field")
-    snp_inputs = {}
-    snp_inputs['samples'] = np.array([samples[i] for i in sel if i < len(samples)]).astype('U')
-    snp_inputs['gt'] = np.array(gts, dtype='U').reshape(len(chroms), len(sel))
-    if have_pl:
-        snp_inputs['wei'] = np.array(pls, dtype=float).reshape(len(chroms), len(sel), 3)
-    snp_inputs['chr'] = np.array(chroms, dtype="str").astype('U')
-    snp_inputs['pos'] = np.array(poss, dtype=int)
-    if have_info_dp:
-        snp_inputs['dp'] = np.array(dps, dtype=int)
-    else:
-        snp_inputs['dp'] = np.repeat("NA", len(poss))
-    if add_fields is not None:
-        for ef in add_fields:
-            log.warning("Field %s is not loaded by this reader" % ef)
-    return snp_inputs
+    out = {'samples': calls["samples"], 'gt': calls["gt"], 'chr': calls["chr"], 'pos': calls["pos"]}
+    if calls["pl"] is not None:
+        out['wei'] = calls["pl"]
+    out['dp'] = calls["dp"] if calls["dp"] is not None else np.repeat("NA", len(calls["pos"]))
+    for name in (add_fields or ()):
+        log.warning("Field %s is not loaded by this reader" % name)
+    return out
 
 
 def potatoParser(inFile, logDebug, outFile="parser"):
-    inputs = ParseInputs(inFile, logDebug, outFile)
-    return (inputs.chrs, inputs.pos, inputs.gt, inputs.wei, inputs.dp)
+    parsed = ParseInputs(inFile, logDebug, outFile)
+    return (parsed.chrs, parsed.pos, parsed.gt, parsed.wei, parsed.dp)
