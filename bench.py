@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--mode", default="exact", choices=["exact", "strict", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=1000)
+    ap.add_argument("--packed", action="store_true",
+                    help="2-bit packed panel (4 accessions per byte) instead of the int8 panel BASELINE.json names")
     # rehearsal of the N>1 code path on a one-GPU box (never used by the driver): gloo instead of
     # RCCL and every rank on device 0
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -125,7 +127,7 @@ def main():
     mode = {"exact": engine.MODE_EXACT, "strict": engine.MODE_STRICT, "fast": engine.MODE_FAST}[args.mode]
 
     t_setup = time.perf_counter()
-    panel = engine.Panel(ctx, n_snp, n_loc)
+    panel = engine.Panel(ctx, n_snp, n_loc, packed=args.packed)
     panel.fill_synthetic(SEED, 0, a0)
     wei = make_sample(n_snp, SEED, PLANTED)
     query = engine.Query(panel, None, wei)
@@ -171,11 +173,12 @@ def main():
     kernel = {"fast": "fast", "exact": "fast", "strict": "strict"}[args.mode]
     launches, k_ms = ctx.profile_read(kernel)
     k_avg_ms = k_ms / max(launches, 1)
-    alg_bytes = float(n_snp) * (n_loc + 24.0)          # 1 B per element + 24 B of fp64 weights per SNP row
+    # algorithmic bytes: 1 B per element (0.25 B on a packed panel) + 24 B of fp64 weights per SNP row
+    alg_bytes = float(n_snp) * ((n_loc / 4.0 if args.packed else n_loc) + 24.0)
     achieved = alg_bytes / (k_avg_ms * 1e-3) / 1e9 if k_avg_ms > 0 else 0.0
     traffic = None           # PMC-measured HBM bytes per launch, only for the shape they were collected on
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc) and kernel == "fast":
+    if os.path.exists(pmc) and kernel == "fast" and not args.packed:
         try:
             rec = json.load(open(pmc)).get("%d" % world, {})
             if rec.get("n_acc") == n_loc and rec.get("n_snp") == n_snp:
@@ -209,13 +212,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "int8 compare + f64 accumulate",
+            "dtype": ("2-bit" if args.packed else "int8") + " compare + f64 accumulate",
             "data": "synthetic",
             "config": {
                 "workload": "configs[3]: synthetic 10k accessions x 50M SNPs int8, accession-sharded; "
                             "per GPU %d accessions x %d SNPs (%.1f GB resident), job = %d x %d"
                             % (n_loc, n_snp, n_snp * panel.pitch / 1e9, n_acc, n_snp),
                 "n_acc": n_acc, "n_snp": n_snp, "acc_per_gpu": n_loc, "mode": args.mode, "chunk": args.chunk,
+                "panel_format": "packed2" if args.packed else "int8",
                 "sample": "planted accession %d, 2%% error, 80%% PL weights" % PLANTED,
                 "parallelism": "acc-shard x%d + all-gather (%s)" % (world, args.backend if world > 1 else "none"),
             },

@@ -71,6 +71,12 @@ int         snpm_synchronize(snpm_ctx *ctx);
 /* ---------------------------------------------------------------- panel (DB genotype matrix in HBM) */
 /* SNP-major int8 [n_snp, pitch], pitch = n_acc rounded up to 256 B, pad bytes = -1. */
 int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out);
+/* Same panel with 2 bits per call (4 accessions per byte: 0 ref, 1 alt, 2 het, 3 missing): 4x less HBM
+   capacity and traffic (the 10k x 50M panel is 125 GB and fits one MI355X).  Rows are uploaded as int8
+   exactly like an int8 panel and packed on the device; codes > 2 cannot be stored (SNPM_ERR_BADARG from the
+   upload).  Every scoring entry point accepts either panel kind and returns identical results. */
+int snpm_panel_create_packed(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out);
+int snpm_panel_is_packed(const snpm_panel *panel, int *packed);
 int snpm_panel_free(snpm_panel *panel);
 int snpm_panel_info(const snpm_panel *panel, int64_t *n_snp, int64_t *n_acc, int64_t *pitch, void **device_ptr);
 /* Asynchronous upload of rows [row0, row0+nrows) from host memory (row stride host_pitch bytes,

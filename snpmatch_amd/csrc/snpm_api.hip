@@ -51,7 +51,7 @@ struct snpm_ctx {
     void *h_pinned = nullptr;
     size_t h_pinned_cap = 0;
     // grow-only device workspaces
-    Buf ws_grp_score, ws_grp_miss;
+    Buf ws_grp_score, ws_grp_miss, ws_stage_dev, ws_flags2;
     Buf ws_part_score, ws_part_miss, ws_seg_score, ws_seg_miss, ws_seg_off, ws_cols, ws_tmp_score, ws_tmp_ninfo, ws_flags;
     Buf ws_lik_y, ws_lik_n, ws_lik_l, ws_lik_r;
     // profiling
@@ -72,7 +72,10 @@ struct snpm_ctx {
 
 struct snpm_panel {
     snpm_ctx *ctx = nullptr;
-    int64_t n_snp = 0, n_acc = 0, pitch = 0;
+    int64_t n_snp = 0, n_acc = 0;
+    int64_t pitch = 0;                  // bytes per SNP row (int8: >= n_acc; packed: >= n_acc / 4), multiple of 256
+    int64_t ld = 0;                     // accessions per row rounded up to 256: leading dimension of result arrays
+    int packed = 0;                     // 0 = int8 (one byte per call), 1 = 2 bits per call (4 accessions per byte)
     int8_t *d = nullptr;
     hipEvent_t uploaded = nullptr;      // last upload / fill enqueued on copy_stream
     bool upload_pending = false;
@@ -253,7 +256,7 @@ int launch_fast_t(snpm_query *q, const FastGeom &g)
     dim3 block(WAVE * g.wpb);
     ProfScope ps(ctx, PK_FAST);
     hipLaunchKernelGGL((k_fast<BPL, SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0,
-                       q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->pitch);
+                       q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }
@@ -296,32 +299,35 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
     int rc = ensure_lut(q, skip);
     if (rc) return rc;
     const bool gather = q->d_row_idx != nullptr;
-    const int bpl = pick_bpl(ctx, p->n_acc);
+    // packed panels: one byte per lane and row = 4 accessions, the same wave/column geometry as int8 at 4 B/lane
+    const int bpl = p->packed ? 4 : pick_bpl(ctx, p->n_acc);
     FastGeom g0 = fast_geom(ctx, p->n_acc, q->n, 2, bpl);   // wpb does not depend on occupancy
     int occ = 0;
     const bool nt = ctx->nt_loads != 0;
     const int thr = WAVE * g0.wpb;
-    if (bpl == 16) occ = nt ? occ_b<16, true>(skip, gather, thr) : occ_b<16, false>(skip, gather, thr);
+    if (p->packed) occ = nt ? occ_b<1, true>(skip, gather, thr) : occ_b<1, false>(skip, gather, thr);
+    else if (bpl == 16) occ = nt ? occ_b<16, true>(skip, gather, thr) : occ_b<16, false>(skip, gather, thr);
     else if (bpl == 8) occ = nt ? occ_b<8, true>(skip, gather, thr) : occ_b<8, false>(skip, gather, thr);
     else occ = nt ? occ_b<4, true>(skip, gather, thr) : occ_b<4, false>(skip, gather, thr);
     FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl);
     if (geom_out) *geom_out = g;
-    rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_slots * p->pitch * sizeof(double));
+    rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_slots * p->ld * sizeof(double));
     if (rc) return rc;
-    rc = ensure(ctx, ctx->ws_part_miss, (size_t)g.n_slots * p->pitch * sizeof(uint32_t));
+    rc = ensure(ctx, ctx->ws_part_miss, (size_t)g.n_slots * p->ld * sizeof(uint32_t));
     if (rc) return rc;
-    rc = ensure(ctx, ctx->ws_grp_score, (size_t)g.n_groups * p->pitch * sizeof(double));
+    rc = ensure(ctx, ctx->ws_grp_score, (size_t)g.n_groups * p->ld * sizeof(double));
     if (rc) return rc;
-    rc = ensure(ctx, ctx->ws_grp_miss, (size_t)g.n_groups * p->pitch * sizeof(uint32_t));
+    rc = ensure(ctx, ctx->ws_grp_miss, (size_t)g.n_groups * p->ld * sizeof(uint32_t));
     if (rc) return rc;
     if (q->n > 0) {
         if (g.n_epochs > 1) {
             // parts with fewer tiles never reach the last epoch slot: those slots must read as zero
-            const size_t off = (size_t)(g.n_epochs - 1) * g.n_parts * p->pitch;
-            HIPCHK(ctx, hipMemsetAsync((double *)ctx->ws_part_score.p + off, 0, (size_t)g.n_parts * p->pitch * sizeof(double), ctx->stream));
-            HIPCHK(ctx, hipMemsetAsync((uint32_t *)ctx->ws_part_miss.p + off, 0, (size_t)g.n_parts * p->pitch * sizeof(uint32_t), ctx->stream));
+            const size_t off = (size_t)(g.n_epochs - 1) * g.n_parts * p->ld;
+            HIPCHK(ctx, hipMemsetAsync((double *)ctx->ws_part_score.p + off, 0, (size_t)g.n_parts * p->ld * sizeof(double), ctx->stream));
+            HIPCHK(ctx, hipMemsetAsync((uint32_t *)ctx->ws_part_miss.p + off, 0, (size_t)g.n_parts * p->ld * sizeof(uint32_t), ctx->stream));
         }
-        if (bpl == 16) rc = nt ? launch_fast_b<16, true>(q, g, skip, gather) : launch_fast_b<16, false>(q, g, skip, gather);
+        if (p->packed) rc = nt ? launch_fast_b<1, true>(q, g, skip, gather) : launch_fast_b<1, false>(q, g, skip, gather);
+        else if (bpl == 16) rc = nt ? launch_fast_b<16, true>(q, g, skip, gather) : launch_fast_b<16, false>(q, g, skip, gather);
         else if (bpl == 8) rc = nt ? launch_fast_b<8, true>(q, g, skip, gather) : launch_fast_b<8, false>(q, g, skip, gather);
         else rc = nt ? launch_fast_b<4, true>(q, g, skip, gather) : launch_fast_b<4, false>(q, g, skip, gather);
         if (rc) return rc;
@@ -334,11 +340,11 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
         if (n_groups > 0) {
             hipLaunchKernelGGL(k_reduce_groups, dim3(cb, (unsigned)n_groups), dim3(thr), 0, ctx->stream,
                                (const double *)ctx->ws_part_score.p, (const uint32_t *)ctx->ws_part_miss.p, g.n_slots,
-                               p->pitch, p->n_acc, (double *)ctx->ws_grp_score.p, (uint32_t *)ctx->ws_grp_miss.p);
+                               p->ld, p->n_acc, (double *)ctx->ws_grp_score.p, (uint32_t *)ctx->ws_grp_miss.p);
             HIPCHK(ctx, hipGetLastError());
         }
         hipLaunchKernelGGL(k_reduce, dim3(cb), dim3(thr), 0, ctx->stream, (const double *)ctx->ws_grp_score.p,
-                           (const uint32_t *)ctx->ws_grp_miss.p, n_groups, p->pitch, p->n_acc, q->n, q->d_score,
+                           (const uint32_t *)ctx->ws_grp_miss.p, n_groups, p->ld, p->n_acc, q->n, q->d_score,
                            q->d_ninfo);
         HIPCHK(ctx, hipGetLastError());
     }
@@ -349,7 +355,7 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
 bool ensure_acc_major(snpm_panel *p)
 {
     snpm_ctx *ctx = p->ctx;
-    if (!ctx->use_acc_major) return false;
+    if (!ctx->use_acc_major || p->packed) return false;   // a packed panel already reads 4x fewer lines per column
     if (p->dT_state == 1) return true;
     if (p->dT_state == -1 || p->n_snp == 0) return false;
     const int64_t pitchT = (((p->n_snp + 3) / 4 + 255) / 256) * 256 + 256;    // + one tile of slack for the last block
@@ -413,7 +419,7 @@ int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64
         }
         ProfScope ps(ctx, PK_STRICT);
 #define LAUNCH_SPARSE(S, G)                                                                                        \
-    hipLaunchKernelGGL((k_strict_sparse<S, G>), sgrid, dim3(256), 0, ctx->stream, p->d, p->pitch, q->d_row_idx,     \
+    hipLaunchKernelGGL((k_strict_sparse<S, G>), sgrid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->packed, q->d_row_idx, \
                        q->row0, q->d_w, d_seg_off, n_seg, d_cols, ncols, (double *)ctx->ws_seg_score.p,            \
                        (uint32_t *)ctx->ws_seg_miss.p, ld)
         if (skip) {
@@ -429,7 +435,7 @@ int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64
     dim3 grid((unsigned)n_seg, (unsigned)((ncols + thr - 1) / thr));
     ProfScope ps(ctx, PK_STRICT);
 #define LAUNCH_STRICT(S, G)                                                                                       \
-    hipLaunchKernelGGL((k_strict<S, G>), grid, dim3(thr), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0,  \
+    hipLaunchKernelGGL((k_strict<S, G>), grid, dim3(thr), 0, ctx->stream, p->d, p->pitch, p->packed, q->d_row_idx, q->row0,  \
                        q->d_w, d_seg_off, d_cols, ncols, (double *)ctx->ws_seg_score.p,                           \
                        (uint32_t *)ctx->ws_seg_miss.p, ld)
     if (skip) {
@@ -571,7 +577,7 @@ int snpm_destroy(snpm_ctx *ctx)
     if (!ctx) return SNPM_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    Buf *bufs[] = {&ctx->ws_grp_score, &ctx->ws_grp_miss, &ctx->ws_part_score, &ctx->ws_part_miss, &ctx->ws_seg_score, &ctx->ws_seg_miss, &ctx->ws_seg_off,
+    Buf *bufs[] = {&ctx->ws_stage_dev, &ctx->ws_flags2, &ctx->ws_grp_score, &ctx->ws_grp_miss, &ctx->ws_part_score, &ctx->ws_part_miss, &ctx->ws_seg_score, &ctx->ws_seg_miss, &ctx->ws_seg_off,
                    &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
                    &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r};
     for (Buf *b : bufs)
@@ -604,7 +610,7 @@ int snpm_synchronize(snpm_ctx *ctx)
 }
 
 // ---------------------------------------------------------------------------------------------- panel
-int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out)
+static int panel_create_fmt(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, int packed, snpm_panel **out)
 {
     if (!ctx) return SNPM_ERR_BADARG;
     CHECK_ARG(ctx, out != nullptr, "out is NULL");
@@ -615,7 +621,9 @@ int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **
     p->ctx = ctx;
     p->n_snp = n_snp;
     p->n_acc = n_acc;
-    p->pitch = ((n_acc + 255) / 256) * 256;
+    p->packed = packed ? 1 : 0;
+    p->ld = ((n_acc + 255) / 256) * 256;
+    p->pitch = packed ? (((n_acc + 3) / 4 + 255) / 256) * 256 : p->ld;
     // PREFETCH_PAD_ROWS extra rows: the fast pass prefetches (and never scores) a few rows past a part
     size_t bytes = (size_t)(n_snp + PREFETCH_PAD_ROWS) * (size_t)p->pitch;
     hipError_t e = hipMalloc((void **)&p->d, bytes);
@@ -629,6 +637,23 @@ int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **
         return set_err(ctx, SNPM_ERR_HIP, "hipEventCreate failed");
     }
     *out = p;
+    return SNPM_OK;
+}
+
+int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out)
+{
+    return panel_create_fmt(ctx, n_snp, n_acc, 0, out);
+}
+
+int snpm_panel_create_packed(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out)
+{
+    return panel_create_fmt(ctx, n_snp, n_acc, 1, out);
+}
+
+int snpm_panel_is_packed(const snpm_panel *p, int *packed)
+{
+    if (!p || !packed) return SNPM_ERR_BADARG;
+    *packed = p->packed;
     return SNPM_OK;
 }
 
@@ -670,7 +695,18 @@ int snpm_panel_upload_rows(snpm_panel *p, int64_t row0, int64_t nrows, const int
             HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
         }
     }
-    const int64_t slab_rows = std::max<int64_t>(1, (int64_t)(snpm_ctx::kStageBytes / (size_t)p->pitch));
+    // staged row pitch: the panel's own pitch for int8 panels (the slab is copied straight into place); a
+    // 16-B multiple of n_acc for packed panels (the slab lands in a device scratch buffer and k_pack_rows
+    // writes the 2-bit rows)
+    const int64_t spitch = p->packed ? ((p->n_acc + 15) / 16) * 16 : p->pitch;
+    const int64_t slab_rows = std::max<int64_t>(1, (int64_t)(snpm_ctx::kStageBytes / (size_t)spitch));
+    if (p->packed) {
+        int rc = ensure(ctx, ctx->ws_stage_dev, 2 * snpm_ctx::kStageBytes);
+        if (rc) return rc;
+        rc = ensure(ctx, ctx->ws_flags2, sizeof(int));
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemsetAsync(ctx->ws_flags2.p, 0, sizeof(int), ctx->copy_stream));
+    }
     int which = 0;
     for (int64_t r = 0; r < nrows; r += slab_rows, which ^= 1) {
         const int64_t nr = std::min(slab_rows, nrows - r);
@@ -679,13 +715,13 @@ int snpm_panel_upload_rows(snpm_panel *p, int64_t row0, int64_t nrows, const int
             ctx->stage_busy[which] = false;
         }
         int8_t *st = (int8_t *)ctx->stage[which];
-        const int64_t pad = p->pitch - p->n_acc;
-        // repack host rows into the pinned slab (row pitch -> 256-B pitch, pad = missing) on a few threads:
+        const int64_t pad = spitch - p->n_acc;
+        // repack host rows into the pinned slab (row pitch -> staged pitch, pad = missing) on a few threads:
         // a single memcpy stream is ~15 GB/s, well under what PCIe gen5 x16 takes
         auto repack = [&](int64_t k0, int64_t k1) {
             for (int64_t k = k0; k < k1; ++k) {
-                memcpy(st + k * p->pitch, host + (r + k) * host_pitch, (size_t)p->n_acc);
-                if (pad) memset(st + k * p->pitch + p->n_acc, 0xff, (size_t)pad);
+                memcpy(st + k * spitch, host + (r + k) * host_pitch, (size_t)p->n_acc);
+                if (pad) memset(st + k * spitch + p->n_acc, 0xff, (size_t)pad);
             }
         };
         const int nthreads = (int)std::min<int64_t>(ctx->stage_threads, std::max<int64_t>(1, nr / 1024));
@@ -700,17 +736,33 @@ int snpm_panel_upload_rows(snpm_panel *p, int64_t row0, int64_t nrows, const int
             }
             for (auto &th : pool) th.join();
         }
-        int8_t *dst = p->d + (row0 + r) * p->pitch;
-        HIPCHK(ctx, hipMemcpyAsync(dst, st, (size_t)nr * p->pitch, hipMemcpyHostToDevice, ctx->copy_stream));
-        {
+        if (!p->packed) {
+            int8_t *dst = p->d + (row0 + r) * p->pitch;
+            HIPCHK(ctx, hipMemcpyAsync(dst, st, (size_t)nr * p->pitch, hipMemcpyHostToDevice, ctx->copy_stream));
             const int64_t n16 = nr * p->pitch / 16;
             const int thr = 256;
             const unsigned blocks = (unsigned)std::min<int64_t>((n16 + thr - 1) / thr, 4096);
             hipLaunchKernelGGL(k_canon, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->copy_stream, (uint4 *)dst, n16);
             HIPCHK(ctx, hipGetLastError());
+        } else {
+            int8_t *scratch = (int8_t *)ctx->ws_stage_dev.p + (size_t)which * snpm_ctx::kStageBytes;
+            HIPCHK(ctx, hipMemcpyAsync(scratch, st, (size_t)nr * spitch, hipMemcpyHostToDevice, ctx->copy_stream));
+            const int64_t total = nr * p->pitch;
+            hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream, scratch,
+                               spitch, nr, p->n_acc, (uint8_t *)p->d + (row0 + r) * p->pitch, p->pitch, (int *)ctx->ws_flags2.p);
+            HIPCHK(ctx, hipGetLastError());
         }
         HIPCHK(ctx, hipEventRecord(ctx->stage_done[which], ctx->copy_stream));
         ctx->stage_busy[which] = true;
+    }
+    if (p->packed) {
+        int bad = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&bad, ctx->ws_flags2.p, sizeof(int), hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+        ctx->stage_busy[0] = ctx->stage_busy[1] = false;
+        if (bad)
+            return set_err(ctx, SNPM_ERR_BADARG, "a packed panel holds only the codes -1 (any negative), 0, 1, 2; "
+                                                 "use the int8 panel for other values");
     }
     HIPCHK(ctx, hipEventRecord(p->uploaded, ctx->copy_stream));
     p->upload_pending = true;
@@ -737,8 +789,26 @@ int snpm_panel_download_rows(snpm_panel *p, int64_t row0, int64_t nrows, int8_t 
     HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (nrows == 0) return SNPM_OK;
-    HIPCHK(ctx, hipMemcpy2D(host, (size_t)host_pitch, p->d + row0 * p->pitch, (size_t)p->pitch, (size_t)p->n_acc,
-                            (size_t)nrows, hipMemcpyDeviceToHost));
+    if (!p->packed) {
+        HIPCHK(ctx, hipMemcpy2D(host, (size_t)host_pitch, p->d + row0 * p->pitch, (size_t)p->pitch, (size_t)p->n_acc,
+                                (size_t)nrows, hipMemcpyDeviceToHost));
+        return SNPM_OK;
+    }
+    // packed: unpack slab by slab into a device scratch buffer, then copy out
+    const int64_t slab = std::max<int64_t>(1, (int64_t)((64u << 20) / (size_t)p->n_acc));
+    int rc = ensure(ctx, ctx->ws_stage_dev, std::max<size_t>(2 * snpm_ctx::kStageBytes, (size_t)slab * p->n_acc));
+    if (rc) return rc;
+    for (int64_t r = 0; r < nrows; r += slab) {
+        const int64_t nr = std::min(slab, nrows - r);
+        const int64_t total = nr * p->n_acc;
+        hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const uint8_t *)p->d + (row0 + r) * p->pitch, p->pitch, nr, p->n_acc,
+                           (int8_t *)ctx->ws_stage_dev.p, p->n_acc);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy2D(host + r * host_pitch, (size_t)host_pitch, ctx->ws_stage_dev.p, (size_t)p->n_acc,
+                                (size_t)p->n_acc, (size_t)nr, hipMemcpyDeviceToHost));
+    }
     return SNPM_OK;
 }
 
@@ -751,10 +821,17 @@ int snpm_panel_fill_synthetic(snpm_panel *p, uint64_t seed, int64_t snp0, int64_
     if (p->n_snp == 0) return SNPM_OK;
     ProfScope ps(ctx, PK_SYNTH);
     const int thr = 256;
-    const int64_t total = p->n_snp * (p->pitch / 4);
-    const unsigned blocks = (unsigned)std::min<int64_t>((total + thr - 1) / thr, (int64_t)ctx->n_cu * 32);
-    hipLaunchKernelGGL(k_synth, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->stream, (uint32_t *)p->d, p->pitch,
-                       p->n_snp, p->n_acc, seed, snp0, acc0);
+    if (p->packed) {
+        const int64_t total = p->n_snp * p->pitch;
+        const unsigned blocks = (unsigned)std::min<int64_t>((total + thr - 1) / thr, (int64_t)ctx->n_cu * 32);
+        hipLaunchKernelGGL(k_synth_packed, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->stream, (uint8_t *)p->d,
+                           p->pitch, p->n_snp, p->n_acc, seed, snp0, acc0);
+    } else {
+        const int64_t total = p->n_snp * (p->pitch / 4);
+        const unsigned blocks = (unsigned)std::min<int64_t>((total + thr - 1) / thr, (int64_t)ctx->n_cu * 32);
+        hipLaunchKernelGGL(k_synth, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->stream, (uint32_t *)p->d, p->pitch,
+                           p->n_snp, p->n_acc, seed, snp0, acc0);
+    }
     HIPCHK(ctx, hipGetLastError());
     p->dT_state = 0;
     return SNPM_OK;
@@ -787,8 +864,8 @@ int snpm_query_create(snpm_panel *p, const int64_t *row_idx, int64_t row0, int64
     if (row_idx && e == hipSuccess) e = hipMalloc((void **)&q->d_row_idx, (nn + PREFETCH_PAD_ROWS) * sizeof(int64_t));
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_w, nn * 3 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&q->d_lut, nn * 4 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&q->own_score, (size_t)p->pitch * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&q->own_ninfo, (size_t)p->pitch * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&q->own_score, (size_t)p->ld * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&q->own_ninfo, (size_t)p->ld * sizeof(int64_t));
     q->d_score = q->own_score;
     q->d_ninfo = q->own_ninfo;
     if (e != hipSuccess) {
@@ -880,13 +957,13 @@ int snpm_query_run_device(snpm_query *q, int64_t chunk, int skip_hets, int mode,
         rc = ensure_chunk_offsets(q, chunk);
         if (rc) return rc;
         const int64_t n_seg = q->chunk_off_nseg;
-        rc = run_strict_segments(q, skip, q->d_chunk_off, n_seg, nullptr, p->n_acc, p->pitch);
+        rc = run_strict_segments(q, skip, q->d_chunk_off, n_seg, nullptr, p->n_acc, p->ld);
         if (rc) return rc;
         ProfScope ps(ctx, PK_SCAN);
         const int thr = 256;
         hipLaunchKernelGGL(k_scan, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
                            (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
-                           q->d_chunk_off, n_seg, p->pitch, p->n_acc, q->d_score, q->d_ninfo);
+                           q->d_chunk_off, n_seg, p->ld, p->n_acc, q->d_score, q->d_ninfo);
         HIPCHK(ctx, hipGetLastError());
     } else {
         FastGeom g;
@@ -989,7 +1066,7 @@ int snpm_query_run_windows(snpm_query *q, const int64_t *win_off, int64_t n_win,
     std::vector<int64_t> off(win_off, win_off + n_win + 1);
     rc = upload_seg_off(ctx, off);
     if (rc) return rc;
-    rc = run_strict_segments(q, skip, (const int64_t *)ctx->ws_seg_off.p, n_win, nullptr, p->n_acc, p->pitch);
+    rc = run_strict_segments(q, skip, (const int64_t *)ctx->ws_seg_off.p, n_win, nullptr, p->n_acc, p->ld);
     if (rc) return rc;
     const int thr = 256;
     const size_t na = (size_t)p->n_acc;
@@ -998,7 +1075,7 @@ int snpm_query_run_windows(snpm_query *q, const int64_t *win_off, int64_t n_win,
             ProfScope ps(ctx, PK_SCAN);
             hipLaunchKernelGGL(k_scan, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
                                (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
-                               (const int64_t *)ctx->ws_seg_off.p, n_win, p->pitch, p->n_acc, q->d_score, q->d_ninfo);
+                               (const int64_t *)ctx->ws_seg_off.p, n_win, p->ld, p->n_acc, q->d_score, q->d_ninfo);
             HIPCHK(ctx, hipGetLastError());
         }
         if (tot_score) HIPCHK(ctx, hipMemcpyAsync(tot_score, q->d_score, na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1015,9 +1092,9 @@ int snpm_query_run_windows(snpm_query *q, const int64_t *win_off, int64_t n_win,
         for (int64_t w0 = 0; w0 < n_win; w0 += 32768) {
             const int64_t nw = std::min<int64_t>(32768, n_win - w0);
             hipLaunchKernelGGL(k_seg_pack, dim3((unsigned)((p->n_acc + thr - 1) / thr), (unsigned)nw), dim3(thr), 0,
-                               ctx->stream, (const double *)ctx->ws_seg_score.p + w0 * p->pitch,
-                               (const uint32_t *)ctx->ws_seg_miss.p + w0 * p->pitch,
-                               (const int64_t *)ctx->ws_seg_off.p + w0, nw, p->pitch, p->n_acc,
+                               ctx->stream, (const double *)ctx->ws_seg_score.p + w0 * p->ld,
+                               (const uint32_t *)ctx->ws_seg_miss.p + w0 * p->ld,
+                               (const int64_t *)ctx->ws_seg_off.p + w0, nw, p->ld, p->n_acc,
                                (double *)ctx->ws_tmp_score.p + w0 * p->n_acc, (int64_t *)ctx->ws_tmp_ninfo.p + w0 * p->n_acc);
             HIPCHK(ctx, hipGetLastError());
         }
@@ -1185,7 +1262,7 @@ int snpm_panel_segregating(snpm_panel *p, const int32_t *cols, int64_t ncols, ui
     if ((rc = ensure(ctx, ctx->ws_tmp_ninfo, (size_t)p->n_snp))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->ws_cols.p, cols, (size_t)ncols * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_segregating, dim3((unsigned)((p->n_snp + 255) / 256)), dim3(256), 0, ctx->stream, p->d, p->pitch,
-                       p->n_snp, (const int32_t *)ctx->ws_cols.p, (int)ncols, (uint8_t *)ctx->ws_tmp_ninfo.p);
+                       p->packed, p->n_snp, (const int32_t *)ctx->ws_cols.p, (int)ncols, (uint8_t *)ctx->ws_tmp_ninfo.p);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(mask, ctx->ws_tmp_ninfo.p, (size_t)p->n_snp, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -30,7 +30,7 @@ constexpr int LUT_ROW_BYTES = 32;       // 4 x fp64
 constexpr int MAX_WAVES_PER_BLOCK = 8;
 constexpr int EPOCH_TILES = 64;         // k_fast writes its partial sums out (and restarts them) every 64 of its tiles
 constexpr int REDUCE_GROUP = 64;        // k_reduce_groups adds this many partials sequentially per group
-constexpr int PREFETCH_PAD_ROWS = 16;   // rows the fast pass may read (never score) past the last row of a part
+constexpr int PREFETCH_PAD_ROWS = 32;   // rows the fast pass may read (never score) past the last row of a part
 
 typedef __attribute__((address_space(3))) const double lds_cdouble;
 
@@ -57,12 +57,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int BPL>
 struct LoadT;
 template <>
+struct LoadT<1> { typedef uint8_t type; };      // packed panel: one byte = 4 accessions x 2 bits
+template <>
 struct LoadT<4> { typedef uint32_t type; };
 template <>
 struct LoadT<8> { typedef u32x2 type; };
 template <>
 struct LoadT<16> { typedef u32x4 type; };
 
+__device__ __forceinline__ uint32_t dword_of(const uint8_t &v, int) { return v; }
 __device__ __forceinline__ uint32_t dword_of(const uint32_t &v, int) { return v; }
 __device__ __forceinline__ uint32_t dword_of(const u32x2 &v, int k) { return k == 0 ? v.x : v.y; }
 __device__ __forceinline__ uint32_t dword_of(const u32x4 &v, int k)
@@ -99,8 +102,28 @@ __device__ __forceinline__ void fast_row(const uint32_t (&x)[NDW], uint32_t grou
     for (int e = 0; e < NDW * 4; ++e) acc[e] += w[e];
 }
 
+// Packed (2 bits per call) variant of fast_row: x holds one byte = 4 accessions, code 3 = missing.
+//   address of element j = row_base + ((x >> 2j) & 3) * 8: one v_bfe_u32 + one v_lshl_add_u32 per element;
+//   missing counts: bit pairs 11 (or 1x with skip_hets) -> one bit per field -> spread to one byte per
+//   field with a multiply (0x41041 = 1 + 2^6 + 2^12 + 2^18 moves bit 2f to bit 8f; no carries reach a kept bit).
+template <bool SKIP, int U>
+__device__ __forceinline__ void fast_row_packed(uint32_t x, uint32_t row_base, double (&acc)[4], uint32_t (&miss8)[1])
+{
+    double w[4];
+    const uint32_t m = SKIP ? ((x >> 1) & 0x55u) : (x & (x >> 1) & 0x55u);
+    miss8[0] += (m * 0x41041u) & 0x01010101u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t idx = (x >> (2 * j)) & 3u;
+        lds_cdouble *ptr = (lds_cdouble *)(uintptr_t)(row_base + (idx << 3));
+        w[j] = ptr[U * 4];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += w[j];
+}
+
 template <int BPL, bool NT>
-__device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[BPL / 4])
+__device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[(BPL >= 4 ? BPL / 4 : 1)])
 {
     typedef typename LoadT<BPL>::type load_t;
     load_t v;
@@ -109,8 +132,17 @@ __device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[BPL / 4]
     else
         v = *reinterpret_cast<const load_t *>(p);
 #pragma unroll
-    for (int k = 0; k < BPL / 4; ++k) x[k] = dword_of(v, k);
+    for (int k = 0; k < (BPL >= 4 ? BPL / 4 : 1); ++k) x[k] = dword_of(v, k);
 }
+
+// one SNP row of one lane: int8 layout -> fast_row (v_perm addresses), packed layout -> fast_row_packed
+#define SCORE_ROW(U, X, GROUP_BASE, ROFF4, ROFF)                                  \
+    do {                                                                          \
+        if constexpr (PACKED)                                                     \
+            fast_row_packed<SKIP, U>((X)[0], (GROUP_BASE) + (ROFF), acc, miss8); \
+        else                                                                      \
+            fast_row<NDW, SKIP, U>((X), (GROUP_BASE), (ROFF4), acc, miss8);       \
+    } while (0)
 
 // Fast pass.
 //   grid.x = column blocks (blockDim.x/64 waves x 64 lanes x BPL bytes), grid.y = P parts.
@@ -128,27 +160,34 @@ __device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[BPL / 4]
 // kernel is latency-bound and 5-wave blocks only fit 4 per CU with 6 wave slots per SIMD (measured:
 // 79-82 % of HBM peak at 80 VGPRs vs 67-70 % at 88)
 template <int BPL, bool SKIP, bool GATHER, bool NT>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (BPL == 4 ? 6 : 1))
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (BPL <= 4 ? 6 : 1))
 k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
        const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
 {
-    constexpr int NDW = BPL / 4;
-    constexpr int G = 4;                    // rows per group (G*32 B = 128 B of LUT = half a 256-B block)
+    // BPL = bytes per lane and row.  BPL == 1 is the packed panel (2 bits per call): the lane's byte holds 4
+    // accessions, exactly like the 4 bytes of the int8 BPL == 4 layout, so everything downstream is shared.
+    constexpr bool PACKED = (BPL == 1);
+    constexpr int NDW = PACKED ? 1 : BPL / 4;
+    constexpr int EPL = PACKED ? 4 : BPL;   // accessions (= accumulators) per lane
+    // rows per prefetch group: 4 (G*32 B = half a 256-B LUT block) for int8; 8 (a whole block) for the packed
+    // layout, whose 64-B-per-wave row loads need twice as many in flight to cover the HBM latency
+    constexpr int G = PACKED ? 8 : 4;
     __shared__ __attribute__((aligned(256))) double s_lut[2][TILE_ROWS * 4];
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
-    const int64_t col0 = ((int64_t)blockIdx.x * nthr + tid) * BPL;
-    const bool lane_on = col0 < pitch;      // pitch is a multiple of 256 >= n_acc: loads stay in the row
+    const int64_t byte0 = ((int64_t)blockIdx.x * nthr + tid) * BPL;     // byte offset of the lane inside a row
+    const int64_t col0 = PACKED ? byte0 * 4 : byte0;                    // first accession of the lane
+    const bool lane_on = byte0 < pitch;     // pitch is a multiple of 256 bytes: loads stay in the row
     const int64_t p = blockIdx.y;
     const int64_t P = gridDim.y;
     const int64_t n_tiles_total = (n + TILE_ROWS - 1) / TILE_ROWS;
 
-    double acc[BPL];
+    double acc[EPL];
     uint32_t miss16[NDW * 2];               // packed 2 x u16 per register, flushed from packed u8 every tile
     uint32_t miss8[NDW];
 #pragma unroll
-    for (int i = 0; i < BPL; ++i) acc[i] = 0.0;
+    for (int i = 0; i < EPL; ++i) acc[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < NDW * 2; ++i) miss16[i] = 0;
 #pragma unroll
@@ -156,7 +195,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
 
     // address = wave-uniform row base (scalar registers) + 32-bit lane offset: global_load saddr form,
     // no per-lane 64-bit address arithmetic
-    const uint32_t lane_off = lane_on ? (uint32_t)col0 : 0u;
+    const uint32_t lane_off = lane_on ? (uint32_t)byte0 : 0u;
     auto row_ptr = [&](int64_t rr) -> const int8_t * {
         const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
         const int8_t *rowbase = db + prow * pitch;                 // wave-uniform: scalar registers
@@ -174,7 +213,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
             double *os = out_score + (epoch * P + p) * ld + col0;
             uint32_t *om = out_miss + (epoch * P + p) * ld + col0;
 #pragma unroll
-            for (int i = 0; i < BPL; i += 2) *reinterpret_cast<double2 *>(os + i) = make_double2(acc[i], acc[i + 1]);
+            for (int i = 0; i < EPL; i += 2) *reinterpret_cast<double2 *>(os + i) = make_double2(acc[i], acc[i + 1]);
 #pragma unroll
             for (int k = 0; k < NDW; ++k) {
                 uint4 m;
@@ -186,7 +225,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
             }
         }
 #pragma unroll
-        for (int i = 0; i < BPL; ++i) acc[i] = 0.0;
+        for (int i = 0; i < EPL; ++i) acc[i] = 0.0;
 #pragma unroll
         for (int i = 0; i < NDW * 2; ++i) miss16[i] = 0;
     };
@@ -230,41 +269,50 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
             const uint32_t lds_base =
                 (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)(&s_lut[buf][0]);
             const int full_groups = rows / G;
+            // one group of G rows: LUT rows [gi*G, gi*G + G) of the tile = 256-B block (gi*G*32)/256, offset
+            // (gi*G*32)%256 inside it (0 or 128 for G = 4, always 0 for G = 8)
+#define SCORE_GROUP(X, GI)                                                                  \
+    do {                                                                                    \
+        const uint32_t goff_ = (uint32_t)(GI) * (uint32_t)(G * LUT_ROW_BYTES);              \
+        const uint32_t gbase_ = lds_base + (goff_ & ~255u);                                 \
+        const uint32_t roff_ = goff_ & 255u;                                                \
+        const uint32_t roff4_ = roff_ * 0x01010101u;                                        \
+        SCORE_ROW(0, (X)[0], gbase_, roff4_, roff_);                                        \
+        SCORE_ROW(1, (X)[1], gbase_, roff4_, roff_);                                        \
+        SCORE_ROW(2, (X)[2], gbase_, roff4_, roff_);                                        \
+        SCORE_ROW(3, (X)[3], gbase_, roff4_, roff_);                                        \
+        if constexpr (G > 4) {                                                              \
+            SCORE_ROW(4, (X)[G > 4 ? 4 : 0], gbase_, roff4_, roff_);                        \
+            SCORE_ROW(5, (X)[G > 4 ? 5 : 0], gbase_, roff4_, roff_);                        \
+            SCORE_ROW(6, (X)[G > 4 ? 6 : 0], gbase_, roff4_, roff_);                        \
+            SCORE_ROW(7, (X)[G > 4 ? 7 : 0], gbase_, roff4_, roff_);                        \
+        }                                                                                   \
+    } while (0)
             // two groups per iteration so that the xa/xb roles are static (no register copies)
             int g = 0;
             for (; g + 2 <= full_groups; g += 2) {
                 const int64_t rnext = tr0 + (int64_t)(g + 1) * G;
                 // the group after the pair: inside this tile, or the first group of my next tile
                 const int64_t rafter = (g + 2 < TILE_ROWS / G) ? rnext + G : ntr0;
-                const uint32_t group_base = lds_base + (uint32_t)(g >> 1) * 256u;   // 256-B aligned, wave-uniform
                 // ---- group g (data in xa); request group g+1 into xb
 #pragma unroll
                 for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rnext + u), xb[u]);
-                fast_row<NDW, SKIP, 0>(xa[0], group_base, 0u, acc, miss8);
-                fast_row<NDW, SKIP, 1>(xa[1], group_base, 0u, acc, miss8);
-                fast_row<NDW, SKIP, 2>(xa[2], group_base, 0u, acc, miss8);
-                fast_row<NDW, SKIP, 3>(xa[3], group_base, 0u, acc, miss8);
+                SCORE_GROUP(xa, g);
                 // ---- group g+1 (data in xb); request the following group into xa
 #pragma unroll
                 for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rafter + u), xa[u]);
-                fast_row<NDW, SKIP, 0>(xb[0], group_base, 0x80808080u, acc, miss8);
-                fast_row<NDW, SKIP, 1>(xb[1], group_base, 0x80808080u, acc, miss8);
-                fast_row<NDW, SKIP, 2>(xb[2], group_base, 0x80808080u, acc, miss8);
-                fast_row<NDW, SKIP, 3>(xb[3], group_base, 0x80808080u, acc, miss8);
+                SCORE_GROUP(xb, g + 1);
             }
             if (g < full_groups) {                               // odd group count: only in the last tile of all
-                const uint32_t group_base = lds_base + (uint32_t)(g >> 1) * 256u;
-                fast_row<NDW, SKIP, 0>(xa[0], group_base, 0u, acc, miss8);
-                fast_row<NDW, SKIP, 1>(xa[1], group_base, 0u, acc, miss8);
-                fast_row<NDW, SKIP, 2>(xa[2], group_base, 0u, acc, miss8);
-                fast_row<NDW, SKIP, 3>(xa[3], group_base, 0u, acc, miss8);
+                SCORE_GROUP(xa, g);
             }
+#undef SCORE_GROUP
             for (int r = full_groups * G; r < rows; ++r) {      // at most G-1 rows: last tile of all
                 uint32_t x[NDW];
                 load_row<BPL, NT>(row_ptr(tr0 + r), x);
                 const uint32_t group_base = lds_base + (uint32_t)(r >> 3) * 256u;
                 const uint32_t roff4 = (uint32_t)(r & 7) * 0x20202020u;        // (r & 7) * 32 in every byte
-                fast_row<NDW, SKIP, 0>(x, group_base, roff4, acc, miss8);
+                SCORE_ROW(0, x, group_base, roff4, (uint32_t)(r & 7) * 32u);
             }
             // flush packed u8 counters (<= TILE_ROWS <= 255 per byte) into packed u16 pairs
 #pragma unroll
@@ -289,6 +337,8 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     // the last (possibly only, possibly empty) epoch; epochs a short part never reaches are zeroed by the host
     store_partials(last_epoch);
 }
+
+#undef SCORE_ROW
 
 // Blocked summation of the M = n_epochs*P partial slots (deterministic, no atomics):
 //   k_reduce_groups: group g = slots [g*REDUCE_GROUP, ...) added sequentially   -> grp [n_groups, ld]
@@ -359,6 +409,17 @@ __global__ void k_reduce(const double *__restrict__ part_score, const uint32_t *
     ninfo[a] = n_rows - m;
 }
 
+// genotype code of (row, accession) in either panel format: int8 -> the byte (negative = missing);
+// packed -> 2-bit field, 3 = missing (returned as -1)
+__device__ __forceinline__ int code_at(const int8_t *__restrict__ db, int64_t pitch, int64_t prow, int64_t col, int packed)
+{
+    if (packed) {
+        const int v = (((const uint8_t *)db)[prow * pitch + (col >> 2)] >> (2 * (int)(col & 3))) & 3;
+        return v == 3 ? -1 : v;
+    }
+    return db[prow * pitch + col];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Strict (reference-order) segment sums.
 //   grid.x = segment, grid.y = column blocks of blockDim.x lanes
@@ -366,7 +427,7 @@ __global__ void k_reduce(const double *__restrict__ part_score, const uint32_t *
 //   out_score [n_seg, ld] fp64 = ((0 + A_ref) + A_het) + A_alt, out_miss [n_seg, ld] u32
 template <bool SKIP, bool GATHER>
 __global__ void __launch_bounds__(256)
-k_strict(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
+k_strict(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx, int64_t row0,
          const double *__restrict__ w, const int64_t *__restrict__ seg_off, const int32_t *__restrict__ cols,
          int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
 {
@@ -375,7 +436,6 @@ k_strict(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict
     if (i >= ncols) return;
     const int64_t col = cols ? (int64_t)cols[i] : i;
     const int64_t r0 = seg_off[seg], r1 = seg_off[seg + 1];
-    const int8_t *colp = db + col;
     double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
     uint32_t miss = 0;
     int64_t r = r0;
@@ -384,7 +444,7 @@ k_strict(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t prow = GATHER ? row_idx[r + u] : (row0 + r + u);
-            b[u] = colp[prow * pitch];
+            b[u] = code_at(db, pitch, prow, col, packed);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -397,7 +457,7 @@ k_strict(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict
     }
     for (; r < r1; ++r) {
         const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
-        const int b = colp[prow * pitch];
+        const int b = code_at(db, pitch, prow, col, packed);
         const double w0 = w[3 * r + 0], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
         a_ref = a_ref + (b == 0 ? w0 : 0.0);
         if (!SKIP) a_het = a_het + (b == 2 ? w1 : 0.0);
@@ -414,8 +474,8 @@ k_strict(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict
 // Same arithmetic and order as k_strict.  out_* [n_seg, ld].
 template <bool SKIP, bool GATHER>
 __global__ void __launch_bounds__(256)
-k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
-                const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t n_seg,
+k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx,
+                int64_t row0, const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t n_seg,
                 const int32_t *__restrict__ cols, int64_t ncols, double *__restrict__ out_score,
                 uint32_t *__restrict__ out_miss, int64_t ld)
 {
@@ -423,7 +483,7 @@ k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__r
     if (id >= n_seg * ncols) return;
     const int64_t seg = id / ncols;
     const int64_t i = id - seg * ncols;
-    const int8_t *colp = db + cols[i];
+    const int64_t col = cols[i];
     const int64_t r0 = seg_off[seg], r1 = seg_off[seg + 1];
     double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
     uint32_t miss = 0;
@@ -434,7 +494,7 @@ k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__r
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t prow = GATHER ? row_idx[r + u] : (row0 + r + u);
-            b[u] = colp[prow * pitch];
+            b[u] = code_at(db, pitch, prow, col, packed);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -447,7 +507,7 @@ k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__r
     }
     for (; r < r1; ++r) {
         const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
-        const int b = colp[prow * pitch];
+        const int b = code_at(db, pitch, prow, col, packed);
         const double w0 = w[3 * r + 0], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
         a_ref = a_ref + (b == 0 ? w0 : 0.0);
         if (!SKIP) a_het = a_het + (b == 2 ? w1 : 0.0);
@@ -761,6 +821,40 @@ __global__ void k_canon(uint4 *__restrict__ p, int64_t n16)
 }
 
 // ------------------------------------------------------------------------------------------------
+// packed panel upload: int8 rows (staging slab on the device, row stride src_pitch) -> 2 bits per call.
+// One thread per output byte.  Codes outside {-1 (any negative), 0, 1, 2} cannot be encoded: *bad |= 1.
+__global__ void k_pack_rows(const int8_t *__restrict__ src, int64_t src_pitch, int64_t nrows, int64_t n_acc,
+                            uint8_t *__restrict__ dst, int64_t dst_pitch, int *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * dst_pitch) return;
+    const int64_t r = i / dst_pitch, b = i - r * dst_pitch;
+    uint32_t out = 0;
+    int saw = 0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int64_t a = b * 4 + f;
+        int v = -1;
+        if (a < n_acc) v = src[r * src_pitch + a];
+        saw |= (v > 2);
+        out |= (uint32_t)(v < 0 ? 3 : (v & 3)) << (2 * f);
+    }
+    if (saw) atomicOr(bad, 1);
+    dst[i] = (uint8_t)out;
+}
+
+// packed rows -> int8 (download / checks): one thread per accession byte of the destination
+__global__ void k_unpack_rows(const uint8_t *__restrict__ src, int64_t src_pitch, int64_t nrows, int64_t n_acc,
+                              int8_t *__restrict__ dst, int64_t dst_pitch)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * n_acc) return;
+    const int64_t r = i / n_acc, a = i - r * n_acc;
+    const int v = (src[r * src_pitch + (a >> 2)] >> (2 * (int)(a & 3))) & 3;
+    dst[r * dst_pitch + a] = (int8_t)(v == 3 ? -1 : v);
+}
+
+// ------------------------------------------------------------------------------------------------
 // synthetic panel fill: counter-based, element (snp, acc) depends only on (seed, snp, acc).
 // One splitmix64 hash per 4 adjacent accessions (16 random bits each).
 __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
@@ -802,6 +896,28 @@ __global__ void k_synth(uint32_t *__restrict__ db, int64_t pitch, int64_t n_snp,
                 if (c + j >= n_acc) v |= 0xffu << (8 * j);
         }
         db[i] = v;
+    }
+}
+
+// packed counterpart of k_synth: the same values, one byte (= one accession quad) per thread step
+__global__ void k_synth_packed(uint8_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n_acc, uint64_t seed,
+                               int64_t snp0, int64_t acc0)
+{
+    const int64_t total = n_snp * pitch;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int64_t row = i / pitch;
+        const int64_t q = i - row * pitch;
+        const uint32_t v = synth_quad(seed, (uint64_t)(snp0 + row), (uint64_t)((acc0 >> 2) + q));
+        uint32_t out = 0;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint32_t c = (v >> (8 * f)) & 0xffu;                      // 0, 1, 2 or 0xff
+            const bool pad = (q * 4 + f) >= n_acc;
+            out |= ((c == 0xffu || pad) ? 3u : c) << (2 * f);
+        }
+        db[i] = (uint8_t)out;
     }
 }
 
@@ -860,16 +976,15 @@ __global__ void k_binom_identity(const double *__restrict__ x, const int64_t *__
 // ------------------------------------------------------------------------------------------------
 // --refine support (identify_segregating_snps, core/snp_genotype.py:188-211): mask[row] = 1 when the
 // informative (non-negative) calls of the listed accessions in that SNP row are not all identical.
-__global__ void k_segregating(const int8_t *__restrict__ db, int64_t pitch, int64_t n_snp,
+__global__ void k_segregating(const int8_t *__restrict__ db, int64_t pitch, int packed, int64_t n_snp,
                               const int32_t *__restrict__ cols, int ncols, uint8_t *__restrict__ mask)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_snp) return;
-    const int8_t *row = db + r * pitch;
     int first = -1;
     int seg = 0;
     for (int i = 0; i < ncols; ++i) {
-        const int b = row[cols[i]];
+        const int b = code_at(db, pitch, r, cols[i], packed);
         if (b < 0) continue;
         if (first < 0) first = b;
         else if (b != first) seg = 1;

@@ -140,12 +140,14 @@ def default_context():
 class Panel(object):
     """int8 [n_snp, n_acc] genotype matrix in HBM (SNP-major, row pitch padded to 256 B)."""
 
-    def __init__(self, ctx, n_snp, n_acc):
+    def __init__(self, ctx, n_snp, n_acc, packed=False):
         self.ctx = ctx
         self.n_snp = int(n_snp)
         self.n_acc = int(n_acc)
+        self.packed = bool(packed)      # 2 bits per call instead of one byte (same results, 4x less HBM)
         h = C.c_void_p()
-        check(ctx.lib.snpm_panel_create(ctx.h, self.n_snp, self.n_acc, C.byref(h)), ctx.h)
+        create = ctx.lib.snpm_panel_create_packed if packed else ctx.lib.snpm_panel_create
+        check(create(ctx.h, self.n_snp, self.n_acc, C.byref(h)), ctx.h)
         self.h = h
         pitch = C.c_int64(0)
         dptr = C.c_void_p()
@@ -156,10 +158,10 @@ class Panel(object):
         ctx._children.add(self)
 
     @classmethod
-    def from_host(cls, ctx, snps, slab_rows=1 << 16):
+    def from_host(cls, ctx, snps, slab_rows=1 << 16, packed=False):
         """Upload an array-like [n_snp, n_acc] (numpy array, memmap or h5py dataset) slab by slab."""
         n_snp, n_acc = snps.shape
-        p = cls(ctx, n_snp, n_acc)
+        p = cls(ctx, n_snp, n_acc, packed=packed)
         for r0 in range(0, n_snp, slab_rows):
             slab = np.ascontiguousarray(snps[r0:r0 + slab_rows], dtype=np.int8)
             p.upload_rows(r0, slab)  # returns once `slab` is repacked into the pinned staging buffers and the

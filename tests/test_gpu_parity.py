@@ -457,3 +457,87 @@ def test_exact_mode_on_accession_major_copy():
         assert info["n_strict_reeval"] >= 1 and bits(s)[9] == bits(want_s)[9]
         assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int)) and np.array_equal(ni, want_n)
     c.close()
+
+
+# ------------------------------------------------------------------ packed (2 bits per call) panel format
+@pytest.mark.parametrize("n_snp,n_acc,n_match,chunk", [(4000, 1, 1000, 1000), (6000, 64, 3001, 1000), (20000, 1135, 7545, 1000),
+                                                       (3000, 1250, None, 1000), (2100, 10000, None, 1000), (130, 17, 129, 7)])
+@pytest.mark.parametrize("skip", [False, True])
+def test_packed_panel_modes_vs_oracle(ctx, n_snp, n_acc, n_match, chunk, skip):
+    rng = np.random.default_rng(n_snp * 17 + n_acc)
+    db = rand_db(rng, n_snp, n_acc)
+    if n_acc > 5:
+        db[:, 2] = -1
+        db[::5, 3] = -7                    # any negative value is "missing"
+    panel = engine.Panel.from_host(ctx, db, packed=True)
+    assert panel.packed and panel.pitch == ((n_acc + 3) // 4 + 255) // 256 * 256
+    back = panel.download_rows(0, n_snp)
+    assert np.array_equal(back, np.where(db < 0, -1, db))
+    if n_match is None:
+        row_idx, n = None, n_snp
+    else:
+        row_idx = np.sort(rng.choice(n_snp, size=n_match, replace=False)).astype(np.int64)
+        n = n_match
+    wei = rand_wei(rng, n)
+    want_s, want_n = c_oracle.genotyper(db, row_idx, wei, chunk, skip)
+    q = engine.Query(panel, row_idx, wei)
+    bound = q.error_bound(chunk)
+    s, ni = q.run(chunk, skip, engine.MODE_STRICT)
+    assert np.array_equal(bits(s), bits(want_s)) and np.array_equal(ni, want_n)
+    s, ni = q.run(chunk, skip, engine.MODE_EXACT)
+    assert np.array_equal(ni, want_n)
+    assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int))
+    assert np.max(np.abs(s - want_s)) <= bound
+    s, ni = q.run(chunk, skip, engine.MODE_FAST)
+    assert np.array_equal(ni, want_n) and np.max(np.abs(s - want_s)) <= bound
+
+
+def test_packed_panel_misc(ctx, golden_dir):
+    # codes > 2 cannot be stored
+    with pytest.raises(AssertionError, match="packed panel"):
+        engine.Panel.from_host(ctx, np.array([[0, 1, 3]], dtype=np.int8), packed=True)
+    # device generator: packed and int8 panels hold the same values
+    a = engine.Panel(ctx, 3000, 1135, packed=True)
+    a.fill_synthetic(1001, snp0=77, acc0=12)
+    assert np.array_equal(a.download_rows(0, 3000), synth.panel_values(1001, 77, 3000, 12, 1135))
+    # windows (cross) on a packed panel: the reference's per-window fp64 bits
+    toy = np.load(os.path.join(golden_dir, "toy_db_cross.npz"))
+    g = np.load(os.path.join(golden_dir, "g5_cross.npz"))
+    panel = engine.Panel.from_host(ctx, toy["snps"], packed=True)
+    for skip in (0, 1):
+        q = engine.Query(panel, g["win_rows_db_skip%d" % skip], toy["s_wei"][g["win_rows_sample_skip%d" % skip]])
+        s, ni, ts, tn = q.run_windows(g["win_off_skip%d" % skip], bool(skip))
+        assert np.array_equal(bits(s), bits(g["win_score_skip%d" % skip])) and np.array_equal(ni, g["win_ninfo_skip%d" % skip])
+    # forced re-evaluation of integer-sum accessions goes through the strided packed reader
+    rng = np.random.default_rng(8)
+    db = rand_db(rng, 6000, 50)
+    codes = db[:, 7].copy()
+    codes[codes < 0] = 0
+    wei = synth.sample_weights(rng, codes, frac_pl=1.0)
+    want_s, want_n = c_oracle.genotyper(db, None, wei, 1000, False)
+    s, ni, info = engine.Query(engine.Panel.from_host(ctx, db, packed=True), None, wei).run(1000, False, engine.MODE_EXACT, return_info=True)
+    assert info["n_strict_reeval"] >= 1 and bits(s)[7] == bits(want_s)[7]
+    assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int)) and np.array_equal(ni, want_n)
+    seg = np.where(engine.Panel.from_host(ctx, db, packed=True).segregating_rows(np.array([1, 4, 9])))[0]
+    ref = np.where(engine.Panel.from_host(ctx, db).segregating_rows(np.array([1, 4, 9])))[0]
+    assert np.array_equal(seg, ref) and len(seg) > 100
+
+
+def test_packed_large_panel_equals_int8(ctx):
+    """10k accessions x 2M SNPs generated on the device in both formats: identical counts, scores within the bound."""
+    n_snp, n_acc = 2_000_000, 10_000
+    rng = np.random.default_rng(3)
+    col = synth.panel_values(777, 0, n_snp, 416, 4)[:, 1]
+    codes, wei = synth.planted_sample(rng, col, 0.02)
+    res = []
+    for packed in (False, True):
+        panel = engine.Panel(ctx, n_snp, n_acc, packed=packed)
+        panel.fill_synthetic(777)
+        q = engine.Query(panel, None, wei)
+        res.append(q.run(1000, False, engine.MODE_EXACT) + (q.error_bound(1000),))
+        q.free()
+        panel.free()
+    assert np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(np.array(res[0][0], dtype=int), np.array(res[1][0], dtype=int))
+    assert np.max(np.abs(res[0][0] - res[1][0])) <= 2 * res[0][2]
+    assert int(np.argmax(res[1][0] / np.maximum(res[1][1], 1))) == 417
