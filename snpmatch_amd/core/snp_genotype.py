@@ -120,11 +120,21 @@ class Genotype(object):
         return self
 
     # ------------------------------------------------------------------ device residency
-    def panel(self, ctx=None):
-        """The DB matrix resident in HBM (created on first use; slabs go through pinned staging)."""
+    def panel(self, ctx=None, packed=None):
+        """The DB matrix resident in HBM (created on first use; slabs go through pinned staging).
+        ``packed`` (default: environment SNPMATCH_PACKED=1) stores 2 bits per call instead of a byte --
+        same results, a quarter of the HBM; DBs with codes other than -1/0/1/2 stay int8."""
         from .. import engine
         if self._panel is None or self._panel.h is None:
             ctx = ctx or engine.default_context()
+            if packed is None:
+                packed = os.environ.get("SNPMATCH_PACKED", "0") not in ("", "0")
+            if packed:
+                try:
+                    self._panel = engine.Panel.from_host(ctx, self.g.snps, packed=True)
+                    return self._panel
+                except AssertionError:
+                    log.info("DB holds codes a packed panel cannot store; using the int8 panel")
             self._panel = engine.Panel.from_host(ctx, self.g.snps)
         return self._panel
 

@@ -236,3 +236,16 @@ def test_config1_sample_vcf_through_cli(golden_dir, tmp_path):
     assert js["interpretation"]["case"] == 0 and js["matches"][0][0] == accs[planted]
     assert js["overlap"] == [1.0, 7545] and js["percent_heterozygosity"] == 110 / 7545.0
     assert os.path.exists(vcf + ".snpmatch.npz") and os.path.exists(vcf + ".snpmatch.stats.json")
+
+
+def test_inbred_on_packed_panel_matches_reference_files(golden_dir, tmp_path, monkeypatch):
+    """SNPMATCH_PACKED=1: the same end-to-end outputs from the 2-bit panel"""
+    monkeypatch.setenv("SNPMATCH_PACKED", "1")
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    gold = json.load(open(os.path.join(golden_dir, "g2_inbred.json")))
+    out = str(tmp_path / "packed")
+    g = make_g(toy)
+    snpmatch.Genotyper(make_inputs(toy), g, out, run_genotyper=True)
+    assert g._panel.packed
+    cmp_scores_table(open(out + ".scores.txt").read(), gold["inbred_skip0"]["scores.txt"])
+    assert open(out + ".matches.json").read() == gold["inbred_skip0"]["matches.json"]
