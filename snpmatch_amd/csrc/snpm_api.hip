@@ -223,11 +223,17 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     } else if (g.n_wc <= 8) {
         g.wpb = (int)g.n_wc;
     } else {
+        // Waves per block.  Two measured effects (round 1, tools/tools_bench_shape.sh): waves of a block that
+        // fall outside the panel only idle at the barriers, but they hold wave slots (cost ~ the idle
+        // fraction); blocks whose wave count is not a multiple of the 4 SIMDs load them unevenly
+        // (5- and 7-wave blocks ran ~10-15 % slower than 4/8-wave blocks of the same shape, 6-wave ~5 %).
+        double best = -1.0;
         int best_w = 8;
-        int64_t best_waste = INT64_MAX;
         for (int w = 8; w >= 4; --w) {
-            int64_t waste = ((g.n_wc + w - 1) / w) * w - g.n_wc;
-            if (waste < best_waste) { best_waste = waste; best_w = w; }
+            const int64_t blocks = (g.n_wc + w - 1) / w;
+            const double active = (double)g.n_wc / (double)(blocks * w);
+            const double balance = (w % 4 == 0) ? 1.0 : ((w % 2 == 0) ? 0.95 : 0.85);
+            if (active * balance > best) { best = active * balance; best_w = w; }
         }
         g.wpb = best_w;
     }
