@@ -92,6 +92,12 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="init the process group and all-gather even at N=1")
     args = ap.parse_args()
 
+    # Contract: ONE JSON line on stdout.  RCCL prints a version banner to stdout when its first communicator
+    # is created, so file descriptor 1 is pointed at stderr until the result line is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -240,7 +246,10 @@ def main():
                        "strict_reevaluations": n_reeval[0]},
             "setup_s": t_setup,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.destroy_process_group()
 
