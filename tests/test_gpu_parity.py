@@ -541,3 +541,50 @@ def test_packed_large_panel_equals_int8(ctx):
     assert np.array_equal(np.array(res[0][0], dtype=int), np.array(res[1][0], dtype=int))
     assert np.max(np.abs(res[0][0] - res[1][0])) <= 2 * res[0][2]
     assert int(np.argmax(res[1][0] / np.maximum(res[1][1], 1))) == 417
+
+
+def test_fuzz_random_configurations(ctx):
+    """300 seeded random configurations (shape, chunk, skip_hets, dense / gathered / repeated rows, int8 / packed,
+    weight mix incl. zero rows and weights > 1 capped by ninfo) against the C oracle:
+    strict mode = fp64 bits, default mode = counts + certified bound, windows = fp64 bits."""
+    rng = np.random.default_rng(20260101)
+    for case in range(300):
+        n_snp = int(rng.integers(1, 7000))
+        n_acc = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 700, 1135, 2049]))
+        packed = bool(rng.integers(0, 2))
+        skip = bool(rng.integers(0, 2))
+        chunk = int(rng.choice([1, 7, 128, 1000, 1001, 5000]))
+        db = rand_db(rng, n_snp, n_acc)
+        if not packed and rng.random() < 0.3:
+            db[rng.integers(0, n_snp), :] = 3
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            rows, n = None, n_snp
+        elif kind == 1:
+            n = int(rng.integers(0, n_snp + 1))
+            rows = np.sort(rng.choice(n_snp, size=n, replace=False)).astype(np.int64)
+        else:
+            n = int(rng.integers(1, 2 * n_snp + 2))
+            rows = rng.integers(0, n_snp, size=n).astype(np.int64)          # unsorted, with repeats
+        wei = rand_wei(rng, n, frac_pl=float(rng.choice([0.0, 0.5, 1.0])))
+        if n > 3:
+            wei[rng.integers(0, n)] = 0.0
+        tag = "case %d: %dx%d packed=%s skip=%s chunk=%d kind=%d n=%d" % (case, n_snp, n_acc, packed, skip, chunk, kind, n)
+        panel = engine.Panel.from_host(ctx, db, packed=packed)
+        q = engine.Query(panel, rows, wei)
+        want_s, want_n = c_oracle.genotyper(db, rows, wei, chunk, skip)
+        s, ni = q.run(chunk, skip, engine.MODE_STRICT)
+        assert np.array_equal(bits(s), bits(want_s)) and np.array_equal(ni, want_n), tag
+        s, ni = q.run(chunk, skip, engine.MODE_EXACT)
+        assert np.array_equal(ni, want_n), tag
+        assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int)), tag
+        assert np.max(np.abs(s - want_s), initial=0.0) <= q.error_bound(chunk), tag
+        if n > 0:
+            cuts = np.sort(rng.integers(0, n + 1, size=int(rng.integers(0, 12))))
+            off = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+            got = q.run_windows(off, skip)
+            want = c_oracle.windows(db, rows, wei, off, skip)
+            assert np.array_equal(bits(got[0]), bits(want[0])) and np.array_equal(got[1], want[1]), tag
+            assert np.array_equal(bits(got[2]), bits(want[2])) and np.array_equal(got[3], want[3]), tag
+        q.free()
+        panel.free()
