@@ -65,6 +65,7 @@ struct snpm_ctx {
     int parts_mult = 1;
     int use_acc_major = 1;  // keep an accession-major packed copy (+25 % memory) for contiguous re-evaluation reads
     int64_t acc_major_min_rows = 1000000;   // ... once a query is long enough for the strided path to hurt
+    int debug_max_parts = 0;   // SNPM_DEBUG_MAX_PARTS=k: cap the parts of the fast pass (tests of multi-epoch parts)
     int debug_reeval = 0;   // SNPM_DEBUG_REEVAL=k: also re-evaluate accessions 0..k-1 (to time that path)
     int stage_threads = 4;  // host threads repacking rows into the pinned staging slabs
     int nt_loads = 1;      // panel bytes are read once: non-temporal loads (+5-8% measured)
@@ -243,6 +244,7 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     int64_t n_parts = std::max<int64_t>(1, resident / g.n_colblocks);
     const int64_t n_tiles = std::max<int64_t>(1, (n + TILE_ROWS - 1) / TILE_ROWS);
     n_parts = std::min(n_parts, n_tiles);                    // part p scores tiles p, p+P, p+2P, ...
+    if (ctx->debug_max_parts > 0) n_parts = std::min<int64_t>(n_parts, ctx->debug_max_parts);   // tests: long parts
     n_parts = std::min<int64_t>(n_parts, 65535);             // grid.y
     g.n_parts = n_parts;
     const int64_t tiles_per_part = (n_tiles + n_parts - 1) / n_parts;
@@ -573,6 +575,7 @@ int snpm_init(int device_id, snpm_ctx **out)
     if (const char *s = getenv("SNPM_ACC_MAJOR")) ctx->use_acc_major = atoi(s);
     if (const char *s = getenv("SNPM_ACC_MAJOR_MIN_ROWS")) ctx->acc_major_min_rows = atoll(s);
     if (const char *s = getenv("SNPM_DEBUG_REEVAL")) ctx->debug_reeval = atoi(s);
+    if (const char *s = getenv("SNPM_DEBUG_MAX_PARTS")) ctx->debug_max_parts = atoi(s);
     if (const char *s = getenv("SNPM_STAGE_THREADS")) ctx->stage_threads = std::max(1, atoi(s));
     *out = ctx;
     return SNPM_OK;

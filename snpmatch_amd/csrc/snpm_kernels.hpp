@@ -178,7 +178,9 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     const int nthr = blockDim.x;
     const int64_t byte0 = ((int64_t)blockIdx.x * nthr + tid) * BPL;     // byte offset of the lane inside a row
     const int64_t col0 = PACKED ? byte0 * 4 : byte0;                    // first accession of the lane
-    const bool lane_on = byte0 < pitch;     // pitch is a multiple of 256 bytes: loads stay in the row
+    // a lane works when its bytes lie inside the row (pitch is a multiple of 256 B) AND its accessions inside
+    // the result arrays (ld): on a packed panel 4*pitch can exceed ld, and blocks may carry spare waves
+    const bool lane_on = byte0 < pitch && col0 < ld;
     const int64_t p = blockIdx.y;
     const int64_t P = gridDim.y;
     const int64_t n_tiles_total = (n + TILE_ROWS - 1) / TILE_ROWS;

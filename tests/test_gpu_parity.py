@@ -588,3 +588,37 @@ def test_fuzz_random_configurations(ctx):
             assert np.array_equal(bits(got[2]), bits(want[2])) and np.array_equal(got[3], want[3]), tag
         q.free()
         panel.free()
+
+
+def test_fuzz_long_parts_multi_epoch():
+    """Same differential check with the fast pass forced into few, long parts (several accumulation epochs
+    per part, partial last tiles, odd tile counts), int8 and packed."""
+    os.environ["SNPM_DEBUG_MAX_PARTS"] = "3"
+    try:
+        c = engine.Context(0)
+    finally:
+        del os.environ["SNPM_DEBUG_MAX_PARTS"]
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        n_snp = int(rng.choice([8191, 8192, 8193, 24576, 24577, 30001, 49153, 70000]))
+        n_acc = int(rng.choice([3, 64, 257, 1135]))
+        packed = bool(rng.integers(0, 2))
+        skip = bool(rng.integers(0, 2))
+        db = rand_db(rng, n_snp, n_acc)
+        wei = rand_wei(rng, n_snp, frac_pl=float(rng.choice([0.0, 0.8])))
+        rows = None
+        if rng.random() < 0.4:
+            rows = np.sort(rng.choice(n_snp, size=n_snp - int(rng.integers(0, 200)), replace=False)).astype(np.int64)
+            wei = wei[:len(rows)]
+        panel = engine.Panel.from_host(c, db, packed=packed)
+        q = engine.Query(panel, rows, wei)
+        want_s, want_n = c_oracle.genotyper(db, rows, wei, 1000, skip)
+        for mode in (engine.MODE_FAST, engine.MODE_EXACT):
+            s, ni = q.run(1000, skip, mode)
+            tag = "case %d: %dx%d packed=%s skip=%s mode=%d" % (case, n_snp, n_acc, packed, skip, mode)
+            assert np.array_equal(ni, want_n), tag
+            assert np.max(np.abs(s - want_s)) <= q.error_bound(1000), tag
+        assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int)), tag
+        q.free()
+        panel.free()
+    c.close()
