@@ -622,3 +622,39 @@ def test_fuzz_long_parts_multi_epoch():
         q.free()
         panel.free()
     c.close()
+
+
+def test_fuzz_likelihood_and_identity(ctx):
+    from scipy import stats
+    rng = np.random.default_rng(99)
+    for case in range(40):
+        m = int(rng.integers(1, 6))
+        ln = int(rng.choice([1, 2, 63, 64, 65, 1000, 1025, 3000]))
+        n = rng.integers(0, 5000, size=(m, ln))
+        frac = rng.random((m, ln))
+        y = np.floor(frac * (n + 1)).clip(0, n).astype(float)
+        if rng.random() < 0.5:
+            y = np.minimum(y + rng.random((m, ln)) * 0.999, n)            # fractional scores (cross windows)
+        y[rng.random((m, ln)) < 0.05] = 0.0
+        perfect = rng.random((m, ln)) < 0.05
+        y[perfect] = n[perfect]
+        if rng.random() < 0.2:
+            y[0, :] = 0.0                                                  # an all-NaN row
+        lik, lrt = ctx.likelihood(y, n)
+        for r in range(m):
+            wl, wr = orc.calculate_likelihoods(y[r], n[r])
+            np.testing.assert_allclose(lik[r], wl, rtol=LIK_RTOL, atol=0, equal_nan=True)
+            np.testing.assert_allclose(lrt[r], wr, rtol=LIK_RTOL, atol=0, equal_nan=True)
+        # truncation as GenotyperOutput does
+        lik_t, _ = ctx.likelihood(y[0], n[0], truncate=True)
+        wl, _ = orc.calculate_likelihoods(np.array(y[0], dtype=int), n[0])
+        np.testing.assert_allclose(lik_t, wl, rtol=LIK_RTOL, equal_nan=True)
+        # identity test against scipy
+        x = y[0]
+        nn = n[0]
+        er = float(rng.choice([0.0005, 0.02, 0.1]))
+        out, sf = ctx.binom_identity(x, nn, er, 0.05, return_sf=True)
+        want_sf = stats.binom.sf(nn - x - 1, nn, er)
+        np.testing.assert_allclose(sf, want_sf, rtol=1e-9, atol=1e-100)      # far tails (1e-280) carry ~1e-8 from lgamma/exp
+        safe = np.abs(want_sf - 0.05) > 1e-9
+        assert np.array_equal(out[safe], (want_sf >= 0.05).astype(int)[safe])
