@@ -224,7 +224,7 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     } else if (g.n_wc <= 8) {
         g.wpb = (int)g.n_wc;
     } else {
-        // Waves per block.  Two measured effects (round 1, tools/tools_bench_shape.sh): waves of a block that
+        // Waves per block.  Two measured effects (round 1, tools/bench_shape.sh): waves of a block that
         // fall outside the panel only idle at the barriers, but they hold wave slots (cost ~ the idle
         // fraction); blocks whose wave count is not a multiple of the 4 SIMDs load them unevenly
         // (5- and 7-wave blocks ran ~10-15 % slower than 4/8-wave blocks of the same shape, 6-wave ~5 %).

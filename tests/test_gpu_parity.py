@@ -658,3 +658,51 @@ def test_fuzz_likelihood_and_identity(ctx):
         np.testing.assert_allclose(sf, want_sf, rtol=1e-9, atol=1e-100)      # far tails (1e-280) carry ~1e-8 from lgamma/exp
         safe = np.abs(want_sf - 0.05) > 1e-9
         assert np.array_equal(out[safe], (want_sf >= 0.05).astype(int)[safe])
+
+
+def test_full_bench_size_properties(ctx):
+    """The N=1 bench shard itself (10 000 accessions x 6.25M SNPs, 64 GB resident), checked through invariants
+    that do not need an oracle run: (1) all-ones weights: every informative call matches exactly one category,
+    so score == ninfo, in fast and default mode; (2) ninfo of sampled accession quads equals the count from the
+    numpy twin of the generator; (3) a hard-weight sample planted on accession 417 matches it perfectly and is
+    the unique top hit; (4) scores and ninfo are additive over a split of the SNP axis (integer weights: exact);
+    (5) mixed PL weights: default-mode counts equal strict-mode counts on the first 300 accessions' worth of
+    columns re-scored in reference order on a 200k-SNP slab."""
+    n_snp, n_acc = 6_250_000, 10_000
+    panel = engine.Panel(ctx, n_snp, n_acc)
+    panel.fill_synthetic(10050)
+    q = engine.Query(panel, None, np.ones((n_snp, 3)))
+    s, ni = q.run(1000, False, engine.MODE_EXACT)
+    assert np.array_equal(s, ni.astype(np.float64)) and ni.min() > 0.94 * n_snp
+    s2, ni2 = q.run(1000, False, engine.MODE_FAST)
+    assert np.array_equal(s2, s) and np.array_equal(ni2, ni)
+    q.free()
+    for c4 in (0, 4996, 9996):
+        miss = np.zeros(4, dtype=np.int64)
+        for r0 in range(0, n_snp, 1_250_000):
+            miss += (synth.panel_values(10050, r0, 1_250_000, c4, 4) < 0).sum(axis=0)
+        assert np.array_equal(ni[c4:c4 + 4], n_snp - miss)
+    col = np.concatenate([synth.panel_values(10050, r0, 1_250_000, 416, 4)[:, 1] for r0 in range(0, n_snp, 1_250_000)])
+    codes = col.copy()
+    codes[codes < 0] = 0
+    wei = orc.weights_from_gt_codes(codes)
+    s, ni = engine.Query(panel, None, wei).run(1000, False, engine.MODE_EXACT)
+    assert s[417] == ni[417] and int(np.argmax(s / ni)) == 417
+    lik, lrt = ctx.likelihood(s, ni, truncate=True)
+    assert lik[417] == 1.0 and (lrt < 3.841).sum() == 1
+    h = 3_000_077
+    s1, n1 = engine.Query(panel, None, wei[:h], row0=0).run(1000, False, engine.MODE_EXACT)
+    s2, n2 = engine.Query(panel, None, wei[h:], row0=h).run(1000, False, engine.MODE_EXACT)
+    assert np.array_equal(s1 + s2, s) and np.array_equal(n1 + n2, ni)
+    rng = np.random.default_rng(1)
+    slab = 200_000
+    r0 = 4_000_000
+    _, wpl = synth.planted_sample(rng, col[r0:r0 + slab], 0.02)
+    qs = engine.Query(panel, None, wpl, row0=r0)
+    se, ne = qs.run(1000, False, engine.MODE_EXACT)
+    ss, ns = qs.run(1000, False, engine.MODE_STRICT)
+    assert np.array_equal(ne, ns) and np.array_equal(np.array(se, dtype=int), np.array(ss, dtype=int))
+    assert np.max(np.abs(se - ss)) <= qs.error_bound(1000)
+    db = panel.download_rows(r0, slab)[:, :300]
+    ws, wn = c_oracle.genotyper(db, None, wpl, 1000, False)
+    assert np.array_equal(bits(ss[:300]), bits(ws)) and np.array_equal(ns[:300], wn)

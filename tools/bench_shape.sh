@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_bench_shape.sh N_ACC SNPS "ENV=.." ...
+# usage: bench_shape.sh N_ACC SNPS "ENV=.." ...
 nacc=$1; snps=$2; shift 2
 for v in "$@"; do
   out=$(env $v timeout -k 10 300 python "$(dirname $0)/../bench.py" --steps 5 --warmup 2 --no-cpu-baseline --mode fast --n-acc $nacc --snps-per-gpu-unit $snps 2>/dev/null)
