@@ -171,7 +171,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     constexpr int EPL = PACKED ? 4 : BPL;   // accessions (= accumulators) per lane
     // rows per prefetch group: 4 (G*32 B = half a 256-B LUT block) for int8; 8 (a whole block) for the packed
     // layout, whose 64-B-per-wave row loads need twice as many in flight to cover the HBM latency
-    constexpr int G = PACKED ? 8 : 4;
+    constexpr int G = PACKED ? 8 : 4;     // (8-row groups for int8 spill at the 80-VGPR budget and measured no gain)
     __shared__ __attribute__((aligned(256))) double s_lut[2][TILE_ROWS * 4];
 
     const int tid = threadIdx.x;
