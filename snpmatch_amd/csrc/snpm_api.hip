@@ -65,6 +65,7 @@ struct snpm_ctx {
     int parts_mult = 1;
     int use_acc_major = 1;  // keep an accession-major packed copy (+25 % memory) for contiguous re-evaluation reads
     int64_t acc_major_min_rows = 1000000;   // ... once a query is long enough for the strided path to hurt
+    int strict4 = 1;           // dense strict scoring with 4 columns per lane (SNPM_STRICT4=0: one column per lane)
     int debug_max_parts = 0;   // SNPM_DEBUG_MAX_PARTS=k: cap the parts of the fast pass (tests of multi-epoch parts)
     int debug_reeval = 0;   // SNPM_DEBUG_REEVAL=k: also re-evaluate accessions 0..k-1 (to time that path)
     int stage_threads = 4;  // host threads repacking rows into the pinned staging slabs
@@ -439,6 +440,24 @@ int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64
         HIPCHK(ctx, hipGetLastError());
         return SNPM_OK;
     }
+    if (!d_cols && !p->packed && ctx->strict4) {
+        // dense int8: 4 columns per lane
+        const int64_t lanes = (ncols + 3) / 4;
+        const int t4 = lanes >= 256 ? 256 : (lanes > 64 ? 128 : 64);
+        dim3 grid4((unsigned)n_seg, (unsigned)((lanes + t4 - 1) / t4));
+        ProfScope ps(ctx, PK_STRICT);
+#define LAUNCH_STRICT4(S, G)                                                                                     \
+    hipLaunchKernelGGL((k_strict4<S, G>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
+                       q->d_w, d_seg_off, ncols, (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld)
+        if (skip) {
+            if (gather) LAUNCH_STRICT4(true, true); else LAUNCH_STRICT4(true, false);
+        } else {
+            if (gather) LAUNCH_STRICT4(false, true); else LAUNCH_STRICT4(false, false);
+        }
+#undef LAUNCH_STRICT4
+        HIPCHK(ctx, hipGetLastError());
+        return SNPM_OK;
+    }
     // grid.x = segments (can be large), grid.y = column blocks
     dim3 grid((unsigned)n_seg, (unsigned)((ncols + thr - 1) / thr));
     ProfScope ps(ctx, PK_STRICT);
@@ -575,6 +594,7 @@ int snpm_init(int device_id, snpm_ctx **out)
     if (const char *s = getenv("SNPM_ACC_MAJOR")) ctx->use_acc_major = atoi(s);
     if (const char *s = getenv("SNPM_ACC_MAJOR_MIN_ROWS")) ctx->acc_major_min_rows = atoll(s);
     if (const char *s = getenv("SNPM_DEBUG_REEVAL")) ctx->debug_reeval = atoi(s);
+    if (const char *s = getenv("SNPM_STRICT4")) ctx->strict4 = atoi(s);
     if (const char *s = getenv("SNPM_DEBUG_MAX_PARTS")) ctx->debug_max_parts = atoi(s);
     if (const char *s = getenv("SNPM_STAGE_THREADS")) ctx->stage_threads = std::max(1, atoi(s));
     *out = ctx;

@@ -470,6 +470,64 @@ k_strict(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t
     out_miss[seg * ld + i] = miss;
 }
 
+// Dense strict kernel for int8 panels: 4 adjacent accession columns per lane (one dword per row), same
+// arithmetic and order as k_strict (three sequential per-category sums per column and segment).
+//   grid.x = segment, grid.y = blocks of blockDim.x lanes x 4 columns;  out_* [n_seg, ld]
+template <bool SKIP, bool GATHER>
+__global__ void __launch_bounds__(256)
+k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
+          const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t ncols,
+          double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
+{
+    const int64_t seg = blockIdx.x;
+    const int64_t c0 = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) * 4;
+    if (c0 >= ncols) return;                 // pitch is a multiple of 256: the dword of an active lane is inside the row
+    const int64_t r0 = seg_off[seg], r1 = seg_off[seg + 1];
+    double a_ref[4] = {0.0, 0.0, 0.0, 0.0}, a_het[4] = {0.0, 0.0, 0.0, 0.0}, a_alt[4] = {0.0, 0.0, 0.0, 0.0};
+    uint32_t miss8 = 0, miss[4] = {0, 0, 0, 0};
+    int since_flush = 0;
+    auto one_row = [&](uint32_t x, int64_t r) {
+        const double w0 = w[3 * r + 0], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t b = (x >> (8 * j)) & 0xffu;
+            a_ref[j] = a_ref[j] + (b == 0u ? w0 : 0.0);
+            if (!SKIP) a_het[j] = a_het[j] + (b == 2u ? w1 : 0.0);
+            a_alt[j] = a_alt[j] + (b == 1u ? w2 : 0.0);
+        }
+        miss8 += SKIP ? (((x >> 7) | ((x >> 1) & ~x)) & 0x01010101u) : ((x >> 7) & 0x01010101u);
+        if (++since_flush == 255) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) miss[j] += (miss8 >> (8 * j)) & 0xffu;
+            miss8 = 0;
+            since_flush = 0;
+        }
+    };
+    const int8_t *colp = db + c0;
+    int64_t r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        uint32_t x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t prow = GATHER ? row_idx[r + u] : (row0 + r + u);
+            x[u] = *reinterpret_cast<const uint32_t *>(colp + prow * pitch);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one_row(x[u], r + u);
+    }
+    for (; r < r1; ++r) {
+        const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
+        one_row(*reinterpret_cast<const uint32_t *>(colp + prow * pitch), r);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (c0 + j < ncols) {
+            out_score[seg * ld + c0 + j] = ((0.0 + a_ref[j]) + a_het[j]) + a_alt[j];
+            out_miss[seg * ld + c0 + j] = miss[j] + ((miss8 >> (8 * j)) & 0xffu);
+        }
+    }
+}
+
 // Strict segment sums for a SHORT list of columns (the accessions SNPM_MODE_EXACT has to re-evaluate):
 // one lane per (segment, column) pair so that every lane of a wave is busy and 8 independent byte
 // loads per lane are in flight (each is its own cache line: this path is latency-bound).
