@@ -80,10 +80,14 @@ int snpm_panel_is_packed(const snpm_panel *panel, int *packed);
 int snpm_panel_free(snpm_panel *panel);
 int snpm_panel_info(const snpm_panel *panel, int64_t *n_snp, int64_t *n_acc, int64_t *pitch, void **device_ptr);
 /* Asynchronous upload of rows [row0, row0+nrows) from host memory (row stride host_pitch bytes,
-   >= n_acc): rows are repacked into double-buffered pinned staging slabs and copied with
-   hipMemcpyAsync on a side stream, canonicalised on the device (negative -> -1, >2 -> 3).
+   >= n_acc): rows are copied into double-buffered pinned staging slabs, sent with hipMemcpyAsync on a side
+   stream and written into the panel by a device kernel (256-B row pitch, codes canonicalised:
+   negative -> -1, >2 -> 3; 2-bit packing for packed panels).
    Returns once the last slab is enqueued; scoring calls wait for it on the device. */
 int snpm_panel_upload_rows(snpm_panel *panel, int64_t row0, int64_t nrows, const int8_t *host, int64_t host_pitch);
+/* Same pipeline fed from a file of tightly packed int8 rows (n_acc bytes per row) that starts at byte
+   file_offset (the data section of snps.npy in a native flat panel): pread() straight into the pinned slabs. */
+int snpm_panel_load_file(snpm_panel *panel, const char *path, int64_t file_offset, int64_t row0, int64_t nrows);
 int snpm_panel_upload_wait(snpm_panel *panel);
 int snpm_panel_download_rows(snpm_panel *panel, int64_t row0, int64_t nrows, int8_t *host, int64_t host_pitch);
 /* Device-side synthetic fill (benchmarks; no PCIe): element (snp, acc) is a pure function of

@@ -26,7 +26,7 @@ MODE_FAST = 2
 # every symbol include/snpmatch_hip.h declares (tests check that the .so exports all of them)
 SYMBOLS = [
     "snpm_version", "snpm_device_count", "snpm_init", "snpm_destroy", "snpm_last_error", "snpm_set_stream",
-    "snpm_synchronize", "snpm_panel_create", "snpm_panel_create_packed", "snpm_panel_is_packed", "snpm_panel_free", "snpm_panel_info", "snpm_panel_upload_rows",
+    "snpm_synchronize", "snpm_panel_create", "snpm_panel_create_packed", "snpm_panel_is_packed", "snpm_panel_free", "snpm_panel_info", "snpm_panel_upload_rows", "snpm_panel_load_file",
     "snpm_panel_upload_wait", "snpm_panel_download_rows", "snpm_panel_fill_synthetic", "snpm_query_create",
     "snpm_query_free", "snpm_query_bind_outputs", "snpm_query_run", "snpm_query_run_device", "snpm_query_error_bound",
     "snpm_query_run_windows", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
@@ -70,6 +70,7 @@ def load():
     lib.snpm_panel_free.argtypes = [p]
     lib.snpm_panel_info.argtypes = [p, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), pp]
     lib.snpm_panel_upload_rows.argtypes = [p, i64, i64, p, i64]
+    lib.snpm_panel_load_file.argtypes = [p, C.c_char_p, i64, i64, i64]
     lib.snpm_panel_upload_wait.argtypes = [p]
     lib.snpm_panel_download_rows.argtypes = [p, i64, i64, p, i64]
     lib.snpm_panel_fill_synthetic.argtypes = [p, C.c_uint64, i64, i64]

@@ -69,7 +69,9 @@ def _load_any(path):
     if os.path.isdir(path):
         meta = np.load(os.path.join(path, "meta.npz"))
         snps = np.load(os.path.join(path, "snps.npy"), mmap_mode="r")
-        return MemGenotype(snps, meta["accessions"], meta["positions"], meta["chrs"].astype("U"), meta["chr_regions"])
+        g = MemGenotype(snps, meta["accessions"], meta["positions"], meta["chrs"].astype("U"), meta["chr_regions"])
+        g.npy_path = os.path.join(path, "snps.npy")      # lets Genotype.panel() stream the file natively
+        return g
     if path.endswith(".npz"):
         d = np.load(path)
         return MemGenotype(d["snps"], d["accessions"], d["positions"], np.asarray(d["chrs"]).astype("U"), d["chr_regions"])
@@ -129,13 +131,16 @@ class Genotype(object):
             ctx = ctx or engine.default_context()
             if packed is None:
                 packed = os.environ.get("SNPMATCH_PACKED", "0") not in ("", "0")
+            npy = getattr(self.g, "npy_path", None)          # native flat panel: file -> pinned slabs -> HBM
+            make = (lambda pk: engine.Panel.from_npy(ctx, npy, packed=pk)) if npy else \
+                   (lambda pk: engine.Panel.from_host(ctx, self.g.snps, packed=pk))
             if packed:
                 try:
-                    self._panel = engine.Panel.from_host(ctx, self.g.snps, packed=True)
+                    self._panel = make(True)
                     return self._panel
                 except AssertionError:
                     log.info("DB holds codes a packed panel cannot store; using the int8 panel")
-            self._panel = engine.Panel.from_host(ctx, self.g.snps)
+            self._panel = make(False)
         return self._panel
 
     # ------------------------------------------------------------------ position intersection (a5)

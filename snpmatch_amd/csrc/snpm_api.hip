@@ -5,7 +5,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -543,6 +547,87 @@ double efast_bound(const snpm_query *q, const FastGeom &g)
     return (double)(q->wsum * (m * u / (1.0 - m * u))) * 1.0000001;
 }
 
+// Staging pipeline shared by snpm_panel_upload_rows (host memory) and snpm_panel_load_file (a file):
+// `fill(dst, first_row, n)` writes n tightly packed rows (n_acc bytes each) into the pinned slab; the slab is
+// copied to a device scratch buffer on the side stream and a device kernel writes the panel rows from it
+// (256-B pitch + canonical codes for int8 panels, 2-bit packing for packed panels).  Two slabs alternate, so
+// filling slab k+1 overlaps the copy and the kernel of slab k.
+template <typename Fill>
+static int stage_rows(snpm_panel *p, int64_t row0, int64_t nrows, Fill fill)
+{
+    snpm_ctx *ctx = p->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->stage[i]) {
+            hipError_t e = hipHostMalloc(&ctx->stage[i], snpm_ctx::kStageBytes, hipHostMallocDefault);
+            if (e != hipSuccess) return set_err(ctx, SNPM_ERR_OOM, "hipHostMalloc staging failed: %s", hipGetErrorString(e));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+        }
+    }
+    int rc = ensure(ctx, ctx->ws_stage_dev, 2 * snpm_ctx::kStageBytes);
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->ws_flags2, sizeof(int));
+    if (rc) return rc;
+    if (p->packed) HIPCHK(ctx, hipMemsetAsync(ctx->ws_flags2.p, 0, sizeof(int), ctx->copy_stream));
+    const int64_t spitch = p->n_acc;                                   // staged rows are tight
+    const int64_t slab_rows = std::max<int64_t>(1, (int64_t)(snpm_ctx::kStageBytes / (size_t)spitch));
+    int which = 0;
+    for (int64_t r = 0; r < nrows; r += slab_rows, which ^= 1) {
+        const int64_t nr = std::min(slab_rows, nrows - r);
+        if (ctx->stage_busy[which]) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->stage_done[which]));
+            ctx->stage_busy[which] = false;
+        }
+        int8_t *st = (int8_t *)ctx->stage[which];
+        rc = fill(st, r, nr);
+        if (rc) return rc;
+        int8_t *scratch = (int8_t *)ctx->ws_stage_dev.p + (size_t)which * snpm_ctx::kStageBytes;
+        HIPCHK(ctx, hipMemcpyAsync(scratch, st, (size_t)nr * spitch, hipMemcpyHostToDevice, ctx->copy_stream));
+        if (!p->packed) {
+            const int64_t total = nr * (p->pitch / 4);
+            hipLaunchKernelGGL(k_repitch_canon, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream,
+                               scratch, spitch, nr, p->n_acc, (uint32_t *)(p->d + (row0 + r) * p->pitch), p->pitch);
+        } else {
+            const int64_t total = nr * p->pitch;
+            hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream, scratch,
+                               spitch, nr, p->n_acc, (uint8_t *)p->d + (row0 + r) * p->pitch, p->pitch, (int *)ctx->ws_flags2.p);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipEventRecord(ctx->stage_done[which], ctx->copy_stream));
+        ctx->stage_busy[which] = true;
+    }
+    if (p->packed) {
+        int bad = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&bad, ctx->ws_flags2.p, sizeof(int), hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+        ctx->stage_busy[0] = ctx->stage_busy[1] = false;
+        if (bad)
+            return set_err(ctx, SNPM_ERR_BADARG, "a packed panel holds only the codes -1 (any negative), 0, 1, 2; "
+                                                 "use the int8 panel for other values");
+    }
+    HIPCHK(ctx, hipEventRecord(p->uploaded, ctx->copy_stream));
+    p->upload_pending = true;
+    p->dT_state = 0;                    // the accession-major copy is stale
+    return SNPM_OK;
+}
+
+// copy n bytes with a few threads (one memcpy stream is ~15 GB/s, well under what PCIe gen5 x16 takes)
+static void parallel_copy(snpm_ctx *ctx, int8_t *dst, const int8_t *src, size_t n)
+{
+    const int nthreads = (int)std::min<size_t>((size_t)ctx->stage_threads, std::max<size_t>(1, n >> 20));
+    if (nthreads <= 1) {
+        memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const size_t per = (n + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; ++t) {
+        const size_t o = (size_t)t * per;
+        if (o < n) pool.emplace_back([=] { memcpy(dst + o, src + o, std::min(per, n - o)); });
+    }
+    for (auto &th : pool) th.join();
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -716,87 +801,75 @@ int snpm_panel_upload_rows(snpm_panel *p, int64_t row0, int64_t nrows, const int
     CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "upload rows outside the panel");
     CHECK_ARG(ctx, nrows == 0 || host != nullptr, "host pointer is NULL");
     CHECK_ARG(ctx, host_pitch >= p->n_acc, "host_pitch smaller than n_acc");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    for (int i = 0; i < 2; ++i) {
-        if (!ctx->stage[i]) {
-            hipError_t e = hipHostMalloc(&ctx->stage[i], snpm_ctx::kStageBytes, hipHostMallocDefault);
-            if (e != hipSuccess) return set_err(ctx, SNPM_ERR_OOM, "hipHostMalloc staging failed: %s", hipGetErrorString(e));
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+    const int64_t n_acc = p->n_acc;
+    return stage_rows(p, row0, nrows, [&](int8_t *dst, int64_t first, int64_t n) -> int {
+        if (host_pitch == n_acc) {
+            parallel_copy(ctx, dst, host + first * host_pitch, (size_t)n * n_acc);       // contiguous: one big copy
+        } else {
+            const int nthreads = (int)std::min<int64_t>(ctx->stage_threads, std::max<int64_t>(1, n / 1024));
+            auto rows = [&](int64_t k0, int64_t k1) {
+                for (int64_t k = k0; k < k1; ++k) memcpy(dst + k * n_acc, host + (first + k) * host_pitch, (size_t)n_acc);
+            };
+            if (nthreads <= 1) {
+                rows(0, n);
+            } else {
+                std::vector<std::thread> pool;
+                const int64_t per = (n + nthreads - 1) / nthreads;
+                for (int t = 0; t < nthreads; ++t)
+                    if (t * per < n) pool.emplace_back(rows, t * per, std::min<int64_t>(n, (t + 1) * per));
+                for (auto &th : pool) th.join();
+            }
         }
-    }
-    // staged row pitch: the panel's own pitch for int8 panels (the slab is copied straight into place); a
-    // 16-B multiple of n_acc for packed panels (the slab lands in a device scratch buffer and k_pack_rows
-    // writes the 2-bit rows)
-    const int64_t spitch = p->packed ? ((p->n_acc + 15) / 16) * 16 : p->pitch;
-    const int64_t slab_rows = std::max<int64_t>(1, (int64_t)(snpm_ctx::kStageBytes / (size_t)spitch));
-    if (p->packed) {
-        int rc = ensure(ctx, ctx->ws_stage_dev, 2 * snpm_ctx::kStageBytes);
-        if (rc) return rc;
-        rc = ensure(ctx, ctx->ws_flags2, sizeof(int));
-        if (rc) return rc;
-        HIPCHK(ctx, hipMemsetAsync(ctx->ws_flags2.p, 0, sizeof(int), ctx->copy_stream));
-    }
-    int which = 0;
-    for (int64_t r = 0; r < nrows; r += slab_rows, which ^= 1) {
-        const int64_t nr = std::min(slab_rows, nrows - r);
-        if (ctx->stage_busy[which]) {
-            HIPCHK(ctx, hipEventSynchronize(ctx->stage_done[which]));
-            ctx->stage_busy[which] = false;
-        }
-        int8_t *st = (int8_t *)ctx->stage[which];
-        const int64_t pad = spitch - p->n_acc;
-        // repack host rows into the pinned slab (row pitch -> staged pitch, pad = missing) on a few threads:
-        // a single memcpy stream is ~15 GB/s, well under what PCIe gen5 x16 takes
-        auto repack = [&](int64_t k0, int64_t k1) {
-            for (int64_t k = k0; k < k1; ++k) {
-                memcpy(st + k * spitch, host + (r + k) * host_pitch, (size_t)p->n_acc);
-                if (pad) memset(st + k * spitch + p->n_acc, 0xff, (size_t)pad);
+        return SNPM_OK;
+    });
+}
+
+// Rows [row0, row0+nrows) straight from a file of tightly packed int8 rows (n_acc bytes per row) starting at
+// byte `file_offset` (e.g. the data section of the .npy inside a native flat panel): pread() into the pinned
+// slabs, no intermediate host copy.
+int snpm_panel_load_file(snpm_panel *p, const char *path, int64_t file_offset, int64_t row0, int64_t nrows)
+{
+    if (!p) return SNPM_ERR_BADARG;
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, path != nullptr && file_offset >= 0, "bad file arguments");
+    CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "load rows outside the panel");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return set_err(ctx, SNPM_ERR_BADARG, "cannot open %s: %s", path, strerror(errno));
+#ifdef POSIX_FADV_SEQUENTIAL
+    (void)posix_fadvise(fd, file_offset, (off_t)(nrows * p->n_acc), POSIX_FADV_SEQUENTIAL);
+#endif
+    const int64_t n_acc = p->n_acc;
+    int rc = stage_rows(p, row0, nrows, [&](int8_t *dst, int64_t first, int64_t n) -> int {
+        // the slab is read by a few threads, each pread()ing its own contiguous piece
+        const size_t want = (size_t)n * n_acc;
+        const off_t base = (off_t)(file_offset + first * n_acc);
+        const int nthreads = (int)std::min<size_t>((size_t)ctx->stage_threads, std::max<size_t>(1, want >> 22));
+        std::vector<int> status((size_t)nthreads, 0);
+        auto piece = [&](int t) {
+            const size_t per = (want + nthreads - 1) / nthreads;
+            size_t o = (size_t)t * per;
+            const size_t end = std::min(want, o + per);
+            while (o < end) {
+                const ssize_t k = pread(fd, dst + o, end - o, base + (off_t)o);
+                if (k < 0 && errno == EINTR) continue;
+                if (k <= 0) { status[(size_t)t] = k < 0 ? errno : -1; return; }
+                o += (size_t)k;
             }
         };
-        const int nthreads = (int)std::min<int64_t>(ctx->stage_threads, std::max<int64_t>(1, nr / 1024));
         if (nthreads <= 1) {
-            repack(0, nr);
+            piece(0);
         } else {
             std::vector<std::thread> pool;
-            const int64_t per = (nr + nthreads - 1) / nthreads;
-            for (int t = 0; t < nthreads; ++t) {
-                const int64_t k0 = t * per, k1 = std::min<int64_t>(nr, k0 + per);
-                if (k0 < k1) pool.emplace_back(repack, k0, k1);
-            }
+            for (int t = 0; t < nthreads; ++t) pool.emplace_back(piece, t);
             for (auto &th : pool) th.join();
         }
-        if (!p->packed) {
-            int8_t *dst = p->d + (row0 + r) * p->pitch;
-            HIPCHK(ctx, hipMemcpyAsync(dst, st, (size_t)nr * p->pitch, hipMemcpyHostToDevice, ctx->copy_stream));
-            const int64_t n16 = nr * p->pitch / 16;
-            const int thr = 256;
-            const unsigned blocks = (unsigned)std::min<int64_t>((n16 + thr - 1) / thr, 4096);
-            hipLaunchKernelGGL(k_canon, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->copy_stream, (uint4 *)dst, n16);
-            HIPCHK(ctx, hipGetLastError());
-        } else {
-            int8_t *scratch = (int8_t *)ctx->ws_stage_dev.p + (size_t)which * snpm_ctx::kStageBytes;
-            HIPCHK(ctx, hipMemcpyAsync(scratch, st, (size_t)nr * spitch, hipMemcpyHostToDevice, ctx->copy_stream));
-            const int64_t total = nr * p->pitch;
-            hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream, scratch,
-                               spitch, nr, p->n_acc, (uint8_t *)p->d + (row0 + r) * p->pitch, p->pitch, (int *)ctx->ws_flags2.p);
-            HIPCHK(ctx, hipGetLastError());
-        }
-        HIPCHK(ctx, hipEventRecord(ctx->stage_done[which], ctx->copy_stream));
-        ctx->stage_busy[which] = true;
-    }
-    if (p->packed) {
-        int bad = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&bad, ctx->ws_flags2.p, sizeof(int), hipMemcpyDeviceToHost, ctx->copy_stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
-        ctx->stage_busy[0] = ctx->stage_busy[1] = false;
-        if (bad)
-            return set_err(ctx, SNPM_ERR_BADARG, "a packed panel holds only the codes -1 (any negative), 0, 1, 2; "
-                                                 "use the int8 panel for other values");
-    }
-    HIPCHK(ctx, hipEventRecord(p->uploaded, ctx->copy_stream));
-    p->upload_pending = true;
-    p->dT_state = 0;                    // the accession-major copy is stale
-    return SNPM_OK;
+        for (int st : status)
+            if (st != 0)
+                return set_err(ctx, SNPM_ERR_BADARG, "short read from %s (%s)", path, st > 0 ? strerror(st) : "end of file");
+        return SNPM_OK;
+    });
+    close(fd);
+    return rc;
 }
 
 int snpm_panel_upload_wait(snpm_panel *p)

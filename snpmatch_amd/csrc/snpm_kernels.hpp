@@ -903,6 +903,27 @@ __global__ void k_pack_rows(const int8_t *__restrict__ src, int64_t src_pitch, i
     dst[i] = (uint8_t)out;
 }
 
+// int8 panel upload: tightly staged rows (row stride src_pitch) -> panel rows (256-B pitch), codes
+// canonicalised on the way (negative -> 0xFF, > 2 -> 3), pad bytes = 0xFF.  One thread per destination dword.
+__global__ void k_repitch_canon(const int8_t *__restrict__ src, int64_t src_pitch, int64_t nrows, int64_t n_acc,
+                                uint32_t *__restrict__ dst, int64_t dst_pitch)
+{
+    const int64_t dwords_per_row = dst_pitch / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * dwords_per_row) return;
+    const int64_t r = i / dwords_per_row, d = i - r * dwords_per_row;
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t a = d * 4 + j;
+        int v = -1;
+        if (a < n_acc) v = src[r * src_pitch + a];
+        const uint32_t c = v < 0 ? 0xffu : (v > 2 ? 3u : (uint32_t)v);
+        out |= c << (8 * j);
+    }
+    dst[r * dwords_per_row + d] = out;
+}
+
 // packed rows -> int8 (download / checks): one thread per accession byte of the destination
 __global__ void k_unpack_rows(const uint8_t *__restrict__ src, int64_t src_pitch, int64_t nrows, int64_t n_acc,
                               int8_t *__restrict__ dst, int64_t dst_pitch)

@@ -172,6 +172,24 @@ class Panel(object):
         assert rows.ndim == 2 and rows.shape[1] == self.n_acc
         check(self.ctx.lib.snpm_panel_upload_rows(self.h, int(row0), rows.shape[0], ptr(rows), rows.shape[1]), self.ctx.h)
 
+    def load_file(self, path, file_offset, row0=0, nrows=None):
+        """Stream rows from a file of tightly packed int8 rows (native flat panel) through the staging path."""
+        nrows = self.n_snp - row0 if nrows is None else nrows
+        check(self.ctx.lib.snpm_panel_load_file(self.h, str(path).encode(), int(file_offset), int(row0), int(nrows)), self.ctx.h)
+
+    @classmethod
+    def from_npy(cls, ctx, path, packed=False):
+        """Panel from an int8 [n_snp, n_acc] .npy file (C order), read natively (no numpy copy)."""
+        with open(path, "rb") as fh:
+            major, minor = np.lib.format.read_magic(fh)
+            shape, fortran, dtype = (np.lib.format.read_array_header_1_0(fh) if major == 1
+                                     else np.lib.format.read_array_header_2_0(fh))
+            offset = fh.tell()
+        assert len(shape) == 2 and not fortran and np.dtype(dtype) == np.int8, "expected a C-ordered int8 matrix"
+        p = cls(ctx, shape[0], shape[1], packed=packed)
+        p.load_file(path, offset)
+        return p
+
     def upload_wait(self):
         check(self.ctx.lib.snpm_panel_upload_wait(self.h), self.ctx.h)
 

@@ -706,3 +706,45 @@ def test_full_bench_size_properties(ctx):
     db = panel.download_rows(r0, slab)[:, :300]
     ws, wn = c_oracle.genotyper(db, None, wpl, 1000, False)
     assert np.array_equal(bits(ss[:300]), bits(ws)) and np.array_equal(ns[:300], wn)
+
+
+def test_native_file_loader(ctx, tmp_path):
+    """snpm_panel_load_file: a flat panel streamed from disk through the pinned staging slabs equals the same
+    matrix uploaded from memory (int8 and packed), row windows included; strided host rows upload correctly."""
+    import time
+    from snpmatch_amd.core import snp_genotype
+    rng = np.random.default_rng(17)
+    n_snp, n_acc = 700_001, 1135
+    db = rand_db(rng, n_snp, n_acc)
+    path = str(tmp_path / "db.snpm")
+    snp_genotype.save_native(path, db, ["a%d" % i for i in range(n_acc)], np.arange(1, n_snp + 1), ["1"], [(0, n_snp)])
+    t0 = time.perf_counter()
+    p1 = engine.Panel.from_npy(ctx, os.path.join(path, "snps.npy"))
+    p1.upload_wait()
+    dt = time.perf_counter() - t0
+    print("file loader: %.2f GB in %.3f s = %.2f GB/s" % (db.nbytes / 1e9, dt, db.nbytes / 1e9 / dt))
+    for r0 in (0, 65536 - 3, n_snp - 500):
+        assert np.array_equal(p1.download_rows(r0, 500), db[r0:r0 + 500])
+    p2 = engine.Panel.from_npy(ctx, os.path.join(path, "snps.npy"), packed=True)
+    assert np.array_equal(p2.download_rows(1234, 4000), db[1234:5234])
+    # the host-side Genotype picks the native loader for flat panels
+    g = snp_genotype.Genotype(path, None)
+    assert np.array_equal(g.panel(ctx).download_rows(7, 100), db[7:107])
+    # partial load into the middle of a panel + strided host rows
+    p3 = engine.Panel(ctx, 1000, n_acc)
+    p3.fill_synthetic(5)
+    with open(os.path.join(path, "snps.npy"), "rb") as fh:
+        np.lib.format.read_magic(fh)
+        np.lib.format.read_array_header_1_0(fh)
+        off = fh.tell()
+    p3.load_file(os.path.join(path, "snps.npy"), off + 50 * n_acc, row0=100, nrows=200)
+    got = p3.download_rows(0, 1000)
+    assert np.array_equal(got[100:300], db[50:250]) and np.array_equal(got[:100], synth.panel_values(5, 0, 100, 0, n_acc))
+    wide = np.full((600, n_acc + 37), 9, dtype=np.int8)
+    wide[:, :n_acc] = db[:600]
+    p4 = engine.Panel(ctx, 600, n_acc)
+    check_rc = ctx.lib.snpm_panel_upload_rows(p4.h, 0, 600, wide.ctypes.data, wide.shape[1])
+    assert check_rc == 0
+    assert np.array_equal(p4.download_rows(0, 600), db[:600])
+    with pytest.raises(AssertionError, match="cannot open"):
+        p4.load_file(str(tmp_path / "missing.npy"), 0)
