@@ -169,7 +169,7 @@ int snpm_panel_segregating(snpm_panel *panel, const int32_t *cols, int64_t ncols
 int snpm_debug_stream_read(snpm_panel *panel, int64_t *bytes_read);
 int snpm_profile_enable(snpm_ctx *ctx, int on);
 int snpm_profile_reset(snpm_ctx *ctx);
-/* kernel: "fast", "strict", "reduce", "scan", "likelihood", "synth", "canon".  Synchronises the stream. */
+/* kernel: "fast", "strict", "reduce", "scan", "likelihood", "synth", "lut".  Synchronises the stream. */
 int snpm_profile_read(snpm_ctx *ctx, const char *kernel, int64_t *launches, double *total_ms);
 
 #ifdef __cplusplus

@@ -29,8 +29,8 @@ namespace {
 
 thread_local std::string g_init_error;
 
-enum ProfKind { PK_FAST = 0, PK_STRICT, PK_REDUCE, PK_SCAN, PK_LIK, PK_SYNTH, PK_CANON, PK_LUT, PK_COUNT };
-const char *kProfNames[PK_COUNT] = {"fast", "strict", "reduce", "scan", "likelihood", "synth", "canon", "lut"};
+enum ProfKind { PK_FAST = 0, PK_STRICT, PK_REDUCE, PK_SCAN, PK_LIK, PK_SYNTH, PK_LUT, PK_COUNT };
+const char *kProfNames[PK_COUNT] = {"fast", "strict", "reduce", "scan", "likelihood", "synth", "lut"};
 
 struct Buf {
     void *p = nullptr;

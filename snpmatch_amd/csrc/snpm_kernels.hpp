@@ -17,7 +17,7 @@
 //              accessions the fast pass cannot certify.
 //   k_scan     sequential accumulation of segment sums (ScoreList += chunk, core/snpmatch.py:224).
 //   k_likelihood  likeliTest + nanmin + ratio on device (core/snpmatch.py:40-55,106-117).
-//   k_build_lut, k_canon, k_synth, k_patch: small helpers.
+//   k_build_lut, k_repitch_canon / k_pack_rows (upload), k_synth, k_patch, ...: small helpers.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -849,34 +849,6 @@ k_likelihood(const double *__restrict__ y, const int64_t *__restrict__ n, int64_
     for (int64_t i = threadIdx.x; i < len; i += blockDim.x) {
         // get_fraction(x, y): nan when y <= 0 (core/snpmatch.py:25-28); y = nan falls through to x / nan
         rr[i] = (top <= 0.0) ? __builtin_nan("") : lr[i] / top;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// canonicalise uploaded bytes in place: negative -> 0xFF, > 2 -> 3 (16 bytes per thread)
-__device__ __forceinline__ uint32_t canon_dword(uint32_t x)
-{
-    uint32_t out = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int b = (int8_t)((x >> (8 * j)) & 0xff);
-        uint32_t c = b < 0 ? 0xffu : (b > 2 ? 3u : (uint32_t)b);
-        out |= c << (8 * j);
-    }
-    return out;
-}
-
-__global__ void k_canon(uint4 *__restrict__ p, int64_t n16)
-{
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n16; i += stride) {
-        uint4 v = p[i];
-        v.x = canon_dword(v.x);
-        v.y = canon_dword(v.y);
-        v.z = canon_dword(v.z);
-        v.w = canon_dword(v.w);
-        p[i] = v;
     }
 }
 
