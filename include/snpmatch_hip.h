@@ -161,6 +161,16 @@ int snpm_intersect_sorted(const int64_t *a, int64_t na, const int64_t *b, int64_
 /* Genotype.identify_segregating_snps on the resident panel (core/snp_genotype.py:188-211, used by --refine):
    mask [n_snp] (host, uint8) = 1 where the informative calls of accessions cols[0..ncols) are not all equal. */
 int snpm_panel_segregating(snpm_panel *panel, const int32_t *cols, int64_t ncols, uint8_t *mask);
+/* CrossIdentifier.match_insilico_f1s (core/csmatch.py:115-125): every pair (i < j, in the order of
+   itertools.combinations) of the n_sel (<= 32) accessions acc_idx is crossed in silico over the query's
+   matched SNPs.  Per pair: "alt" SNPs (both calls 1) take W[:, 2], "ref" SNPs (both 0) take W[:, 0], SNPs
+   where both calls are informative and differ take W[:, 1];
+       score = (np.sum(alt weights) + np.sum(ref weights)) + np.sum(het weights),  ninfo = the three counts.
+   The reference prints these scores as floats, so each np.sum is evaluated in numpy's order (pairwise
+   summation inside 8192-element chunks, chunks added in sequence): fp64 bit patterns of the reference.
+   score / ninfo: host arrays [n_sel * (n_sel - 1) / 2].  DB codes other than -1, 0, 1, 2 count as one
+   further class (differs from 0/1/2, equal to itself). */
+int snpm_query_f1_pairs(snpm_query *query, const int32_t *acc_idx, int n_sel, double *score, int64_t *ninfo);
 
 /* ---------------------------------------------------------------- profiling (HIP events on the ctx stream) */
 /* PMC calibration: reads the whole panel once with the access shape of the scoring kernel (4 B per

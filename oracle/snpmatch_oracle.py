@@ -274,6 +274,63 @@ def test_identity(x, n, error_rate=0.02, pthres=0.05):
 test_identity.__test__ = False  # not a pytest test
 
 
+# --------------------------------------------------------------------------- in-silico F1s
+def insilico_f1_pairs(cols, wei):
+    """match_insilico_f1s, core/csmatch.py:115-125: ``cols`` int8 [n, k] = the calls of the k selected accessions
+    at the matched SNPs, ``wei`` float [n, 3].  Returns (score [k(k-1)/2], ninfo) in combination order.  The sums
+    are numpy's own np.sum over freshly gathered contiguous vectors, exactly as the reference writes them."""
+    import itertools
+    cols = np.asarray(cols)
+    wei = np.asarray(wei, dtype=float)
+    score, ninfo = [], []
+    for i, j in itertools.combinations(range(cols.shape[1]), 2):
+        gtp1, gtp2 = cols[:, i], cols[:, j]
+        homalt = np.where((gtp1 == 1) & (gtp2 == 1))[0]
+        homref = np.where((gtp1 == 0) & (gtp2 == 0))[0]
+        het = np.where((gtp1 != -1) & (gtp2 != -1) & (gtp1 != gtp2))[0]
+        score.append(np.sum(wei[homalt, 2]) + np.sum(wei[homref, 0]) + np.sum(wei[het, 1]))
+        ninfo.append(len(homalt) + len(homref) + len(het))
+    return np.array(score, dtype=float), np.array(ninfo, dtype=np.int64)
+
+
+NP_SUM_CHUNK = 8192           # numpy's default ufunc buffer size (np.getbufsize())
+NP_PW_LEAF = 128              # PW_BLOCKSIZE of numpy's pairwise summation
+
+
+def np_pairwise_sum(a):
+    """numpy's DOUBLE_pairwise_sum (numpy/_core/src/umath/loops_utils.h.src), restated: the order the device
+    kernels of the in-silico F1 scores reproduce."""
+    n = len(a)
+    if n < 8:
+        res = np.float64(0.0)
+        for x in a:
+            res = res + x
+        return res
+    if n <= NP_PW_LEAF:
+        r = np.array(a[:8], dtype=np.float64)
+        k8 = n - n % 8
+        for i in range(8, k8, 8):
+            r = r + a[i:i + 8]
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        for i in range(k8, n):
+            res = res + a[i]
+        return res
+    n2 = n // 2
+    n2 -= n2 % 8
+    return np_pairwise_sum(a[:n2]) + np_pairwise_sum(a[n2:])
+
+
+def np_sum_restated(a):
+    """np.sum of a contiguous float64 vector as numpy 2.2 evaluates it: the reduction runs over the ufunc
+    buffer (8192 elements) at a time, each piece summed pairwise, pieces added in order starting from 0.0
+    (checked bit-for-bit against np.sum in tests/test_oracle_golden.py)."""
+    a = np.asarray(a, dtype=np.float64)
+    res = np.float64(0.0)
+    for c0 in range(0, len(a), NP_SUM_CHUNK):
+        res = res + np_pairwise_sum(a[c0:c0 + NP_SUM_CHUNK])
+    return res
+
+
 # --------------------------------------------------------------------------- helpers
 def weights_from_pl(pl):
     """PL -> weights (core/parsers.py:147-150): exp(PL / -10)."""

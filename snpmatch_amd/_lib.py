@@ -31,6 +31,7 @@ SYMBOLS = [
     "snpm_query_free", "snpm_query_bind_outputs", "snpm_query_run", "snpm_query_run_device", "snpm_query_error_bound",
     "snpm_query_run_windows", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
     "snpm_binom_identity", "snpm_binom_sf_host", "snpm_intersect_sorted", "snpm_panel_segregating",
+    "snpm_query_f1_pairs",
     "snpm_debug_stream_read", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
 ]
 
@@ -88,6 +89,7 @@ def load():
     lib.snpm_binom_sf_host.argtypes = [p, p, i64, dbl, p]
     lib.snpm_intersect_sorted.argtypes = [p, i64, p, i64, p, p, C.POINTER(i64)]
     lib.snpm_panel_segregating.argtypes = [p, p, i64, p]
+    lib.snpm_query_f1_pairs.argtypes = [p, p, ci, p, p]
     lib.snpm_debug_stream_read.argtypes = [p, C.POINTER(i64)]
     lib.snpm_profile_enable.argtypes = [p, ci]
     lib.snpm_profile_reset.argtypes = [p]

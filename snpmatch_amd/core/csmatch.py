@@ -9,8 +9,9 @@ Public surface follows the reference module ``snpmatch.core.csmatch`` (core/csma
 The reference scores window after window (one ``matchGTsAccs`` call each, :80-90).  Here the matched DB
 rows of ALL windows form one device query with a segment per window (``k_strict``: reference summation
 order, fp64 bit-exact), the per-window likelihoods / minima / ratios are one ``k_likelihood`` launch with
-a row per window, and the binomial identity test runs on the device as well.  The window table, the
-in-silico F1 scores of the ten best accessions and the JSON interpretation are host glue (``_report``).
+a row per window, and the binomial identity test runs on the device as well.  The window table and the
+JSON interpretation are host glue (``_report``); the 45 in-silico F1s of the ten best accessions are one
+more device call (``k_f1_*``, numpy's summation order).
 """
 import itertools
 import json
@@ -136,17 +137,12 @@ class CrossIdentifier(object):
         log.info("simulating F1s for top 10 accessions")
         best = np.argsort(-snpmatch_result.probabilies)[0:10]
         db_rows, sample_rows = self.g.get_positions_idxs(self.inputs.chrs, self.inputs.pos)
-        w_ref, w_het, w_alt = (self.inputs.wei[sample_rows, c] for c in (0, 1, 2))
-        calls = dict((i, np.asarray(self.g.g_acc.snps[:, i])[db_rows]) for i in best)
-        extra_s, extra_n, extra_a = [], [], []
-        for i, j in itertools.combinations(best, 2):
-            a, b = calls[i], calls[j]
-            both_alt = np.flatnonzero((a == 1) & (b == 1))
-            both_ref = np.flatnonzero((a == 0) & (b == 0))
-            differ = np.flatnonzero((a != -1) & (b != -1) & (a != b))
-            extra_s.append(np.sum(w_alt[both_alt]) + np.sum(w_ref[both_ref]) + np.sum(w_het[differ]))
-            extra_n.append(len(both_alt) + len(both_ref) + len(differ))
-            extra_a.append(self.g.accessions[i] + "x" + self.g.accessions[j])
+        # all pairs in one device call (k_f1_*): per pair np.sum(W[alt, 2]) + np.sum(W[ref, 0]) + np.sum(W[het, 1])
+        # with numpy's summation order, so the float scores printed below carry the reference's digits
+        query = engine.Query(self.g.panel(), db_rows, self.inputs.wei[sample_rows, ])
+        extra_s, extra_n = query.f1_pairs(best)
+        query.free()
+        extra_a = [self.g.accessions[i] + "x" + self.g.accessions[j] for i, j in itertools.combinations(best, 2)]
         if extra_a:
             snpmatch_result.scores = np.append(snpmatch_result.scores, extra_s)      # becomes a float column
             snpmatch_result.ninfo = np.append(snpmatch_result.ninfo, extra_n)

@@ -1371,6 +1371,91 @@ int snpm_panel_segregating(snpm_panel *p, const int32_t *cols, int64_t ncols, ui
     return SNPM_OK;
 }
 
+// match_insilico_f1s (core/csmatch.py:115-125) on the resident panel: scores of all pairs of the selected
+// accessions over the query's rows, in numpy's summation order (k_f1_* in snpm_kernels.hpp)
+int snpm_query_f1_pairs(snpm_query *q, const int32_t *acc_idx, int n_sel, double *score, int64_t *ninfo)
+{
+    if (!q) return SNPM_ERR_BADARG;
+    snpm_panel *p = q->panel;
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, n_sel >= 0 && n_sel <= F1_MAX_SEL, "between 0 and 32 accessions can be crossed in silico");
+    const int n_pairs = n_sel * (n_sel - 1) / 2;
+    if (n_pairs == 0) return SNPM_OK;
+    CHECK_ARG(ctx, acc_idx && score && ninfo, "NULL argument");
+    for (int i = 0; i < n_sel; ++i) CHECK_ARG(ctx, acc_idx[i] >= 0 && acc_idx[i] < p->n_acc, "accession index outside the panel");
+    CHECK_ARG(ctx, q->n < (int64_t(1) << 31), "too many matched SNPs for the in-silico crosses");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = wait_upload(p);
+    if (rc) return rc;
+    const int64_t n = q->n;
+    if (n == 0) {
+        for (int k = 0; k < n_pairs; ++k) { score[k] = 0.0; ninfo[k] = 0; }
+        return SNPM_OK;
+    }
+    const int64_t stride = (n + F1_ROWS_PER_BLOCK - 1) / F1_ROWS_PER_BLOCK * F1_ROWS_PER_BLOCK;
+    const int64_t nblk = stride / F1_ROWS_PER_BLOCK;
+    const int64_t max_chunks = (n + NP_SUM_CHUNK - 1) / NP_SUM_CHUNK;
+    // pairs per batch: the compacted weights of a pair take n doubles; keep the slab around 2 GiB
+    const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(n_pairs, (int64_t(2) << 30) / (n * 8)));
+
+    std::vector<int32_t> tab((size_t)n_sel + 2 * (size_t)n_pairs);      // [acc | (i, j) per pair, combination order]
+    for (int i = 0; i < n_sel; ++i) tab[(size_t)i] = acc_idx[i];
+    for (int i = 0, k = 0; i < n_sel; ++i)
+        for (int j = i + 1; j < n_sel; ++j, ++k) {
+            tab[(size_t)n_sel + 2 * k] = i;
+            tab[(size_t)n_sel + 2 * k + 1] = j;
+        }
+
+    struct Scratch {                    // freed on every return path
+        std::vector<void *> ptrs;
+        ~Scratch() { for (void *x : ptrs) (void)hipFree(x); }
+        hipError_t get(void **out, size_t bytes)
+        {
+            hipError_t e = hipMalloc(out, std::max<size_t>(bytes, 256));
+            if (e == hipSuccess) ptrs.push_back(*out);
+            return e;
+        }
+    } scratch;
+    uint8_t *d_codes = nullptr;
+    int32_t *d_tab = nullptr;
+    uint32_t *d_cnt = nullptr, *d_m = nullptr;
+    double *d_cw = nullptr, *d_chunk = nullptr, *d_score = nullptr;
+    int64_t *d_ninfo = nullptr;
+    HIPCHK(ctx, scratch.get((void **)&d_codes, (size_t)n_sel * stride));
+    HIPCHK(ctx, scratch.get((void **)&d_tab, tab.size() * sizeof(int32_t)));
+    HIPCHK(ctx, scratch.get((void **)&d_cnt, (size_t)batch * 3 * nblk * sizeof(uint32_t)));
+    HIPCHK(ctx, scratch.get((void **)&d_m, (size_t)batch * 3 * sizeof(uint32_t)));
+    HIPCHK(ctx, scratch.get((void **)&d_cw, (size_t)batch * n * sizeof(double)));
+    HIPCHK(ctx, scratch.get((void **)&d_chunk, (size_t)batch * 3 * max_chunks * sizeof(double)));
+    HIPCHK(ctx, scratch.get((void **)&d_score, (size_t)n_pairs * sizeof(double)));
+    HIPCHK(ctx, scratch.get((void **)&d_ninfo, (size_t)n_pairs * sizeof(int64_t)));
+
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_f1_gather, dim3((unsigned)(stride / 256)), dim3(256), 0, st, p->d, p->pitch, p->packed,
+                       (const int64_t *)q->d_row_idx, q->row0, n, (const int32_t *)d_tab, n_sel, d_codes, stride);
+    HIPCHK(ctx, hipGetLastError());
+    const int32_t *d_pairs = d_tab + n_sel;
+    for (int pair0 = 0; pair0 < n_pairs; pair0 += batch) {
+        const int nb = std::min(batch, n_pairs - pair0);
+        hipLaunchKernelGGL(k_f1_count, dim3((unsigned)nblk, (unsigned)nb), dim3(F1_BLOCK), 0, st, (const uint8_t *)d_codes,
+                           stride, d_pairs, pair0, d_cnt, nblk);
+        hipLaunchKernelGGL(k_f1_scan, dim3((unsigned)(nb * 3)), dim3(256), 0, st, d_cnt, nblk, d_m);
+        hipLaunchKernelGGL(k_f1_compact, dim3((unsigned)nblk, (unsigned)nb), dim3(F1_BLOCK), 0, st, (const uint8_t *)d_codes,
+                           stride, d_pairs, pair0, (const double *)q->d_w, n, (const uint32_t *)d_cnt, nblk,
+                           (const uint32_t *)d_m, d_cw);
+        hipLaunchKernelGGL(k_f1_chunks, dim3((unsigned)max_chunks, (unsigned)(nb * 3)), dim3(256), 0, st,
+                           (const double *)d_cw, (const uint32_t *)d_m, n, max_chunks, d_chunk);
+        hipLaunchKernelGGL(k_f1_finish, dim3((unsigned)nb), dim3(192), 0, st, (const double *)d_chunk,
+                           (const uint32_t *)d_m, max_chunks, pair0, d_score, d_ninfo);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipMemcpyAsync(score, d_score, (size_t)n_pairs * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ninfo, d_ninfo, (size_t)n_pairs * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return SNPM_OK;
+}
+
 // PMC calibration helper: stream the whole panel once (known byte count = n_snp * pitch)
 int snpm_debug_stream_read(snpm_panel *p, int64_t *bytes_read)
 {

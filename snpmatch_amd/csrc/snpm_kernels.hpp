@@ -1046,6 +1046,263 @@ __global__ void k_segregating(const int8_t *__restrict__ db, int64_t pitch, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// In-silico F1s (match_insilico_f1s, core/csmatch.py:115-125).  For a pair (i, j) of accession columns a
+// matched SNP is "alt" when both calls are 1, "ref" when both are 0, "het" when both are informative and
+// differ; the pair's score is np.sum(W[alt, 2]) + np.sum(W[ref, 0]) + np.sum(W[het, 1]) and the reference
+// prints it as a float, so the bits of numpy's summation matter.  np.sum of a contiguous fp64 vector is
+//   res = 0.0;  for every 8192-element chunk (the ufunc buffer):  res += pairwise(chunk)
+// with pairwise() = numpy's DOUBLE_pairwise_sum: < 8 elements sequential; <= 128 elements eight strided
+// accumulators, ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the tail sequentially; otherwise split at
+// n/2 rounded down to a multiple of 8.  The kernels below compact each category's weights in SNP order
+// (count -> scan -> scatter) and evaluate exactly that tree.
+constexpr int F1_BLOCK = 256;
+constexpr int F1_ROWS_PER_THREAD = 8;
+constexpr int F1_ROWS_PER_BLOCK = F1_BLOCK * F1_ROWS_PER_THREAD;   // 2048
+constexpr int NP_SUM_CHUNK = 8192;
+constexpr int NP_PW_LEAF = 128;
+constexpr int F1_MAX_SEL = 32;
+
+// codes[c][s] = call of selected accession c at matched SNP s (0 ref, 1 alt, 2 het, 3 other, 0xFF missing);
+// rows n..stride-1 are padding (missing)
+__global__ void __launch_bounds__(256)
+k_f1_gather(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx, int64_t row0,
+            int64_t n, const int32_t *__restrict__ acc, int n_sel, uint8_t *__restrict__ codes, int64_t stride)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= stride) return;
+    const int64_t prow = (s < n) ? (row_idx ? row_idx[s] : row0 + s) : 0;
+    for (int c = 0; c < n_sel; ++c)
+        codes[(int64_t)c * stride + s] = (s < n) ? (uint8_t)code_at(db, pitch, prow, acc[c], packed) : (uint8_t)0xFF;
+}
+
+// category of one SNP for a pair: 0 alt, 1 ref, 2 het, 3 not informative
+__device__ __forceinline__ int f1_cat(uint32_t a, uint32_t b)
+{
+    if (a == 1u && b == 1u) return 0;
+    if (a == 0u && b == 0u) return 1;
+    if (a != 0xFFu && b != 0xFFu && a != b) return 2;
+    return 3;
+}
+
+// per-thread category counts of its 8 consecutive SNPs, packed in 16-bit fields (alt | ref << 16 | het << 32)
+__device__ __forceinline__ uint64_t f1_thread_counts(uint64_t xa, uint64_t xb)
+{
+    uint64_t c = 0;
+#pragma unroll
+    for (int k = 0; k < F1_ROWS_PER_THREAD; ++k) {
+        const int cat = f1_cat((uint32_t)(xa >> (8 * k)) & 0xFFu, (uint32_t)(xb >> (8 * k)) & 0xFFu);
+        if (cat < 3) c += 1ull << (16 * cat);
+    }
+    return c;
+}
+
+// grid (stride / 2048, pairs of this batch): cnt[(pair_local * 3 + cat) * nblk + blk]
+__global__ void __launch_bounds__(F1_BLOCK)
+k_f1_count(const uint8_t *__restrict__ codes, int64_t stride, const int32_t *__restrict__ pair_ij, int pair0,
+           uint32_t *__restrict__ cnt, int64_t nblk)
+{
+    __shared__ uint64_t wave_tot[F1_BLOCK / WAVE];
+    const int pair = pair0 + blockIdx.y;
+    const uint8_t *ci = codes + (int64_t)pair_ij[2 * pair] * stride;
+    const uint8_t *cj = codes + (int64_t)pair_ij[2 * pair + 1] * stride;
+    const int64_t base = (int64_t)blockIdx.x * F1_ROWS_PER_BLOCK + (int64_t)threadIdx.x * F1_ROWS_PER_THREAD;
+    uint64_t c = f1_thread_counts(*(const uint64_t *)(ci + base), *(const uint64_t *)(cj + base));
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & (WAVE - 1)) == 0) wave_tot[threadIdx.x / WAVE] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < F1_BLOCK / WAVE; ++w) t += wave_tot[w];
+        for (int cat = 0; cat < 3; ++cat)
+            cnt[((int64_t)blockIdx.y * 3 + cat) * nblk + blockIdx.x] = (uint32_t)((t >> (16 * cat)) & 0xFFFFu);
+    }
+}
+
+// one block per list: cnt -> exclusive prefix (in place), total -> m[list]
+__global__ void __launch_bounds__(256)
+k_f1_scan(uint32_t *__restrict__ cnt, int64_t nblk, uint32_t *__restrict__ m)
+{
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t carry_s;
+    uint32_t *c = cnt + (int64_t)blockIdx.x * nblk;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nblk; b0 += 256) {
+        const int64_t b = b0 + threadIdx.x;
+        const uint32_t v = (b < nblk) ? c[b] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint32_t t = __shfl_up(inc, d);
+            if ((int)(threadIdx.x & (WAVE - 1)) >= d) inc += t;
+        }
+        if ((threadIdx.x & (WAVE - 1)) == WAVE - 1) wave_tot[threadIdx.x / WAVE] = inc;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (int w = 0; w < (int)(threadIdx.x / WAVE); ++w) before += wave_tot[w];
+        if (b < nblk) c[b] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry_s = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) m[blockIdx.x] = carry_s;
+}
+
+// first element of list (pair_local, cat) inside the pair's compacted-weight slab
+__device__ __forceinline__ int64_t f1_list_base(const uint32_t *__restrict__ m, int pair_local, int cat, int64_t n)
+{
+    int64_t off = (int64_t)pair_local * n;
+    if (cat >= 1) off += m[pair_local * 3];
+    if (cat >= 2) off += m[pair_local * 3 + 1];
+    return off;
+}
+
+// same grid as k_f1_count: cw[list base + rank of the SNP inside its list] = weight of the SNP's category
+__global__ void __launch_bounds__(F1_BLOCK)
+k_f1_compact(const uint8_t *__restrict__ codes, int64_t stride, const int32_t *__restrict__ pair_ij, int pair0,
+             const double *__restrict__ w, int64_t n, const uint32_t *__restrict__ blk_off, int64_t nblk,
+             const uint32_t *__restrict__ m, double *__restrict__ cw)
+{
+    __shared__ uint64_t wave_tot[F1_BLOCK / WAVE];
+    const int pair = pair0 + blockIdx.y;
+    const uint8_t *ci = codes + (int64_t)pair_ij[2 * pair] * stride;
+    const uint8_t *cj = codes + (int64_t)pair_ij[2 * pair + 1] * stride;
+    const int64_t base = (int64_t)blockIdx.x * F1_ROWS_PER_BLOCK + (int64_t)threadIdx.x * F1_ROWS_PER_THREAD;
+    const uint64_t xa = *(const uint64_t *)(ci + base), xb = *(const uint64_t *)(cj + base);
+    const uint64_t mine = f1_thread_counts(xa, xb);
+    uint64_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint64_t t = __shfl_up(inc, d);
+        if ((int)(threadIdx.x & (WAVE - 1)) >= d) inc += t;
+    }
+    if ((threadIdx.x & (WAVE - 1)) == WAVE - 1) wave_tot[threadIdx.x / WAVE] = inc;
+    __syncthreads();
+    uint64_t before = inc - mine;
+    for (int wv = 0; wv < (int)(threadIdx.x / WAVE); ++wv) before += wave_tot[wv];
+    int64_t pos[3];
+#pragma unroll
+    for (int cat = 0; cat < 3; ++cat)
+        pos[cat] = f1_list_base(m, blockIdx.y, cat, n) + blk_off[((int64_t)blockIdx.y * 3 + cat) * nblk + blockIdx.x] +
+                   (int64_t)((before >> (16 * cat)) & 0xFFFFu);
+#pragma unroll
+    for (int k = 0; k < F1_ROWS_PER_THREAD; ++k) {
+        const int cat = f1_cat((uint32_t)(xa >> (8 * k)) & 0xFFu, (uint32_t)(xb >> (8 * k)) & 0xFFu);
+        if (cat == 0) cw[pos[0]++] = w[(base + k) * 3 + 2];
+        else if (cat == 1) cw[pos[1]++] = w[(base + k) * 3 + 0];
+        else if (cat == 2) cw[pos[2]++] = w[(base + k) * 3 + 1];
+    }
+}
+
+// child of the pairwise-sum node [lo, lo + len) that contains element p (len > NP_PW_LEAF)
+__device__ __forceinline__ void np_pw_descend(int p, int &lo, int &len)
+{
+    int n2 = len / 2;
+    n2 -= n2 % 8;
+    if (p < lo + n2) len = n2;
+    else { lo += n2; len -= n2; }
+}
+
+// grid (max chunks, lists of this batch): chunk_sum[list * max_chunks + c] = numpy pairwise sum of the c-th
+// 8192-element chunk of the list.  Blocks past the list's last chunk exit.
+__global__ void __launch_bounds__(256)
+k_f1_chunks(const double *__restrict__ cw, const uint32_t *__restrict__ m, int64_t n, int64_t max_chunks,
+            double *__restrict__ chunk_sum)
+{
+    __shared__ double val[NP_SUM_CHUNK / 8];
+    const int list = blockIdx.y;
+    const int64_t mm = m[list];
+    const int64_t first = (int64_t)blockIdx.x * NP_SUM_CHUNK;
+    if (first >= mm) return;
+    const int len = (int)((mm - first < NP_SUM_CHUNK) ? (mm - first) : NP_SUM_CHUNK);
+    const double *a = cw + f1_list_base(m, list / 3, list % 3, n) + first;
+    double *out = chunk_sum + (int64_t)list * max_chunks + blockIdx.x;
+    if (len < 8) {
+        if (threadIdx.x == 0) {
+            double r = 0.0;
+            for (int i = 0; i < len; ++i) r = r + a[i];
+            *out = r;
+        }
+        return;
+    }
+    const int ncand = (len + 7) / 8;          // every leaf starts at a multiple of 8
+    const int j = threadIdx.x & 7;
+    for (int cand = threadIdx.x >> 3; cand < ncand; cand += 256 / 8) {
+        const int p = cand * 8;
+        int lo = 0, ln = len;
+        while (ln > NP_PW_LEAF) np_pw_descend(p, lo, ln);
+        if (lo == p) {                        // the 8 lanes of the group own the 8 accumulators of this leaf
+            const int k8 = ln - ln % 8;
+            double r = a[lo + j];
+            for (int i = 8; i < k8; i += 8) r = r + a[lo + i + j];
+            r = r + __shfl_xor(r, 1);
+            r = r + __shfl_xor(r, 2);
+            r = r + __shfl_xor(r, 4);
+            if (j == 0) {
+                for (int i = k8; i < ln; ++i) r = r + a[lo + i];
+                val[cand] = r;
+            }
+        }
+    }
+    // inner nodes, deepest level first: a node's value replaces its left child's slot
+    for (int d = 7; d >= 0; --d) {
+        __syncthreads();
+        for (int cand = threadIdx.x; cand < ncand; cand += 256) {
+            const int p = cand * 8;
+            int lo = 0, ln = len;
+            bool inner = true;
+            for (int lvl = 0; lvl < d; ++lvl) {
+                if (ln <= NP_PW_LEAF) { inner = false; break; }
+                np_pw_descend(p, lo, ln);
+            }
+            if (inner && ln > NP_PW_LEAF && lo == p) {
+                int n2 = ln / 2;
+                n2 -= n2 % 8;
+                val[lo / 8] = val[lo / 8] + val[(lo + n2) / 8];
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *out = val[0];
+}
+
+// one block per pair of the batch: add the chunk sums of its three lists in order, then
+// score = (S_alt + S_ref) + S_het and ninfo = the three list lengths
+__global__ void __launch_bounds__(192)
+k_f1_finish(const double *__restrict__ chunk_sum, const uint32_t *__restrict__ m, int64_t max_chunks, int pair0,
+            double *__restrict__ score, int64_t *__restrict__ ninfo)
+{
+    __shared__ double tile[3][1024];
+    __shared__ double total[3];
+    const int cat = threadIdx.x / WAVE, lane = threadIdx.x & (WAVE - 1);
+    const int list = blockIdx.x * 3 + cat;
+    const int64_t nch = ((int64_t)m[list] + NP_SUM_CHUNK - 1) / NP_SUM_CHUNK;
+    int64_t nch_max = 0;
+    for (int c = 0; c < 3; ++c) {
+        const int64_t t = ((int64_t)m[blockIdx.x * 3 + c] + NP_SUM_CHUNK - 1) / NP_SUM_CHUNK;
+        nch_max = t > nch_max ? t : nch_max;
+    }
+    const double *cs = chunk_sum + (int64_t)list * max_chunks;
+    double r = 0.0;
+    for (int64_t c0 = 0; c0 < nch_max; c0 += 1024) {
+        const int64_t left = nch - c0;
+        const int cnt = (int)(left < 0 ? 0 : (left < 1024 ? left : 1024));
+        for (int i = lane; i < cnt; i += WAVE) tile[cat][i] = cs[c0 + i];
+        __syncthreads();
+        if (lane == 0)
+            for (int i = 0; i < cnt; ++i) r = r + tile[cat][i];
+        __syncthreads();
+    }
+    if (lane == 0) total[cat] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        score[pair0 + blockIdx.x] = (total[0] + total[1]) + total[2];
+        ninfo[pair0 + blockIdx.x] = (int64_t)m[blockIdx.x * 3] + m[blockIdx.x * 3 + 1] + m[blockIdx.x * 3 + 2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PMC calibration: reads `n_dwords` dwords exactly once with the access shape of k_fast (one dword
 // per lane, 256 contiguous bytes per wave instruction, non-temporal), so that FETCH_SIZE can be
 // calibrated on a known byte count (MI355X_MICROARCH.md, HBM section).  The xor keeps the loads live.

@@ -295,6 +295,18 @@ class Query(object):
                                              ptr(ts) if totals else None, ptr(tn) if totals else None), ctx.h)
         return score, ninfo, ts, tn
 
+    def f1_pairs(self, acc_idx):
+        """In-silico crosses of every pair of ``acc_idx`` (order of itertools.combinations) over the query's
+        rows: (score float64 [n_pairs] with numpy's np.sum bits, ninfo int64 [n_pairs])."""
+        ctx = self.panel.ctx
+        acc_idx = np.ascontiguousarray(acc_idx, dtype=np.int32)
+        k = len(acc_idx)
+        n_pairs = k * (k - 1) // 2
+        score = np.zeros(n_pairs, dtype=np.float64)
+        ninfo = np.zeros(n_pairs, dtype=np.int64)
+        check(ctx.lib.snpm_query_f1_pairs(self.h, ptr(acc_idx), k, ptr(score), ptr(ninfo)), ctx.h)
+        return score, ninfo
+
     def free(self):
         if self.h:
             if self.panel.ctx.h and self.panel.h:

@@ -748,3 +748,47 @@ def test_native_file_loader(ctx, tmp_path):
     assert np.array_equal(p4.download_rows(0, 600), db[:600])
     with pytest.raises(AssertionError, match="cannot open"):
         p4.load_file(str(tmp_path / "missing.npy"), 0)
+
+
+# ------------------------------------------------------------------ in-silico F1s (core/csmatch.py:106-129)
+@pytest.mark.parametrize("n_snp,n_match,n_acc,k,packed", [
+    (50, None, 12, 2, False), (7, None, 5, 3, False), (2048, None, 40, 10, False), (2049, 2047, 40, 10, True),
+    (30000, 9000, 64, 10, False), (70000, None, 33, 10, True), (300000, 250000, 16, 5, False),
+    (120000, None, 12, 10, False), (20000, 17000, 1135, 32, False)])
+def test_insilico_f1_pairs_bitexact(ctx, n_snp, n_match, n_acc, k, packed):
+    """k_f1_*: scores carry the bits of the reference's np.sum expression, counts are exact"""
+    rng = np.random.default_rng(n_snp + 7 * k)
+    db = rand_db(rng, n_snp, n_acc)
+    db[:, 1] = db[:, 0]                                    # identical parents: no het class at all
+    if n_acc > 4:
+        db[rng.random(n_snp) < 0.9, 3] = -1                # mostly missing parent: short lists
+    panel = engine.Panel.from_host(ctx, db, packed=packed)
+    row_idx = None if n_match is None else np.sort(rng.choice(n_snp, size=n_match, replace=False)).astype(np.int64)
+    n = n_snp if n_match is None else n_match
+    wei = rand_wei(rng, n)
+    sel = np.concatenate(([0, 1], rng.permutation(np.arange(2, n_acc))[:k - 2]))[:k]
+    q = engine.Query(panel, row_idx, wei)
+    s, ni = q.f1_pairs(sel)
+    rows = slice(None) if row_idx is None else row_idx
+    want_s, want_n = orc.insilico_f1_pairs(db[rows][:, sel], wei)
+    assert np.array_equal(ni, want_n)
+    assert np.array_equal(bits(s), bits(want_s))
+    assert ni[0] == np.count_nonzero((db[rows, 0] == 0) | (db[rows, 0] == 1))    # pair (0, 1): clones
+    q.free()
+
+
+def test_insilico_f1_pairs_edges(ctx):
+    rng = np.random.default_rng(8)
+    db = rand_db(rng, 100, 9)
+    panel = engine.Panel.from_host(ctx, db)
+    q = engine.Query(panel, np.zeros(0, dtype=np.int64), np.zeros((0, 3)))
+    s, ni = q.f1_pairs([0, 1, 2])
+    assert s.tolist() == [0.0, 0.0, 0.0] and ni.tolist() == [0, 0, 0]            # no matched SNPs
+    q.free()
+    q = engine.Query(panel, None, rand_wei(rng, 100))
+    assert len(q.f1_pairs([4])[0]) == 0 and len(q.f1_pairs([])[0]) == 0           # fewer than two accessions
+    with pytest.raises(AssertionError, match="outside the panel"):
+        q.f1_pairs([0, 9])
+    with pytest.raises(AssertionError, match="between 0 and 32"):
+        q.f1_pairs(list(range(9)) * 4)
+    q.free()

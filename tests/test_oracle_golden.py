@@ -162,3 +162,41 @@ def test_common_positions_golden(golden_dir):
         i1, i2 = orc.get_common_positions(g[name + "_c1"], g[name + "_p1"], g[name + "_c2"], g[name + "_p2"])
         assert np.array_equal(i1, g[name + "_i1"]), name
         assert np.array_equal(i2, g[name + "_i2"]), name
+
+
+# ------------------------------------------------------------------ G7: in-silico F1 rows of the cross table
+def test_np_sum_restatement_bitexact():
+    """np.sum == pairwise sums of 8192-element pieces added in order: the order the k_f1_* kernels follow"""
+    rng = np.random.default_rng(5)
+    sizes = list(range(0, 140)) + [255, 256, 257, 1000, 4095, 4096, 4097, 8191, 8192, 8193, 8199, 8200,
+                                   9000, 16384, 16385, 20000, 40000, 80000, 100003]
+    for n in sizes:
+        for _ in range(3):
+            a = np.exp(-rng.integers(0, 256, n) / 10.0)
+            assert bits(np.sum(a)) == bits(orc.np_sum_restated(a)), n
+    w = np.exp(-rng.integers(0, 256, (60000, 3)) / 10.0)
+    idx = np.flatnonzero(rng.random(60000) < 0.4)
+    assert bits(np.sum(w[idx, 2])) == bits(orc.np_sum_restated(w[idx, 2]))     # the reference's operand shape
+
+
+@pytest.mark.parametrize("kind", ["f1", "f2", "f2hom"])
+def test_insilico_f1_rows_golden(golden_dir, kind):
+    """the 45 'AxB' rows the reference appends to <out>.scores.txt (core/csmatch.py:106-129)"""
+    toy = np.load(os.path.join(golden_dir, "toy_db_cross.npz"))
+    smp = np.load(os.path.join(golden_dir, "g7_cross_samples.npz"))
+    with open(os.path.join(golden_dir, "g7_cross_cases.json")) as fh:
+        table = json.load(fh)[kind][".scores.txt"]
+    rows = [ln.split("\t") for ln in table.splitlines()]
+    crosses = [r for r in rows if "x" in r[0]]
+    assert len(crosses) == 45
+    accs = [str(a) for a in toy["accs"]]
+    order = []
+    for r in crosses:                                   # combination order -> the ten selected accessions
+        for name in r[0].split("x"):
+            if accs.index(name) not in order:
+                order.append(accs.index(name))
+    db_chr = np.repeat(toy["chrs"], [b - a for a, b in toy["regions"]])
+    db_rows, smp_rows = orc.get_common_positions(db_chr, toy["positions"], smp[kind + "_chrs"], smp[kind + "_pos"])
+    score, ninfo = orc.insilico_f1_pairs(toy["snps"][db_rows][:, order], smp[kind + "_wei"][smp_rows])
+    for k, r in enumerate(crosses):
+        assert float(r[1]) == score[k] and int(float(r[2])) == ninfo[k], r[0]
