@@ -79,3 +79,29 @@ def sharded_genotyper_scores(score_local_fn, n_acc, world, rank, device="cpu", g
     sh.set_local(s, n)
     fs, fn = sh.gather()
     return sh.unpad(fs), sh.unpad(fn)
+
+
+def sharded_window_scores(score_local_fn, n_acc, n_win, world, rank, device="cpu", group=None):
+    """Per-window variant (core/csmatch.py:80-95): `score_local_fn(a0, a1) -> (score [n_win, a1 - a0],
+    ninfo [n_win, a1 - a0])` on this rank's shard; one all-gather per result array along the accession axis;
+    returns the full (score [n_win, n_acc], ninfo [n_win, n_acc]) numpy arrays on every rank."""
+    import torch
+    import torch.distributed as dist
+    sh = AccessionShards(n_acc, world, rank, device, group)
+    s, n = score_local_fn(sh.a0, sh.a1)
+    loc_s = torch.zeros((n_win, sh.per), dtype=torch.float64, device=device)
+    loc_n = torch.zeros((n_win, sh.per), dtype=torch.int64, device=device)
+    loc_s[:, :sh.n_local] = torch.as_tensor(np.asarray(s, dtype=np.float64).reshape(n_win, sh.n_local), device=device)
+    loc_n[:, :sh.n_local] = torch.as_tensor(np.asarray(n, dtype=np.int64).reshape(n_win, sh.n_local), device=device)
+    if world > 1:
+        all_s = torch.zeros((world * n_win, sh.per), dtype=torch.float64, device=device)
+        all_n = torch.zeros((world * n_win, sh.per), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(all_s, loc_s, group=group)
+        dist.all_gather_into_tensor(all_n, loc_n, group=group)
+    else:
+        all_s, all_n = loc_s, loc_n
+    idx = sh.padded_index()
+
+    def full(t):          # [world * n_win, per] -> [n_win, world * per] -> accession order
+        return t.reshape(world, n_win, sh.per).permute(1, 0, 2).reshape(n_win, world * sh.per).cpu().numpy()[:, idx]
+    return full(all_s), full(all_n)

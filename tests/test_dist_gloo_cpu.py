@@ -64,6 +64,40 @@ def test_sharded_scores_equal_unsharded(world, n_acc, tmp_path):
         assert int(np.nanargmin(lik)) == 417
 
 
+def window_worker(rank, world, port, n_snp, n_acc, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(11)
+        wei = synth.sample_weights(rng, rng.choice(np.array([0, 1, 2], dtype=np.int8), size=n_snp), 0.8)
+        off = np.array([0, 0, 400, 401, 1500, n_snp], dtype=np.int64)       # an empty window included
+
+        def local(a0, a1):
+            db = synth.panel_values(5, 0, n_snp, a0, a1 - a0)
+            return orc.window_scores(wei, db, off)[:2]
+
+        score, ninfo = sdist.sharded_window_scores(local, n_acc, len(off) - 1, world, rank)
+        np.savez(os.path.join(out_dir, "win_rank%d.npz" % rank), score=score, ninfo=ninfo)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_acc", [(2, 70), (3, 50)])
+def test_sharded_window_scores_equal_unsharded(world, n_acc, tmp_path):
+    n_snp = 2000
+    port = free_port()
+    mp.spawn(window_worker, args=(world, port, n_snp, n_acc, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(11)
+    wei = synth.sample_weights(rng, rng.choice(np.array([0, 1, 2], dtype=np.int8), size=n_snp), 0.8)
+    off = np.array([0, 0, 400, 401, 1500, n_snp], dtype=np.int64)
+    want_s, want_n = orc.window_scores(wei, synth.panel_values(5, 0, n_snp, 0, n_acc), off)[:2]
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "win_rank%d.npz" % r))
+        assert np.array_equal(got["score"].view(np.uint64), np.asarray(want_s, dtype=np.float64).view(np.uint64))
+        assert np.array_equal(got["ninfo"], want_n)
+
+
 def test_shard_bounds_and_padding():
     b, per = sdist.shard_bounds(10000, 8)
     assert per == 1252 and b[0] == (0, 1252) and b[7] == (8764, 10000) and all(a % 4 == 0 for a, _ in b)
