@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnpmatch_hip.so")
+# SNPMATCH_HIP_LIB: load another build of the library (kernel experiments, system-wide installs)
+LIB_PATH = os.environ.get("SNPMATCH_HIP_LIB") or os.path.join(_HERE, "libsnpmatch_hip.so")
 
 SNPM_OK = 0
 SNPM_ERR_BADARG = -1

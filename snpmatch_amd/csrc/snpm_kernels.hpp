@@ -24,6 +24,9 @@
 
 namespace snpm {
 
+#ifndef SNPM_FAST_MIN_WAVES
+#define SNPM_FAST_MIN_WAVES 6
+#endif
 constexpr int WAVE = 64;
 constexpr int TILE_ROWS = 128;          // rows per LDS LUT tile (4 KiB); also the SWAR counter flush period (<= 255)
 constexpr int LUT_ROW_BYTES = 32;       // 4 x fp64
@@ -158,9 +161,10 @@ __device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[(BPL >= 
 //   out_score [n_epochs*P, ld] fp64, out_miss [n_epochs*P, ld] u32 (ld = pitch).
 // launch bound: <= 512 threads and (for the 4 B/lane layout) >= 6 waves per SIMD, i.e. <= 80 VGPRs: the
 // kernel is latency-bound and 5-wave blocks only fit 4 per CU with 6 wave slots per SIMD (measured:
-// 79-82 % of HBM peak at 80 VGPRs vs 67-70 % at 88)
+// 79-82 % of HBM peak at 80 VGPRs vs 67-70 % at 88; asking for 7 waves changes nothing -- the kernel already
+// needs only 70 VGPRs -- and 8 waves (64 VGPRs, 7 spilled) costs 1-8 %: -DSNPM_FAST_MIN_WAVES=n to re-measure)
 template <int BPL, bool SKIP, bool GATHER, bool NT>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (BPL <= 4 ? 6 : 1))
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (BPL <= 4 ? SNPM_FAST_MIN_WAVES : 1))
 k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
        const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
 {
