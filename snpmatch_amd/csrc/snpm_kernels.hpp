@@ -709,23 +709,50 @@ __global__ void k_scan(const double *__restrict__ seg_score, const uint32_t *__r
     if (tot_ninfo) tot_ninfo[i] = (seg_off[n_seg] - seg_off[0]) - m;
 }
 
-// Same result for a SHORT column list (ncols <= 64, one block): the segment sums of a tile are
-// fetched by all 256 threads in parallel into LDS, then one thread per column adds them in order.
+// Same result for a SHORT column list (ncols <= 64, one block of 4 waves).  The chain of additions is
+// sequential by contract, and a single wave issues in order, so what bounds it is the number of instructions
+// per addition.  Wave 0 only adds: lane c owns column c, whose segment sums lie contiguously in an LDS tile
+// (column-major, stride = tile length + 2 doubles: conflict-free 16-B reads), fetched with ds_read_b128 at
+// immediate offsets (0.5 LDS instruction and no address arithmetic per addition) two 16-value sets ahead.
+// Waves 1-3 meanwhile load the next tile from global memory into the other LDS buffer.
+// The LDS reads are issued from inline asm, so their completion is waited for by hand: LDS operations of a
+// wave complete in order, lgkmcnt(8) therefore means "everything but the 8 reads just issued has arrived";
+// the registers are operands of the wait so that the additions cannot be scheduled before it.
 constexpr int SCAN_TILE_ELEMS = 4096;
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+#define SCAN_READ8(S, ADDR, OFF)                                                                             \
+    asm volatile("ds_read_b128 %0, %8 offset:%9\n\tds_read_b128 %1, %8 offset:%9+16\n\t"                   \
+                 "ds_read_b128 %2, %8 offset:%9+32\n\tds_read_b128 %3, %8 offset:%9+48\n\t"                 \
+                 "ds_read_b128 %4, %8 offset:%9+64\n\tds_read_b128 %5, %8 offset:%9+80\n\t"                 \
+                 "ds_read_b128 %6, %8 offset:%9+96\n\tds_read_b128 %7, %8 offset:%9+112"                    \
+                 : "=v"(S##0), "=v"(S##1), "=v"(S##2), "=v"(S##3), "=v"(S##4), "=v"(S##5), "=v"(S##6), "=v"(S##7) \
+                 : "v"(ADDR), "n"(OFF))
+#define SCAN_WAIT8(S, N)                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                               \
+                 : "+v"(S##0), "+v"(S##1), "+v"(S##2), "+v"(S##3), "+v"(S##4), "+v"(S##5), "+v"(S##6), "+v"(S##7))
+#define SCAN_ADD16(S)                                                                                        \
+    do {                                                                                                     \
+        s = s + (S##0).x; s = s + (S##0).y; s = s + (S##1).x; s = s + (S##1).y; s = s + (S##2).x; s = s + (S##2).y;      \
+        s = s + (S##3).x; s = s + (S##3).y; s = s + (S##4).x; s = s + (S##4).y; s = s + (S##5).x; s = s + (S##5).y;      \
+        s = s + (S##6).x; s = s + (S##6).y; s = s + (S##7).x; s = s + (S##7).y;                                      \
+    } while (0)
+
 __global__ void __launch_bounds__(256)
 k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, int ncols, double *__restrict__ tot_score)
 {
-    __shared__ double tile[SCAN_TILE_ELEMS];
-    const int ts = SCAN_TILE_ELEMS / ncols;          // segments per tile
-    double s = 0.0;
-    for (int64_t base = 0; base < n_seg; base += ts) {
+    __shared__ __attribute__((aligned(16))) double tile[2][SCAN_TILE_ELEMS + 2 * WAVE];
+    const int ts = (SCAN_TILE_ELEMS / ncols) & ~31;  // segments per tile: a multiple of 32, >= 64
+    const int cs = ts + 2;                           // column stride: 16 B more than a multiple of 256 B
+    const int wave = threadIdx.x / WAVE;
+    auto load_tile = [&](int buf, int64_t base, int first, int nthr) {
         const int nseg = (int)((n_seg - base < ts) ? (n_seg - base) : ts);
         const int n_elem = nseg * ncols;
-        for (int e0 = threadIdx.x; e0 < n_elem; e0 += 8 * blockDim.x) {     // 8 independent loads in flight per thread
+        for (int e0 = first; e0 < n_elem; e0 += 8 * nthr) {           // 8 independent loads in flight per thread
             double v8[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * blockDim.x;
+                const int e = e0 + u * nthr;
                 if (e < n_elem) {
                     const int sg = e / ncols, c = e - sg * ncols;
                     v8[u] = seg_score[(base + sg) * ld + c];
@@ -733,44 +760,52 @@ k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, int 
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = e0 + u * blockDim.x;
-                if (e < n_elem) tile[e] = v8[u];
+                const int e = e0 + u * nthr;
+                if (e < n_elem) {
+                    const int sg = e / ncols, c = e - sg * ncols;
+                    tile[buf][c * cs + sg] = v8[u];
+                }
             }
         }
-        __syncthreads();
-        if ((int)threadIdx.x < ncols) {
-            // the adds form one dependent chain; the LDS reads of the next 16 values are issued before the
-            // 16 adds of the current ones
+    };
+    if (n_seg > 0) load_tile(0, 0, threadIdx.x, 256);
+    __syncthreads();
+    double s = 0.0;
+    int buf = 0;
+    for (int64_t base = 0; base < n_seg; base += ts, buf ^= 1) {
+        if (wave > 0) {
+            if (base + ts < n_seg) load_tile(buf ^ 1, base + ts, threadIdx.x - WAVE, 256 - WAVE);
+        } else if ((int)threadIdx.x < ncols) {
+            const int nseg = (int)((n_seg - base < ts) ? (n_seg - base) : ts);
+            const double *col = &tile[buf][threadIdx.x * cs];
+            uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const double *)col;
             int sg = 0;
-            double va[16], vb[16];
-            const double *tp = tile + threadIdx.x;
-            if (nseg >= 16) {
-#pragma unroll
-                for (int u = 0; u < 16; ++u) va[u] = tp[u * ncols];
-            }
-            // two register sets with static roles (no copies): while one set is added, the other is read
+            f64x2 a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3, b4, b5, b6, b7;
+            if (nseg >= 16) SCAN_READ8(a, addr, 0);                  // a = [0, 16)
             while (sg + 48 <= nseg) {
-#pragma unroll
-                for (int u = 0; u < 16; ++u) vb[u] = tp[(sg + 16 + u) * ncols];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) s = s + va[u];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) va[u] = tp[(sg + 32 + u) * ncols];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) s = s + vb[u];
+                SCAN_READ8(b, addr, 128);                             // b = [sg + 16, sg + 32)
+                SCAN_WAIT8(a, 8);
+                SCAN_ADD16(a);
+                SCAN_READ8(a, addr, 256);                             // a = [sg + 32, sg + 48)
+                SCAN_WAIT8(b, 8);
+                SCAN_ADD16(b);
+                addr += 256;
                 sg += 32;
             }
-            if (sg + 16 <= nseg) {          // va holds [sg, sg+16)
-#pragma unroll
-                for (int u = 0; u < 16; ++u) s = s + va[u];
+            if (sg + 16 <= nseg) {                                    // a holds [sg, sg + 16)
+                SCAN_WAIT8(a, 0);
+                SCAN_ADD16(a);
                 sg += 16;
             }
-            for (; sg < nseg; ++sg) s = s + tile[sg * ncols + threadIdx.x];
+            for (; sg < nseg; ++sg) s = s + col[sg];
         }
         __syncthreads();
     }
     if ((int)threadIdx.x < ncols) tot_score[threadIdx.x] = s;
 }
+#undef SCAN_READ8
+#undef SCAN_WAIT8
+#undef SCAN_ADD16
 
 // per-segment ninfo [n_seg, n_acc] i64 and score copy-out into a dense [n_seg, n_acc] host-shaped layout
 __global__ void k_seg_pack(const double *__restrict__ seg_score, const uint32_t *__restrict__ seg_miss,
