@@ -667,7 +667,8 @@ def test_full_bench_size_properties(ctx):
     numpy twin of the generator; (3) a hard-weight sample planted on accession 417 matches it perfectly and is
     the unique top hit; (4) scores and ninfo are additive over a split of the SNP axis (integer weights: exact);
     (5) mixed PL weights: default-mode counts equal strict-mode counts on the first 300 accessions' worth of
-    columns re-scored in reference order on a 200k-SNP slab."""
+    columns re-scored in reference order on a 200k-SNP slab; (6) mixed PL weights over all 6.25M SNPs: default-mode
+    counts equal reference-order counts for every accession and 16 accessions equal the C oracle bit for bit."""
     n_snp, n_acc = 6_250_000, 10_000
     panel = engine.Panel(ctx, n_snp, n_acc)
     panel.fill_synthetic(10050)
@@ -706,6 +707,23 @@ def test_full_bench_size_properties(ctx):
     db = panel.download_rows(r0, slab)[:, :300]
     ws, wn = c_oracle.genotyper(db, None, wpl, 1000, False)
     assert np.array_equal(bits(ss[:300]), bits(ws)) and np.array_equal(ns[:300], wn)
+    qs.free()
+    # (6) the whole SNP axis with mixed PL weights (SURVEY 8d spot check): default-mode counts == reference-order
+    # counts for all 10 000 accessions, and 16 accessions (4 quads regenerated by the numpy twin) agree with the
+    # C oracle over all 6.25M rows -- strict scores bit for bit
+    _, wfull = synth.planted_sample(rng, col, 0.02)
+    qf = engine.Query(panel, None, wfull)
+    se, ne, info = qf.run(1000, False, engine.MODE_EXACT, return_info=True)
+    ss, ns = qf.run(1000, False, engine.MODE_STRICT)
+    assert np.array_equal(ne, ns) and np.array_equal(np.array(se, dtype=np.int64), np.array(ss, dtype=np.int64))
+    assert np.max(np.abs(se - ss)) <= qf.error_bound(1000) and info["n_strict_reeval"] < 50
+    for c4 in (416, 0, 5000, 9996):
+        quad = np.concatenate([synth.panel_values(10050, r, 1_250_000, c4, 4) for r in range(0, n_snp, 1_250_000)])
+        ws, wn = c_oracle.genotyper(quad, None, wfull, 1000, False)
+        assert np.array_equal(bits(ss[c4:c4 + 4]), bits(ws)) and np.array_equal(ns[c4:c4 + 4], wn)
+        assert np.array_equal(np.array(se[c4:c4 + 4], dtype=np.int64), np.array(ws, dtype=np.int64))
+    assert int(np.argmax(se / ne)) == 417
+    qf.free()
 
 
 def test_native_file_loader(ctx, tmp_path):
