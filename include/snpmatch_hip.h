@@ -158,6 +158,11 @@ int snpm_binom_sf_host(const double *k, const double *n, int64_t len, double p, 
    strictly increasing (the caller then takes its generic path). */
 int snpm_intersect_sorted(const int64_t *a, int64_t na, const int64_t *b, int64_t nb, int64_t *ia, int64_t *ib,
                           int64_t *n_out);
+/* Same result for a short list b against a long list a: galloping search, O(nb log(na / nb)).  a must be
+   strictly increasing and is NOT checked here (DB positions are verified once, when the DB is opened);
+   b is checked (SNPM_ERR_STATE). */
+int snpm_intersect_sorted_search(const int64_t *a, int64_t na, const int64_t *b, int64_t nb, int64_t *ia, int64_t *ib,
+                                 int64_t *n_out);
 /* Genotype.identify_segregating_snps on the resident panel (core/snp_genotype.py:188-211, used by --refine):
    mask [n_snp] (host, uint8) = 1 where the informative calls of accessions cols[0..ncols) are not all equal. */
 int snpm_panel_segregating(snpm_panel *panel, const int32_t *cols, int64_t ncols, uint8_t *mask);

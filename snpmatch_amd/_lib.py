@@ -32,7 +32,7 @@ SYMBOLS = [
     "snpm_query_free", "snpm_query_bind_outputs", "snpm_query_run", "snpm_query_run_device", "snpm_query_error_bound",
     "snpm_query_run_windows", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
     "snpm_binom_identity", "snpm_binom_sf_host", "snpm_intersect_sorted", "snpm_panel_segregating",
-    "snpm_query_f1_pairs",
+    "snpm_query_f1_pairs", "snpm_intersect_sorted_search",
     "snpm_debug_stream_read", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
 ]
 
@@ -91,6 +91,7 @@ def load():
     lib.snpm_intersect_sorted.argtypes = [p, i64, p, i64, p, p, C.POINTER(i64)]
     lib.snpm_panel_segregating.argtypes = [p, p, i64, p]
     lib.snpm_query_f1_pairs.argtypes = [p, p, ci, p, p]
+    lib.snpm_intersect_sorted_search.argtypes = [p, i64, p, i64, p, p, C.POINTER(i64)]
     lib.snpm_debug_stream_read.argtypes = [p, C.POINTER(i64)]
     lib.snpm_profile_enable.argtypes = [p, ci]
     lib.snpm_profile_reset.argtypes = [p]
@@ -120,8 +121,9 @@ def check(rc, ctx_handle=None):
     raise SnpmError(rc, msg)
 
 
-def intersect_sorted(a, b):
-    """indices (ia, ib) of the common values of two strictly increasing integer arrays (native sorted merge);
+def intersect_sorted(a, b, a_verified=False):
+    """indices (ia, ib) of the common values of two strictly increasing integer arrays (native sorted merge, or
+    a galloping search when ``a`` is known to be strictly increasing and much longer than ``b``);
     None when an input is not strictly increasing."""
     a = np.ascontiguousarray(a, dtype=np.int64)
     b = np.ascontiguousarray(b, dtype=np.int64)
@@ -129,7 +131,8 @@ def intersect_sorted(a, b):
     ia = np.empty(m, dtype=np.int64)
     ib = np.empty(m, dtype=np.int64)
     n = C.c_int64(0)
-    rc = load().snpm_intersect_sorted(ptr(a), len(a), ptr(b), len(b), ptr(ia), ptr(ib), C.byref(n))
+    fn = load().snpm_intersect_sorted_search if (a_verified and len(a) > 8 * len(b)) else load().snpm_intersect_sorted
+    rc = fn(ptr(a), len(a), ptr(b), len(b), ptr(ia), ptr(ib), C.byref(n))
     if rc == SNPM_ERR_STATE:
         return None
     if rc != SNPM_OK:

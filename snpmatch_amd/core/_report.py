@@ -115,6 +115,30 @@ def window_rows(window_index, accs, scores, ninfo, likelihood, lrt, identical, l
     return frame
 
 
+def window_table(window_index, accs, scores, ninfo, likelihood, lrt, identical, lr_thres):
+    """``window_rows`` of many windows at once: 2-D inputs [n_windows, n_accessions], ``window_index`` [n_windows];
+    rows in window order, accessions ascending inside a window (the concatenation of the per-window frames)."""
+    lrt = np.asarray(lrt)
+    keep = lrt < lr_thres
+    n_amb = keep.sum(axis=1)
+    keep &= ((n_amb > 0) & (n_amb < lrt.shape[1]))[:, None]
+    w, a = np.nonzero(keep)
+    if len(w) == 0:
+        return pd.DataFrame(columns=list(WINDOW_COLUMNS))
+    sc = np.asarray(scores, dtype=float)[w, a]
+    ni = np.asarray(ninfo)[w, a]
+    return pd.DataFrame({
+        "acc": np.asarray(accs)[a].astype(str),
+        "snps_match": sc.astype(int),
+        "snps_info": ni.astype(float).astype(int),
+        "score": float_text(ratio_or_nan(sc, ni)).astype(object),
+        "likelihood": float_text(np.asarray(likelihood)[w, a]).astype(object),
+        "identical": np.asarray(identical, dtype=float)[w, a],
+        "num_amb": n_amb[w],
+        "window_index": np.asarray(window_index)[w],
+    }, columns=list(WINDOW_COLUMNS))
+
+
 # ----------------------------------------------------------------------------- cross: interpretation
 def json_default(o):
     """numpy integers -> int; anything else unserialisable becomes null (as the reference's encoder hook)"""

@@ -25,15 +25,64 @@ from . import genomes
 from . import parsers
 from . import snp_genotype  # noqa: F401  (part of the reference's module surface)
 from . import snpmatch
+from .. import _lib
 from .. import engine
 
 log = logging.getLogger(__name__)
 chunk_size = 1000
 
 
+def _window_segments_sorted(genome, db, sample, bin_len):
+    """``_window_segments`` for the normal case -- per chromosome the DB rows are one range with strictly
+    increasing positions and so are the sample's entries: one native sorted intersection per chromosome, the
+    window of a matched position is (pos - 1) // bin_len.  Returns None when the inputs are not of that form."""
+    bin_len = int(bin_len)
+    db_ids = genomes._bare(db.chrs)
+    names, inverse = np.unique(np.asarray(sample.chrs, dtype="str"), return_inverse=True)
+    smp_ids = genomes._bare(names)
+    genome._check(db_ids, "genotype hdf5 file")
+    genome._check(np.unique(smp_ids), "given SNPs")
+    db_pos = db.__dict__.get("_positions_i64")
+    if db_pos is None:
+        db_pos = db._positions_i64 = np.ascontiguousarray(db.positions, dtype=np.int64)
+    increasing = db.__dict__.setdefault("_increasing_chr", {})
+    smp_pos = np.ascontiguousarray(sample.pos, dtype=np.int64)
+    per_db, per_sample, counts, chrom = [], [], [], []
+    for chr_ix, cid in enumerate(genome.chrs_ids):
+        n_win = len(range(1, int(genome.chrlen[chr_ix]), bin_len))
+        chrom.append(np.full(n_win, chr_ix, dtype=int))
+        where = np.flatnonzero(db_ids == cid)
+        mine = np.flatnonzero(np.isin(inverse, np.flatnonzero(smp_ids == cid)))
+        if len(where) == 0 or len(mine) == 0 or n_win == 0:
+            counts.append(np.zeros(n_win, dtype=np.int64))
+            continue
+        row0, row1 = int(db.chr_regions[where[0]][0]), int(db.chr_regions[where[0]][1])
+        p1, p2 = db_pos[row0:row1], smp_pos[mine]
+        if cid not in increasing:
+            increasing[cid] = bool(len(p1) == 0 or (p1[0] >= 1 and np.all(p1[1:] > p1[:-1])))
+        if not increasing[cid] or int(mine[-1]) - int(mine[0]) + 1 != len(mine) or p2[0] < 1:
+            return None
+        hit = _lib.intersect_sorted(p1, p2, a_verified=True)
+        if hit is None:                                    # sample positions not strictly increasing
+            return None
+        win = (p1[hit[0]] - 1) // bin_len
+        inside = win < n_win
+        per_db.append(row0 + hit[0][inside])
+        per_sample.append(int(mine[0]) + hit[1][inside])
+        counts.append(np.bincount(win[inside], minlength=n_win).astype(np.int64))
+    empty = np.zeros(0, dtype=int)
+    offsets = np.concatenate(([0], np.cumsum(np.concatenate(counts)))).astype(np.int64) if counts else np.zeros(1, np.int64)
+    return (np.concatenate(per_db).astype(int) if per_db else empty,
+            np.concatenate(per_sample).astype(int) if per_sample else empty,
+            offsets, np.concatenate(chrom) if chrom else empty)
+
+
 def _window_segments(genome, db, sample, bin_len):
     """Matched (DB row, sample row) pairs grouped by genome window.
     Returns db_rows, sample_rows (concatenated in window order), offsets [n_win + 1], chromosome index per window."""
+    fast = _window_segments_sorted(genome, db, sample, bin_len)
+    if fast is not None:
+        return fast
     db_pos = np.asarray(db.positions)
     per_db, per_sample, offsets, chrom = [], [], [0], []
     windows = zip(genome.get_bins_genome(db, bin_len), genome.get_bins_arrays(sample.chrs, sample.pos, bin_len))
@@ -102,7 +151,7 @@ class CrossIdentifier(object):
         query.free()
 
         accs = np.asarray(self.g.accessions)[shown]
-        frames = []
+        self.windows_data = pd.DataFrame(columns=list(_report.WINDOW_COLUMNS))
         filled = np.flatnonzero(np.diff(offsets) > 0)                     # empty windows produce no rows
         if len(filled):
             dev = engine.default_context()
@@ -110,14 +159,8 @@ class CrossIdentifier(object):
             ni = np.ascontiguousarray(w_ninfo[filled][:, shown])
             lik, lrt = dev.likelihood(sc, ni)                              # one device row per window
             same = dev.binom_identity(sc.ravel(), ni.ravel(), self.error_rate, 0.05).reshape(sc.shape)
-            for k, w in enumerate(filled):
-                rows = _report.window_rows(int(w) + 1, accs, sc[k], ni[k], lik[k], lrt[k], same[k], snpmatch.lr_thres)
-                if len(rows):
-                    frames.append(rows)
-                if (w + 1) % 50 == 0:
-                    log.info("Done analysing %s positions", int(offsets[w + 1]))
-        self.windows_data = (pd.concat(frames, ignore_index=True) if frames
-                             else pd.DataFrame(columns=list(_report.WINDOW_COLUMNS)))
+            self.windows_data = _report.window_table(filled + 1, accs, sc, ni, lik, lrt, same, snpmatch.lr_thres)
+            log.info("Done analysing %s positions", n_matched)
 
         totals = snpmatch.GenotyperOutput(accs, tot_score[shown], tot_ninfo[shown],
                                           snpmatch.get_fraction(n_matched, len(self.inputs.pos)), n_matched, self.inputs.dp)

@@ -144,6 +144,13 @@ class Genotype(object):
         return self._panel
 
     # ------------------------------------------------------------------ position intersection (a5)
+    def _region_is_increasing(self, ci, pos):
+        """DB positions of chromosome ``ci`` strictly increasing?  (checked once per DB object)"""
+        cache = self.__dict__.setdefault("_increasing_regions", {})
+        if ci not in cache:
+            cache[ci] = bool(len(pos) < 2 or np.all(pos[1:] > pos[:-1]))
+        return cache[ci]
+
     def get_positions_idxs(self, commonSNPsCHR, commonSNPsPOS):
         """(db_row_idx, sample_idx) of the positions present in both; core/snp_genotype.py:43-44.
         Same result as ``get_common_positions(chromosomes, positions, ...)`` without materialising one
@@ -152,7 +159,9 @@ class Genotype(object):
         ins.load_snp_info(snpCHR=commonSNPsCHR, snpPOS=commonSNPsPOS, snpGT="", snpWEI=np.nan, DPmean=0)
         ins.filter_chr_names()
         db_ids = np.array([re.sub("chr", "", c, flags=re.IGNORECASE) for c in self.g.chrs.astype("U").tolist()], dtype="str")
-        positions = np.asarray(self.g.positions)
+        positions = self.__dict__.get("_positions_i64")
+        if positions is None:                    # one int64 copy per DB object (HDF5 stores int32)
+            positions = self._positions_i64 = np.ascontiguousarray(self.g.positions, dtype=np.int64)
         regions = np.asarray(self.g.chr_regions)
         idx1 = [np.zeros(0, dtype=int)]
         idx2 = [np.zeros(0, dtype=int)]
@@ -165,9 +174,11 @@ class Genotype(object):
                 continue
             s, e = int(regions[ci][0]), int(regions[ci][1])
             ix2 = np.where(ins.g_chrs == cid)[0]
-            p1 = np.array(positions[s:e], dtype=int)
-            p2 = np.array(ins.pos[ix2], dtype=int)
-            merged = _lib.intersect_sorted(p1, p2)          # native sorted merge (strictly increasing inputs)
+            p1 = np.asarray(positions[s:e], dtype=int)
+            p2 = np.asarray(ins.pos[ix2], dtype=int)
+            # native sorted merge (strictly increasing inputs); the DB side is verified once per chromosome, after
+            # which a short sample list is located by galloping search instead of a walk over every DB position
+            merged = _lib.intersect_sorted(p1, p2, a_verified=self._region_is_increasing(ci, p1))
             if merged is not None:
                 idx1.append(s + merged[0])
                 idx2.append(ix2[merged[1]])

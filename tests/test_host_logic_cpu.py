@@ -57,6 +57,77 @@ def test_windows_match_reference(golden_dir):
     assert genome.get_chr_ind("Chr3") == 2 and genome.get_chr_ind("7") is None
 
 
+def test_window_segments_fast_path_equals_window_walk(golden_dir):
+    """csmatch._window_segments: the sorted-input path (one native intersection per chromosome) against the
+    golden windows of the reference and against the window-by-window walk it replaces"""
+    from snpmatch_amd.core import csmatch
+    toy = np.load(os.path.join(golden_dir, "toy_db_cross.npz"))
+    gold = np.load(os.path.join(golden_dir, "g5_cross.npz"))
+    g = toy_genotype(toy)
+    genome = genomes.Genome("athaliana_tair10")
+
+    def sample(chrs, pos):
+        inp = parsers.ParseInputs("")
+        inp.load_snp_info(chrs, pos, np.array(["0/0"] * len(pos)), np.ones((len(pos), 3)), 1)
+        return inp
+
+    def walk(inp):
+        keep = csmatch._window_segments_sorted
+        csmatch._window_segments_sorted = lambda *a: None
+        try:
+            return csmatch._window_segments(genome, g.g, inp, 300000)
+        finally:
+            csmatch._window_segments_sorted = keep
+
+    inp = sample(toy["s_chrs"], toy["s_pos"])
+    fast = csmatch._window_segments_sorted(genome, g.g, inp, 300000)
+    assert fast is not None
+    assert np.array_equal(fast[0], gold["win_rows_db_skip0"]) and np.array_equal(fast[1], gold["win_rows_sample_skip0"])
+    assert np.array_equal(fast[2], gold["win_off_skip0"]) and np.array_equal(fast[3], gold["win_chr_skip0"])
+    for a, b in zip(fast, walk(inp)):
+        assert np.array_equal(a, b)
+    # a chromosome missing from the sample, one unknown to the DB side of a window, positions past the last window
+    keep = np.flatnonzero(toy["s_chrs"] != "Chr2")
+    pos = toy["s_pos"][keep].copy()
+    last5 = np.flatnonzero(toy["s_chrs"][keep] == "Chr5")[-1]
+    pos[last5] = 26975502 + 300000
+    inp = sample(toy["s_chrs"][keep], pos)
+    fast = csmatch._window_segments_sorted(genome, g.g, inp, 300000)
+    assert fast is not None and len(fast[3]) == 399
+    for a, b in zip(fast, walk(inp)):
+        assert np.array_equal(a, b)
+    # unsorted or duplicated sample positions are left to the window walk
+    pos = toy["s_pos"].copy()
+    pos[[10, 11]] = pos[[11, 10]]
+    assert csmatch._window_segments_sorted(genome, g.g, sample(toy["s_chrs"], pos), 300000) is None
+    pos = toy["s_pos"].copy()
+    pos[11] = pos[10]
+    assert csmatch._window_segments_sorted(genome, g.g, sample(toy["s_chrs"], pos), 300000) is None
+
+
+def test_window_table_equals_per_window_rows():
+    import pandas as pd
+    from snpmatch_amd.core import _report
+    rng = np.random.default_rng(0)
+    n_win, n_acc = 40, 57
+    accs = np.array(["a%d" % i for i in range(n_acc)])
+    sc = rng.integers(300, 500, (n_win, n_acc)).astype(float) + rng.random((n_win, n_acc))
+    ni = rng.integers(480, 520, (n_win, n_acc))
+    lik = rng.random((n_win, n_acc)) * 100 + 1
+    lrt = lik / lik.min(axis=1, keepdims=True)
+    lrt[3] = 0.5                                   # every accession qualifies: the window is not reported
+    lrt[7] = 99.0                                  # none qualifies
+    lrt[9, 4] = np.nan
+    same = (rng.random((n_win, n_acc)) < 0.1).astype(float)
+    wins = np.arange(1, n_win + 1) * 3
+    frames = [_report.window_rows(wins[w], accs, sc[w], ni[w], lik[w], lrt[w], same[w], 3.841) for w in range(n_win)]
+    want = pd.concat([f for f in frames if len(f)], ignore_index=True)
+    got = _report.window_table(wins, accs, sc, ni, lik, lrt, same, 3.841)
+    assert got.equals(want) and list(got.columns) == list(_report.WINDOW_COLUMNS)
+    assert 12 not in set(got.window_index) and 24 not in set(got.window_index)
+    assert len(_report.window_table(wins[:1], accs, sc[:1], ni[:1], lik[:1], np.full((1, n_acc), 9.0), same[:1], 3.841)) == 0
+
+
 def test_segregating_snps():
     snps = np.array([[0, 0, 0, 1], [0, 1, -1, 0], [-1, -1, -1, 0], [1, 1, 1, 1], [2, 1, 1, 0], [0, -1, 0, 1]], dtype=np.int8)
     g = snp_genotype.Genotype.from_arrays(np.repeat(snps, 3, axis=1), ["a%d" % i for i in range(12)],
@@ -110,6 +181,18 @@ def test_native_sorted_merge_equals_numpy_isin():
     assert _lib.intersect_sorted(np.array([5, 1]), np.array([1])) is None                  # unsorted -> generic path
     ia, ib = _lib.intersect_sorted(np.zeros(0, dtype=int), np.array([1, 2]))
     assert len(ia) == 0 and len(ib) == 0
+    # long verified list against a short one: galloping search, same answers
+    for trial in range(30):
+        a = np.sort(rng.choice(200000, size=int(rng.integers(1000, 60000)), replace=False))
+        b = np.sort(rng.choice(210000, size=int(rng.integers(0, 100)), replace=False)) - 3000
+        ia, ib = _lib.intersect_sorted(a, b, a_verified=True)
+        assert np.array_equal(ia, np.where(np.isin(a, b, assume_unique=True))[0])
+        assert np.array_equal(ib, np.where(np.isin(b, a, assume_unique=True))[0])
+    ia, ib = _lib.intersect_sorted(np.arange(100), np.array([99]), a_verified=True)
+    assert ia.tolist() == [99] and ib.tolist() == [0]
+    ia, ib = _lib.intersect_sorted(np.arange(100), np.array([0, 50, 99, 100]), a_verified=True)
+    assert ia.tolist() == [0, 50, 99] and ib.tolist() == [0, 1, 2]
+    assert _lib.intersect_sorted(np.arange(100), np.array([7, 7]), a_verified=True) is None   # the short side is checked
 
 
 def test_binom_sf_algorithm_matches_scipy(golden_dir):
