@@ -33,6 +33,7 @@ SYMBOLS = [
     "snpm_query_run_windows", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
     "snpm_binom_identity", "snpm_binom_sf_host", "snpm_intersect_sorted", "snpm_panel_segregating",
     "snpm_query_f1_pairs", "snpm_intersect_sorted_search",
+    "snpm_vcf_parse", "snpm_vcf_dims", "snpm_vcf_fill", "snpm_vcf_sample_name", "snpm_vcf_free",
     "snpm_debug_stream_read", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
 ]
 
@@ -92,6 +93,12 @@ def load():
     lib.snpm_panel_segregating.argtypes = [p, p, i64, p]
     lib.snpm_query_f1_pairs.argtypes = [p, p, ci, p, p]
     lib.snpm_intersect_sorted_search.argtypes = [p, i64, p, i64, p, p, C.POINTER(i64)]
+    lib.snpm_vcf_parse.argtypes = [C.c_char_p, ci, pp]
+    lib.snpm_vcf_dims.argtypes = [p, C.POINTER(i64), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    lib.snpm_vcf_fill.argtypes = [p, p, p, p, p, p]
+    lib.snpm_vcf_sample_name.argtypes = [p, ci]
+    lib.snpm_vcf_sample_name.restype = C.c_char_p
+    lib.snpm_vcf_free.argtypes = [p]
     lib.snpm_debug_stream_read.argtypes = [p, C.POINTER(i64)]
     lib.snpm_profile_enable.argtypes = [p, ci]
     lib.snpm_profile_reset.argtypes = [p]
@@ -138,6 +145,33 @@ def intersect_sorted(a, b, a_verified=False):
     if rc != SNPM_OK:
         raise AssertionError("snpm_intersect_sorted: bad arguments")
     return ia[:n.value], ib[:n.value]
+
+
+def vcf_parse(path, sample_index=0):
+    """native single-pass VCF reader (snpm_vcf_*): dict with chr, pos, gt, pl, dp, flags, sample names; None when
+    the library declines the file (the caller then uses the Python reader)"""
+    lib = load()
+    h = C.c_void_p()
+    rc = lib.snpm_vcf_parse(os.fsencode(path), int(sample_index), C.byref(h))
+    if rc == SNPM_ERR_STATE:
+        return None
+    if rc != SNPM_OK:
+        raise IOError("cannot read %s" % path)
+    try:
+        n, cw, gw, flags, ns = C.c_int64(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        lib.snpm_vcf_dims(h, C.byref(n), C.byref(cw), C.byref(gw), C.byref(flags), C.byref(ns))
+        n = n.value
+        chrom = np.zeros(n, dtype="S%d" % cw.value)
+        gt = np.zeros(n, dtype="S%d" % gw.value)
+        pos = np.zeros(n, dtype=np.int64)
+        dp = np.zeros(n, dtype=np.int64)
+        pl = np.zeros((n, 3), dtype=np.float64)
+        lib.snpm_vcf_fill(h, ptr(chrom), ptr(pos), ptr(gt), ptr(pl), ptr(dp))
+        names = [lib.snpm_vcf_sample_name(h, i).decode() for i in range(ns.value)]
+    finally:
+        lib.snpm_vcf_free(h)
+    return {"chr": chrom, "pos": pos, "gt": gt, "pl": pl, "dp": dp, "names": names,
+            "has_gt": bool(flags.value & 1), "has_pl": bool(flags.value & 2), "has_dp": bool(flags.value & 4)}
 
 
 def binom_sf_host(k, n, p):

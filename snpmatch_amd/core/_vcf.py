@@ -1,6 +1,8 @@
 """
 Plain-text VCF reader for single-sample SNP calls (the reference delegates this to scikit-allel,
-core/parsers.py:178-213; scikit-allel is not a dependency of this package).
+core/parsers.py:178-213; scikit-allel is not a dependency of this package).  A single sample column goes
+through the library's C++ reader (``snpm_vcf_parse``, one pass over the file); the Python loop below is the
+generic path (several samples, or files the native reader declines).
 
 ``read_calls`` returns, for the selected samples, what the scoring path consumes:
   chr  [n]        CHROM as text
@@ -43,7 +45,29 @@ def _sample_fields(keys, text):
     return gt, pl
 
 
-def read_calls(path, samples=(0,)):
+def _read_calls_native(path, sample):
+    """one sample column through the library's single-pass reader; None when it declines the file"""
+    from .. import _lib
+    raw = _lib.vcf_parse(path, sample)
+    if raw is None:
+        return None
+    n = len(raw["pos"])
+    return {
+        "samples": np.array(raw["names"][sample:sample + 1], dtype="U"),
+        "has_gt": raw["has_gt"] or n == 0,
+        "chr": raw["chr"].astype("U"),
+        "pos": raw["pos"].astype(int),
+        "gt": raw["gt"].astype("U").reshape(n, 1),
+        "pl": raw["pl"].reshape(n, 1, 3) if raw["has_pl"] else None,
+        "dp": raw["dp"].astype(int) if raw["has_dp"] else None,
+    }
+
+
+def read_calls(path, samples=(0,), native=True):
+    if native and len(samples) == 1:
+        fast = _read_calls_native(path, int(samples[0]))
+        if fast is not None:
+            return fast
     names, chrom, pos, depth, gts, pls = [], [], [], [], [], []
     any_gt = any_pl = any_dp = False
     with _open(path) as fh:

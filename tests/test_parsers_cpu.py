@@ -74,3 +74,58 @@ def test_parse_gt_and_chr_names():
     ins.filter_chr_names()
     assert ins.g_chrs.tolist() == ["2", "2", "1", "1", "M"]
     assert ins.g_chrs_ids.tolist() == ["2", "1", "M"]           # order of first appearance
+
+
+def _same_calls(a, b):
+    for k in ("samples", "chr", "pos", "gt", "pl", "dp"):
+        if b[k] is None:
+            assert a[k] is None, k
+        else:
+            assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+    assert a["has_gt"] == b["has_gt"]
+
+
+def test_native_vcf_reader_equals_python_reader(golden_dir, tmp_path):
+    """snpm_vcf_parse (C++, one pass) against the Python reader it accelerates: identical arrays"""
+    from snpmatch_amd.core import _vcf
+    src = os.path.join(golden_dir, "701_501.filter.vcf.gz")
+    _same_calls(_vcf.read_calls(src, native=True), _vcf.read_calls(src, native=False))
+    head = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\tS2\n"
+    body = [
+        "Chr1\t10\t.\tA\tT\t50\tPASS\tDP=7;AF=0.5\tGT:PL\t0/1:10,0,30\t1/1:99,9,0",
+        "Chr1\t20\t.\tA\tT\t50\tPASS\tAF=0.5;DP=12\tGT:DP:PL\t1|1:5:255,30.5,0\t./.:.:.",
+        "Chr1\t30\t.\tA\tT\t50\tPASS\t.\tGT\t.\t0/0",                         # bare '.', no PL
+        "chr2\t5\t.\tA\tT,G\t50\tPASS\tDP=\tGT:PL\t0/2:1,2,3,4,5,6\t0/0:0,1",   # empty DP, six PL values, short PL
+        "chr2\t7\t.\tA\tT\t50\tPASS\tXDP=3\tPL:GT\t.,3,.:0/0\t1e1,+2,.5:1/1",   # PL before GT, '.' items, float forms
+        "short\t9\t.\tA",                                                         # short record: skipped
+        "",                                                                       # empty line: skipped
+        "Mt\t11\t.\tA\tT\t50\tPASS\tDP=3\tGT:PL",                                 # FORMAT but no sample column
+        "Mt\t12\t.\tA\tT\t50\tPASS\tDP=4",                                        # eight columns only
+    ]
+    vcf = tmp_path / "edge.vcf"
+    vcf.write_text(head + "\n".join(body) + "\n")
+    for sample in (0, 1):
+        fast = _vcf.read_calls(str(vcf), samples=(sample,), native=True)
+        slow = _vcf.read_calls(str(vcf), samples=(sample,), native=False)
+        _same_calls(fast, slow)
+    assert fast["gt"][:, 0].tolist() == ["1/1", "./.", "0/0", "0/0", "1/1", "./.", "./."]
+    assert fast["pl"][4, 0].tolist() == [10.0, 2.0, 0.5] and fast["dp"].tolist() == [7, 12, -1, -1, -1, 3, 4]
+    # a file without PL / DP anywhere
+    plain = tmp_path / "plain.vcf"
+    plain.write_text(head + "1\t100\t.\tA\tT\t.\t.\t.\tGT\t0/0\t1/1\n1\t200\t.\tA\tT\t.\t.\t.\tGT\t1/1\t0/0\n")
+    fast, slow = _vcf.read_calls(str(plain), native=True), _vcf.read_calls(str(plain), native=False)
+    _same_calls(fast, slow)
+    assert fast["pl"] is None and fast["dp"] is None
+    # things the native reader leaves to the generic one
+    from snpmatch_amd import _lib
+    crlf = tmp_path / "crlf.vcf"
+    crlf.write_bytes((head + body[0] + "\n").replace("\n", "\r\n").encode())
+    assert _lib.vcf_parse(str(crlf), 0) is None
+    odd = tmp_path / "odd.vcf"
+    odd.write_text(head + "1\t1_0\t.\tA\tT\t.\t.\t.\tGT\t0/0\t1/1\n")
+    assert _lib.vcf_parse(str(odd), 0) is None and _vcf.read_calls(str(odd))["pos"].tolist() == [10]
+    odd.write_text(head + "1\t10\t.\tA\tT\t.\t.\tDP= 5\tGT\t0/0\t1/1\n")
+    assert _lib.vcf_parse(str(odd), 0) is None and _vcf.read_calls(str(odd))["dp"].tolist() == [5]
+    empty = tmp_path / "empty.vcf"
+    empty.write_text(head)
+    _same_calls(_vcf.read_calls(str(empty), native=True), _vcf.read_calls(str(empty), native=False))
