@@ -74,6 +74,7 @@ struct snpm_ctx {
     int debug_reeval = 0;   // SNPM_DEBUG_REEVAL=k: also re-evaluate accessions 0..k-1 (to time that path)
     int stage_threads = 4;  // host threads repacking rows into the pinned staging slabs
     int nt_loads = 1;      // panel bytes are read once: non-temporal loads (+5-8% measured)
+    int packed_byte = 0;   // SNPM_PACKED_BYTE=1: packed panels through the one-byte-per-lane k_fast instead of k_fast_packed16
 };
 
 struct snpm_panel {
@@ -218,7 +219,7 @@ int pick_bpl(snpm_ctx *ctx, int64_t n_acc)
     return 4;
 }
 
-FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint, int bpl)
+FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint, int bpl, int tile_rows = TILE_ROWS)
 {
     FastGeom g;
     g.bpl = bpl;
@@ -247,13 +248,13 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     int occ = occ_blocks_hint > 0 ? occ_blocks_hint : 2;
     int64_t resident = (int64_t)ctx->n_cu * occ * std::max(1, ctx->parts_mult);
     int64_t n_parts = std::max<int64_t>(1, resident / g.n_colblocks);
-    const int64_t n_tiles = std::max<int64_t>(1, (n + TILE_ROWS - 1) / TILE_ROWS);
+    const int64_t n_tiles = std::max<int64_t>(1, (n + tile_rows - 1) / tile_rows);
     n_parts = std::min(n_parts, n_tiles);                    // part p scores tiles p, p+P, p+2P, ...
     if (ctx->debug_max_parts > 0) n_parts = std::min<int64_t>(n_parts, ctx->debug_max_parts);   // tests: long parts
     n_parts = std::min<int64_t>(n_parts, 65535);             // grid.y
     g.n_parts = n_parts;
     const int64_t tiles_per_part = (n_tiles + n_parts - 1) / n_parts;
-    g.part_rows = tiles_per_part * TILE_ROWS;                // rows per part (upper bound)
+    g.part_rows = tiles_per_part * tile_rows;                // rows per part (upper bound)
     g.n_epochs = std::max<int64_t>(1, (tiles_per_part + EPOCH_TILES - 1) / EPOCH_TILES);
     g.n_slots = g.n_epochs * g.n_parts;
     g.n_groups = (g.n_slots + REDUCE_GROUP - 1) / REDUCE_GROUP;
@@ -280,6 +281,36 @@ int launch_fast_b(snpm_query *q, const FastGeom &g, bool skip, bool gather)
     if (skip)
         return gather ? launch_fast_t<BPL, true, true, NT>(q, g) : launch_fast_t<BPL, true, false, NT>(q, g);
     return gather ? launch_fast_t<BPL, false, true, NT>(q, g) : launch_fast_t<BPL, false, false, NT>(q, g);
+}
+
+// packed panels, 16 accessions per lane (k_fast_packed16)
+template <bool SKIP, bool GATHER, bool NT>
+int launch_p16_t(snpm_query *q, const FastGeom &g, int *occ_out, int threads)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    if (occ_out) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_packed16<SKIP, GATHER, NT>, threads, 0) != hipSuccess) nb = 0;
+        *occ_out = nb;
+        return SNPM_OK;
+    }
+    dim3 grid((unsigned)g.n_colblocks, (unsigned)g.n_parts);
+    dim3 block(WAVE * g.wpb);
+    ProfScope ps(ctx, PK_FAST);
+    hipLaunchKernelGGL((k_fast_packed16<SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx,
+                       q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+int launch_p16(snpm_query *q, const FastGeom &g, bool skip, bool gather, bool nt, int *occ_out, int threads)
+{
+#define P16_CASE(S, G, N) if (skip == S && gather == G && nt == N) return launch_p16_t<S, G, N>(q, g, occ_out, threads)
+    P16_CASE(false, false, false); P16_CASE(false, false, true); P16_CASE(false, true, false); P16_CASE(false, true, true);
+    P16_CASE(true, false, false);  P16_CASE(true, false, true);  P16_CASE(true, true, false);  P16_CASE(true, true, true);
+#undef P16_CASE
+    return SNPM_ERR_STATE;
 }
 
 template <int BPL, bool NT>
@@ -312,17 +343,21 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
     int rc = ensure_lut(q, skip);
     if (rc) return rc;
     const bool gather = q->d_row_idx != nullptr;
-    // packed panels: one byte per lane and row = 4 accessions, the same wave/column geometry as int8 at 4 B/lane
-    const int bpl = p->packed ? 4 : pick_bpl(ctx, p->n_acc);
-    FastGeom g0 = fast_geom(ctx, p->n_acc, q->n, 2, bpl);   // wpb does not depend on occupancy
+    // packed panels: 16 accessions (one dword) per lane and row, pair-table lookups (k_fast_packed16); the older
+    // one-byte-per-lane instantiation of k_fast stays selectable (SNPM_PACKED_BYTE=1) for comparison
+    const bool p16 = p->packed && !ctx->packed_byte;
+    const int bpl = p16 ? 16 : (p->packed ? 4 : pick_bpl(ctx, p->n_acc));
+    const int tile_rows = p16 ? P16_TILE_ROWS : TILE_ROWS;
+    FastGeom g0 = fast_geom(ctx, p->n_acc, q->n, 2, bpl, tile_rows);   // wpb does not depend on occupancy
     int occ = 0;
     const bool nt = ctx->nt_loads != 0;
     const int thr = WAVE * g0.wpb;
-    if (p->packed) occ = nt ? occ_b<1, true>(skip, gather, thr) : occ_b<1, false>(skip, gather, thr);
+    if (p16) (void)launch_p16(q, g0, skip, gather, nt, &occ, thr);
+    else if (p->packed) occ = nt ? occ_b<1, true>(skip, gather, thr) : occ_b<1, false>(skip, gather, thr);
     else if (bpl == 16) occ = nt ? occ_b<16, true>(skip, gather, thr) : occ_b<16, false>(skip, gather, thr);
     else if (bpl == 8) occ = nt ? occ_b<8, true>(skip, gather, thr) : occ_b<8, false>(skip, gather, thr);
     else occ = nt ? occ_b<4, true>(skip, gather, thr) : occ_b<4, false>(skip, gather, thr);
-    FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl);
+    FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl, tile_rows);
     if (geom_out) *geom_out = g;
     rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_slots * p->ld * sizeof(double));
     if (rc) return rc;
@@ -339,7 +374,8 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
             HIPCHK(ctx, hipMemsetAsync((double *)ctx->ws_part_score.p + off, 0, (size_t)g.n_parts * p->ld * sizeof(double), ctx->stream));
             HIPCHK(ctx, hipMemsetAsync((uint32_t *)ctx->ws_part_miss.p + off, 0, (size_t)g.n_parts * p->ld * sizeof(uint32_t), ctx->stream));
         }
-        if (p->packed) rc = nt ? launch_fast_b<1, true>(q, g, skip, gather) : launch_fast_b<1, false>(q, g, skip, gather);
+        if (p16) rc = launch_p16(q, g, skip, gather, nt, nullptr, thr);
+        else if (p->packed) rc = nt ? launch_fast_b<1, true>(q, g, skip, gather) : launch_fast_b<1, false>(q, g, skip, gather);
         else if (bpl == 16) rc = nt ? launch_fast_b<16, true>(q, g, skip, gather) : launch_fast_b<16, false>(q, g, skip, gather);
         else if (bpl == 8) rc = nt ? launch_fast_b<8, true>(q, g, skip, gather) : launch_fast_b<8, false>(q, g, skip, gather);
         else rc = nt ? launch_fast_b<4, true>(q, g, skip, gather) : launch_fast_b<4, false>(q, g, skip, gather);
@@ -676,6 +712,7 @@ int snpm_init(int device_id, snpm_ctx **out)
     if (const char *s = getenv("SNPM_PARTS_MULT")) ctx->parts_mult = std::max(1, atoi(s));
     if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
     if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
+    if (const char *s = getenv("SNPM_PACKED_BYTE")) ctx->packed_byte = atoi(s);
     if (const char *s = getenv("SNPM_ACC_MAJOR")) ctx->use_acc_major = atoi(s);
     if (const char *s = getenv("SNPM_ACC_MAJOR_MIN_ROWS")) ctx->acc_major_min_rows = atoll(s);
     if (const char *s = getenv("SNPM_DEBUG_REEVAL")) ctx->debug_reeval = atoi(s);
@@ -1035,8 +1072,9 @@ int snpm_query_error_bound(snpm_query *q, int64_t chunk, double *bound)
     if (q->all_integer) { *bound = 0.0; return SNPM_OK; }
     auto it = q->eref_cache.find(chunk);
     double eref = (it != q->eref_cache.end()) ? it->second : (q->eref_cache[chunk] = eref_bound(q, chunk));
-    const int bpl = pick_bpl(ctx, q->panel->n_acc);
-    FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl);   // occ 1 -> longest parts -> largest bound
+    const bool p16 = q->panel->packed && !ctx->packed_byte;
+    const int bpl = p16 ? 16 : (q->panel->packed ? 4 : pick_bpl(ctx, q->panel->n_acc));
+    FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl, p16 ? P16_TILE_ROWS : TILE_ROWS);   // occ 1 -> longest parts -> largest bound
     *bound = eref + efast_bound(q, g);
     return SNPM_OK;
 }
