@@ -68,22 +68,29 @@ def cpu_baseline(panel, wei, n_acc, seconds_target=20.0):
     t0 = time.perf_counter()
     s, n = orc.genotyper_scores(wei[:chunk * n_chunks], db, chunk, False, match=orc.match_gts_accs_graph)
     dt = time.perf_counter() - t0
-    # the same sample once more over accession blocks on every host core this process may use (threads:
-    # numpy releases the GIL; a GPU-initialised process must not fork).  The reference itself is single-threaded.
+    # for scale: the plain-C restatement of the same arithmetic (oracle/snpmatch_oracle.c, reference summation
+    # order) on the host cores of a one-GPU share, one thread per accession block (ctypes releases the GIL; a
+    # GPU-initialised process must not fork).  The reference itself is single-threaded numpy: that is `value`.
     from concurrent.futures import ThreadPoolExecutor
-    cores = len(os.sched_getaffinity(0))
+    from oracle import c_oracle
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     edges = np.linspace(0, n_acc, cores + 1).astype(int)
     blocks = [np.ascontiguousarray(db[:, a:b]) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+    wsub = np.ascontiguousarray(wei[:chunk * n_chunks])
+    c_oracle.genotyper(blocks[0][:chunk], None, wsub[:chunk], chunk, False)        # load the library
+    reps = 3
     t0 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=cores) as pool:
-        list(pool.map(lambda blk: orc.genotyper_scores(wei[:chunk * n_chunks], blk, chunk, False,
-                                                       match=orc.match_gts_accs_graph), blocks))
-    dt_all = time.perf_counter() - t0
+        for _ in range(reps):
+            parts = list(pool.map(lambda blk: c_oracle.genotyper(blk, None, wsub, chunk, False), blocks))
+    dt_all = (time.perf_counter() - t0) / reps
+    c_counts_ok = bool(np.array_equal(np.concatenate([p_[1] for p_ in parts]), n) and
+                       np.array_equal(np.concatenate([p_[0] for p_ in parts]).astype(np.int64), np.asarray(s).astype(np.int64)))
     return {"value": chunk * n_chunks * n_acc / dt, "unit": "comparisons/s", "cores": 1, "kind": "port",
             "sample": "%d x 1000-SNP chunks x %d accessions of the same panel, numpy restatement of "
                       "matchGTsAccs (oracle.match_gts_accs_graph), %.1f s" % (n_chunks, n_acc, dt),
-            "all_cores": {"value": chunk * n_chunks * n_acc / dt_all, "cores": cores,
-                          "how": "same sample split into accession blocks, one thread per core"}}, (s, n, chunk * n_chunks)
+            "c_port_all_cores": {"value": chunk * n_chunks * n_acc / dt_all, "cores": cores, "counts_equal_numpy_port": c_counts_ok,
+                                 "how": "C restatement (oracle/snpmatch_oracle.c), same sample, one thread per accession block"}},             (s, n, chunk * n_chunks)
 
 
 def main():
