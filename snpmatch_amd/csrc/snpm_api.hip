@@ -74,6 +74,7 @@ struct snpm_ctx {
     int debug_reeval = 0;   // SNPM_DEBUG_REEVAL=k: also re-evaluate accessions 0..k-1 (to time that path)
     int stage_threads = 4;  // host threads repacking rows into the pinned staging slabs
     int nt_loads = 1;      // panel bytes are read once: non-temporal loads (+5-8% measured)
+    int64_t f1_slab_bytes = int64_t(2) << 30;   // SNPM_F1_SLAB_BYTES: compacted-weight scratch of the in-silico crosses
     int packed_byte = 0;   // SNPM_PACKED_BYTE=1: packed panels through the one-byte-per-lane k_fast instead of k_fast_packed16
 };
 
@@ -713,6 +714,7 @@ int snpm_init(int device_id, snpm_ctx **out)
     if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
     if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
     if (const char *s = getenv("SNPM_PACKED_BYTE")) ctx->packed_byte = atoi(s);
+    if (const char *s = getenv("SNPM_F1_SLAB_BYTES")) ctx->f1_slab_bytes = std::max<int64_t>(1, atoll(s));
     if (const char *s = getenv("SNPM_ACC_MAJOR")) ctx->use_acc_major = atoi(s);
     if (const char *s = getenv("SNPM_ACC_MAJOR_MIN_ROWS")) ctx->acc_major_min_rows = atoll(s);
     if (const char *s = getenv("SNPM_DEBUG_REEVAL")) ctx->debug_reeval = atoi(s);
@@ -1459,7 +1461,7 @@ int snpm_query_f1_pairs(snpm_query *q, const int32_t *acc_idx, int n_sel, double
     const int64_t nblk = stride / F1_ROWS_PER_BLOCK;
     const int64_t max_chunks = (n + NP_SUM_CHUNK - 1) / NP_SUM_CHUNK;
     // pairs per batch: the compacted weights of a pair take n doubles; keep the slab around 2 GiB
-    const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(n_pairs, (int64_t(2) << 30) / (n * 8)));
+    const int batch = (int)std::max<int64_t>(1, std::min<int64_t>(n_pairs, ctx->f1_slab_bytes / (n * 8)));
 
     std::vector<int32_t> tab((size_t)n_sel + 2 * (size_t)n_pairs);      // [acc | (i, j) per pair, combination order]
     for (int i = 0; i < n_sel; ++i) tab[(size_t)i] = acc_idx[i];

@@ -795,6 +795,25 @@ def test_insilico_f1_pairs_bitexact(ctx, n_snp, n_match, n_acc, k, packed):
     q.free()
 
 
+def test_insilico_f1_pairs_in_several_batches():
+    """the 45 pairs processed a few at a time (scratch slab limited through SNPM_F1_SLAB_BYTES): same bits"""
+    os.environ["SNPM_F1_SLAB_BYTES"] = str(70000 * 8 * 7)          # 7 pairs per batch
+    try:
+        c = engine.Context(0)
+    finally:
+        del os.environ["SNPM_F1_SLAB_BYTES"]
+    rng = np.random.default_rng(12)
+    db = rand_db(rng, 70000, 24)
+    wei = rand_wei(rng, 70000)
+    sel = rng.permutation(24)[:10]
+    q = engine.Query(engine.Panel.from_host(c, db), None, wei)
+    s, ni = q.f1_pairs(sel)
+    want_s, want_n = orc.insilico_f1_pairs(db[:, sel], wei)
+    assert np.array_equal(ni, want_n) and np.array_equal(bits(s), bits(want_s))
+    q.free()
+    c.close()
+
+
 def test_insilico_f1_pairs_edges(ctx):
     rng = np.random.default_rng(8)
     db = rand_db(rng, 100, 9)
