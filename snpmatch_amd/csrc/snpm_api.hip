@@ -481,15 +481,21 @@ int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64
         HIPCHK(ctx, hipGetLastError());
         return SNPM_OK;
     }
-    if (!d_cols && !p->packed && ctx->strict4) {
-        // dense int8: 4 columns per lane
+    if (!d_cols && ctx->strict4) {
+        // dense: 4 columns per lane (one dword of an int8 panel, one byte of a packed panel)
         const int64_t lanes = (ncols + 3) / 4;
         const int t4 = lanes >= 256 ? 256 : (lanes > 64 ? 128 : 64);
         dim3 grid4((unsigned)n_seg, (unsigned)((lanes + t4 - 1) / t4));
         ProfScope ps(ctx, PK_STRICT);
 #define LAUNCH_STRICT4(S, G)                                                                                     \
-    hipLaunchKernelGGL((k_strict4<S, G>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
-                       q->d_w, d_seg_off, ncols, (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld)
+    do {                                                                                                         \
+        if (p->packed)                                                                                           \
+            hipLaunchKernelGGL((k_strict4<S, G, true>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
+                               q->d_w, d_seg_off, ncols, (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_strict4<S, G, false>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
+                               q->d_w, d_seg_off, ncols, (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld); \
+    } while (0)
         if (skip) {
             if (gather) LAUNCH_STRICT4(true, true); else LAUNCH_STRICT4(true, false);
         } else {
