@@ -75,6 +75,7 @@ struct snpm_ctx {
     int stage_threads = 4;  // host threads repacking rows into the pinned staging slabs
     int nt_loads = 1;      // panel bytes are read once: non-temporal loads (+5-8% measured)
     int64_t f1_slab_bytes = int64_t(2) << 30;   // SNPM_F1_SLAB_BYTES: compacted-weight scratch of the in-silico crosses
+    int full_occupancy = 0;   // SNPM_FULL_OCCUPANCY=1: as many resident blocks as the occupancy API allows
     int packed_byte = 0;   // SNPM_PACKED_BYTE=1: packed panels through the one-byte-per-lane k_fast instead of k_fast_packed16
 };
 
@@ -247,6 +248,15 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     }
     g.n_colblocks = (g.n_wc + g.wpb - 1) / g.wpb;
     int occ = occ_blocks_hint > 0 ? occ_blocks_hint : 2;
+    // Resident blocks per CU of the int8 kernel.  On long scans full occupancy is not the optimum for 4- and
+    // 5-wave blocks (measured, fast mode, panels of 64 GB: 5-wave blocks 3 per CU 80.0 % of HBM peak vs 78.1 % at
+    // 4 per CU on 1252 x 50M, 78.5 vs 76.1 % on 2500 x 25M; 4-wave blocks 4-5 per CU 80 % vs 77.5 % at 6 on
+    // 5000 x 12.5M), while 6- to 8-wave blocks and short scans (1135 x 11M, 14 GB) are 1-3 % better at full
+    // occupancy.  The part count stays a multiple of the CU count either way (uneven counts cost 5-10 %).
+    const int64_t pitch_bytes = ((n_acc + 255) / 256) * 256;
+    if (bpl == 4 && tile_rows == TILE_ROWS && occ_blocks_hint > 0 && !ctx->full_occupancy && (g.wpb == 4 || g.wpb == 5) &&
+        n * pitch_bytes >= (int64_t(32) << 30))
+        occ = std::min(occ, std::max(3, 18 / g.wpb));
     int64_t resident = (int64_t)ctx->n_cu * occ * std::max(1, ctx->parts_mult);
     int64_t n_parts = std::max<int64_t>(1, resident / g.n_colblocks);
     const int64_t n_tiles = std::max<int64_t>(1, (n + tile_rows - 1) / tile_rows);
@@ -720,6 +730,7 @@ int snpm_init(int device_id, snpm_ctx **out)
     if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
     if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
     if (const char *s = getenv("SNPM_PACKED_BYTE")) ctx->packed_byte = atoi(s);
+    if (const char *s = getenv("SNPM_FULL_OCCUPANCY")) ctx->full_occupancy = atoi(s);
     if (const char *s = getenv("SNPM_F1_SLAB_BYTES")) ctx->f1_slab_bytes = std::max<int64_t>(1, atoll(s));
     if (const char *s = getenv("SNPM_ACC_MAJOR")) ctx->use_acc_major = atoi(s);
     if (const char *s = getenv("SNPM_ACC_MAJOR_MIN_ROWS")) ctx->acc_major_min_rows = atoll(s);
