@@ -829,3 +829,39 @@ def test_insilico_f1_pairs_edges(ctx):
     with pytest.raises(AssertionError, match="between 0 and 32"):
         q.f1_pairs(list(range(9)) * 4)
     q.free()
+
+
+def test_no_device_memory_leak_over_many_objects():
+    """panels, queries (all modes, windows, in-silico crosses) created and freed in a loop: the free device
+    memory reported by the driver comes back to where it started"""
+    import torch
+    c = engine.Context(0)
+    rng = np.random.default_rng(21)
+    db = rand_db(rng, 20000, 300)
+    wei = rand_wei(rng, 20000)
+    off = np.array([0, 5000, 5000, 20000], dtype=np.int64)
+
+    def cycle(packed):
+        panel = engine.Panel.from_host(c, db, packed=packed)
+        q = engine.Query(panel, None, wei)
+        for mode in (engine.MODE_EXACT, engine.MODE_STRICT, engine.MODE_FAST):
+            q.run(1000, False, mode)
+        q.run_windows(off)
+        q.f1_pairs(np.arange(10))
+        q.free()
+        rows = np.sort(rng.choice(20000, size=3000, replace=False)).astype(np.int64)
+        q = engine.Query(panel, rows, wei[:3000])
+        q.run(1000, True, engine.MODE_EXACT)
+        q.free()
+        panel.free()
+
+    cycle(False)
+    cycle(True)                      # grow-only workspaces of the context are now at their final size
+    c.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for i in range(40):
+        cycle(bool(i & 1))
+    c.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert free0 - free1 < (8 << 20), "device memory leaked: %d bytes" % (free0 - free1)
+    c.close()
