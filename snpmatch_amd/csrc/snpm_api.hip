@@ -58,6 +58,9 @@ struct snpm_ctx {
     Buf ws_grp_score, ws_grp_miss, ws_stage_dev, ws_flags2;
     Buf ws_part_score, ws_part_miss, ws_seg_score, ws_seg_miss, ws_seg_off, ws_cols, ws_tmp_score, ws_tmp_ninfo, ws_flags;
     Buf ws_lik_y, ws_lik_n, ws_lik_l, ws_lik_r;
+    // device buffers of freed queries, kept for the next query (hipMalloc / hipFree cost more than a small query's run)
+    struct Cached { void *p; size_t cap; };
+    std::vector<Cached> qcache;
     // profiling
     bool prof_on = false;
     std::vector<hipEvent_t> ev_pool;
@@ -110,6 +113,7 @@ struct snpm_query {
     bool all_integer = false;
     std::map<int64_t, double> eref_cache;  // chunk -> E_ref
     int64_t *d_chunk_off = nullptr;        // device copy of the chunk offsets for `chunk_off_chunk`
+    std::vector<snpm_ctx::Cached> owned;   // every device buffer of this query with its capacity
     int64_t chunk_off_chunk = -1, chunk_off_nseg = 0;
 };
 
@@ -156,6 +160,49 @@ int ensure(snpm_ctx *ctx, Buf &b, size_t bytes)
     HIPCHK(ctx, hipMalloc(&b.p, want));
     b.cap = want;
     return SNPM_OK;
+}
+
+// Query buffers come from / go back to a small per-context cache.  Everything that touches them is ordered on
+// ctx->stream, so a buffer can be handed to the next query without a synchronisation.
+constexpr size_t kQueryCacheEntries = 24;
+constexpr size_t kQueryCacheMaxBytes = size_t(64) << 20;
+
+hipError_t query_alloc(snpm_query *q, void **out, size_t bytes)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    bytes = std::max<size_t>(bytes, 256);
+    size_t best = ctx->qcache.size();
+    for (size_t i = 0; i < ctx->qcache.size(); ++i)
+        if (ctx->qcache[i].cap >= bytes && ctx->qcache[i].cap <= 2 * bytes &&
+            (best == ctx->qcache.size() || ctx->qcache[i].cap < ctx->qcache[best].cap))
+            best = i;
+    if (best < ctx->qcache.size()) {
+        q->owned.push_back(ctx->qcache[best]);
+        *out = ctx->qcache[best].p;
+        ctx->qcache.erase(ctx->qcache.begin() + (long)best);
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess) q->owned.push_back({*out, bytes});
+    return e;
+}
+
+void query_release(snpm_query *q, void *ptr)
+{
+    if (!ptr) return;
+    snpm_ctx *ctx = q->panel->ctx;
+    for (size_t i = 0; i < q->owned.size(); ++i) {
+        if (q->owned[i].p != ptr) continue;
+        const snpm_ctx::Cached c = q->owned[i];
+        q->owned.erase(q->owned.begin() + (long)i);
+        if (c.cap <= kQueryCacheMaxBytes && ctx->qcache.size() < kQueryCacheEntries) {
+            ctx->qcache.push_back(c);
+        } else {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(c.p);
+        }
+        return;
+    }
 }
 
 struct ProfScope {
@@ -560,11 +607,10 @@ int ensure_chunk_offsets(snpm_query *q, int64_t chunk)
     if (q->d_chunk_off && q->chunk_off_chunk == chunk) return SNPM_OK;
     std::vector<int64_t> off = chunk_offsets(q->n, chunk);
     if (q->d_chunk_off) {
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        HIPCHK(ctx, hipFree(q->d_chunk_off));
+        query_release(q, q->d_chunk_off);
         q->d_chunk_off = nullptr;
     }
-    HIPCHK(ctx, hipMalloc((void **)&q->d_chunk_off, off.size() * sizeof(int64_t)));
+    HIPCHK(ctx, query_alloc(q, (void **)&q->d_chunk_off, off.size() * sizeof(int64_t)));
     HIPCHK(ctx, hipMemcpyAsync(q->d_chunk_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     q->chunk_off_chunk = chunk;
@@ -747,6 +793,8 @@ int snpm_destroy(snpm_ctx *ctx)
     if (!ctx) return SNPM_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    for (auto &c : ctx->qcache) (void)hipFree(c.p);
+    ctx->qcache.clear();
     Buf *bufs[] = {&ctx->ws_stage_dev, &ctx->ws_flags2, &ctx->ws_grp_score, &ctx->ws_grp_miss, &ctx->ws_part_score, &ctx->ws_part_miss, &ctx->ws_seg_score, &ctx->ws_seg_miss, &ctx->ws_seg_off,
                    &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
                    &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r};
@@ -767,6 +815,9 @@ int snpm_destroy(snpm_ctx *ctx)
 int snpm_set_stream(snpm_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return SNPM_ERR_BADARG;
+    // work queued on the old stream (and the cached query buffers it may still use) finishes before the switch
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return SNPM_OK;
 }
@@ -1019,11 +1070,11 @@ int snpm_query_create(snpm_panel *p, const int64_t *row_idx, int64_t row0, int64
     q->row0 = row_idx ? 0 : row0;
     const size_t nn = (size_t)std::max<int64_t>(n, 1);
     hipError_t e = hipSuccess;
-    if (row_idx && e == hipSuccess) e = hipMalloc((void **)&q->d_row_idx, (nn + PREFETCH_PAD_ROWS) * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&q->d_w, nn * 3 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&q->d_lut, nn * 4 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&q->own_score, (size_t)p->ld * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void **)&q->own_ninfo, (size_t)p->ld * sizeof(int64_t));
+    if (row_idx && e == hipSuccess) e = query_alloc(q, (void **)&q->d_row_idx, (nn + PREFETCH_PAD_ROWS) * sizeof(int64_t));
+    if (e == hipSuccess) e = query_alloc(q, (void **)&q->d_w, nn * 3 * sizeof(double));
+    if (e == hipSuccess) e = query_alloc(q, (void **)&q->d_lut, nn * 4 * sizeof(double));
+    if (e == hipSuccess) e = query_alloc(q, (void **)&q->own_score, (size_t)p->ld * sizeof(double));
+    if (e == hipSuccess) e = query_alloc(q, (void **)&q->own_ninfo, (size_t)p->ld * sizeof(int64_t));
     q->d_score = q->own_score;
     q->d_ninfo = q->own_ninfo;
     if (e != hipSuccess) {
@@ -1062,13 +1113,7 @@ int snpm_query_free(snpm_query *q)
     if (!q) return SNPM_OK;
     snpm_ctx *ctx = q->panel->ctx;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    if (q->d_row_idx) (void)hipFree(q->d_row_idx);
-    if (q->d_w) (void)hipFree(q->d_w);
-    if (q->d_lut) (void)hipFree(q->d_lut);
-    if (q->d_chunk_off) (void)hipFree(q->d_chunk_off);
-    if (q->own_score) (void)hipFree(q->own_score);
-    if (q->own_ninfo) (void)hipFree(q->own_ninfo);
+    while (!q->owned.empty()) query_release(q, q->owned.back().p);
     delete q;
     return SNPM_OK;
 }
