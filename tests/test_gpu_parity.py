@@ -599,9 +599,9 @@ def test_fuzz_long_parts_multi_epoch():
     finally:
         del os.environ["SNPM_DEBUG_MAX_PARTS"]
     rng = np.random.default_rng(77)
-    for case in range(24):
+    for case in range(30):
         n_snp = int(rng.choice([8191, 8192, 8193, 24576, 24577, 30001, 49153, 70000]))
-        n_acc = int(rng.choice([3, 64, 257, 1135]))
+        n_acc = int(rng.choice([3, 64, 257, 1135, 4200]))      # 4200: blocks of >= 256 threads (register-staged LUT tiles)
         packed = bool(rng.integers(0, 2))
         skip = bool(rng.integers(0, 2))
         db = rand_db(rng, n_snp, n_acc)
