@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--mode", default="exact", choices=["exact", "strict", "fast"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk", type=int, default=1000)
+    ap.add_argument("--hard-calls", action="store_true",
+                    help="sample with hard genotype calls only (all weights 0 or 1, as from a BED file or a VCF without PL)")
     ap.add_argument("--packed", action="store_true",
                     help="2-bit packed panel (4 accessions per byte) instead of the int8 panel BASELINE.json names")
     # rehearsal of the N>1 code path on a one-GPU box (never used by the driver): gloo instead of
@@ -163,7 +165,7 @@ def main():
     t_setup = time.perf_counter()
     panel = engine.Panel(ctx, n_snp, n_loc, packed=args.packed)
     panel.fill_synthetic(SEED, 0, a0)
-    wei = make_sample(n_snp, SEED, PLANTED)
+    wei = make_sample(n_snp, SEED, PLANTED, frac_pl=0.0 if args.hard_calls else 0.8)
     query = engine.Query(panel, None, wei)
     # results land in torch tensors (plumbing for the all-gather); padded to the common shard size
     query.bind_outputs(shards.score_loc.data_ptr(), shards.ninfo_loc.data_ptr())

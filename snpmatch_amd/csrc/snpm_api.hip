@@ -79,6 +79,7 @@ struct snpm_ctx {
     int nt_loads = 1;      // panel bytes are read once: non-temporal loads (+5-8% measured)
     int64_t f1_slab_bytes = int64_t(2) << 30;   // SNPM_F1_SLAB_BYTES: compacted-weight scratch of the in-silico crosses
     int full_occupancy = 0;   // SNPM_FULL_OCCUPANCY=1: as many resident blocks as the occupancy API allows
+    int bits_path = 1;     // SNPM_BITS=0: hard-call samples on packed panels go through k_fast_packed16 like any other
     int packed_byte = 0;   // SNPM_PACKED_BYTE=1: packed panels through the one-byte-per-lane k_fast instead of k_fast_packed16
 };
 
@@ -111,6 +112,8 @@ struct snpm_query {
     std::vector<double> wmax;           // host: max_c |W[r,c]| per matched row
     long double wsum = 0;               // sum of wmax
     bool all_integer = false;
+    bool hard01 = false;                // every weight is 0 or 1: scores are counts (k_fast_bits on packed panels)
+    uint8_t *d_wbits = nullptr;         // [n + pad] ref | het << 1 | alt << 2 per matched row (only when hard01)
     std::map<int64_t, double> eref_cache;  // chunk -> E_ref
     int64_t *d_chunk_off = nullptr;        // device copy of the chunk offsets for `chunk_off_chunk`
     std::vector<snpm_ctx::Cached> owned;   // every device buffer of this query with its capacity
@@ -371,6 +374,35 @@ int launch_p16(snpm_query *q, const FastGeom &g, bool skip, bool gather, bool nt
     return SNPM_ERR_STATE;
 }
 
+// hard-call samples on packed panels (k_fast_bits)
+template <bool SKIP, bool GATHER, bool NT>
+int launch_bits_t(snpm_query *q, const FastGeom &g, int *occ_out, int threads)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    if (occ_out) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_bits<SKIP, GATHER, NT>, threads, 0) != hipSuccess) nb = 0;
+        *occ_out = nb;
+        return SNPM_OK;
+    }
+    ProfScope ps(ctx, PK_FAST);
+    hipLaunchKernelGGL((k_fast_bits<SKIP, GATHER, NT>), dim3((unsigned)g.n_colblocks, (unsigned)g.n_parts), dim3(WAVE * g.wpb), 0,
+                       ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, q->n, (const uint8_t *)q->d_wbits,
+                       (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+int launch_bits(snpm_query *q, const FastGeom &g, bool skip, bool gather, bool nt, int *occ_out, int threads)
+{
+#define BITS_CASE(S, G, N) if (skip == S && gather == G && nt == N) return launch_bits_t<S, G, N>(q, g, occ_out, threads)
+    BITS_CASE(false, false, false); BITS_CASE(false, false, true); BITS_CASE(false, true, false); BITS_CASE(false, true, true);
+    BITS_CASE(true, false, false);  BITS_CASE(true, false, true);  BITS_CASE(true, true, false);  BITS_CASE(true, true, true);
+#undef BITS_CASE
+    return SNPM_ERR_STATE;
+}
+
 template <int BPL, bool NT>
 int occ_b(bool skip, bool gather, int threads)
 {
@@ -410,7 +442,9 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
     int occ = 0;
     const bool nt = ctx->nt_loads != 0;
     const int thr = WAVE * g0.wpb;
-    if (p16) (void)launch_p16(q, g0, skip, gather, nt, &occ, thr);
+    const bool bits = p16 && q->hard01 && ctx->bits_path;      // counts instead of weighted sums
+    if (bits) (void)launch_bits(q, g0, skip, gather, nt, &occ, thr);
+    else if (p16) (void)launch_p16(q, g0, skip, gather, nt, &occ, thr);
     else if (p->packed) occ = nt ? occ_b<1, true>(skip, gather, thr) : occ_b<1, false>(skip, gather, thr);
     else if (bpl == 16) occ = nt ? occ_b<16, true>(skip, gather, thr) : occ_b<16, false>(skip, gather, thr);
     else if (bpl == 8) occ = nt ? occ_b<8, true>(skip, gather, thr) : occ_b<8, false>(skip, gather, thr);
@@ -432,7 +466,8 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
             HIPCHK(ctx, hipMemsetAsync((double *)ctx->ws_part_score.p + off, 0, (size_t)g.n_parts * p->ld * sizeof(double), ctx->stream));
             HIPCHK(ctx, hipMemsetAsync((uint32_t *)ctx->ws_part_miss.p + off, 0, (size_t)g.n_parts * p->ld * sizeof(uint32_t), ctx->stream));
         }
-        if (p16) rc = launch_p16(q, g, skip, gather, nt, nullptr, thr);
+        if (bits) rc = launch_bits(q, g, skip, gather, nt, nullptr, thr);
+        else if (p16) rc = launch_p16(q, g, skip, gather, nt, nullptr, thr);
         else if (p->packed) rc = nt ? launch_fast_b<1, true>(q, g, skip, gather) : launch_fast_b<1, false>(q, g, skip, gather);
         else if (bpl == 16) rc = nt ? launch_fast_b<16, true>(q, g, skip, gather) : launch_fast_b<16, false>(q, g, skip, gather);
         else if (bpl == 8) rc = nt ? launch_fast_b<8, true>(q, g, skip, gather) : launch_fast_b<8, false>(q, g, skip, gather);
@@ -776,6 +811,7 @@ int snpm_init(int device_id, snpm_ctx **out)
     if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
     if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
     if (const char *s = getenv("SNPM_PACKED_BYTE")) ctx->packed_byte = atoi(s);
+    if (const char *s = getenv("SNPM_BITS")) ctx->bits_path = atoi(s);
     if (const char *s = getenv("SNPM_FULL_OCCUPANCY")) ctx->full_occupancy = atoi(s);
     if (const char *s = getenv("SNPM_F1_SLAB_BYTES")) ctx->f1_slab_bytes = std::max<int64_t>(1, atoll(s));
     if (const char *s = getenv("SNPM_ACC_MAJOR")) ctx->use_acc_major = atoi(s);
@@ -1103,6 +1139,26 @@ int snpm_query_create(snpm_panel *p, const int64_t *row_idx, int64_t row0, int64
     for (double w : q->wmax) tot += w;
     q->wsum = tot;
     q->all_integer = all_int && tot < 9.0e15L;     // every partial sum exactly representable
+    // hard calls: all weights 0 or 1 -> one byte of three weight bits per row for the bit-parallel pass
+    std::vector<uint8_t> wb;
+    if (q->all_integer && p->packed && n > 0) {
+        bool hard = true;
+        wb.assign((size_t)n + 16, 0);
+        for (int64_t i = 0; i < n && hard; ++i) {
+            const double a = wei[3 * i], b = wei[3 * i + 1], c = wei[3 * i + 2];
+            hard = (a == 0.0 || a == 1.0) && (b == 0.0 || b == 1.0) && (c == 0.0 || c == 1.0);
+            wb[(size_t)i] = (uint8_t)((a == 1.0 ? 1 : 0) | (b == 1.0 ? 2 : 0) | (c == 1.0 ? 4 : 0));
+        }
+        if (hard) {
+            hipError_t e2 = query_alloc(q, (void **)&q->d_wbits, wb.size());
+            if (e2 != hipSuccess) {
+                snpm_query_free(q);
+                return set_err(ctx, SNPM_ERR_OOM, "query allocation failed: %s", hipGetErrorString(e2));
+            }
+            HIPCHK(ctx, hipMemcpyAsync(q->d_wbits, wb.data(), wb.size(), hipMemcpyHostToDevice, ctx->stream));
+            q->hard01 = true;
+        }
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host buffers may be released by the caller
     *out = q;
     return SNPM_OK;

@@ -660,6 +660,192 @@ k_fast_packed16(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__r
 }
 #undef P16_CSA
 
+// ------------------------------------------------------------------------------------------------
+// Fast pass for HARD-CALL samples on a packed panel: every weight is 0 or 1 (BED input, VCF without PL:
+// ParseInputs.get_wei_from_GT, core/parsers.py:118-127), so the score of an accession is a COUNT of SNPs and
+// needs neither the LUT nor fp64: with the two bit planes of the 16 calls of a dword,
+//     lo = x & 0x5555..., hi = (x >> 1) & 0x5555...      (code = lo + 2 hi: 0 ref, 1 alt, 2 het, 3 missing)
+// a call scores when  (~lo & ~hi & R_ref) | (lo & ~hi & R_alt) | (~lo & hi & R_het),  R_c = 0x5555... or 0 from the
+// row's three weight bits (wave-uniform, scalar registers), and is missing when lo & hi (or hi with skip_hets).
+// Both bit vectors are counted per accession with the bit-sliced carry-save scheme of k_fast_packed16, flushed
+// into 16-bit counters every 64 rows.  ~1.1 integer operations and 0.25 B per comparison, no LDS, no barriers.
+// Geometry (16 accessions per lane, tile-interleaved parts, epochs, prefetch pipeline) as k_fast_packed16;
+// partial scores are written as fp64 counts so that the reduce kernels are shared.  wbits[r] = ref | het << 1 |
+// alt << 2 for query row r, padded to a multiple of 8 entries.
+#define BITS_CSA(H, L, A, B, C)           \
+    do {                                  \
+        const uint32_t u_ = (A) ^ (B);    \
+        const uint32_t h_ = ((A) & (B)) | (u_ & (C)); \
+        (L) = u_ ^ (C);                   \
+        (H) = h_;                         \
+    } while (0)
+
+template <bool SKIP, bool GATHER, bool NT>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, 6)
+k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
+            const uint8_t *__restrict__ wbits, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
+{
+    constexpr int G = P16_G;
+    constexpr int TR = P16_TILE_ROWS;
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int64_t byte0 = ((int64_t)blockIdx.x * nthr + tid) * 4;
+    const int64_t col0 = byte0 * 4;
+    const bool lane_on = byte0 < pitch && col0 < ld;
+    const int64_t p = blockIdx.y;
+    const int64_t P = gridDim.y;
+    const int64_t n_tiles_total = (n + TR - 1) / TR;
+
+    uint32_t hit16[8], miss16[8];       // [d]: accession d (low half) and d + 8 (high half)
+    uint32_t h1 = 0, h2 = 0, h4 = 0, h8 = 0, h16 = 0, h32 = 0, h64 = 0;   // bit-sliced hit counts of the current tile
+    uint32_t m1 = 0, m2 = 0, m4 = 0, m8 = 0, m16 = 0, m32 = 0, m64 = 0;   // ... and missing counts
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hit16[i] = miss16[i] = 0;
+
+    const uint32_t lane_off = lane_on ? (uint32_t)byte0 : 0u;
+    auto load = [&](int64_t rr) -> uint32_t {
+        const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
+        const int8_t *rowbase = db + prow * pitch;
+        uint32_t off = lane_off;
+        asm volatile("" : "+v"(off));
+        const uint32_t *ptr = reinterpret_cast<const uint32_t *>(rowbase + off);
+        return NT ? __builtin_nontemporal_load(ptr) : *ptr;
+    };
+    // (hit bits, missing bits) of one row
+    auto classify = [&](uint32_t x, uint32_t wb, uint32_t &hit, uint32_t &mis) {
+        const uint32_t lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
+        const uint32_t r_ref = (wb & 1u) ? 0x55555555u : 0u;
+        const uint32_t r_het = (!SKIP && (wb & 2u)) ? 0x55555555u : 0u;
+        const uint32_t r_alt = (wb & 4u) ? 0x55555555u : 0u;
+        hit = (~(lo | hi) & r_ref) | (lo & ~hi & r_alt) | (hi & ~lo & r_het);
+        mis = SKIP ? hi : (lo & hi);
+    };
+    auto ripple = [&](uint32_t c, uint32_t &a1, uint32_t &a2, uint32_t &a4, uint32_t &a8, uint32_t &a16, uint32_t &a32, uint32_t &a64) {
+        uint32_t t;
+        t = a1 & c; a1 ^= c; c = t;
+        t = a2 & c; a2 ^= c; c = t;
+        t = a4 & c; a4 ^= c; c = t;
+        t = a8 & c; a8 ^= c; c = t;
+        t = a16 & c; a16 ^= c; c = t;
+        t = a32 & c; a32 ^= c; c = t;
+        a64 ^= c;
+    };
+    auto flush = [&]() {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const uint32_t k = 0x00010001u;
+            hit16[d] += ((h1 >> (2 * d)) & k) + (((h2 >> (2 * d)) & k) << 1) + (((h4 >> (2 * d)) & k) << 2) +
+                        (((h8 >> (2 * d)) & k) << 3) + (((h16 >> (2 * d)) & k) << 4) + (((h32 >> (2 * d)) & k) << 5) +
+                        (((h64 >> (2 * d)) & k) << 6);
+            miss16[d] += ((m1 >> (2 * d)) & k) + (((m2 >> (2 * d)) & k) << 1) + (((m4 >> (2 * d)) & k) << 2) +
+                         (((m8 >> (2 * d)) & k) << 3) + (((m16 >> (2 * d)) & k) << 4) + (((m32 >> (2 * d)) & k) << 5) +
+                         (((m64 >> (2 * d)) & k) << 6);
+        }
+        h1 = h2 = h4 = h8 = h16 = h32 = h64 = 0;
+        m1 = m2 = m4 = m8 = m16 = m32 = m64 = 0;
+    };
+    auto store_partials = [&](int64_t epoch) {
+        if (lane_on) {
+            double *os = out_score + (epoch * P + p) * ld + col0;
+            uint32_t *om = out_miss + (epoch * P + p) * ld + col0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {                 // accessions 8k .. 8k+7
+#pragma unroll
+                for (int d = 0; d < 8; d += 2) {
+                    const uint32_t c0 = k ? (hit16[d] >> 16) : (hit16[d] & 0xffffu);
+                    const uint32_t c1 = k ? (hit16[d + 1] >> 16) : (hit16[d + 1] & 0xffffu);
+                    *reinterpret_cast<double2 *>(os + 8 * k + d) = make_double2((double)c0, (double)c1);
+                }
+                uint4 a, b;
+                a.x = k ? (miss16[0] >> 16) : (miss16[0] & 0xffffu);
+                a.y = k ? (miss16[1] >> 16) : (miss16[1] & 0xffffu);
+                a.z = k ? (miss16[2] >> 16) : (miss16[2] & 0xffffu);
+                a.w = k ? (miss16[3] >> 16) : (miss16[3] & 0xffffu);
+                b.x = k ? (miss16[4] >> 16) : (miss16[4] & 0xffffu);
+                b.y = k ? (miss16[5] >> 16) : (miss16[5] & 0xffffu);
+                b.z = k ? (miss16[6] >> 16) : (miss16[6] & 0xffffu);
+                b.w = k ? (miss16[7] >> 16) : (miss16[7] & 0xffffu);
+                *reinterpret_cast<uint4 *>(om + 8 * k) = a;
+                *reinterpret_cast<uint4 *>(om + 8 * k + 4) = b;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) hit16[i] = miss16[i] = 0;
+    };
+    int64_t last_epoch = 0;
+
+    if (p < n_tiles_total) {
+        uint32_t xa[G], xb[G];
+#pragma unroll
+        for (int u = 0; u < G; ++u) xa[u] = load(p * TR + u);
+
+        int tiles_in_epoch = 0;
+        int64_t epoch = 0;
+        for (int64_t T = p; T < n_tiles_total; T += P) {
+            if (tiles_in_epoch == EPOCH_TILES) {
+                store_partials(epoch);
+                ++epoch;
+                tiles_in_epoch = 0;
+            }
+            ++tiles_in_epoch;
+            const int64_t tr0 = T * TR;
+            const int rows = (int)((n - tr0 < TR) ? (n - tr0) : TR);
+            const bool more = (T + P < n_tiles_total);
+            const int64_t ntr0 = more ? (T + P) * TR : tr0;
+            const int full_groups = rows / G;
+
+            // 8 rows: classify, then both bit vectors into their bit-sliced counters with carry-save adders
+#define BITS_GROUP(X, R0)                                                                           \
+    do {                                                                                            \
+        _Pragma("unroll") for (int u_ = 0; u_ < G; ++u_) asm volatile("" : "+v"((X)[u_]));         \
+        const uint64_t wb8_ = *reinterpret_cast<const uint64_t *>(wbits + (R0));                   \
+        uint32_t hb_[8], mb_[8];                                                                    \
+        _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_)                                            \
+            classify((X)[u_], (uint32_t)(wb8_ >> (8 * u_)) & 0xffu, hb_[u_], mb_[u_]);              \
+        uint32_t t2a_, t2b_, t4a_, t4b_, t8_, c_, d_;                                               \
+        BITS_CSA(t2a_, h1, h1, hb_[0], hb_[1]); BITS_CSA(t2b_, h1, h1, hb_[2], hb_[3]);             \
+        BITS_CSA(t4a_, h2, h2, t2a_, t2b_);                                                         \
+        BITS_CSA(t2a_, h1, h1, hb_[4], hb_[5]); BITS_CSA(t2b_, h1, h1, hb_[6], hb_[7]);             \
+        BITS_CSA(t4b_, h2, h2, t2a_, t2b_);                                                         \
+        BITS_CSA(t8_, h4, h4, t4a_, t4b_);                                                          \
+        c_ = h8 & t8_;  h8 ^= t8_;  d_ = h16 & c_;  h16 ^= c_;  c_ = h32 & d_;  h32 ^= d_;  h64 ^= c_; \
+        BITS_CSA(t2a_, m1, m1, mb_[0], mb_[1]); BITS_CSA(t2b_, m1, m1, mb_[2], mb_[3]);             \
+        BITS_CSA(t4a_, m2, m2, t2a_, t2b_);                                                         \
+        BITS_CSA(t2a_, m1, m1, mb_[4], mb_[5]); BITS_CSA(t2b_, m1, m1, mb_[6], mb_[7]);             \
+        BITS_CSA(t4b_, m2, m2, t2a_, t2b_);                                                         \
+        BITS_CSA(t8_, m4, m4, t4a_, t4b_);                                                          \
+        c_ = m8 & t8_;  m8 ^= t8_;  d_ = m16 & c_;  m16 ^= c_;  c_ = m32 & d_;  m32 ^= d_;  m64 ^= c_; \
+    } while (0)
+
+            int g = 0;
+            for (; g + 2 <= full_groups; g += 2) {
+                const int64_t rnext = tr0 + (int64_t)(g + 1) * G;
+                const int64_t rafter = (g + 2 < TR / G) ? rnext + G : ntr0;
+#pragma unroll
+                for (int u = 0; u < G; ++u) xb[u] = load(rnext + u);
+                BITS_GROUP(xa, tr0 + (int64_t)g * G);
+#pragma unroll
+                for (int u = 0; u < G; ++u) xa[u] = load(rafter + u);
+                BITS_GROUP(xb, rnext);
+            }
+            if (g < full_groups) {                               // odd group count: only in the last tile of all
+                BITS_GROUP(xa, tr0 + (int64_t)g * G);
+            }
+#undef BITS_GROUP
+            for (int r = full_groups * G; r < rows; ++r) {      // at most G-1 rows: last tile of all
+                uint32_t hb, mb;
+                classify(load(tr0 + r), wbits[tr0 + r], hb, mb);
+                ripple(hb, h1, h2, h4, h8, h16, h32, h64);
+                ripple(mb, m1, m2, m4, m8, m16, m32, m64);
+            }
+            flush();
+        }
+        last_epoch = epoch;
+    }
+    store_partials(last_epoch);
+}
+#undef BITS_CSA
+
 // Blocked summation of the M = n_epochs*P partial slots (deterministic, no atomics):
 //   k_reduce_groups: group g = slots [g*REDUCE_GROUP, ...) added sequentially   -> grp [n_groups, ld]
 //   k_reduce       : groups added sequentially                                  -> score, ninfo = n - miss

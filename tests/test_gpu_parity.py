@@ -865,3 +865,53 @@ def test_no_device_memory_leak_over_many_objects():
     free1 = torch.cuda.mem_get_info(0)[0]
     assert free0 - free1 < (8 << 20), "device memory leaked: %d bytes" % (free0 - free1)
     c.close()
+
+
+# ------------------------------------------------------------------ hard-call samples on packed panels (k_fast_bits)
+def _hard_weights(rng, n, one_hot=True):
+    if one_hot:
+        codes = rng.choice(np.array([0, 1, 2], dtype=np.int8), size=n, p=[0.6, 0.3, 0.1])
+        return orc.weights_from_gt_codes(codes)
+    return rng.integers(0, 2, size=(n, 3)).astype(np.float64)          # any 0/1 pattern, also all-zero rows
+
+
+@pytest.mark.parametrize("max_parts", [0, 3])
+def test_packed_hard_calls_bit_parallel_path(max_parts):
+    """all weights 0 or 1 on a packed panel: scores are counts (k_fast_bits) and equal the oracle exactly in every
+    mode; short / long parts (several epochs), dense and gathered rows, skip_hets, non-one-hot 0/1 patterns"""
+    old = os.environ.get("SNPM_DEBUG_MAX_PARTS")
+    if max_parts:
+        os.environ["SNPM_DEBUG_MAX_PARTS"] = str(max_parts)
+    try:
+        c = engine.Context(0)
+    finally:
+        if max_parts:
+            if old is None:
+                del os.environ["SNPM_DEBUG_MAX_PARTS"]
+            else:
+                os.environ["SNPM_DEBUG_MAX_PARTS"] = old
+    rng = np.random.default_rng(50 + max_parts)
+    shapes = [(1, 1), (7, 5), (63, 64), (64, 17), (65, 1135), (1000, 4200), (8191, 257), (30001, 1135), (70000, 64), (24577, 4200)]
+    for n_snp, n_acc in shapes:
+        db = rand_db(rng, n_snp, n_acc)
+        panel = engine.Panel.from_host(c, db, packed=True)
+        for gather in (False, True):
+            rows = None
+            n = n_snp
+            if gather:
+                n = int(rng.integers(0, n_snp + 1))
+                rows = np.sort(rng.choice(n_snp, size=n, replace=False)).astype(np.int64)
+            for one_hot in (True, False):
+                wei = _hard_weights(rng, n, one_hot)
+                q = engine.Query(panel, rows, wei)
+                assert q.error_bound(1000) == 0.0
+                for skip in (False, True):
+                    want_s, want_n = c_oracle.genotyper(db, rows, wei, 1000, skip)
+                    for mode in (engine.MODE_FAST, engine.MODE_EXACT, engine.MODE_STRICT):
+                        s, ni = q.run(1000, skip, mode)
+                        tag = "%d x %d gather=%s one_hot=%s skip=%s mode=%d" % (n_snp, n_acc, gather, one_hot, skip, mode)
+                        assert np.array_equal(ni, want_n), tag
+                        assert np.array_equal(s, want_s), tag
+                q.free()
+        panel.free()
+    c.close()
