@@ -713,12 +713,16 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
     };
     // (hit bits, missing bits) of one row
     auto classify = [&](uint32_t x, uint32_t wb, uint32_t &hit, uint32_t &mis) {
+        // the row's truth table T[code] = (ref, alt, het, 0) in algebraic normal form over (lo, hi):
+        //   hit = D ^ (lo & A) ^ (hi & B) ^ (lo & hi & C),  D = ref, A = ref ^ alt, B = ref ^ het, C = ref ^ alt ^ het
+        // (four wave-uniform masks; three 3-input boolean operations per row instead of eight 2-input ones)
         const uint32_t lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
-        const uint32_t r_ref = (wb & 1u) ? 0x55555555u : 0u;
-        const uint32_t r_het = (!SKIP && (wb & 2u)) ? 0x55555555u : 0u;
-        const uint32_t r_alt = (wb & 4u) ? 0x55555555u : 0u;
-        hit = (~(lo | hi) & r_ref) | (lo & ~hi & r_alt) | (hi & ~lo & r_het);
-        mis = SKIP ? hi : (lo & hi);
+        const uint32_t r = wb & 1u, h = SKIP ? 0u : ((wb >> 1) & 1u), a = (wb >> 2) & 1u;
+        const uint32_t md = r ? 0x55555555u : 0u, ma = (r ^ a) ? 0x55555555u : 0u;
+        const uint32_t mb = (r ^ h) ? 0x55555555u : 0u, mc = (r ^ a ^ h) ? 0x55555555u : 0u;
+        const uint32_t both = lo & hi;
+        hit = md ^ (lo & ma) ^ (hi & mb) ^ (both & mc);
+        mis = SKIP ? hi : both;
     };
     auto ripple = [&](uint32_t c, uint32_t &a1, uint32_t &a2, uint32_t &a4, uint32_t &a8, uint32_t &a16, uint32_t &a32, uint32_t &a64) {
         uint32_t t;
