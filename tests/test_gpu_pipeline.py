@@ -249,3 +249,21 @@ def test_inbred_on_packed_panel_matches_reference_files(golden_dir, tmp_path, mo
     assert g._panel.packed
     cmp_scores_table(open(out + ".scores.txt").read(), gold["inbred_skip0"]["scores.txt"])
     assert open(out + ".matches.json").read() == gold["inbred_skip0"]["matches.json"]
+
+
+def test_cross_on_packed_panel_matches_reference_files(golden_dir, tmp_path, monkeypatch):
+    """SNPMATCH_PACKED=1: window scores (strict order on the 2-bit panel), identity test, in-silico crosses and
+    the interpretation reproduce the reference's cross outputs"""
+    monkeypatch.setenv("SNPMATCH_PACKED", "1")
+    toy = np.load(os.path.join(golden_dir, "toy_db_cross.npz"))
+    gold = json.load(open(os.path.join(golden_dir, "g5_cross.json")))
+    for skip in (False, True):
+        out = str(tmp_path / ("pcross%d" % skip))
+        g = make_g(toy)
+        ci = csmatch.CrossIdentifier(make_inputs(toy), g, "athaliana_tair10", 300000, out, run_identifier=True, skip_db_hets=skip)
+        assert g._panel.packed
+        want = gold["cross_skip%d" % int(skip)]
+        cmp_window_table(open(out + ".windowscore.txt").read(), want[".windowscore.txt"])
+        cmp_scores_table(open(out + ".scores.txt").read(), want[".scores.txt"])
+        assert open(out + ".scores.txt.matches.json").read() == want[".scores.txt.matches.json"]
+        assert len(ci.result.accs) == 30 + 45
