@@ -11,13 +11,21 @@
 //              (byte & 3); every element costs one ds_read_b64 + one v_add_f64 instead of three
 //              compare/select pairs.  Missing counts are SWAR (packed u8 lanes).  Partials per part
 //              are written once; k_reduce adds them in part order (deterministic, no atomics).
-//   k_strict   reference summation order (three per-category sequential fp64 sums per segment,
-//              core/snpmatch.py:85-87): one lane per accession column, one wave per (segment, 64
-//              columns).  Used for cross windows, for SNPM_MODE_STRICT and to re-evaluate the few
-//              accessions the fast pass cannot certify.
-//   k_scan     sequential accumulation of segment sums (ScoreList += chunk, core/snpmatch.py:224).
+//   k_fast_packed16  the fast pass on a 2-bit packed panel: 16 accessions per lane, pair-table lookups
+//              (one ds_read_b128 + two v_add_f64 per two comparisons), bit-sliced missing counts, LDS reads
+//              issued and waited for by hand.
+//   k_fast_bits  hard-call samples (all weights 0 or 1) on a packed panel: bit-plane boolean scoring and
+//              bit-sliced counting, no LDS, no fp64.
+//   k_strict4 / k_strict / k_strict_sparse(_T)  reference summation order (three per-category sequential fp64
+//              sums per segment, core/snpmatch.py:85-87).  Used for cross windows, for SNPM_MODE_STRICT and to
+//              re-evaluate the few accessions the fast pass cannot certify (sparse variants; _T reads the
+//              accession-major packed copy built by k_pack_transpose).
+//   k_scan / k_scan_few  sequential accumulation of segment sums (ScoreList += chunk, core/snpmatch.py:224).
 //   k_likelihood  likeliTest + nanmin + ratio on device (core/snpmatch.py:40-55,106-117).
-//   k_build_lut, k_repitch_canon / k_pack_rows (upload), k_synth, k_patch, ...: small helpers.
+//   k_binom_identity  np_test_identity (core/snpmatch.py:57-72).   k_segregating  --refine support.
+//   k_f1_*     in-silico F1 scores in numpy's summation order (core/csmatch.py:115-125).
+//   k_build_lut, k_repitch_canon / k_pack_rows / k_unpack_rows (upload / download), k_synth*, k_seg_pack,
+//   k_patch, k_calib_read: small helpers.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
