@@ -21,6 +21,12 @@
  *   - the caller owns every host buffer it passes in (inputs are never modified) and every output
  *     buffer (pre-allocated, C-contiguous); the library owns device memory and pinned staging
  *     buffers behind the opaque handles.  No pointer handed out outlives its handle.
+ *   - lifetime: free queries before their panel and panels before their context.  The other orders are
+ *     tolerated: snpm_panel_free releases the device memory of the panel's live queries, snpm_destroy that of
+ *     the context's live panels and queries; the orphaned handles stay valid for exactly one call, their own
+ *     snpm_query_free / snpm_panel_free (a host-side delete), every other entry point refuses them with
+ *     SNPM_ERR_STATE.  After the process has started to exit (exit handlers running) free / destroy only drop
+ *     host bookkeeping and make no HIP call.
  *   - calls are blocking from the caller's view unless the name says otherwise; one ctx must not
  *     be used from two threads at once; distinct ctx are independent.  One ctx == one GPU; a
  *     multi-GPU job is one process (one ctx) per GPU with the accession axis sharded by the host

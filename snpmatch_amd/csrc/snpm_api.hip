@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdarg>
@@ -16,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -50,6 +53,7 @@ struct snpm_ctx {
     static constexpr size_t kStageBytes = 32u << 20;
     void *stage[2] = {nullptr, nullptr};
     hipEvent_t stage_done[2] = {nullptr, nullptr};
+    hipEvent_t compute_mark = nullptr;  // "everything queued on the compute stream so far": uploads wait for it
     bool stage_busy[2] = {false, false};
     // pinned host buffer for small result readbacks (exactness check)
     void *h_pinned = nullptr;
@@ -81,6 +85,9 @@ struct snpm_ctx {
     int full_occupancy = 0;   // SNPM_FULL_OCCUPANCY=1: as many resident blocks as the occupancy API allows
     int bits_path = 1;     // SNPM_BITS=0: hard-call samples on packed panels go through k_fast_packed16 like any other
     int packed_byte = 0;   // SNPM_PACKED_BYTE=1: packed panels through the one-byte-per-lane k_fast instead of k_fast_packed16
+    // live panels of this context: snpm_destroy releases their device memory and orphans them (and their
+    // queries), so that a panel / query handle freed AFTER its context is a harmless host-side delete
+    std::vector<snpm_panel *> panels;
 };
 
 struct snpm_panel {
@@ -96,6 +103,7 @@ struct snpm_panel {
     uint8_t *dT = nullptr;
     int64_t pitchT = 0;
     int dT_state = 0;                   // 0 = not built / stale, 1 = valid, -1 = unusable (code 3 present or no memory)
+    std::vector<snpm_query *> queries;  // live queries against this panel (orphaned when the panel goes away)
 };
 
 struct snpm_query {
@@ -118,6 +126,7 @@ struct snpm_query {
     int64_t *d_chunk_off = nullptr;        // device copy of the chunk offsets for `chunk_off_chunk`
     std::vector<snpm_ctx::Cached> owned;   // every device buffer of this query with its capacity
     int64_t chunk_off_chunk = -1, chunk_off_nseg = 0;
+    int reeval_path = 0;                   // last sparse re-evaluation: 1 = accession-major copy, 2 = SNP-major (strided)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -148,6 +157,36 @@ int set_err(snpm_ctx *ctx, int code, const char *fmt, ...)
 #define CHECK_ARG(ctx, cond, msg)                                   \
     do {                                                            \
         if (!(cond)) return set_err((ctx), SNPM_ERR_BADARG, "%s", msg); \
+    } while (0)
+
+
+// Set by an atexit handler registered at the first snpm_init, i.e. after the HIP runtime registered its own
+// teardown: exit handlers run in reverse order of registration, so the flag is up before the runtime's static
+// objects go away.  From then on free / destroy only drop host-side bookkeeping (the process is exiting and
+// the driver reclaims device memory); no HIP call is made on a runtime that may be half torn down.
+std::atomic<bool> g_exiting{false};
+void mark_exiting() { g_exiting.store(true); }
+
+bool hip_alive() { return !g_exiting.load(); }
+
+// an entry point that allocates host memory (std::vector, std::string, new) ends with SNPM_GUARD(ctx): no C++
+// exception crosses the C ABI (ctypes would call std::terminate)
+#define SNPM_GUARD(CTX)                                                                              \
+    catch (const std::bad_alloc &) { return set_err((CTX), SNPM_ERR_OOM, "out of host memory"); }    \
+    catch (const std::exception &e_) { return set_err((CTX), SNPM_ERR_STATE, "internal error: %s", e_.what()); } \
+    catch (...) { return set_err((CTX), SNPM_ERR_STATE, "internal error"); }
+
+// handles whose context (panel: or panel, query) is gone: every entry point except the matching free refuses them
+#define CHECK_PANEL(P)                                                                               \
+    do {                                                                                             \
+        if (!(P)) return set_err(nullptr, SNPM_ERR_BADARG, "panel is NULL");                         \
+        if (!(P)->ctx) return set_err(nullptr, SNPM_ERR_STATE, "panel outlived its context (snpm_destroy was called)"); \
+    } while (0)
+#define CHECK_QUERY(Q)                                                                               \
+    do {                                                                                             \
+        if (!(Q)) return set_err(nullptr, SNPM_ERR_BADARG, "query is NULL");                         \
+        if (!(Q)->panel || !(Q)->panel->ctx)                                                         \
+            return set_err(nullptr, SNPM_ERR_STATE, "query outlived its panel or context");          \
     } while (0)
 
 int ensure(snpm_ctx *ctx, Buf &b, size_t bytes)
@@ -241,7 +280,8 @@ int wait_upload(snpm_panel *p)
     // make the compute stream wait for any pending staging copies into this panel
     if (p->upload_pending) {
         HIPCHK(p->ctx, hipStreamWaitEvent(p->ctx->stream, p->uploaded, 0));
-    }
+        p->upload_pending = false;      // the compute stream is ordered after the upload from here on
+    }                                   // (snpm_set_stream drains the copy stream before switching streams)
     return SNPM_OK;
 }
 
@@ -545,6 +585,7 @@ int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64
         const int64_t total = n_seg * ncols;
         dim3 sgrid((unsigned)((total + 255) / 256));
         if (q->n >= ctx->acc_major_min_rows && ensure_acc_major(p)) {
+            q->reeval_path = 1;
             ProfScope ps(ctx, PK_STRICT);
 #define LAUNCH_SPARSE_T(S, G)                                                                                      \
     hipLaunchKernelGGL((k_strict_sparse_T<S, G>), sgrid, dim3(256), 0, ctx->stream, p->dT, p->pitchT, q->d_row_idx, \
@@ -559,6 +600,7 @@ int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64
             HIPCHK(ctx, hipGetLastError());
             return SNPM_OK;
         }
+        q->reeval_path = 2;
         ProfScope ps(ctx, PK_STRICT);
 #define LAUNCH_SPARSE(S, G)                                                                                        \
     hipLaunchKernelGGL((k_strict_sparse<S, G>), sgrid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->packed, q->d_row_idx, \
@@ -702,6 +744,11 @@ static int stage_rows(snpm_panel *p, int64_t row0, int64_t nrows, Fill fill)
     if (rc) return rc;
     rc = ensure(ctx, ctx->ws_flags2, sizeof(int));
     if (rc) return rc;
+    // rows about to be overwritten may still be read by scoring kernels queued on the compute stream (async
+    // run_device, a caller-provided stream): the copy stream waits for everything queued there so far
+    if (!ctx->compute_mark) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->compute_mark, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventRecord(ctx->compute_mark, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->compute_mark, 0));
     if (p->packed) HIPCHK(ctx, hipMemsetAsync(ctx->ws_flags2.p, 0, sizeof(int), ctx->copy_stream));
     const int64_t spitch = p->n_acc;                                   // staged rows are tight
     const int64_t slab_rows = std::max<int64_t>(1, (int64_t)(snpm_ctx::kStageBytes / (size_t)spitch));
@@ -785,7 +832,7 @@ int snpm_device_count(int *count)
 const char *snpm_last_error(const snpm_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
 
 int snpm_init(int device_id, snpm_ctx **out)
-{
+try {
     if (!out) return set_err(nullptr, SNPM_ERR_BADARG, "out is NULL");
     *out = nullptr;
     int n = 0;
@@ -796,6 +843,8 @@ int snpm_init(int device_id, snpm_ctx **out)
     if (device_id < 0 || device_id >= n)
         return set_err(nullptr, SNPM_ERR_BADARG, "device_id %d out of range (0..%d)", device_id, n - 1);
     HIPCHK(nullptr, hipSetDevice(device_id));
+    static std::atomic<bool> exit_hook{false};
+    if (!exit_hook.exchange(true)) std::atexit(mark_exiting);      // after the HIP runtime's own registrations
     snpm_ctx *ctx = new snpm_ctx();
     ctx->device = device_id;
     hipDeviceProp_t prop;
@@ -822,28 +871,67 @@ int snpm_init(int device_id, snpm_ctx **out)
     if (const char *s = getenv("SNPM_STAGE_THREADS")) ctx->stage_threads = std::max(1, atoi(s));
     *out = ctx;
     return SNPM_OK;
+} SNPM_GUARD(nullptr)
+
+// device buffers of a query go back to the context (cache) or to the driver; the handle stays valid for its free
+static void orphan_query(snpm_query *q, bool use_hip)
+{
+    snpm_ctx *ctx = q->panel ? q->panel->ctx : nullptr;
+    if (use_hip && ctx) {
+        while (!q->owned.empty()) query_release(q, q->owned.back().p);
+    } else {
+        q->owned.clear();
+    }
+    q->d_row_idx = nullptr; q->d_w = nullptr; q->d_lut = nullptr; q->d_score = nullptr; q->d_ninfo = nullptr;
+    q->own_score = nullptr; q->own_ninfo = nullptr; q->d_wbits = nullptr; q->d_chunk_off = nullptr;
+    q->panel = nullptr;
+}
+
+// device memory of a panel is released, its queries are orphaned; the handle stays valid for snpm_panel_free
+static void orphan_panel(snpm_panel *p, bool use_hip)
+{
+    for (snpm_query *q : p->queries) orphan_query(q, use_hip);
+    p->queries.clear();
+    if (use_hip) {
+        if (p->d) (void)hipFree(p->d);
+        if (p->dT) (void)hipFree(p->dT);
+        if (p->uploaded) (void)hipEventDestroy(p->uploaded);
+    }
+    p->d = nullptr;
+    p->dT = nullptr;
+    p->uploaded = nullptr;
+    p->ctx = nullptr;
 }
 
 int snpm_destroy(snpm_ctx *ctx)
 {
     if (!ctx) return SNPM_OK;
-    (void)hipSetDevice(ctx->device);
-    (void)hipDeviceSynchronize();
-    for (auto &c : ctx->qcache) (void)hipFree(c.p);
-    ctx->qcache.clear();
-    Buf *bufs[] = {&ctx->ws_stage_dev, &ctx->ws_flags2, &ctx->ws_grp_score, &ctx->ws_grp_miss, &ctx->ws_part_score, &ctx->ws_part_miss, &ctx->ws_seg_score, &ctx->ws_seg_miss, &ctx->ws_seg_off,
-                   &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
-                   &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r};
-    for (Buf *b : bufs)
-        if (b->p) (void)hipFree(b->p);
-    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
-    for (int i = 0; i < 2; ++i) {
-        if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
-        if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
+    const bool use_hip = hip_alive();
+    if (use_hip) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipDeviceSynchronize();
     }
-    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
-    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    // panels and queries created from this context may be freed later (or never): they become orphans now
+    for (snpm_panel *p : ctx->panels) orphan_panel(p, use_hip);
+    ctx->panels.clear();
+    if (use_hip) {
+        for (auto &c : ctx->qcache) (void)hipFree(c.p);
+        Buf *bufs[] = {&ctx->ws_stage_dev, &ctx->ws_flags2, &ctx->ws_grp_score, &ctx->ws_grp_miss, &ctx->ws_part_score, &ctx->ws_part_miss, &ctx->ws_seg_score, &ctx->ws_seg_miss, &ctx->ws_seg_off,
+                       &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
+                       &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r};
+        for (Buf *b : bufs)
+            if (b->p) (void)hipFree(b->p);
+        if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+        for (int i = 0; i < 2; ++i) {
+            if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
+            if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
+        }
+        for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+        if (ctx->compute_mark) (void)hipEventDestroy(ctx->compute_mark);
+        if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+        if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    ctx->qcache.clear();
     delete ctx;
     return SNPM_OK;
 }
@@ -853,6 +941,7 @@ int snpm_set_stream(snpm_ctx *ctx, void *hip_stream)
     if (!ctx) return SNPM_ERR_BADARG;
     // work queued on the old stream (and the cached query buffers it may still use) finishes before the switch
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));   // uploads in flight were only ordered against the old stream
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return SNPM_OK;
@@ -868,7 +957,7 @@ int snpm_synchronize(snpm_ctx *ctx)
 
 // ---------------------------------------------------------------------------------------------- panel
 static int panel_create_fmt(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, int packed, snpm_panel **out)
-{
+try {
     if (!ctx) return SNPM_ERR_BADARG;
     CHECK_ARG(ctx, out != nullptr, "out is NULL");
     CHECK_ARG(ctx, n_snp >= 0 && n_acc >= 1, "panel needs n_snp >= 0 and n_acc >= 1");
@@ -893,9 +982,10 @@ static int panel_create_fmt(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, int pac
         delete p;
         return set_err(ctx, SNPM_ERR_HIP, "hipEventCreate failed");
     }
+    ctx->panels.push_back(p);
     *out = p;
     return SNPM_OK;
-}
+} SNPM_GUARD(ctx)
 
 int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out)
 {
@@ -917,19 +1007,24 @@ int snpm_panel_is_packed(const snpm_panel *p, int *packed)
 int snpm_panel_free(snpm_panel *p)
 {
     if (!p) return SNPM_OK;
-    (void)hipSetDevice(p->ctx->device);
-    (void)hipStreamSynchronize(p->ctx->copy_stream);
-    (void)hipStreamSynchronize(p->ctx->stream);
-    if (p->d) (void)hipFree(p->d);
-    if (p->dT) (void)hipFree(p->dT);
-    if (p->uploaded) (void)hipEventDestroy(p->uploaded);
+    snpm_ctx *ctx = p->ctx;
+    if (ctx) {                              // NULL: the context was destroyed first, the device memory went with it
+        const bool use_hip = hip_alive();
+        if (use_hip) {
+            (void)hipSetDevice(ctx->device);
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+        ctx->panels.erase(std::remove(ctx->panels.begin(), ctx->panels.end(), p), ctx->panels.end());
+        orphan_panel(p, use_hip);
+    }
     delete p;
     return SNPM_OK;
 }
 
 int snpm_panel_info(const snpm_panel *p, int64_t *n_snp, int64_t *n_acc, int64_t *pitch, void **device_ptr)
 {
-    if (!p) return SNPM_ERR_BADARG;
+    CHECK_PANEL(p);
     if (n_snp) *n_snp = p->n_snp;
     if (n_acc) *n_acc = p->n_acc;
     if (pitch) *pitch = p->pitch;
@@ -938,8 +1033,8 @@ int snpm_panel_info(const snpm_panel *p, int64_t *n_snp, int64_t *n_acc, int64_t
 }
 
 int snpm_panel_upload_rows(snpm_panel *p, int64_t row0, int64_t nrows, const int8_t *host, int64_t host_pitch)
-{
-    if (!p) return SNPM_ERR_BADARG;
+try {
+    CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
     CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "upload rows outside the panel");
     CHECK_ARG(ctx, nrows == 0 || host != nullptr, "host pointer is NULL");
@@ -965,14 +1060,14 @@ int snpm_panel_upload_rows(snpm_panel *p, int64_t row0, int64_t nrows, const int
         }
         return SNPM_OK;
     });
-}
+} SNPM_GUARD((p ? p->ctx : nullptr))
 
 // Rows [row0, row0+nrows) straight from a file of tightly packed int8 rows (n_acc bytes per row) starting at
 // byte `file_offset` (e.g. the data section of the .npy inside a native flat panel): pread() into the pinned
 // slabs, no intermediate host copy.
 int snpm_panel_load_file(snpm_panel *p, const char *path, int64_t file_offset, int64_t row0, int64_t nrows)
-{
-    if (!p) return SNPM_ERR_BADARG;
+try {
+    CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
     CHECK_ARG(ctx, path != nullptr && file_offset >= 0, "bad file arguments");
     CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "load rows outside the panel");
@@ -1013,11 +1108,11 @@ int snpm_panel_load_file(snpm_panel *p, const char *path, int64_t file_offset, i
     });
     close(fd);
     return rc;
-}
+} SNPM_GUARD((p ? p->ctx : nullptr))
 
 int snpm_panel_upload_wait(snpm_panel *p)
 {
-    if (!p) return SNPM_ERR_BADARG;
+    CHECK_PANEL(p);
     HIPCHK(p->ctx, hipStreamSynchronize(p->ctx->copy_stream));
     p->upload_pending = false;
     p->ctx->stage_busy[0] = p->ctx->stage_busy[1] = false;
@@ -1026,7 +1121,7 @@ int snpm_panel_upload_wait(snpm_panel *p)
 
 int snpm_panel_download_rows(snpm_panel *p, int64_t row0, int64_t nrows, int8_t *host, int64_t host_pitch)
 {
-    if (!p) return SNPM_ERR_BADARG;
+    CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
     CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "download rows outside the panel");
     CHECK_ARG(ctx, host_pitch >= p->n_acc, "host_pitch smaller than n_acc");
@@ -1059,7 +1154,7 @@ int snpm_panel_download_rows(snpm_panel *p, int64_t row0, int64_t nrows, int8_t 
 
 int snpm_panel_fill_synthetic(snpm_panel *p, uint64_t seed, int64_t snp0, int64_t acc0)
 {
-    if (!p) return SNPM_ERR_BADARG;
+    CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
     CHECK_ARG(ctx, (acc0 & 3) == 0 && acc0 >= 0 && snp0 >= 0, "acc0 must be a non-negative multiple of 4");
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1085,8 +1180,8 @@ int snpm_panel_fill_synthetic(snpm_panel *p, uint64_t seed, int64_t snp0, int64_
 // ---------------------------------------------------------------------------------------------- query
 int snpm_query_create(snpm_panel *p, const int64_t *row_idx, int64_t row0, int64_t n, const double *wei,
                       snpm_query **out)
-{
-    if (!p) return SNPM_ERR_BADARG;
+try {
+    CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
     CHECK_ARG(ctx, out != nullptr, "out is NULL");
     CHECK_ARG(ctx, n >= 0, "n must be >= 0");
@@ -1102,6 +1197,7 @@ int snpm_query_create(snpm_panel *p, const int64_t *row_idx, int64_t row0, int64
     HIPCHK(ctx, hipSetDevice(ctx->device));
     snpm_query *q = new snpm_query();
     q->panel = p;
+    p->queries.push_back(q);
     q->n = n;
     q->row0 = row_idx ? 0 : row0;
     const size_t nn = (size_t)std::max<int64_t>(n, 1);
@@ -1162,21 +1258,25 @@ int snpm_query_create(snpm_panel *p, const int64_t *row_idx, int64_t row0, int64
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host buffers may be released by the caller
     *out = q;
     return SNPM_OK;
-}
+} SNPM_GUARD((p ? p->ctx : nullptr))
 
 int snpm_query_free(snpm_query *q)
 {
     if (!q) return SNPM_OK;
-    snpm_ctx *ctx = q->panel->ctx;
-    (void)hipSetDevice(ctx->device);
-    while (!q->owned.empty()) query_release(q, q->owned.back().p);
+    snpm_panel *p = q->panel;
+    if (p) {                                // NULL: the panel or the context went first
+        const bool use_hip = hip_alive() && p->ctx;
+        if (use_hip) (void)hipSetDevice(p->ctx->device);
+        p->queries.erase(std::remove(p->queries.begin(), p->queries.end(), q), p->queries.end());
+        orphan_query(q, use_hip);
+    }
     delete q;
     return SNPM_OK;
 }
 
 int snpm_query_bind_outputs(snpm_query *q, void *d_score, void *d_ninfo)
 {
-    if (!q) return SNPM_ERR_BADARG;
+    CHECK_QUERY(q);
     snpm_ctx *ctx = q->panel->ctx;
     CHECK_ARG(ctx, (d_score == nullptr) == (d_ninfo == nullptr), "bind both outputs or neither");
     q->d_score = d_score ? (double *)d_score : q->own_score;
@@ -1185,8 +1285,9 @@ int snpm_query_bind_outputs(snpm_query *q, void *d_score, void *d_ninfo)
 }
 
 int snpm_query_error_bound(snpm_query *q, int64_t chunk, double *bound)
-{
-    if (!q || !bound) return SNPM_ERR_BADARG;
+try {
+    CHECK_QUERY(q);
+    if (!bound) return SNPM_ERR_BADARG;
     snpm_ctx *ctx = q->panel->ctx;
     CHECK_ARG(ctx, chunk >= 1, "chunk must be >= 1");
     if (q->all_integer) { *bound = 0.0; return SNPM_OK; }
@@ -1197,12 +1298,12 @@ int snpm_query_error_bound(snpm_query *q, int64_t chunk, double *bound)
     FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl, p16 ? P16_TILE_ROWS : TILE_ROWS);   // occ 1 -> longest parts -> largest bound
     *bound = eref + efast_bound(q, g);
     return SNPM_OK;
-}
+} SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
 
 int snpm_query_run_device(snpm_query *q, int64_t chunk, int skip_hets, int mode, void **d_score, void **d_ninfo,
                           int64_t *info)
-{
-    if (!q) return SNPM_ERR_BADARG;
+try {
+    CHECK_QUERY(q);
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
     CHECK_ARG(ctx, chunk >= 1, "chunk must be >= 1");
@@ -1291,11 +1392,11 @@ int snpm_query_run_device(snpm_query *q, int64_t chunk, int skip_hets, int mode,
     if (info) {
         info[0] = n_flag;
         info[1] = q->all_integer ? 1 : 0;
-        info[2] = 0;
+        info[2] = n_flag > 0 ? q->reeval_path : 0;
         info[3] = 0;
     }
     return SNPM_OK;
-}
+} SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
 
 int snpm_query_run(snpm_query *q, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo, int64_t *info)
 {
@@ -1311,8 +1412,8 @@ int snpm_query_run(snpm_query *q, int64_t chunk, int skip_hets, int mode, double
 
 int snpm_query_run_windows(snpm_query *q, const int64_t *win_off, int64_t n_win, int skip_hets, double *score,
                            int64_t *ninfo, double *tot_score, int64_t *tot_ninfo)
-{
-    if (!q) return SNPM_ERR_BADARG;
+try {
+    CHECK_QUERY(q);
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
     CHECK_ARG(ctx, n_win >= 0 && win_off != nullptr, "window offsets missing");
@@ -1365,7 +1466,7 @@ int snpm_query_run_windows(snpm_query *q, const int64_t *win_off, int64_t n_win,
     }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SNPM_OK;
-}
+} SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
 
 // ---------------------------------------------------------------------------------------------- one-shot
 int snpm_score_dense_host(snpm_ctx *ctx, const int8_t *db, int64_t db_pitch, int64_t n, int64_t n_acc,
@@ -1535,7 +1636,7 @@ int snpm_intersect_sorted_search(const int64_t *a, int64_t na, const int64_t *b,
 // identify_segregating_snps on the resident panel: mask [n_snp] (host, uint8)
 int snpm_panel_segregating(snpm_panel *p, const int32_t *cols, int64_t ncols, uint8_t *mask)
 {
-    if (!p) return SNPM_ERR_BADARG;
+    CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
     CHECK_ARG(ctx, ncols >= 1 && cols && mask, "provide an np array for list of indices to be considered");
     for (int64_t i = 0; i < ncols; ++i) CHECK_ARG(ctx, cols[i] >= 0 && cols[i] < p->n_acc, "accession index outside the panel");
@@ -1557,8 +1658,8 @@ int snpm_panel_segregating(snpm_panel *p, const int32_t *cols, int64_t ncols, ui
 // match_insilico_f1s (core/csmatch.py:115-125) on the resident panel: scores of all pairs of the selected
 // accessions over the query's rows, in numpy's summation order (k_f1_* in snpm_kernels.hpp)
 int snpm_query_f1_pairs(snpm_query *q, const int32_t *acc_idx, int n_sel, double *score, int64_t *ninfo)
-{
-    if (!q) return SNPM_ERR_BADARG;
+try {
+    CHECK_QUERY(q);
     snpm_panel *p = q->panel;
     snpm_ctx *ctx = p->ctx;
     CHECK_ARG(ctx, n_sel >= 0 && n_sel <= F1_MAX_SEL, "between 0 and 32 accessions can be crossed in silico");
@@ -1637,12 +1738,12 @@ int snpm_query_f1_pairs(snpm_query *q, const int32_t *acc_idx, int n_sel, double
     HIPCHK(ctx, hipMemcpyAsync(ninfo, d_ninfo, (size_t)n_pairs * sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     return SNPM_OK;
-}
+} SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
 
 // PMC calibration helper: stream the whole panel once (known byte count = n_snp * pitch)
 int snpm_debug_stream_read(snpm_panel *p, int64_t *bytes_read)
 {
-    if (!p) return SNPM_ERR_BADARG;
+    CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = ensure(ctx, ctx->ws_flags, sizeof(int));

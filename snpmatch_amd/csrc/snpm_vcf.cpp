@@ -11,6 +11,8 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -105,13 +107,15 @@ int read_all(const char *path, std::string &data)
 
 extern "C" {
 
+// No C++ exception leaves this function (ctypes would turn it into std::terminate): running out of host memory
+// on a very large file is reported as SNPM_ERR_STATE, i.e. "use the generic reader", like any other declined file.
 int snpm_vcf_parse(const char *path, int sample_index, snpm_vcf **out)
-{
+try {
     if (!path || !out || sample_index < 0 || sample_index > 4000) return SNPM_ERR_BADARG;
     std::string data;
     int rc = read_all(path, data);
     if (rc) return rc;
-    snpm_vcf *v = new snpm_vcf();
+    std::unique_ptr<snpm_vcf> v(new snpm_vcf());
     v->chr_off.push_back(0);
     v->gt_off.push_back(0);
     const char *s = data.data(), *end = s + data.size();
@@ -206,12 +210,11 @@ int snpm_vcf_parse(const char *path, int sample_index, snpm_vcf **out)
         v->pl.push_back(pl[1]);
         v->pl.push_back(pl[2]);
     }
-    if (!ok) {
-        delete v;
-        return SNPM_ERR_STATE;
-    }
-    *out = v;
+    if (!ok) return SNPM_ERR_STATE;
+    *out = v.release();
     return SNPM_OK;
+} catch (...) {
+    return SNPM_ERR_STATE;
 }
 
 int snpm_vcf_dims(const snpm_vcf *v, int64_t *n_records, int *chr_width, int *gt_width, int *flags, int *n_samples)

@@ -2,6 +2,7 @@
 Thin object layer over the C ABI: Context (one GPU), Panel (DB genotype matrix resident in HBM),
 Query (one sample's matched SNPs resident in HBM).  All compute happens in libsnpmatch_hip.so.
 """
+import atexit
 import ctypes as C
 import weakref
 
@@ -23,6 +24,12 @@ class Context(object):
         self.h = h
         self.device_id = int(device_id)
         self._children = weakref.WeakSet()      # panels and queries: freed before the context
+        # every context is closed before the interpreter (and with it the HIP runtime) goes down, also when the
+        # script ends with an exception; the weak reference keeps the hook from pinning the object.  The library
+        # tolerates the other order too (snpm_destroy orphans live panels / queries, include/snpmatch_hip.h).
+        ref = weakref.ref(self)
+        self._atexit = lambda: (ref() is not None) and ref().close()
+        atexit.register(self._atexit)
 
     def close(self):
         if self.h:
@@ -35,6 +42,10 @@ class Context(object):
                     k.free()
             self.lib.snpm_destroy(self.h)
             self.h = None
+            try:
+                atexit.unregister(self._atexit)
+            except Exception:
+                pass
 
     def __del__(self):
         try:
@@ -131,9 +142,7 @@ def default_context():
     if _default_ctx is None:
         import os
         dev = int(os.environ.get("SNPMATCH_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-        _default_ctx = Context(dev)
-        import atexit
-        atexit.register(_default_ctx.close)     # free device objects before the HIP runtime unloads
+        _default_ctx = Context(dev)         # closed at interpreter exit by its own atexit hook
     return _default_ctx
 
 

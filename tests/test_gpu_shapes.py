@@ -1,0 +1,122 @@
+"""
+The per-GPU shapes of BASELINE.json configs[3] and configs[4] under test (-m gpu), through size-independent
+properties plus the C oracle on a few whole columns:
+
+  * 1252 accessions x 50M SNPs int8 (64 GB): the shard every rank of the 8-GPU run of configs[3] holds
+    (5-wave blocks with the resident-block cap, 8 accumulation epochs per part, 50 000 reference chunks);
+  * 12 500 accessions x 16M SNPs int8 (200 GB): the per-GPU slab of configs[4] (the accession-major copy does
+    not fit beside it, so the re-evaluation takes the SNP-major path).
+
+Both contexts run with SNPM_DEBUG_REEVAL=2: accessions 0 and 1 are re-evaluated in reference order in every
+certified run, so k_pack_transpose + k_strict_sparse_T (or the strided k_strict_sparse) + k_scan_few + k_patch
+execute at full length whether or not the certificate flags anything.  Reference: core/snpmatch.py:207-233.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import snpmatch_oracle as orc
+from snpmatch_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+SEED = 10050
+BLOCK = 1_250_000
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def twin_quad(n_snp, acc0, c4):
+    """columns [c4, c4 + 4) of the shard starting at accession acc0, all n_snp rows, from the numpy twin"""
+    return np.concatenate([synth.panel_values(SEED, r0, min(BLOCK, n_snp - r0), acc0 + c4, 4)
+                           for r0 in range(0, n_snp, BLOCK)])
+
+
+def reeval_context():
+    os.environ["SNPM_DEBUG_REEVAL"] = "2"
+    try:
+        return engine.Context(0)
+    finally:
+        del os.environ["SNPM_DEBUG_REEVAL"]
+
+
+def check_shape(n_snp, n_acc, acc0, planted, oracle_quads, ninfo_quads):
+    ctx = reeval_context()
+    try:
+        panel = engine.Panel(ctx, n_snp, n_acc)
+        panel.fill_synthetic(SEED, 0, acc0)
+        # (1) all-ones weights: every informative call matches exactly one class -> score == ninfo (fast and
+        #     certified mode agree; integer weights need no re-evaluation)
+        q = engine.Query(panel, None, np.ones((n_snp, 3)))
+        s, ni, info = q.run(1000, False, engine.MODE_EXACT, return_info=True)
+        assert info["all_integer_weights"] and info["n_strict_reeval"] == 0
+        assert np.array_equal(s, ni.astype(np.float64)) and ni.min() > 0.94 * n_snp
+        s2, ni2 = q.run(1000, False, engine.MODE_FAST)
+        assert np.array_equal(s2, s) and np.array_equal(ni2, ni)
+        q.free()
+        # (2) informative counts of whole accession quads against the numpy twin of the generator
+        quads = {}
+        for c4 in sorted(set(ninfo_quads) | set(oracle_quads) | {planted // 4 * 4}):
+            quads[c4] = twin_quad(n_snp, acc0, c4)
+        for c4 in ninfo_quads:
+            assert np.array_equal(ni[c4:c4 + 4], n_snp - (quads[c4] < 0).sum(axis=0)), c4
+        # (3) a hard-call sample planted on one accession matches it perfectly and is the unique top hit
+        p4 = planted // 4 * 4
+        col = quads[p4][:, planted - p4]
+        codes = col.copy()
+        codes[codes < 0] = 0
+        hard = orc.weights_from_gt_codes(codes)
+        s, ni = engine.Query(panel, None, hard).run(1000, False, engine.MODE_EXACT)
+        assert s[planted] == ni[planted] and int(np.argmax(s / ni)) == planted
+        lik, lrt = ctx.likelihood(s, ni, truncate=True)
+        assert lik[planted] == 1.0 and (lrt < 3.841).sum() == 1
+        del hard
+        # (4) mixed PL weights over the whole SNP axis: certified counts == reference-order counts for every
+        #     accession; the forced re-evaluation of accessions 0, 1 carries the reference's bits; whole columns
+        #     agree with the C oracle bit for bit
+        rng = np.random.default_rng(n_acc)
+        _, wpl = synth.planted_sample(rng, col, 0.02)
+        q = engine.Query(panel, None, wpl)
+        bound = q.error_bound(1000)
+        assert 0 < bound < 1e-2
+        se, ne, info = q.run(1000, False, engine.MODE_EXACT, return_info=True)
+        assert 2 <= info["n_strict_reeval"] < 60
+        ss, ns = q.run(1000, False, engine.MODE_STRICT)
+        assert np.array_equal(ne, ns)
+        assert np.array_equal(np.array(se, dtype=np.int64), np.array(ss, dtype=np.int64))
+        assert np.max(np.abs(se - ss)) <= bound
+        assert np.array_equal(bits(se[:2]), bits(ss[:2]))              # re-evaluated columns are patched in
+        for c4 in oracle_quads:
+            ws, wn = c_oracle.genotyper(quads[c4], None, wpl, 1000, False)
+            assert np.array_equal(bits(ss[c4:c4 + 4]), bits(ws)) and np.array_equal(ns[c4:c4 + 4], wn), c4
+            assert np.array_equal(np.array(se[c4:c4 + 4], dtype=np.int64), np.array(ws, dtype=np.int64)), c4
+        assert int(np.argmax(se / ne)) == planted
+        # skip_hets: hets of the DB count as missing (core/snpmatch.py:78-79)
+        sk, nk = q.run(1000, True, engine.MODE_EXACT)
+        c4 = oracle_quads[0]
+        ws, wn = c_oracle.genotyper(quads[c4], None, wpl, 1000, True)
+        assert np.array_equal(nk[c4:c4 + 4], wn)
+        assert np.array_equal(np.array(sk[c4:c4 + 4], dtype=np.int64), np.array(ws, dtype=np.int64))
+        q.free()
+        panel.free()
+    finally:
+        ctx.close()
+
+
+def test_config3_per_gpu_shard_1252_x_50M():
+    """rank 0's shard of the 8-GPU run (accessions 0..1251 of 10 000, all 50M SNPs)"""
+    check_shape(50_000_000, 1252, 0, planted=417, oracle_quads=[0, 416], ninfo_quads=[0, 1248])
+
+
+def test_config3_last_rank_shard_1236_x_50M():
+    """rank 7's shard: 10 000 - 7 * 1252 = 1236 accessions starting at accession 8764 (uneven shards)"""
+    check_shape(50_000_000, 1236, 8764, planted=1001, oracle_quads=[1000], ninfo_quads=[1232])
+
+
+def test_config4_per_gpu_slab_12500_x_16M():
+    """the per-GPU slab of configs[4] (100k x 100M over 8 GPUs: 12 500 accessions x <= 16M SNPs, 200 GB)"""
+    check_shape(16_000_000, 12_500, 0, planted=417, oracle_quads=[0, 416], ninfo_quads=[0, 12_496])
