@@ -62,6 +62,7 @@ extern "C" {
 typedef struct snpm_ctx   snpm_ctx;
 typedef struct snpm_panel snpm_panel;
 typedef struct snpm_query snpm_query;
+typedef struct snpm_carry snpm_carry;
 
 /* ---------------------------------------------------------------- lifecycle */
 int         snpm_version(void);
@@ -100,25 +101,47 @@ int snpm_panel_download_rows(snpm_panel *panel, int64_t row0, int64_t nrows, int
    (seed, snp0 + row, acc0 + col) with P(-1,0,1,2) = (3277, 39321, 21627, 1311)/65536.
    snpmatch_amd.synth.panel_values() is the numpy twin used by the tests. */
 int snpm_panel_fill_synthetic(snpm_panel *panel, uint64_t seed, int64_t snp0, int64_t acc0);
+/* the same for panel rows [row0, row0 + nrows) only: row r receives SNP snp0 + (r - row0) of the synthetic panel
+   (slab-streamed benchmarks refill a resident buffer with the next SNP slab) */
+int snpm_panel_fill_synthetic_rows(snpm_panel *panel, uint64_t seed, int64_t snp0, int64_t acc0, int64_t row0, int64_t nrows);
+/* Device-side synthetic sample for benchmarks (the recipe of SURVEY 8d, no host pass over the SNP axis): rows
+   [snp0, snp0 + n) of accession `planted` of the synthetic panel `seed`, with a fraction err_permille / 1000 of the
+   calls replaced at random; pl_permille / 1000 of the rows get PL-derived weights exp(-PL/10) (integer PL 1..255, 0
+   for the called genotype), the others hard 0/1 weights.  d_wei: DEVICE float64 [n, 3].  exp_table: HOST float64
+   [256], exp_table[k] = exp(-k / 10) as the caller's libm rounds it (so that a host twin reproduces the bits);
+   snpmatch_amd.synth.sample_weights_twin() is that twin. */
+int snpm_sample_synthetic(snpm_ctx *ctx, uint64_t seed, int64_t snp0, int64_t n, int64_t planted, int err_permille,
+                          int pl_permille, const double *exp_table, void *d_wei);
 
 /* ---------------------------------------------------------------- query (one sample's matched SNPs, resident) */
 /* row_idx: int64 [n] panel rows matched by the sample (commonSNPs[0]); NULL = the dense range
    [row0, row0+n).  wei: float64 [n,3] = inputs.wei[commonSNPs[1]].  Both are copied to the device. */
 int snpm_query_create(snpm_panel *panel, const int64_t *row_idx, int64_t row0, int64_t n,
                       const double *wei, snpm_query **out);
+/* The same query from DEVICE arrays (int64 row list or NULL, float64 [n,3] weights); both are copied.  The row
+   indices are not read back: the caller guarantees that they lie inside the panel. */
+int snpm_query_create_device(snpm_panel *panel, const void *d_row_idx, int64_t row0, int64_t n, const void *d_wei,
+                             snpm_query **out);
 int snpm_query_free(snpm_query *query);
 
 /* Genotyper.genotyper over the whole matched list with `chunk`-row matchGTsAccs calls (1000 in the
    reference).  Outputs (host pointers, may be NULL): score float64 [n_acc] (ScoreList before the int
    truncation), ninfo int64 [n_acc].  info (may be NULL), int64 [4]:
    [0] accessions re-evaluated in strict order, [1] 1 if all weights are integers (any order exact),
-   and double bound via snpm_query_error_bound.  */
+   [2] how they were re-read (1 accession-major copy, 2 SNP-major strided, 3 every accession: more than 64 flagged);
+   the bound itself via snpm_query_error_bound.
+   SNPM_MODE_EXACT never waits for the certificate on the host: the accessions the fast pass cannot vouch for
+   are flagged by the last reduce kernel, and the re-evaluation kernels queued behind it read that list on the
+   device (asking for `info` costs one synchronisation).  */
 int snpm_query_run(snpm_query *query, int64_t chunk, int skip_hets, int mode,
                    double *score, int64_t *ninfo, int64_t *info);
 /* Same, leaving results in device memory (pointers owned by the query, valid until the next run /
    free): d_score float64 [n_acc], d_ninfo int64 [n_acc].  Work is enqueued on the ctx stream. */
 int snpm_query_run_device(snpm_query *query, int64_t chunk, int skip_hets, int mode,
                           void **d_score, void **d_ninfo, int64_t *info);
+/* number of accessions the last certified run re-evaluated (synchronises), name of its scoring kernel */
+int snpm_query_last_reeval(snpm_query *query, int64_t *n_flagged);
+const char *snpm_query_last_kernel(const snpm_query *query);
 /* Redirect the results of subsequent runs into caller-owned DEVICE buffers (e.g. torch tensors that
    feed an RCCL all-gather): d_score float64 [n_acc], d_ninfo int64 [n_acc].  NULL, NULL restores the
    query's own buffers. */
@@ -132,6 +155,34 @@ int snpm_query_error_bound(snpm_query *query, int64_t chunk, double *bound);
    window: tot_score float64 [n_acc], tot_ninfo int64 [n_acc]. */
 int snpm_query_run_windows(snpm_query *query, const int64_t *win_off, int64_t n_win, int skip_hets,
                            double *score, int64_t *ninfo, double *tot_score, int64_t *tot_ninfo);
+
+/* ---------------------------------------------------------------- jobs larger than HBM: SNP slab after SNP slab */
+/* The reference walks the whole SNP axis in `chunk`-row pieces and adds every piece onto ScoreList / NumInfoSites
+   (core/snpmatch.py:218-225).  When the panel does not fit in HBM the caller loads (or regenerates) one SNP slab
+   after the other into a resident panel, makes a query of the slab's rows and weights, and scores it with a
+   snpm_carry that holds the running totals:
+     STRICT  the chain of additions continues across slabs: fp64 bits of the reference over the whole job;
+     EXACT / FAST  fast pass per slab, totals added in slab order; the error bounds of the slabs add up
+             (chunks_after = number of `chunk`-row pieces in the slabs still to come, they lengthen the reference's
+             chain) and snpm_carry_finish certifies the TOTALS: it returns the accessions whose int(score) is not
+             yet proven.  For those the caller streams the slabs once more through a second, column-list carry
+             (snpm_carry_set_columns + snpm_query_run_carry in STRICT mode) and patches the result in
+             (snpm_carry_patch); more than 64 flagged: a second pass in STRICT mode over all accessions.
+   Every slab but the last must hold a multiple of `chunk` rows.  snpmatch_amd.engine.SlabScorer drives this. */
+int snpm_carry_create(snpm_ctx *ctx, int64_t n_acc, snpm_carry **out);
+int snpm_carry_reset(snpm_carry *carry);
+int snpm_carry_free(snpm_carry *carry);
+/* keep the totals in caller-owned DEVICE buffers (float64 [n_acc], int64 [n_acc]); resets the carry */
+int snpm_carry_bind_outputs(snpm_carry *carry, void *d_score, void *d_ninfo);
+int snpm_carry_set_columns(snpm_carry *carry, const int32_t *cols, int64_t ncols);
+int snpm_query_run_carry(snpm_query *query, int64_t chunk, int skip_hets, int mode, int64_t chunks_after,
+                         snpm_carry *carry);
+/* score / ninfo (host, may be NULL): the totals; flagged [cap] / n_flagged: see above (0 unless EXACT) */
+int snpm_carry_finish(snpm_carry *carry, double *score, int64_t *ninfo, int32_t *flagged, int64_t cap,
+                      int64_t *n_flagged);
+int snpm_carry_patch(snpm_carry *totals, const snpm_carry *cols_pass);
+/* device pointers of the totals (float64 [n_acc], int64 [n_acc]): input of snpm_likelihood_device / an all-gather */
+int snpm_carry_device_ptrs(snpm_carry *carry, void **d_score, void **d_ninfo);
 
 /* ---------------------------------------------------------------- one-shot forms */
 /* matchGTsAccs on host arrays: db int8 [n, n_acc] (row stride db_pitch), wei float64 [n,3].

@@ -35,6 +35,9 @@ SYMBOLS = [
     "snpm_query_f1_pairs", "snpm_intersect_sorted_search",
     "snpm_vcf_parse", "snpm_vcf_dims", "snpm_vcf_fill", "snpm_vcf_sample_name", "snpm_vcf_free",
     "snpm_debug_stream_read", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
+    "snpm_panel_fill_synthetic_rows", "snpm_sample_synthetic", "snpm_query_create_device", "snpm_query_last_reeval",
+    "snpm_query_last_kernel", "snpm_carry_create", "snpm_carry_reset", "snpm_carry_free", "snpm_carry_set_columns", "snpm_carry_bind_outputs",
+    "snpm_query_run_carry", "snpm_carry_finish", "snpm_carry_patch", "snpm_carry_device_ptrs",
 ]
 
 _lib = None
@@ -77,6 +80,21 @@ def load():
     lib.snpm_panel_upload_wait.argtypes = [p]
     lib.snpm_panel_download_rows.argtypes = [p, i64, i64, p, i64]
     lib.snpm_panel_fill_synthetic.argtypes = [p, C.c_uint64, i64, i64]
+    lib.snpm_panel_fill_synthetic_rows.argtypes = [p, C.c_uint64, i64, i64, i64, i64]
+    lib.snpm_sample_synthetic.argtypes = [p, C.c_uint64, i64, i64, i64, ci, ci, p, p]
+    lib.snpm_query_create_device.argtypes = [p, p, i64, i64, p, pp]
+    lib.snpm_query_last_reeval.argtypes = [p, C.POINTER(i64)]
+    lib.snpm_query_last_kernel.argtypes = [p]
+    lib.snpm_query_last_kernel.restype = C.c_char_p
+    lib.snpm_carry_create.argtypes = [p, i64, pp]
+    lib.snpm_carry_reset.argtypes = [p]
+    lib.snpm_carry_free.argtypes = [p]
+    lib.snpm_carry_set_columns.argtypes = [p, p, i64]
+    lib.snpm_carry_bind_outputs.argtypes = [p, p, p]
+    lib.snpm_query_run_carry.argtypes = [p, i64, ci, ci, i64, p]
+    lib.snpm_carry_finish.argtypes = [p, p, p, p, i64, C.POINTER(i64)]
+    lib.snpm_carry_patch.argtypes = [p, p]
+    lib.snpm_carry_device_ptrs.argtypes = [p, pp, pp]
     lib.snpm_query_create.argtypes = [p, p, i64, i64, p, pp]
     lib.snpm_query_free.argtypes = [p]
     lib.snpm_query_bind_outputs.argtypes = [p, p, p]

@@ -62,6 +62,7 @@ struct snpm_ctx {
     Buf ws_grp_score, ws_grp_miss, ws_stage_dev, ws_flags2;
     Buf ws_part_score, ws_part_miss, ws_seg_score, ws_seg_miss, ws_seg_off, ws_cols, ws_tmp_score, ws_tmp_ninfo, ws_flags;
     Buf ws_lik_y, ws_lik_n, ws_lik_l, ws_lik_r;
+    Buf ws_wprops, ws_epart;            // partial sums of k_wprops / k_eref
     // device buffers of freed queries, kept for the next query (hipMalloc / hipFree cost more than a small query's run)
     struct Cached { void *p; size_t cap; };
     std::vector<Cached> qcache;
@@ -88,6 +89,7 @@ struct snpm_ctx {
     // live panels of this context: snpm_destroy releases their device memory and orphans them (and their
     // queries), so that a panel / query handle freed AFTER its context is a harmless host-side delete
     std::vector<snpm_panel *> panels;
+    std::vector<snpm_carry *> carries;
 };
 
 struct snpm_panel {
@@ -106,6 +108,8 @@ struct snpm_panel {
     std::vector<snpm_query *> queries;  // live queries against this panel (orphaned when the panel goes away)
 };
 
+constexpr int REEVAL_CAP = 64;          // flagged accessions the sparse re-evaluation tier takes; more -> dense tier
+
 struct snpm_query {
     snpm_panel *panel = nullptr;
     int64_t n = 0, row0 = 0;
@@ -117,16 +121,40 @@ struct snpm_query {
     int64_t *d_ninfo = nullptr;
     double *own_score = nullptr;
     int64_t *own_ninfo = nullptr;
-    std::vector<double> wmax;           // host: max_c |W[r,c]| per matched row
-    long double wsum = 0;               // sum of wmax
+    double wsum = 0;                    // sum over rows of max_c |W[r,c]| (k_wprops)
     bool all_integer = false;
     bool hard01 = false;                // every weight is 0 or 1: scores are counts (k_fast_bits on packed panels)
     uint8_t *d_wbits = nullptr;         // [n + pad] ref | het << 1 | alt << 2 per matched row (only when hard01)
-    std::map<int64_t, double> eref_cache;  // chunk -> E_ref
-    int64_t *d_chunk_off = nullptr;        // device copy of the chunk offsets for `chunk_off_chunk`
+    // certificate state, all on the device: one small block {double eref; int count; int pad; int32 cols[REEVAL_CAP]}
+    void *d_cert = nullptr;
+    int64_t eref_chunk = -1, eref_after = -1;   // what d_cert->eref currently holds
+    bool count_valid = false;           // the last run was a certified one (count / cols are meaningful)
     std::vector<snpm_ctx::Cached> owned;   // every device buffer of this query with its capacity
-    int64_t chunk_off_chunk = -1, chunk_off_nseg = 0;
-    int reeval_path = 0;                   // last sparse re-evaluation: 1 = accession-major copy, 2 = SNP-major (strided)
+    const char *last_kernel = "";       // scoring kernel of the last run (reports)
+    int reeval_path = 0;                // sparse re-evaluation reads: 1 = accession-major copy, 2 = SNP-major (strided)
+    bool transient_panel = false;       // slab-streamed scoring: never build a transposed copy of a transient slab
+    double *cert_eref() const { return (double *)d_cert; }
+    int *cert_count() const { return (int *)((char *)d_cert + 8); }
+    int32_t *cert_cols() const { return (int32_t *)((char *)d_cert + 16); }
+};
+
+// running totals of a job scored SNP slab after SNP slab (snpm_query_run_carry)
+struct snpm_carry {
+    snpm_ctx *ctx = nullptr;
+    int64_t n_acc = 0, ld = 0;
+    double *d_score = nullptr;          // [ld] totals so far (fast-pass totals, or the reference's chain in strict mode)
+    int64_t *d_ninfo = nullptr;         // [ld]
+    double *d_E = nullptr;              // [0] sum of the slabs' error bounds (device)
+    int32_t *d_cols = nullptr;          // column-list mode (second pass): [n_cols] accessions
+    int *d_ncols = nullptr;
+    int64_t n_cols = -1;                // -1: all accessions
+    int64_t n_rows = 0, n_slabs = 0;
+    long double wsum = 0;               // of all slabs (bound of the slab-total additions)
+    int mode = -1;                      // mode of the first slab; later slabs must agree
+    bool finished = false;
+    double *own_score = nullptr;        // d_score / d_ninfo point here unless the caller bound its own buffers
+    int64_t *own_ninfo = nullptr;
+    int64_t len = 0;                    // entries of d_score / d_ninfo (ld for own buffers, n_acc for bound ones)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -465,8 +493,61 @@ int ensure_lut(snpm_query *q, int skip)
     return SNPM_OK;
 }
 
-// fast pass + ordered reduce -> q->d_score / q->d_ninfo; returns geometry used (for the error bound)
-int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
+// ---- certificate: error bounds on the device (see DESIGN.md "Exactness") -------------------------------
+// For sums of terms x_i with |x_i| <= wmax_i, a computed sum differs from the exact one by at most
+// sum_i wmax_i * gamma(m_i), gamma(m) = m*u/(1-m*u), u = 2^-53, m_i = number of fp64 additions the
+// term passes through.  Reference order: m_i <= (rows of its chunk) + 3 + (chunks left, later slabs included):
+// k_eref / k_efinish evaluate that sum where the weights live and leave it in q->cert_eref()[0].
+int ensure_pinned(snpm_ctx *ctx, size_t bytes)
+{
+    if (ctx->h_pinned_cap >= bytes) return SNPM_OK;
+    if (ctx->h_pinned) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipHostFree(ctx->h_pinned);
+    }
+    ctx->h_pinned = nullptr;
+    ctx->h_pinned_cap = 0;
+    const size_t want = std::max<size_t>(bytes, 64 << 10);
+    HIPCHK(ctx, hipHostMalloc(&ctx->h_pinned, want, hipHostMallocDefault));
+    ctx->h_pinned_cap = want;
+    return SNPM_OK;
+}
+
+int ensure_eref(snpm_query *q, int64_t chunk, int64_t chunks_after)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    if (q->eref_chunk == chunk && q->eref_after == chunks_after) return SNPM_OK;
+    const int64_t K = (q->n + chunk - 1) / chunk;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(K, 2048));
+    int rc = ensure(ctx, ctx->ws_epart, (size_t)grid * sizeof(double));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_eref, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const double *)q->d_w, q->n, chunk,
+                       chunks_after, (double *)ctx->ws_epart.p);
+    hipLaunchKernelGGL(k_efinish, dim3(1), dim3(256), 0, ctx->stream, (const double *)ctx->ws_epart.p, grid, q->n, chunk,
+                       chunks_after, q->cert_eref());
+    HIPCHK(ctx, hipGetLastError());
+    q->eref_chunk = chunk;
+    q->eref_after = chunks_after;
+    return SNPM_OK;
+}
+
+double efast_bound(const snpm_query *q, const FastGeom &g)
+{
+    const double u = 1.1102230246251565e-16;
+    // a term passes through <= EPOCH_TILES*TILE_ROWS adds inside k_fast, REDUCE_GROUP in its group, n_groups after
+    const double m = (double)(std::min<int64_t>(g.part_rows, (int64_t)EPOCH_TILES * TILE_ROWS) + REDUCE_GROUP + g.n_groups + 2);
+    return (q->wsum * (m * u / (1.0 - m * u))) * 1.0000001;
+}
+
+struct Certify {            // what the last reduce step of a fast pass should certify against (on == false: nothing)
+    bool on = false;
+    bool flag = true;       // false: only the bound is prepared (slab-streamed jobs certify their totals at the end)
+    int64_t chunk = 1000, chunks_after = 0;
+};
+
+// fast pass + ordered reduce -> q->d_score / q->d_ninfo (+ the list of accessions the certificate cannot vouch
+// for, left on the device); returns the geometry used
+int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
 {
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
@@ -491,6 +572,7 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
     else occ = nt ? occ_b<4, true>(skip, gather, thr) : occ_b<4, false>(skip, gather, thr);
     FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl, tile_rows);
     if (geom_out) *geom_out = g;
+    q->last_kernel = bits ? "k_fast_bits" : (p16 ? "k_fast_packed16" : "k_fast");
     rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_slots * p->ld * sizeof(double));
     if (rc) return rc;
     rc = ensure(ctx, ctx->ws_part_miss, (size_t)g.n_slots * p->ld * sizeof(uint32_t));
@@ -499,6 +581,13 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
     if (rc) return rc;
     rc = ensure(ctx, ctx->ws_grp_miss, (size_t)g.n_groups * p->ld * sizeof(uint32_t));
     if (rc) return rc;
+    const bool certify = cert.on && !q->all_integer && q->n > 0;
+    if (certify) {
+        rc = ensure_eref(q, cert.chunk, cert.chunks_after);
+        if (rc) return rc;
+    }
+    HIPCHK(ctx, hipMemsetAsync(q->cert_count(), 0, sizeof(int), ctx->stream));
+    q->count_valid = cert.on;
     if (q->n > 0) {
         if (g.n_epochs > 1) {
             // parts with fewer tiles never reach the last epoch slot: those slots must read as zero
@@ -527,7 +616,9 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
         }
         hipLaunchKernelGGL(k_reduce, dim3(cb), dim3(thr), 0, ctx->stream, (const double *)ctx->ws_grp_score.p,
                            (const uint32_t *)ctx->ws_grp_miss.p, n_groups, p->ld, p->n_acc, q->n, q->d_score,
-                           q->d_ninfo);
+                           q->d_ninfo, (certify && cert.flag) ? (const double *)q->cert_eref() : (const double *)nullptr,
+                           certify ? efast_bound(q, g) : 0.0, ctx->debug_reeval, q->cert_cols(), q->cert_count(),
+                           REEVAL_CAP);
         HIPCHK(ctx, hipGetLastError());
     }
     return SNPM_OK;
@@ -537,7 +628,7 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out)
 bool ensure_acc_major(snpm_panel *p)
 {
     snpm_ctx *ctx = p->ctx;
-    if (!ctx->use_acc_major || p->packed) return false;   // a packed panel already reads 4x fewer lines per column
+    if (!ctx->use_acc_major) return false;
     if (p->dT_state == 1) return true;
     if (p->dT_state == -1 || p->n_snp == 0) return false;
     const int64_t pitchT = (((p->n_snp + 3) / 4 + 255) / 256) * 256 + 256;    // + one tile of slack for the last block
@@ -552,9 +643,15 @@ bool ensure_acc_major(snpm_panel *p)
     }
     if (ensure(ctx, ctx->ws_flags, sizeof(int)) != SNPM_OK) return false;
     if (hipMemsetAsync(ctx->ws_flags.p, 0, sizeof(int), ctx->stream) != hipSuccess) return false;
-    dim3 grid((unsigned)((p->n_snp + PT_ROWS - 1) / PT_ROWS), (unsigned)((p->n_acc + PT_COLS - 1) / PT_COLS));
-    hipLaunchKernelGGL(k_pack_transpose, grid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->n_snp, p->n_acc, p->dT,
-                       p->pitchT, (int *)ctx->ws_flags.p);
+    if (p->packed) {
+        dim3 grid((unsigned)((p->n_snp + PTP_ROWS - 1) / PTP_ROWS), (unsigned)((p->n_acc + PTP_COLS - 1) / PTP_COLS));
+        hipLaunchKernelGGL(k_pack_transpose_packed, grid, dim3(256), 0, ctx->stream, (const uint8_t *)p->d, p->pitch, p->n_snp,
+                           p->n_acc, p->dT, p->pitchT);
+    } else {
+        dim3 grid((unsigned)((p->n_snp + PT_ROWS - 1) / PT_ROWS), (unsigned)((p->n_acc + PT_COLS - 1) / PT_COLS));
+        hipLaunchKernelGGL(k_pack_transpose, grid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->n_snp, p->n_acc, p->dT,
+                           p->pitchT, (int *)ctx->ws_flags.p);
+    }
     int bad = 0;
     if (hipGetLastError() != hipSuccess ||
         hipMemcpyAsync(&bad, ctx->ws_flags.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -566,57 +663,21 @@ bool ensure_acc_major(snpm_panel *p)
     return p->dT_state == 1;
 }
 
-// strict segment sums for `ncols` columns (d_cols NULL = all accessions) over segments d_seg_off[n_seg+1]
-int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64_t n_seg, const int32_t *d_cols,
-                        int64_t ncols, int64_t ld)
+// ---- reference-order (strict) launches ---------------------------------------------------------------------
+// Dense: every accession, segments [seg0, seg0 + n_seg) -> ctx->ws_seg_* [n_seg, ld].  Segments are explicit
+// (d_seg_off: windows) or `chunk`-row pieces of the query.  gate (may be NULL): device count; the launch is a
+// no-op unless *gate > REEVAL_CAP.
+int launch_strict_dense(snpm_query *q, int skip, const int64_t *d_seg_off, int64_t chunk, int64_t seg0, int64_t n_seg,
+                        const int *gate)
 {
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
-    int rc = ensure(ctx, ctx->ws_seg_score, (size_t)std::max<int64_t>(n_seg, 1) * ld * sizeof(double));
-    if (rc) return rc;
-    rc = ensure(ctx, ctx->ws_seg_miss, (size_t)std::max<int64_t>(n_seg, 1) * ld * sizeof(uint32_t));
-    if (rc) return rc;
-    if (n_seg == 0 || ncols == 0) return SNPM_OK;
-    const int thr = ncols >= 256 ? 256 : (ncols > 128 ? 256 : (ncols > 64 ? 128 : 64));
+    const int64_t ncols = p->n_acc, ld = p->ld;
     const bool gather = q->d_row_idx != nullptr;
-    if (d_cols && ncols <= 64) {
-        // short column list: one lane per (segment, column), see k_strict_sparse; on the accession-major
-        // packed copy when there is one (contiguous column reads), else strided over the SNP-major panel
-        const int64_t total = n_seg * ncols;
-        dim3 sgrid((unsigned)((total + 255) / 256));
-        if (q->n >= ctx->acc_major_min_rows && ensure_acc_major(p)) {
-            q->reeval_path = 1;
-            ProfScope ps(ctx, PK_STRICT);
-#define LAUNCH_SPARSE_T(S, G)                                                                                      \
-    hipLaunchKernelGGL((k_strict_sparse_T<S, G>), sgrid, dim3(256), 0, ctx->stream, p->dT, p->pitchT, q->d_row_idx, \
-                       q->row0, q->d_w, d_seg_off, n_seg, d_cols, ncols, (double *)ctx->ws_seg_score.p,            \
-                       (uint32_t *)ctx->ws_seg_miss.p, ld)
-            if (skip) {
-                if (gather) LAUNCH_SPARSE_T(true, true); else LAUNCH_SPARSE_T(true, false);
-            } else {
-                if (gather) LAUNCH_SPARSE_T(false, true); else LAUNCH_SPARSE_T(false, false);
-            }
-#undef LAUNCH_SPARSE_T
-            HIPCHK(ctx, hipGetLastError());
-            return SNPM_OK;
-        }
-        q->reeval_path = 2;
-        ProfScope ps(ctx, PK_STRICT);
-#define LAUNCH_SPARSE(S, G)                                                                                        \
-    hipLaunchKernelGGL((k_strict_sparse<S, G>), sgrid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->packed, q->d_row_idx, \
-                       q->row0, q->d_w, d_seg_off, n_seg, d_cols, ncols, (double *)ctx->ws_seg_score.p,            \
-                       (uint32_t *)ctx->ws_seg_miss.p, ld)
-        if (skip) {
-            if (gather) LAUNCH_SPARSE(true, true); else LAUNCH_SPARSE(true, false);
-        } else {
-            if (gather) LAUNCH_SPARSE(false, true); else LAUNCH_SPARSE(false, false);
-        }
-#undef LAUNCH_SPARSE
-        HIPCHK(ctx, hipGetLastError());
-        return SNPM_OK;
-    }
-    if (!d_cols && ctx->strict4) {
-        // dense: 4 columns per lane (one dword of an int8 panel, one byte of a packed panel)
+    const int64_t *seg_off = d_seg_off ? d_seg_off + seg0 : nullptr;
+    if (n_seg == 0) return SNPM_OK;
+    if (ctx->strict4) {
+        // 4 columns per lane (one dword of an int8 panel, one byte of a packed panel)
         const int64_t lanes = (ncols + 3) / 4;
         const int t4 = lanes >= 256 ? 256 : (lanes > 64 ? 128 : 64);
         dim3 grid4((unsigned)n_seg, (unsigned)((lanes + t4 - 1) / t4));
@@ -625,10 +686,12 @@ int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64
     do {                                                                                                         \
         if (p->packed)                                                                                           \
             hipLaunchKernelGGL((k_strict4<S, G, true>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
-                               q->d_w, d_seg_off, ncols, (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld); \
+                               q->d_w, seg_off, chunk, q->n, seg0, ncols, (double *)ctx->ws_seg_score.p,         \
+                               (uint32_t *)ctx->ws_seg_miss.p, ld, gate, REEVAL_CAP);                            \
         else                                                                                                     \
             hipLaunchKernelGGL((k_strict4<S, G, false>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
-                               q->d_w, d_seg_off, ncols, (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld); \
+                               q->d_w, seg_off, chunk, q->n, seg0, ncols, (double *)ctx->ws_seg_score.p,         \
+                               (uint32_t *)ctx->ws_seg_miss.p, ld, gate, REEVAL_CAP);                            \
     } while (0)
         if (skip) {
             if (gather) LAUNCH_STRICT4(true, true); else LAUNCH_STRICT4(true, false);
@@ -639,13 +702,13 @@ int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64
         HIPCHK(ctx, hipGetLastError());
         return SNPM_OK;
     }
-    // grid.x = segments (can be large), grid.y = column blocks
+    const int thr = ncols > 128 ? 256 : (ncols > 64 ? 128 : 64);
     dim3 grid((unsigned)n_seg, (unsigned)((ncols + thr - 1) / thr));
     ProfScope ps(ctx, PK_STRICT);
 #define LAUNCH_STRICT(S, G)                                                                                       \
     hipLaunchKernelGGL((k_strict<S, G>), grid, dim3(thr), 0, ctx->stream, p->d, p->pitch, p->packed, q->d_row_idx, q->row0,  \
-                       q->d_w, d_seg_off, d_cols, ncols, (double *)ctx->ws_seg_score.p,                           \
-                       (uint32_t *)ctx->ws_seg_miss.p, ld)
+                       q->d_w, seg_off, chunk, q->n, seg0, (const int32_t *)nullptr, ncols,                       \
+                       (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld, gate, REEVAL_CAP)
     if (skip) {
         if (gather) LAUNCH_STRICT(true, true); else LAUNCH_STRICT(true, false);
     } else {
@@ -653,6 +716,111 @@ int run_strict_segments(snpm_query *q, int skip, const int64_t *d_seg_off, int64
     }
 #undef LAUNCH_STRICT
     HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+// The reference's whole chunk loop for every accession: strict chunk sums in groups of segments (bounded
+// workspace), each group's sums added onto the running totals in order (ScoreList += chunk, core/snpmatch.py:224).
+// carry_*: totals of earlier SNP slabs (or NULL).  gate as above.
+constexpr size_t kStrictGroupBytes = size_t(512) << 20;
+
+int run_strict_chain(snpm_query *q, int skip, int64_t chunk, const int *gate, const double *carry_score,
+                     const int64_t *carry_ninfo, double *dst_score, int64_t *dst_ninfo)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    const int64_t n_seg = (q->n + chunk - 1) / chunk;
+    const int64_t per_seg = p->ld * (int64_t)(sizeof(double) + sizeof(uint32_t));
+    const int64_t group = std::max<int64_t>(1, std::min<int64_t>(std::max<int64_t>(n_seg, 1), (int64_t)kStrictGroupBytes / per_seg));
+    int rc = ensure(ctx, ctx->ws_seg_score, (size_t)group * p->ld * sizeof(double));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->ws_seg_miss, (size_t)group * p->ld * sizeof(uint32_t));
+    if (rc) return rc;
+    const int thr = 256;
+    const unsigned cb = (unsigned)((p->n_acc + thr - 1) / thr);
+    bool first = true;
+    for (int64_t g0 = 0; g0 < n_seg || first; g0 += group) {
+        const int64_t ns = std::max<int64_t>(0, std::min<int64_t>(group, n_seg - g0));
+        rc = launch_strict_dense(q, skip, nullptr, chunk, g0, ns, gate);
+        if (rc) return rc;
+        const int64_t rows = std::min<int64_t>(q->n, (g0 + ns) * chunk) - std::min<int64_t>(q->n, g0 * chunk);
+        ProfScope ps(ctx, PK_SCAN);
+        hipLaunchKernelGGL(k_scan, dim3(cb), dim3(thr), 0, ctx->stream, (const double *)ctx->ws_seg_score.p,
+                           (const uint32_t *)ctx->ws_seg_miss.p, rows, ns, p->ld, p->n_acc, dst_score, dst_ninfo,
+                           first ? carry_score : (const double *)dst_score, first ? carry_ninfo : (const int64_t *)dst_ninfo,
+                           gate, REEVAL_CAP);
+        HIPCHK(ctx, hipGetLastError());
+        first = false;
+    }
+    return SNPM_OK;
+}
+
+// Sparse tier: reference-order chunk sums of the accessions listed on the device (d_cols, *d_ncols <= REEVAL_CAP;
+// the kernels do nothing for other counts) -> ws_seg_score [n_seg, REEVAL_CAP] -> chain of additions ->
+// ws_tmp_score [REEVAL_CAP].  carry (may be NULL): compact totals of earlier slabs, continued by the chain.
+int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_cols, const int *d_ncols, const double *carry)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    const int64_t n_seg = (q->n + chunk - 1) / chunk;
+    const int64_t ld = REEVAL_CAP;
+    int rc = ensure(ctx, ctx->ws_seg_score, (size_t)std::max<int64_t>(n_seg, 1) * ld * sizeof(double));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->ws_seg_miss, (size_t)std::max<int64_t>(n_seg, 1) * ld * sizeof(uint32_t));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->ws_tmp_score, (size_t)ld * sizeof(double));
+    if (rc) return rc;
+    const bool gather = q->d_row_idx != nullptr;
+    const int64_t total = n_seg * ld;
+    if (total > 0) {
+        dim3 sgrid((unsigned)((total + 255) / 256));
+        const bool use_T = !q->transient_panel && q->n >= ctx->acc_major_min_rows && p->dT_state == 1;
+        ProfScope ps(ctx, PK_STRICT);
+        if (use_T) {
+            q->reeval_path = 1;
+#define LAUNCH_SPARSE_T(S, G)                                                                                      \
+    hipLaunchKernelGGL((k_strict_sparse_T<S, G>), sgrid, dim3(256), 0, ctx->stream, p->dT, p->pitchT, q->d_row_idx, \
+                       q->row0, q->d_w, (const int64_t *)nullptr, chunk, q->n, n_seg, d_cols, d_ncols, REEVAL_CAP, \
+                       (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld)
+            if (skip) {
+                if (gather) LAUNCH_SPARSE_T(true, true); else LAUNCH_SPARSE_T(true, false);
+            } else {
+                if (gather) LAUNCH_SPARSE_T(false, true); else LAUNCH_SPARSE_T(false, false);
+            }
+#undef LAUNCH_SPARSE_T
+        } else {
+            q->reeval_path = 2;
+#define LAUNCH_SPARSE(S, G)                                                                                        \
+    hipLaunchKernelGGL((k_strict_sparse<S, G>), sgrid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->packed, q->d_row_idx, \
+                       q->row0, q->d_w, (const int64_t *)nullptr, chunk, q->n, n_seg, d_cols, d_ncols, REEVAL_CAP, \
+                       (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld)
+            if (skip) {
+                if (gather) LAUNCH_SPARSE(true, true); else LAUNCH_SPARSE(true, false);
+            } else {
+                if (gather) LAUNCH_SPARSE(false, true); else LAUNCH_SPARSE(false, false);
+            }
+#undef LAUNCH_SPARSE
+        }
+        HIPCHK(ctx, hipGetLastError());
+    }
+    ProfScope ps(ctx, PK_SCAN);
+    hipLaunchKernelGGL(k_scan_few, dim3(1), dim3(256), 0, ctx->stream, (const double *)ctx->ws_seg_score.p, n_seg, ld,
+                       d_ncols, REEVAL_CAP, (double *)ctx->ws_tmp_score.p, carry);
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+// number of accessions the last certified run flagged (synchronises the stream)
+int read_count(snpm_query *q, int64_t *out)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    *out = 0;
+    if (!q->count_valid) return SNPM_OK;
+    int rc = ensure_pinned(ctx, 64);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, q->cert_count(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = *(const int *)ctx->h_pinned;
     return SNPM_OK;
 }
 
@@ -664,63 +832,6 @@ int upload_seg_off(snpm_ctx *ctx, const std::vector<int64_t> &off)
                                ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // `off` is a host temporary
     return SNPM_OK;
-}
-
-int ensure_chunk_offsets(snpm_query *q, int64_t chunk);
-
-std::vector<int64_t> chunk_offsets(int64_t n, int64_t chunk)
-{
-    std::vector<int64_t> off;
-    for (int64_t j = 0; j < n; j += chunk) off.push_back(j);
-    off.push_back(n);
-    if (n == 0) off.assign(1, 0);
-    return off;
-}
-
-// device-resident chunk offsets of a query, rebuilt only when `chunk` changes
-int ensure_chunk_offsets(snpm_query *q, int64_t chunk)
-{
-    snpm_ctx *ctx = q->panel->ctx;
-    if (q->d_chunk_off && q->chunk_off_chunk == chunk) return SNPM_OK;
-    std::vector<int64_t> off = chunk_offsets(q->n, chunk);
-    if (q->d_chunk_off) {
-        query_release(q, q->d_chunk_off);
-        q->d_chunk_off = nullptr;
-    }
-    HIPCHK(ctx, query_alloc(q, (void **)&q->d_chunk_off, off.size() * sizeof(int64_t)));
-    HIPCHK(ctx, hipMemcpyAsync(q->d_chunk_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    q->chunk_off_chunk = chunk;
-    q->chunk_off_nseg = (int64_t)off.size() - 1;
-    return SNPM_OK;
-}
-
-// ---- rigorous error bounds (see DESIGN.md "Exactness") -----------------------------------------
-// For sums of terms x_i with |x_i| <= wmax_i, a computed sum differs from the exact one by at most
-// sum_i wmax_i * gamma(m_i), gamma(m) = m*u/(1-m*u), u = 2^-53, m_i = number of fp64 additions the
-// term passes through.  Reference order: m_i <= (rows left in its chunk) + 3 + (chunks left).
-double eref_bound(const snpm_query *q, int64_t chunk)
-{
-    const double u = 1.1102230246251565e-16;
-    const int64_t n = q->n;
-    const int64_t K = (n + chunk - 1) / chunk;
-    long double acc = 0;
-    for (int64_t k = 0; k < K; ++k) {
-        int64_t r0 = k * chunk, r1 = std::min(n, r0 + chunk);
-        long double s = 0;
-        for (int64_t r = r0; r < r1; ++r) s += q->wmax[r];
-        acc += s * (long double)((r1 - r0) + 3 + (K - k));
-    }
-    const double mmax = (double)(chunk + 3 + K);
-    return (double)(acc * u / (1.0 - mmax * u)) * 1.0000001;
-}
-
-double efast_bound(const snpm_query *q, const FastGeom &g)
-{
-    const double u = 1.1102230246251565e-16;
-    // a term passes through <= EPOCH_TILES*TILE_ROWS adds inside k_fast, REDUCE_GROUP in its group, n_groups after
-    const double m = (double)(std::min<int64_t>(g.part_rows, (int64_t)EPOCH_TILES * TILE_ROWS) + REDUCE_GROUP + g.n_groups + 2);
-    return (double)(q->wsum * (m * u / (1.0 - m * u))) * 1.0000001;
 }
 
 // Staging pipeline shared by snpm_panel_upload_rows (host memory) and snpm_panel_load_file (a file):
@@ -883,7 +994,7 @@ static void orphan_query(snpm_query *q, bool use_hip)
         q->owned.clear();
     }
     q->d_row_idx = nullptr; q->d_w = nullptr; q->d_lut = nullptr; q->d_score = nullptr; q->d_ninfo = nullptr;
-    q->own_score = nullptr; q->own_ninfo = nullptr; q->d_wbits = nullptr; q->d_chunk_off = nullptr;
+    q->own_score = nullptr; q->own_ninfo = nullptr; q->d_wbits = nullptr; q->d_cert = nullptr;
     q->panel = nullptr;
 }
 
@@ -914,11 +1025,22 @@ int snpm_destroy(snpm_ctx *ctx)
     // panels and queries created from this context may be freed later (or never): they become orphans now
     for (snpm_panel *p : ctx->panels) orphan_panel(p, use_hip);
     ctx->panels.clear();
+    for (snpm_carry *c : ctx->carries) {
+        if (use_hip) {
+            (void)hipFree(c->own_score);
+            (void)hipFree(c->own_ninfo);
+            (void)hipFree(c->d_E);
+        }
+        c->own_score = nullptr; c->own_ninfo = nullptr;
+        c->d_score = nullptr; c->d_ninfo = nullptr; c->d_E = nullptr; c->d_cols = nullptr; c->d_ncols = nullptr;
+        c->ctx = nullptr;
+    }
+    ctx->carries.clear();
     if (use_hip) {
         for (auto &c : ctx->qcache) (void)hipFree(c.p);
         Buf *bufs[] = {&ctx->ws_stage_dev, &ctx->ws_flags2, &ctx->ws_grp_score, &ctx->ws_grp_miss, &ctx->ws_part_score, &ctx->ws_part_miss, &ctx->ws_seg_score, &ctx->ws_seg_miss, &ctx->ws_seg_off,
                        &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
-                       &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r};
+                       &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r, &ctx->ws_wprops, &ctx->ws_epart};
         for (Buf *b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -1152,32 +1274,129 @@ int snpm_panel_download_rows(snpm_panel *p, int64_t row0, int64_t nrows, int8_t 
     return SNPM_OK;
 }
 
-int snpm_panel_fill_synthetic(snpm_panel *p, uint64_t seed, int64_t snp0, int64_t acc0)
+int snpm_panel_fill_synthetic_rows(snpm_panel *p, uint64_t seed, int64_t snp0, int64_t acc0, int64_t row0, int64_t nrows)
 {
     CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
     CHECK_ARG(ctx, (acc0 & 3) == 0 && acc0 >= 0 && snp0 >= 0, "acc0 must be a non-negative multiple of 4");
+    CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "fill rows outside the panel");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if (p->n_snp == 0) return SNPM_OK;
+    if (nrows == 0) return SNPM_OK;
+    int rc = wait_upload(p);
+    if (rc) return rc;
     ProfScope ps(ctx, PK_SYNTH);
     const int thr = 256;
     if (p->packed) {
-        const int64_t total = p->n_snp * p->pitch;
+        const int64_t total = nrows * p->pitch;
         const unsigned blocks = (unsigned)std::min<int64_t>((total + thr - 1) / thr, (int64_t)ctx->n_cu * 32);
-        hipLaunchKernelGGL(k_synth_packed, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->stream, (uint8_t *)p->d,
-                           p->pitch, p->n_snp, p->n_acc, seed, snp0, acc0);
+        hipLaunchKernelGGL(k_synth_packed, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->stream,
+                           (uint8_t *)p->d + row0 * p->pitch, p->pitch, nrows, p->n_acc, seed, snp0, acc0);
     } else {
-        const int64_t total = p->n_snp * (p->pitch / 4);
+        const int64_t total = nrows * (p->pitch / 4);
         const unsigned blocks = (unsigned)std::min<int64_t>((total + thr - 1) / thr, (int64_t)ctx->n_cu * 32);
-        hipLaunchKernelGGL(k_synth, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->stream, (uint32_t *)p->d, p->pitch,
-                           p->n_snp, p->n_acc, seed, snp0, acc0);
+        hipLaunchKernelGGL(k_synth, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->stream,
+                           (uint32_t *)(p->d + row0 * p->pitch), p->pitch, nrows, p->n_acc, seed, snp0, acc0);
     }
     HIPCHK(ctx, hipGetLastError());
     p->dT_state = 0;
     return SNPM_OK;
 }
 
+int snpm_panel_fill_synthetic(snpm_panel *p, uint64_t seed, int64_t snp0, int64_t acc0)
+{
+    CHECK_PANEL(p);
+    return snpm_panel_fill_synthetic_rows(p, seed, snp0, acc0, 0, p->n_snp);
+}
+
+int snpm_sample_synthetic(snpm_ctx *ctx, uint64_t seed, int64_t snp0, int64_t n, int64_t planted, int err_permille,
+                          int pl_permille, const double *exp_table, void *d_wei)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    CHECK_ARG(ctx, n >= 0 && snp0 >= 0 && planted >= 0, "negative size");
+    CHECK_ARG(ctx, err_permille >= 0 && err_permille <= 1000 && pl_permille >= 0 && pl_permille <= 1000, "permille out of range");
+    if (n == 0) return SNPM_OK;
+    CHECK_ARG(ctx, exp_table && d_wei, "NULL pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure(ctx, ctx->ws_lik_y, 256 * sizeof(double));
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_lik_y.p, exp_table, 256 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // exp_table is the caller's
+    hipLaunchKernelGGL(k_synth_sample, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, seed, snp0, n, planted,
+                       (uint32_t)err_permille, (uint32_t)pl_permille, (const double *)ctx->ws_lik_y.p, (double *)d_wei);
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- query
+// buffers of a new query; weights / row list are filled by the caller
+static int query_alloc_all(snpm_panel *p, int64_t n, bool gather, snpm_query **out)
+{
+    snpm_ctx *ctx = p->ctx;
+    snpm_query *q = new snpm_query();
+    q->panel = p;
+    p->queries.push_back(q);
+    q->n = n;
+    const size_t nn = (size_t)std::max<int64_t>(n, 1);
+    hipError_t e = hipSuccess;
+    if (gather) e = query_alloc(q, (void **)&q->d_row_idx, (nn + PREFETCH_PAD_ROWS) * sizeof(int64_t));
+    if (e == hipSuccess) e = query_alloc(q, (void **)&q->d_w, nn * 3 * sizeof(double));
+    if (e == hipSuccess) e = query_alloc(q, (void **)&q->d_lut, nn * 4 * sizeof(double));
+    if (e == hipSuccess) e = query_alloc(q, (void **)&q->own_score, (size_t)p->ld * sizeof(double));
+    if (e == hipSuccess) e = query_alloc(q, (void **)&q->own_ninfo, (size_t)p->ld * sizeof(int64_t));
+    if (e == hipSuccess) e = query_alloc(q, &q->d_cert, 16 + REEVAL_CAP * sizeof(int32_t));
+    q->d_score = q->own_score;
+    q->d_ninfo = q->own_ninfo;
+    if (e != hipSuccess) {
+        snpm_query_free(q);
+        return set_err(ctx, SNPM_ERR_OOM, "query allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = q;
+    return SNPM_OK;
+}
+
+// weight properties from the device copy (k_wprops): wsum, all-integer, hard 0/1 calls (+ the weight bits for the
+// bit-parallel pass on packed panels).  Synchronises: the caller's host buffers are free afterwards.
+static int query_finish_setup(snpm_query *q)
+{
+    snpm_panel *p = q->panel;
+    snpm_ctx *ctx = p->ctx;
+    const int64_t n = q->n;
+    if (q->d_row_idx)      // pad entries: a valid row (0), only ever prefetched
+        HIPCHK(ctx, hipMemsetAsync(q->d_row_idx + n, 0, PREFETCH_PAD_ROWS * sizeof(int64_t), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(q->d_cert, 0, 16, ctx->stream));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 1024));
+    int rc = ensure(ctx, ctx->ws_wprops, (size_t)grid * sizeof(double) + 64);
+    if (rc) return rc;
+    rc = ensure_pinned(ctx, (size_t)grid * sizeof(double) + 64);
+    if (rc) return rc;
+    int *d_flags = (int *)((char *)ctx->ws_wprops.p + (size_t)grid * sizeof(double));
+    HIPCHK(ctx, hipMemsetAsync(d_flags, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_wprops, dim3((unsigned)grid), dim3(256), 0, ctx->stream, (const double *)q->d_w, n,
+                       (double *)ctx->ws_wprops.p, d_flags);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ctx->ws_wprops.p, (size_t)grid * sizeof(double) + sizeof(int),
+                               hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    long double tot = 0;
+    const double *part = (const double *)ctx->h_pinned;
+    for (int i = 0; i < grid; ++i) tot += part[i];
+    const int flags = *(const int *)((const char *)ctx->h_pinned + (size_t)grid * sizeof(double));
+    q->wsum = (double)tot * 1.0000001;              // block sums carry ~1e-13 relative rounding: round up
+    q->all_integer = !(flags & 1) && tot < 9.0e15L; // every partial sum exactly representable
+    q->hard01 = q->all_integer && !(flags & 2);
+    if (q->hard01 && p->packed && n > 0) {
+        const int64_t padded = n + 16;
+        hipError_t e2 = query_alloc(q, (void **)&q->d_wbits, (size_t)padded);
+        if (e2 != hipSuccess) return set_err(ctx, SNPM_ERR_OOM, "query allocation failed: %s", hipGetErrorString(e2));
+        hipLaunchKernelGGL(k_wbits, dim3((unsigned)((padded + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const double *)q->d_w, n, padded, q->d_wbits);
+        HIPCHK(ctx, hipGetLastError());
+    } else {
+        q->hard01 = q->hard01 && p->packed;
+    }
+    return SNPM_OK;
+}
+
 int snpm_query_create(snpm_panel *p, const int64_t *row_idx, int64_t row0, int64_t n, const double *wei,
                       snpm_query **out)
 try {
@@ -1195,67 +1414,59 @@ try {
         CHECK_ARG(ctx, row0 >= 0 && row0 + n <= p->n_snp, "dense row range outside the panel");
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    snpm_query *q = new snpm_query();
-    q->panel = p;
-    p->queries.push_back(q);
-    q->n = n;
+    snpm_query *q = nullptr;
+    int rc = query_alloc_all(p, n, row_idx != nullptr, &q);
+    if (rc) return rc;
     q->row0 = row_idx ? 0 : row0;
-    const size_t nn = (size_t)std::max<int64_t>(n, 1);
     hipError_t e = hipSuccess;
-    if (row_idx && e == hipSuccess) e = query_alloc(q, (void **)&q->d_row_idx, (nn + PREFETCH_PAD_ROWS) * sizeof(int64_t));
-    if (e == hipSuccess) e = query_alloc(q, (void **)&q->d_w, nn * 3 * sizeof(double));
-    if (e == hipSuccess) e = query_alloc(q, (void **)&q->d_lut, nn * 4 * sizeof(double));
-    if (e == hipSuccess) e = query_alloc(q, (void **)&q->own_score, (size_t)p->ld * sizeof(double));
-    if (e == hipSuccess) e = query_alloc(q, (void **)&q->own_ninfo, (size_t)p->ld * sizeof(int64_t));
-    q->d_score = q->own_score;
-    q->d_ninfo = q->own_ninfo;
-    if (e != hipSuccess) {
+    if (n > 0 && row_idx)
+        e = hipMemcpyAsync(q->d_row_idx, row_idx, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+    if (n > 0 && e == hipSuccess)
+        e = hipMemcpyAsync(q->d_w, wei, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) rc = set_err(ctx, SNPM_ERR_HIP, "query upload failed: %s", hipGetErrorString(e));
+    if (!rc) rc = query_finish_setup(q);
+    if (rc) {
+        const std::string keep = ctx->err;
+        (void)hipStreamSynchronize(ctx->stream);
         snpm_query_free(q);
-        return set_err(ctx, SNPM_ERR_OOM, "query allocation failed: %s", hipGetErrorString(e));
+        ctx->err = keep;
+        return rc;
     }
-    if (n > 0) {
-        if (row_idx)
-            HIPCHK(ctx, hipMemcpyAsync(q->d_row_idx, row_idx, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    *out = q;
+    return SNPM_OK;
+} SNPM_GUARD((p ? p->ctx : nullptr))
+
+// Same query from DEVICE arrays (row list and weights already in HBM, e.g. produced by snpm_sample_synthetic or
+// by a caller's own kernels); both are copied, the caller keeps ownership of its buffers.  Row indices must lie
+// inside the panel: the caller guarantees it (they are not read back to the host).
+int snpm_query_create_device(snpm_panel *p, const void *d_row_idx, int64_t row0, int64_t n, const void *d_wei,
+                             snpm_query **out)
+try {
+    CHECK_PANEL(p);
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, out != nullptr, "out is NULL");
+    CHECK_ARG(ctx, n >= 0, "n must be >= 0");
+    CHECK_ARG(ctx, n == 0 || d_wei != nullptr, "SNP weights should be a np.array with  shape == n,3");
+    if (!d_row_idx) CHECK_ARG(ctx, row0 >= 0 && row0 + n <= p->n_snp, "dense row range outside the panel");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    snpm_query *q = nullptr;
+    int rc = query_alloc_all(p, n, d_row_idx != nullptr, &q);
+    if (rc) return rc;
+    q->row0 = d_row_idx ? 0 : row0;
+    hipError_t e = hipSuccess;
+    if (n > 0 && d_row_idx)
+        e = hipMemcpyAsync(q->d_row_idx, d_row_idx, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream);
+    if (n > 0 && e == hipSuccess)
+        e = hipMemcpyAsync(q->d_w, d_wei, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) rc = set_err(ctx, SNPM_ERR_HIP, "query copy failed: %s", hipGetErrorString(e));
+    if (!rc) rc = query_finish_setup(q);
+    if (rc) {
+        const std::string keep = ctx->err;
+        (void)hipStreamSynchronize(ctx->stream);
+        snpm_query_free(q);
+        ctx->err = keep;
+        return rc;
     }
-    if (row_idx) {      // pad entries: a valid row (0), only ever prefetched
-        HIPCHK(ctx, hipMemsetAsync(q->d_row_idx + n, 0, PREFETCH_PAD_ROWS * sizeof(int64_t), ctx->stream));
-    }
-    if (n > 0) {
-        HIPCHK(ctx, hipMemcpyAsync(q->d_w, wei, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    }
-    q->wmax.resize((size_t)n);
-    bool all_int = true;
-    for (int64_t i = 0; i < n; ++i) {
-        const double a = std::fabs(wei[3 * i]), b = std::fabs(wei[3 * i + 1]), c = std::fabs(wei[3 * i + 2]);
-        q->wmax[(size_t)i] = std::max(a, std::max(b, c));
-        if (all_int && !(a == std::floor(a) && b == std::floor(b) && c == std::floor(c))) all_int = false;
-        if (!std::isfinite(a) || !std::isfinite(b) || !std::isfinite(c)) all_int = false;
-    }
-    long double tot = 0;
-    for (double w : q->wmax) tot += w;
-    q->wsum = tot;
-    q->all_integer = all_int && tot < 9.0e15L;     // every partial sum exactly representable
-    // hard calls: all weights 0 or 1 -> one byte of three weight bits per row for the bit-parallel pass
-    std::vector<uint8_t> wb;
-    if (q->all_integer && p->packed && n > 0) {
-        bool hard = true;
-        wb.assign((size_t)n + 16, 0);
-        for (int64_t i = 0; i < n && hard; ++i) {
-            const double a = wei[3 * i], b = wei[3 * i + 1], c = wei[3 * i + 2];
-            hard = (a == 0.0 || a == 1.0) && (b == 0.0 || b == 1.0) && (c == 0.0 || c == 1.0);
-            wb[(size_t)i] = (uint8_t)((a == 1.0 ? 1 : 0) | (b == 1.0 ? 2 : 0) | (c == 1.0 ? 4 : 0));
-        }
-        if (hard) {
-            hipError_t e2 = query_alloc(q, (void **)&q->d_wbits, wb.size());
-            if (e2 != hipSuccess) {
-                snpm_query_free(q);
-                return set_err(ctx, SNPM_ERR_OOM, "query allocation failed: %s", hipGetErrorString(e2));
-            }
-            HIPCHK(ctx, hipMemcpyAsync(q->d_wbits, wb.data(), wb.size(), hipMemcpyHostToDevice, ctx->stream));
-            q->hard01 = true;
-        }
-    }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host buffers may be released by the caller
     *out = q;
     return SNPM_OK;
 } SNPM_GUARD((p ? p->ctx : nullptr))
@@ -1290,15 +1501,45 @@ try {
     if (!bound) return SNPM_ERR_BADARG;
     snpm_ctx *ctx = q->panel->ctx;
     CHECK_ARG(ctx, chunk >= 1, "chunk must be >= 1");
-    if (q->all_integer) { *bound = 0.0; return SNPM_OK; }
-    auto it = q->eref_cache.find(chunk);
-    double eref = (it != q->eref_cache.end()) ? it->second : (q->eref_cache[chunk] = eref_bound(q, chunk));
+    if (q->all_integer || q->n == 0) { *bound = 0.0; return SNPM_OK; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_eref(q, chunk, 0);
+    if (rc) return rc;
+    rc = ensure_pinned(ctx, 64);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, q->cert_eref(), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const double eref = *(const double *)ctx->h_pinned;
     const bool p16 = q->panel->packed && !ctx->packed_byte;
     const int bpl = p16 ? 16 : (q->panel->packed ? 4 : pick_bpl(ctx, q->panel->n_acc));
     FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl, p16 ? P16_TILE_ROWS : TILE_ROWS);   // occ 1 -> longest parts -> largest bound
     *bound = eref + efast_bound(q, g);
     return SNPM_OK;
 } SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
+
+// After a certified fast pass: both re-evaluation tiers are enqueued behind it and decide on the device whether
+// they have anything to do (see dense_tier_off / the sparse kernels), so the host never waits for the flag count.
+// The accession-major copy is built the first time something is flagged on a long query -- the one case that
+// reads the count back (once per panel).
+static int enqueue_reevaluation(snpm_query *q, int skip, int64_t chunk)
+{
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    const bool want_T = ctx->use_acc_major && !q->transient_panel && q->n >= ctx->acc_major_min_rows;
+    if (want_T && p->dT_state == 0) {
+        int64_t cnt = 0;
+        int rc = read_count(q, &cnt);
+        if (rc) return rc;
+        if (cnt >= 1 && cnt <= REEVAL_CAP) (void)ensure_acc_major(p);
+    }
+    int rc = run_strict_sparse(q, skip, chunk, q->cert_cols(), q->cert_count(), nullptr);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_patch, dim3(1), dim3(REEVAL_CAP), 0, ctx->stream, (const double *)ctx->ws_tmp_score.p,
+                       (const int32_t *)q->cert_cols(), (const int *)q->cert_count(), REEVAL_CAP, q->d_score);
+    HIPCHK(ctx, hipGetLastError());
+    // more than REEVAL_CAP flagged (many exact-integer scores, e.g. clonal accessions): everything in reference order
+    return run_strict_chain(q, skip, chunk, q->cert_count(), nullptr, nullptr, q->d_score, q->d_ninfo);
+}
 
 int snpm_query_run_device(snpm_query *q, int64_t chunk, int skip_hets, int mode, void **d_score, void **d_ninfo,
                           int64_t *info)
@@ -1312,91 +1553,51 @@ try {
     int rc = wait_upload(p);
     if (rc) return rc;
     const int skip = skip_hets ? 1 : 0;
-    int64_t n_flag = 0;
+    bool certified = false;
 
     if (mode == SNPM_MODE_STRICT) {
-        rc = ensure_chunk_offsets(q, chunk);
+        q->count_valid = false;
+        q->last_kernel = "k_strict4";
+        rc = run_strict_chain(q, skip, chunk, nullptr, nullptr, nullptr, q->d_score, q->d_ninfo);
         if (rc) return rc;
-        const int64_t n_seg = q->chunk_off_nseg;
-        rc = run_strict_segments(q, skip, q->d_chunk_off, n_seg, nullptr, p->n_acc, p->ld);
-        if (rc) return rc;
-        ProfScope ps(ctx, PK_SCAN);
-        const int thr = 256;
-        hipLaunchKernelGGL(k_scan, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
-                           (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
-                           q->d_chunk_off, n_seg, p->ld, p->n_acc, q->d_score, q->d_ninfo);
-        HIPCHK(ctx, hipGetLastError());
     } else {
-        FastGeom g;
-        rc = run_fast(q, skip, &g);
+        Certify cert;
+        cert.on = (mode == SNPM_MODE_EXACT);
+        cert.chunk = chunk;
+        rc = run_fast(q, skip, nullptr, cert);
         if (rc) return rc;
-        if (mode == SNPM_MODE_EXACT && !q->all_integer && q->n > 0) {
-            auto it = q->eref_cache.find(chunk);
-            const double eref = (it != q->eref_cache.end()) ? it->second : (q->eref_cache[chunk] = eref_bound(q, chunk));
-            const double E = eref + efast_bound(q, g);
-            const size_t hbytes = (size_t)p->n_acc * sizeof(double);
-            if (ctx->h_pinned_cap < hbytes) {
-                if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
-                ctx->h_pinned = nullptr;
-                ctx->h_pinned_cap = 0;
-                HIPCHK(ctx, hipHostMalloc(&ctx->h_pinned, hbytes, hipHostMallocDefault));
-                ctx->h_pinned_cap = hbytes;
-            }
-            const double *h = (const double *)ctx->h_pinned;
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, q->d_score, hbytes, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            std::vector<int32_t> cols;
-            for (int64_t a = 0; a < p->n_acc; ++a) {
-                const double f = h[a];
-                const double lo = f - E, hi = f + E;
-                if (!(lo >= 0.0) || std::floor(lo) != std::floor(hi) || a < ctx->debug_reeval) cols.push_back((int32_t)a);
-            }
-            n_flag = (int64_t)cols.size();
-            if (n_flag > 0) {
-                rc = ensure_chunk_offsets(q, chunk);
-                if (rc) return rc;
-                const int64_t n_seg = q->chunk_off_nseg;
-                rc = ensure(ctx, ctx->ws_cols, cols.size() * sizeof(int32_t));
-                if (rc) return rc;
-                HIPCHK(ctx, hipMemcpyAsync(ctx->ws_cols.p, cols.data(), cols.size() * sizeof(int32_t),
-                                           hipMemcpyHostToDevice, ctx->stream));
-                const int64_t ld = n_flag;       // compact [n_seg, n_flag]: the scan reads it contiguously
-                rc = run_strict_segments(q, skip, q->d_chunk_off, n_seg, (const int32_t *)ctx->ws_cols.p, n_flag, ld);
-                if (rc) return rc;
-                rc = ensure(ctx, ctx->ws_tmp_score, (size_t)ld * sizeof(double));
-                if (rc) return rc;
-                const int thr = 256;
-                {
-                    ProfScope ps(ctx, PK_SCAN);
-                    if (n_flag <= 64) {
-                        hipLaunchKernelGGL(k_scan_few, dim3(1), dim3(256), 0, ctx->stream,
-                                           (const double *)ctx->ws_seg_score.p, n_seg, ld, (int)n_flag,
-                                           (double *)ctx->ws_tmp_score.p);
-                    } else {
-                        hipLaunchKernelGGL(k_scan, dim3((unsigned)((n_flag + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
-                                           (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
-                                           q->d_chunk_off, n_seg, ld, n_flag,
-                                           (double *)ctx->ws_tmp_score.p, (int64_t *)nullptr);
-                    }
-                    HIPCHK(ctx, hipGetLastError());
-                }
-                hipLaunchKernelGGL(k_patch, dim3((unsigned)((n_flag + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
-                                   (const double *)ctx->ws_tmp_score.p, (const int32_t *)ctx->ws_cols.p, n_flag, q->d_score);
-                HIPCHK(ctx, hipGetLastError());
-                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // `cols` is a host temporary
-            }
+        certified = cert.on && !q->all_integer && q->n > 0;
+        if (certified) {
+            rc = enqueue_reevaluation(q, skip, chunk);
+            if (rc) return rc;
         }
     }
     if (d_score) *d_score = q->d_score;
     if (d_ninfo) *d_ninfo = q->d_ninfo;
-    if (info) {
+    if (info) {                 // asking for the counters costs a synchronisation
+        int64_t n_flag = 0;
+        if (certified) {
+            rc = read_count(q, &n_flag);
+            if (rc) return rc;
+        }
         info[0] = n_flag;
         info[1] = q->all_integer ? 1 : 0;
-        info[2] = n_flag > 0 ? q->reeval_path : 0;
+        info[2] = n_flag > REEVAL_CAP ? 3 : (n_flag > 0 ? q->reeval_path : 0);
         info[3] = 0;
     }
     return SNPM_OK;
 } SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
+
+int snpm_query_last_reeval(snpm_query *q, int64_t *n_flagged)
+{
+    CHECK_QUERY(q);
+    if (!n_flagged) return SNPM_ERR_BADARG;
+    HIPCHK(q->panel->ctx, hipSetDevice(q->panel->ctx->device));
+    if (q->all_integer || q->n == 0) { *n_flagged = 0; return SNPM_OK; }
+    return read_count(q, n_flagged);
+}
+
+const char *snpm_query_last_kernel(const snpm_query *q) { return q ? q->last_kernel : ""; }
 
 int snpm_query_run(snpm_query *q, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo, int64_t *info)
 {
@@ -1424,10 +1625,15 @@ try {
     int rc = wait_upload(p);
     if (rc) return rc;
     const int skip = skip_hets ? 1 : 0;
+    q->count_valid = false;
     std::vector<int64_t> off(win_off, win_off + n_win + 1);
     rc = upload_seg_off(ctx, off);
     if (rc) return rc;
-    rc = run_strict_segments(q, skip, (const int64_t *)ctx->ws_seg_off.p, n_win, nullptr, p->n_acc, p->ld);
+    rc = ensure(ctx, ctx->ws_seg_score, (size_t)std::max<int64_t>(n_win, 1) * p->ld * sizeof(double));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->ws_seg_miss, (size_t)std::max<int64_t>(n_win, 1) * p->ld * sizeof(uint32_t));
+    if (rc) return rc;
+    rc = launch_strict_dense(q, skip, (const int64_t *)ctx->ws_seg_off.p, 0, 0, n_win, nullptr);
     if (rc) return rc;
     const int thr = 256;
     const size_t na = (size_t)p->n_acc;
@@ -1436,7 +1642,8 @@ try {
             ProfScope ps(ctx, PK_SCAN);
             hipLaunchKernelGGL(k_scan, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
                                (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
-                               (const int64_t *)ctx->ws_seg_off.p, n_win, p->ld, p->n_acc, q->d_score, q->d_ninfo);
+                               win_off[n_win] - win_off[0], n_win, p->ld, p->n_acc, q->d_score, q->d_ninfo,
+                               (const double *)nullptr, (const int64_t *)nullptr, (const int *)nullptr, 0);
             HIPCHK(ctx, hipGetLastError());
         }
         if (tot_score) HIPCHK(ctx, hipMemcpyAsync(tot_score, q->d_score, na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1467,6 +1674,218 @@ try {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SNPM_OK;
 } SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
+
+// ---------------------------------------------------------------------------------------------- slab-streamed jobs
+// A panel larger than HBM is scored SNP slab after SNP slab; a snpm_carry holds the running per-accession totals
+// so that the result equals one pass of the reference's chunk loop over the whole SNP axis (core/snpmatch.py:218-225).
+int snpm_carry_create(snpm_ctx *ctx, int64_t n_acc, snpm_carry **out)
+try {
+    if (!ctx) return SNPM_ERR_BADARG;
+    CHECK_ARG(ctx, out != nullptr && n_acc >= 1, "carry needs n_acc >= 1");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    snpm_carry *c = new snpm_carry();
+    c->ctx = ctx;
+    c->n_acc = n_acc;
+    c->ld = ((n_acc + 255) / 256) * 256;
+    hipError_t e = hipMalloc((void **)&c->own_score, (size_t)c->ld * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->own_ninfo, (size_t)c->ld * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_E, 256 + REEVAL_CAP * sizeof(int32_t));
+    c->d_score = c->own_score;
+    c->d_ninfo = c->own_ninfo;
+    c->len = c->ld;
+    if (e != hipSuccess) {
+        if (c->own_score) (void)hipFree(c->own_score);
+        if (c->own_ninfo) (void)hipFree(c->own_ninfo);
+        delete c;
+        return set_err(ctx, SNPM_ERR_OOM, "carry allocation failed: %s", hipGetErrorString(e));
+    }
+    c->d_ncols = (int *)((char *)c->d_E + 8);
+    c->d_cols = (int32_t *)((char *)c->d_E + 256);
+    ctx->carries.push_back(c);
+    *out = c;
+    return snpm_carry_reset(c);
+} SNPM_GUARD(ctx)
+
+#define CHECK_CARRY(C)                                                                               \
+    do {                                                                                             \
+        if (!(C)) return set_err(nullptr, SNPM_ERR_BADARG, "carry is NULL");                         \
+        if (!(C)->ctx) return set_err(nullptr, SNPM_ERR_STATE, "carry outlived its context");        \
+    } while (0)
+
+int snpm_carry_reset(snpm_carry *c)
+{
+    CHECK_CARRY(c);
+    snpm_ctx *ctx = c->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(c->d_score, 0, (size_t)c->len * sizeof(double), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(c->d_ninfo, 0, (size_t)c->len * sizeof(int64_t), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(c->d_E, 0, 256 + REEVAL_CAP * sizeof(int32_t), ctx->stream));
+    c->n_rows = 0;
+    c->n_slabs = 0;
+    c->wsum = 0;
+    c->mode = -1;
+    c->n_cols = -1;
+    c->finished = false;
+    return SNPM_OK;
+}
+
+int snpm_carry_free(snpm_carry *c)
+{
+    if (!c) return SNPM_OK;
+    snpm_ctx *ctx = c->ctx;
+    if (ctx) {
+        if (hip_alive()) {
+            (void)hipSetDevice(ctx->device);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(c->own_score);
+            (void)hipFree(c->own_ninfo);
+            (void)hipFree(c->d_E);
+        }
+        ctx->carries.erase(std::remove(ctx->carries.begin(), ctx->carries.end(), c), ctx->carries.end());
+    }
+    delete c;
+    return SNPM_OK;
+}
+
+// totals live in caller-owned DEVICE buffers (float64 [n_acc], int64 [n_acc]; e.g. torch tensors feeding an
+// all-gather) from the next reset on; NULL, NULL restores the carry's own buffers
+int snpm_carry_bind_outputs(snpm_carry *c, void *d_score, void *d_ninfo)
+{
+    CHECK_CARRY(c);
+    snpm_ctx *ctx = c->ctx;
+    CHECK_ARG(ctx, (d_score == nullptr) == (d_ninfo == nullptr), "bind both outputs or neither");
+    CHECK_ARG(ctx, c->n_slabs == 0, "bind the outputs before the first slab");
+    c->d_score = d_score ? (double *)d_score : c->own_score;
+    c->d_ninfo = d_ninfo ? (int64_t *)d_ninfo : c->own_ninfo;
+    c->len = d_score ? c->n_acc : c->ld;
+    return snpm_carry_reset(c);
+}
+
+int snpm_carry_set_columns(snpm_carry *c, const int32_t *cols, int64_t ncols)
+{
+    CHECK_CARRY(c);
+    snpm_ctx *ctx = c->ctx;
+    CHECK_ARG(ctx, c->n_slabs == 0, "set the column list before the first slab");
+    CHECK_ARG(ctx, ncols >= 1 && ncols <= REEVAL_CAP && cols, "a column list holds 1..64 accessions (more: a strict pass over all of them)");
+    for (int64_t i = 0; i < ncols; ++i) CHECK_ARG(ctx, cols[i] >= 0 && cols[i] < c->n_acc, "accession index outside the panel");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const int nc = (int)ncols;
+    HIPCHK(ctx, hipMemcpyAsync(c->d_cols, cols, (size_t)ncols * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(c->d_ncols, &nc, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    c->n_cols = ncols;
+    return SNPM_OK;
+}
+
+int snpm_query_run_carry(snpm_query *q, int64_t chunk, int skip_hets, int mode, int64_t chunks_after, snpm_carry *c)
+try {
+    CHECK_QUERY(q);
+    CHECK_CARRY(c);
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    CHECK_ARG(ctx, c->ctx == ctx && c->n_acc == p->n_acc, "the carry belongs to another context or panel width");
+    CHECK_ARG(ctx, chunk >= 1 && chunks_after >= 0, "chunk must be >= 1 and chunks_after >= 0");
+    CHECK_ARG(ctx, mode == SNPM_MODE_EXACT || mode == SNPM_MODE_STRICT || mode == SNPM_MODE_FAST, "unknown mode");
+    CHECK_ARG(ctx, !c->finished, "the carry was finished: reset it first");
+    CHECK_ARG(ctx, c->mode < 0 || c->mode == mode, "every slab of a job is scored in the same mode");
+    // the reference's chunks are cut over the whole SNP axis: a slab boundary must be a chunk boundary
+    CHECK_ARG(ctx, chunks_after == 0 || q->n % chunk == 0, "every slab but the last must hold a multiple of `chunk` rows");
+    CHECK_ARG(ctx, c->n_cols < 0 || mode == SNPM_MODE_STRICT, "a column-list carry takes strict slabs");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = wait_upload(p);
+    if (rc) return rc;
+    const int skip = skip_hets ? 1 : 0;
+    q->transient_panel = true;
+    q->count_valid = false;
+    if (c->n_cols >= 0) {
+        // second pass: the listed accessions only, chain continued from the compact totals
+        rc = run_strict_sparse(q, skip, chunk, c->d_cols, c->d_ncols, c->d_score);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(c->d_score, ctx->ws_tmp_score.p, (size_t)c->n_cols * sizeof(double),
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (mode == SNPM_MODE_STRICT) {
+        q->last_kernel = "k_strict4";
+        rc = run_strict_chain(q, skip, chunk, nullptr, c->d_score, c->d_ninfo, c->d_score, c->d_ninfo);
+        if (rc) return rc;
+    } else {
+        Certify cert;
+        cert.on = (mode == SNPM_MODE_EXACT);
+        cert.flag = false;                  // certified once, over the totals (snpm_carry_finish)
+        cert.chunk = chunk;
+        cert.chunks_after = chunks_after;
+        FastGeom g;
+        rc = run_fast(q, skip, &g, cert);
+        if (rc) return rc;
+        const bool bounded = cert.on && !q->all_integer && q->n > 0;
+        hipLaunchKernelGGL(k_carry_add, dim3((unsigned)((p->n_acc + 255) / 256)), dim3(256), 0, ctx->stream, c->d_score,
+                           c->d_ninfo, (const double *)q->d_score, (const int64_t *)q->d_ninfo, p->n_acc, c->d_E,
+                           bounded ? (const double *)q->cert_eref() : (const double *)nullptr,
+                           bounded ? efast_bound(q, g) : 0.0);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    c->mode = mode;
+    c->n_rows += q->n;
+    c->n_slabs += 1;
+    c->wsum += q->wsum;
+    return SNPM_OK;
+} SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
+
+int snpm_carry_finish(snpm_carry *c, double *score, int64_t *ninfo, int32_t *flagged, int64_t cap, int64_t *n_flagged)
+{
+    CHECK_CARRY(c);
+    snpm_ctx *ctx = c->ctx;
+    CHECK_ARG(ctx, c->n_cols < 0, "a column-list carry is read with snpm_carry_patch");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int64_t nf = 0;
+    if (c->mode == SNPM_MODE_EXACT) {
+        // the slab totals were added in slab order: n_slabs more additions per term
+        const double u = 1.1102230246251565e-16;
+        const double m = (double)(c->n_slabs + 1);
+        const double e_extra = (double)(c->wsum * (long double)(m * u / (1.0 - m * u))) * 1.0000001;
+        HIPCHK(ctx, hipMemsetAsync(c->d_ncols, 0, sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_carry_flag, dim3((unsigned)((c->n_acc + 255) / 256)), dim3(256), 0, ctx->stream,
+                           (const double *)c->d_score, c->n_acc, (const double *)c->d_E, e_extra, ctx->debug_reeval,
+                           c->d_cols, c->d_ncols, REEVAL_CAP);
+        HIPCHK(ctx, hipGetLastError());
+        int rc = ensure_pinned(ctx, 1024);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, c->d_ncols, 256 - 8 + REEVAL_CAP * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        nf = *(const int *)ctx->h_pinned;
+        const int32_t *hc = (const int32_t *)((const char *)ctx->h_pinned + 256 - 8);
+        if (flagged)
+            for (int64_t i = 0; i < std::min<int64_t>(std::min<int64_t>(nf, REEVAL_CAP), cap); ++i) flagged[i] = hc[i];
+    }
+    c->finished = true;
+    if (n_flagged) *n_flagged = nf;
+    if (score) HIPCHK(ctx, hipMemcpyAsync(score, c->d_score, (size_t)c->n_acc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (ninfo) HIPCHK(ctx, hipMemcpyAsync(ninfo, c->d_ninfo, (size_t)c->n_acc * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SNPM_OK;
+}
+
+// totals[cols[i]] = reference-order totals of the second pass (a column-list carry)
+int snpm_carry_patch(snpm_carry *totals, const snpm_carry *cols_pass)
+{
+    CHECK_CARRY(totals);
+    CHECK_CARRY(cols_pass);
+    snpm_ctx *ctx = totals->ctx;
+    CHECK_ARG(ctx, cols_pass->ctx == ctx && cols_pass->n_cols >= 1 && cols_pass->n_acc == totals->n_acc, "not a column-list carry of this job");
+    CHECK_ARG(ctx, cols_pass->n_rows == totals->n_rows, "the second pass covered other rows than the first");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_patch, dim3(1), dim3(REEVAL_CAP), 0, ctx->stream, (const double *)cols_pass->d_score,
+                       (const int32_t *)cols_pass->d_cols, (const int *)cols_pass->d_ncols, REEVAL_CAP, totals->d_score);
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+int snpm_carry_device_ptrs(snpm_carry *c, void **d_score, void **d_ninfo)
+{
+    CHECK_CARRY(c);
+    if (d_score) *d_score = c->d_score;
+    if (d_ninfo) *d_ninfo = c->d_ninfo;
+    return SNPM_OK;
+}
 
 // ---------------------------------------------------------------------------------------------- one-shot
 int snpm_score_dense_host(snpm_ctx *ctx, const int8_t *db, int64_t db_pitch, int64_t n, int64_t n_acc,

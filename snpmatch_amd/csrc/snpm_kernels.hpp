@@ -66,6 +66,85 @@ __global__ void k_build_lut(const double *__restrict__ w, double *__restrict__ l
 }
 
 // ------------------------------------------------------------------------------------------------
+// Properties of a sample's weights, computed where the weights live (no host pass over the rows):
+//   k_wprops  block partial sums of wmax_r = max_c |W[r,c]| and two flags: bit 0 = some weight is not an integer
+//             (or not finite), bit 1 = some weight is neither 0 nor 1.
+//   k_wbits   hard-call samples: one byte of three weight bits per row (ref | het << 1 | alt << 2) for k_fast_bits.
+//   k_eref / k_efinish   the reference-order part of the certificate's error bound (DESIGN.md "Exactness"):
+//             E_ref = u / (1 - m_max u) * sum_k s_k * (len_k + 3 + K - k + chunks_after),  s_k = sum of wmax over
+//             chunk k, rounded up by 1e-7 relative (the fp64 sums of non-negative terms below are good to ~1e-12).
+__device__ __forceinline__ double block_sum_256(double v, double *sm)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[wave] = v;
+    __syncthreads();
+    return ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+
+__global__ void __launch_bounds__(256)
+k_wprops(const double *__restrict__ w, int64_t n, double *__restrict__ partial, int *__restrict__ flags)
+{
+    __shared__ double sm[4];
+    double acc = 0.0;
+    int f = 0;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (int64_t)gridDim.x * 256) {
+        const double a = fabs(w[3 * r]), b = fabs(w[3 * r + 1]), c = fabs(w[3 * r + 2]);
+        acc += fmax(a, fmax(b, c));
+        if (!(a == floor(a) && b == floor(b) && c == floor(c)) || !(a < 1e300 && b < 1e300 && c < 1e300)) f |= 1;
+        const double x = w[3 * r], y = w[3 * r + 1], z = w[3 * r + 2];
+        if (!((x == 0.0 || x == 1.0) && (y == 0.0 || y == 1.0) && (z == 0.0 || z == 1.0))) f |= 2;
+    }
+    const double tot = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+    if (f) atomicOr(flags, f);
+}
+
+__global__ void k_wbits(const double *__restrict__ w, int64_t n, int64_t n_padded, uint8_t *__restrict__ wbits)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_padded) return;
+    uint8_t b = 0;
+    if (r < n) b = (uint8_t)((w[3 * r] == 1.0 ? 1 : 0) | (w[3 * r + 1] == 1.0 ? 2 : 0) | (w[3 * r + 2] == 1.0 ? 4 : 0));
+    wbits[r] = b;
+}
+
+__global__ void __launch_bounds__(256)
+k_eref(const double *__restrict__ w, int64_t n, int64_t chunk, int64_t chunks_after, double *__restrict__ partial)
+{
+    __shared__ double sm[4];
+    const int64_t K = (n + chunk - 1) / chunk;
+    double acc = 0.0;                                     // meaningful in thread 0
+    for (int64_t k = blockIdx.x; k < K; k += gridDim.x) {
+        const int64_t r0 = k * chunk, r1 = (r0 + chunk < n) ? r0 + chunk : n;
+        double s = 0.0;
+        for (int64_t r = r0 + threadIdx.x; r < r1; r += 256)
+            s += fmax(fabs(w[3 * r]), fmax(fabs(w[3 * r + 1]), fabs(w[3 * r + 2])));
+        s = block_sum_256(s, sm);
+        acc += s * (double)((r1 - r0) + 3 + (K - k) + chunks_after);
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+
+__global__ void __launch_bounds__(256)
+k_efinish(const double *__restrict__ partial, int n_partial, int64_t n, int64_t chunk, int64_t chunks_after,
+          double *__restrict__ eref)
+{
+    __shared__ double sm[4];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n_partial; i += 256) v += partial[i];
+    v = block_sum_256(v, sm);
+    if (threadIdx.x == 0) {
+        const double u = 1.1102230246251565e-16;
+        const int64_t K = (n + chunk - 1) / chunk;
+        const double mmax = (double)(chunk + 3 + K + chunks_after);
+        eref[0] = (v * u / (1.0 - mmax * u)) * 1.0000001;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -896,9 +975,25 @@ __global__ void k_reduce_groups(const double *__restrict__ part_score, const uin
     grp_miss[g * ld + a] = m;
 }
 
+// Certificate of SNPM_MODE_EXACT, fused into the last reduce step: accession a is appended to `cols` when an
+// integer lies inside [score - E, score + E] (or the interval reaches below zero, or a < force_first: tests),
+// E = *d_eref + efast.  The list order depends on the atomics; what is computed from it does not.  *count may
+// exceed `cap` (then only the first cap entries were stored and the caller's dense fallback runs).
+__device__ __forceinline__ void flag_if_uncertain(double s, int64_t a, const double *__restrict__ d_eref, double efast,
+                                                  int force_first, int32_t *__restrict__ cols, int *__restrict__ count, int cap)
+{
+    const double E = *d_eref + efast;
+    const double lo = s - E, hi = s + E;
+    if (!(lo >= 0.0) || floor(lo) != floor(hi) || a < force_first) {
+        const int k = atomicAdd(count, 1);
+        if (k < cap) cols[k] = (int32_t)a;
+    }
+}
+
 __global__ void k_reduce(const double *__restrict__ part_score, const uint32_t *__restrict__ part_miss,
                          int64_t n_parts, int64_t ld, int64_t n_acc, int64_t n_rows, double *__restrict__ score,
-                         int64_t *__restrict__ ninfo)
+                         int64_t *__restrict__ ninfo, const double *__restrict__ d_eref, double efast, int force_first,
+                         int32_t *__restrict__ cols, int *__restrict__ count, int cap)
 {
     int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= n_acc) return;
@@ -925,6 +1020,31 @@ __global__ void k_reduce(const double *__restrict__ part_score, const uint32_t *
     }
     score[a] = s;
     ninfo[a] = n_rows - m;
+    if (d_eref) flag_if_uncertain(s, a, d_eref, efast, force_first, cols, count, cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Jobs scored SNP slab after SNP slab (panels larger than HBM): running totals.
+//   k_carry_add   totals += this slab's fast-pass results (one fp64 addition per slab and accession, in slab
+//                 order); thread 0 adds the slab's error bound (*d_eref + efast) onto the job's.
+//   k_carry_flag  the certificate over the whole job, after the last slab: as flag_if_uncertain with the summed bound.
+__global__ void k_carry_add(double *__restrict__ tot_score, int64_t *__restrict__ tot_ninfo, const double *__restrict__ score,
+                            const int64_t *__restrict__ ninfo, int64_t n_acc, double *__restrict__ tot_E,
+                            const double *__restrict__ d_eref, double efast)
+{
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a == 0) tot_E[0] += (d_eref ? d_eref[0] : 0.0) + efast;
+    if (a >= n_acc) return;
+    tot_score[a] = tot_score[a] + score[a];
+    tot_ninfo[a] += ninfo[a];
+}
+
+__global__ void k_carry_flag(const double *__restrict__ tot_score, int64_t n_acc, const double *__restrict__ tot_E,
+                             double e_extra, int force_first, int32_t *__restrict__ cols, int *__restrict__ count, int cap)
+{
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n_acc) return;
+    flag_if_uncertain(tot_score[a], a, tot_E, e_extra, force_first, cols, count, cap);
 }
 
 // A + (match ? w : 0.0) in the reference's per-class sums, evaluated as fma(m, w, A) with m = 1.0 or 0.0: the
@@ -950,6 +1070,26 @@ __device__ __forceinline__ int code_at(const int8_t *__restrict__ db, int64_t pi
     return db[prow * pitch + col];
 }
 
+// Rows of segment `seg`: explicit offsets (windows of a cross) or implicit `chunk`-row pieces of [0, n)
+// (the reference's chunk loop, core/snpmatch.py:218-222) -- no offset table to build or upload.
+__device__ __forceinline__ void seg_bounds(const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg,
+                                           int64_t &r0, int64_t &r1)
+{
+    if (seg_off) {
+        r0 = seg_off[seg];
+        r1 = seg_off[seg + 1];
+    } else {
+        r0 = seg * chunk;
+        r1 = (r0 + chunk < n) ? r0 + chunk : n;
+    }
+}
+
+// Re-evaluation kernels are launched before the host knows how many accessions the certificate flagged; they
+// read the count on the device and leave at once when their tier is not the one that has to run:
+//   sparse tier: 1 <= *count <= cap   (k_strict_sparse / _T, k_scan_few, k_patch)
+//   dense tier : *count > cap         (k_strict4 / k_strict, k_scan: every accession in reference order)
+__device__ __forceinline__ bool dense_tier_off(const int *__restrict__ gate, int cap) { return gate && *gate <= cap; }
+
 // ------------------------------------------------------------------------------------------------
 // Strict (reference-order) segment sums.
 //   grid.x = segment, grid.y = column blocks of blockDim.x lanes
@@ -958,14 +1098,17 @@ __device__ __forceinline__ int code_at(const int8_t *__restrict__ db, int64_t pi
 template <bool SKIP, bool GATHER>
 __global__ void __launch_bounds__(256)
 k_strict(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx, int64_t row0,
-         const double *__restrict__ w, const int64_t *__restrict__ seg_off, const int32_t *__restrict__ cols,
-         int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
+         const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
+         const int32_t *__restrict__ cols, int64_t ncols, double *__restrict__ out_score,
+         uint32_t *__restrict__ out_miss, int64_t ld, const int *__restrict__ gate, int gate_cap)
 {
-    const int64_t seg = blockIdx.x;
+    if (dense_tier_off(gate, gate_cap)) return;
+    const int64_t seg = blockIdx.x;          // output row; the segment itself is seg0 + seg when the pieces are implicit
     const int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
     if (i >= ncols) return;
     const int64_t col = cols ? (int64_t)cols[i] : i;
-    const int64_t r0 = seg_off[seg], r1 = seg_off[seg + 1];
+    int64_t r0, r1;
+    seg_bounds(seg_off, chunk, n, seg_off ? seg : seg0 + seg, r0, r1);
     double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
     uint32_t miss = 0;
     int64_t r = r0;
@@ -1005,13 +1148,16 @@ k_strict(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t
 template <bool SKIP, bool GATHER, bool PACKED>
 __global__ void __launch_bounds__(256)
 k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
-          const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t ncols,
-          double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
+          const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
+          int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
+          const int *__restrict__ gate, int gate_cap)
 {
+    if (dense_tier_off(gate, gate_cap)) return;
     const int64_t seg = blockIdx.x;
     const int64_t c0 = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) * 4;
     if (c0 >= ncols) return;                 // pitch is a multiple of 256: the dword / byte of an active lane is inside the row
-    const int64_t r0 = seg_off[seg], r1 = seg_off[seg + 1];
+    int64_t r0, r1;
+    seg_bounds(seg_off, chunk, n, seg_off ? seg : seg0 + seg, r0, r1);
     double a_ref[4] = {0.0, 0.0, 0.0, 0.0}, a_het[4] = {0.0, 0.0, 0.0, 0.0}, a_alt[4] = {0.0, 0.0, 0.0, 0.0};
     uint32_t miss8 = 0, miss[4] = {0, 0, 0, 0};
     int since_flush = 0;
@@ -1072,16 +1218,19 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
 template <bool SKIP, bool GATHER>
 __global__ void __launch_bounds__(256)
 k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx,
-                int64_t row0, const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t n_seg,
-                const int32_t *__restrict__ cols, int64_t ncols, double *__restrict__ out_score,
-                uint32_t *__restrict__ out_miss, int64_t ld)
+                int64_t row0, const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n,
+                int64_t n_seg, const int32_t *__restrict__ cols, const int *__restrict__ d_ncols, int cap,
+                double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
 {
+    const int64_t ncols = *d_ncols;           // flagged accessions (device-side count): sparse tier only
+    if (ncols > cap) return;
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_seg * ncols) return;
     const int64_t seg = id / ncols;
     const int64_t i = id - seg * ncols;
     const int64_t col = cols[i];
-    const int64_t r0 = seg_off[seg], r1 = seg_off[seg + 1];
+    int64_t r0, r1;
+    seg_bounds(seg_off, chunk, n, seg, r0, r1);
     double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
     uint32_t miss = 0;
     constexpr int U = 32;                 // byte loads in flight per lane (each its own cache line)
@@ -1161,20 +1310,65 @@ k_pack_transpose(const int8_t *__restrict__ db, int64_t pitch, int64_t n_snp, in
     }
 }
 
+// The same copy from a PACKED panel (2 bits per call on both sides; the copy is as large as the panel, so it is
+// only built when it fits): tile of 256 SNPs x 256 accessions = 64 B per SNP row through LDS; thread = one
+// accession, 256 SNPs -> 64 contiguous bytes of its row in the copy.
+constexpr int PTP_ROWS = 256;
+constexpr int PTP_COLS = 256;
+__global__ void __launch_bounds__(256)
+k_pack_transpose_packed(const uint8_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n_acc,
+                        uint8_t *__restrict__ dT, int64_t pitchT)
+{
+    __shared__ uint32_t tile[PTP_ROWS][PTP_COLS / 16 + 1];     // 16 dwords of 16 calls per row (+1: conflict-free columns)
+    const int64_t snp0 = (int64_t)blockIdx.x * PTP_ROWS;
+    const int64_t acc0 = (int64_t)blockIdx.y * PTP_COLS;
+    const int t = threadIdx.x;
+    for (int pass = 0; pass < PTP_ROWS / 16; ++pass) {
+        const int r = pass * 16 + (t >> 4);
+        const int64_t row = snp0 + r;
+        const int64_t byte = acc0 / 4 + (t & 15) * 4;
+        uint32_t v = 0xffffffffu;                                // rows / bytes past the end: missing
+        if (row < n_snp && byte < pitch) v = *reinterpret_cast<const uint32_t *>(db + row * pitch + byte);
+        tile[r][t & 15] = v;
+    }
+    __syncthreads();
+    const int c = t;
+    if (acc0 + c < n_acc) {
+        uint32_t out[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) out[k] = 0;
+#pragma unroll 16
+        for (int k = 0; k < PTP_ROWS; ++k) {
+            const uint32_t code = (tile[k][c >> 4] >> (2 * (c & 15))) & 3u;
+            out[k >> 4] |= code << (2 * (k & 15));
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(dT + (acc0 + c) * pitchT + snp0 / 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint4 o;
+            o.x = out[4 * k]; o.y = out[4 * k + 1]; o.z = out[4 * k + 2]; o.w = out[4 * k + 3];
+            dst[k] = o;
+        }
+    }
+}
+
 // k_strict_sparse on the accession-major packed copy: same arithmetic and order.
 template <bool SKIP, bool GATHER>
 __global__ void __launch_bounds__(256)
 k_strict_sparse_T(const uint8_t *__restrict__ dT, int64_t pitchT, const int64_t *__restrict__ row_idx, int64_t row0,
-                  const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t n_seg,
-                  const int32_t *__restrict__ cols, int64_t ncols, double *__restrict__ out_score,
-                  uint32_t *__restrict__ out_miss, int64_t ld)
+                  const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n,
+                  int64_t n_seg, const int32_t *__restrict__ cols, const int *__restrict__ d_ncols, int cap,
+                  double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
 {
+    const int64_t ncols = *d_ncols;
+    if (ncols > cap) return;
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= n_seg * ncols) return;
     const int64_t seg = id / ncols;
     const int64_t i = id - seg * ncols;
     const uint8_t *colp = dT + (int64_t)cols[i] * pitchT;
-    const int64_t r0 = seg_off[seg], r1 = seg_off[seg + 1];
+    int64_t r0, r1;
+    seg_bounds(seg_off, chunk, n, seg, r0, r1);
     double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
     uint32_t miss = 0;
     constexpr int U = 8;
@@ -1211,13 +1405,17 @@ k_strict_sparse_T(const uint8_t *__restrict__ dT, int64_t pitchT, const int64_t 
 // total[i] = (((0 + s0) + s1) + ...) over the segments in order; ninfo[i] = n_rows - sum(miss).
 // The adds are sequential by contract (ScoreList += chunk, core/snpmatch.py:224); the loads are not:
 // 8 are issued ahead of the adds that consume them.
+// carry_score / carry_ninfo (may be NULL): totals of the SNP slabs scored before this one -- the chain of
+// additions continues from them, as the reference's loop does over the whole SNP axis.
 __global__ void k_scan(const double *__restrict__ seg_score, const uint32_t *__restrict__ seg_miss,
-                       const int64_t *__restrict__ seg_off, int64_t n_seg, int64_t ld, int64_t ncols,
-                       double *__restrict__ tot_score, int64_t *__restrict__ tot_ninfo)
+                       int64_t n_rows, int64_t n_seg, int64_t ld, int64_t ncols,
+                       double *tot_score, int64_t *tot_ninfo, const double *carry_score, const int64_t *carry_ninfo,
+                       const int *__restrict__ gate, int gate_cap)     // carry_* may alias tot_* (in-place continuation)
 {
+    if (dense_tier_off(gate, gate_cap)) return;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncols) return;
-    double s = 0.0;
+    double s = carry_score ? carry_score[i] : 0.0;
     int64_t m = 0;
     int64_t k = 0;
     for (; k + 8 <= n_seg; k += 8) {
@@ -1239,7 +1437,7 @@ __global__ void k_scan(const double *__restrict__ seg_score, const uint32_t *__r
         m += seg_miss[k * ld + i];
     }
     tot_score[i] = s;
-    if (tot_ninfo) tot_ninfo[i] = (seg_off[n_seg] - seg_off[0]) - m;
+    if (tot_ninfo) tot_ninfo[i] = (carry_ninfo ? carry_ninfo[i] : 0) + n_rows - m;
 }
 
 // Same result for a SHORT column list (ncols <= 64, one block of 4 waves).  The chain of additions is
@@ -1272,9 +1470,12 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
     } while (0)
 
 __global__ void __launch_bounds__(256)
-k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, int ncols, double *__restrict__ tot_score)
+k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, const int *__restrict__ d_ncols, int cap,
+           double *__restrict__ tot_score, const double *__restrict__ carry)
 {
     __shared__ __attribute__((aligned(16))) double tile[2][SCAN_TILE_ELEMS + 2 * WAVE];
+    const int ncols = *d_ncols;
+    if (ncols < 1 || ncols > cap) return;          // block-uniform
     const int ts = (SCAN_TILE_ELEMS / ncols) & ~31;  // segments per tile: a multiple of 32, >= 64
     const int cs = ts + 2;                           // column stride: 16 B more than a multiple of 256 B
     const int wave = threadIdx.x / WAVE;
@@ -1303,7 +1504,7 @@ k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, int 
     };
     if (n_seg > 0) load_tile(0, 0, threadIdx.x, 256);
     __syncthreads();
-    double s = 0.0;
+    double s = (carry && (int)threadIdx.x < ncols) ? carry[threadIdx.x] : 0.0;     // totals of earlier slabs
     int buf = 0;
     for (int64_t base = 0; base < n_seg; base += ts, buf ^= 1) {
         if (wave > 0) {
@@ -1354,9 +1555,11 @@ __global__ void k_seg_pack(const double *__restrict__ seg_score, const uint32_t 
 }
 
 // score[cols[i]] = strict_total[i]
-__global__ void k_patch(const double *__restrict__ strict_total, const int32_t *__restrict__ cols, int64_t ncols,
-                        double *__restrict__ score)
+__global__ void k_patch(const double *__restrict__ strict_total, const int32_t *__restrict__ cols,
+                        const int *__restrict__ d_ncols, int cap, double *__restrict__ score)
 {
+    const int ncols = *d_ncols;
+    if (ncols > cap) return;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < ncols) score[cols[i]] = strict_total[i];
 }
@@ -1522,6 +1725,38 @@ __global__ void k_synth(uint32_t *__restrict__ db, int64_t pitch, int64_t n_snp,
         }
         db[i] = v;
     }
+}
+
+// synthetic SAMPLE (benchmarks; SURVEY 8d recipe) generated where it is used: weights [n,3] (ref, het, alt) of a
+// sample planted on accession `planted` of the synthetic panel `seed`, rows snp0 .. snp0 + n - 1.  Counter-based
+// like the panel: row s depends on (seed, s) only.  exp_tab[k] = exp(-k/10) comes from the host so that the
+// numpy twin (snpmatch_amd.synth.sample_weights_twin) reproduces the bits.
+__global__ void k_synth_sample(uint64_t seed, int64_t snp0, int64_t n, int64_t planted, uint32_t err_permille,
+                               uint32_t pl_permille, const double *__restrict__ exp_tab, double *__restrict__ wei)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint64_t s = (uint64_t)(snp0 + r);
+    const uint32_t quad = synth_quad(seed, s, (uint64_t)(planted >> 2));
+    uint32_t code = (quad >> (8 * (uint32_t)(planted & 3))) & 0xffu;          // 0, 1, 2 or 0xff (missing)
+    const uint64_t h = splitmix64(splitmix64((seed ^ 0x5851F42D4C957F2Dull) + s * 0x9FB21C651E98DF25ull));
+    const uint64_t h2 = splitmix64(h + 0x2545F4914F6CDD1Dull);
+    if (code == 0xffu) code = (uint32_t)(h & 1u);                               // missing in the DB: ref or alt
+    if ((uint32_t)((h >> 8) & 0xFFFFFFu) % 1000u < err_permille) code = (uint32_t)((h >> 40) & 0xFFFFu) % 3u;
+    const int called = code == 0u ? 0 : (code == 2u ? 1 : 2);                   // column of the called genotype
+    double w[3];
+    if ((uint32_t)(h2 & 0xFFFFFFu) % 1000u < pl_permille) {
+        const uint32_t pa = 1u + (uint32_t)((h2 >> 24) & 0xFFFFu) % 255u, pb = 1u + (uint32_t)((h2 >> 40) & 0xFFFFu) % 255u;
+        w[called] = exp_tab[0];
+        w[(called + 1) % 3] = exp_tab[pa];
+        w[(called + 2) % 3] = exp_tab[pb];
+    } else {
+        w[0] = w[1] = w[2] = 0.0;
+        w[called] = 1.0;
+    }
+    wei[3 * r] = w[0];
+    wei[3 * r + 1] = w[1];
+    wei[3 * r + 2] = w[2];
 }
 
 // packed counterpart of k_synth: the same values, one byte (= one accession quad) per thread step

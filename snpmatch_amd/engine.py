@@ -38,7 +38,7 @@ class Context(object):
                 if isinstance(k, Query):
                     k.free()
             for k in kids:
-                if isinstance(k, Panel):
+                if isinstance(k, (Panel, Carry)):
                     k.free()
             self.lib.snpm_destroy(self.h)
             self.h = None
@@ -126,6 +126,16 @@ class Context(object):
         check(self.lib.snpm_likelihood(self.h, ptr(y), ptr(n), m, ln, int(bool(truncate)), a, ptr(lik), ptr(lrt)), self.h)
         return lik, lrt
 
+    def sample_synthetic(self, seed, snp0, n, planted, d_wei, err=0.02, frac_pl=0.8):
+        """Benchmark sample generated on the device into ``d_wei`` (raw device pointer of a float64 [n, 3] buffer):
+        accession ``planted`` of the synthetic panel ``seed`` with a fraction ``err`` of random calls and a fraction
+        ``frac_pl`` of PL-derived weights.  ``snpmatch_amd.synth.sample_weights_twin`` is the numpy twin."""
+        from . import synth
+        tab = synth.exp_table()
+        check(self.lib.snpm_sample_synthetic(self.h, C.c_uint64(int(seed)), int(snp0), int(n), int(planted),
+                                             int(round(err * 1000)), int(round(frac_pl * 1000)), ptr(tab),
+                                             C.c_void_p(int(d_wei))), self.h)
+
     def binom_identity(self, x, n, error_rate=0.0005, pthres=0.05, return_sf=False):
         x = np.ascontiguousarray(x, dtype=np.float64)
         n = np.ascontiguousarray(n, dtype=np.int64)
@@ -207,8 +217,11 @@ class Panel(object):
         check(self.ctx.lib.snpm_panel_download_rows(self.h, int(row0), int(nrows), ptr(out), self.n_acc), self.ctx.h)
         return out
 
-    def fill_synthetic(self, seed, snp0=0, acc0=0):
-        check(self.ctx.lib.snpm_panel_fill_synthetic(self.h, C.c_uint64(int(seed)), int(snp0), int(acc0)), self.ctx.h)
+    def fill_synthetic(self, seed, snp0=0, acc0=0, row0=0, nrows=None):
+        """rows [row0, row0 + nrows) <- SNPs snp0 .. of the synthetic panel ``seed`` (columns acc0 ..)"""
+        nrows = self.n_snp - row0 if nrows is None else nrows
+        check(self.ctx.lib.snpm_panel_fill_synthetic_rows(self.h, C.c_uint64(int(seed)), int(snp0), int(acc0), int(row0),
+                                                          int(nrows)), self.ctx.h)
 
     def segregating_rows(self, cols):
         """uint8 mask [n_snp]: 1 where the informative calls of accessions `cols` differ (device scan)."""
@@ -241,9 +254,19 @@ class Panel(object):
 class Query(object):
     """A sample's matched SNPs (panel rows + weights) resident on the device."""
 
-    def __init__(self, panel, row_idx, wei, row0=0):
+    def __init__(self, panel, row_idx, wei, row0=0, _device=None):
         self.panel = panel
         ctx = panel.ctx
+        if _device is not None:             # (d_row_idx or None, d_wei, n): raw device pointers, see from_device
+            d_rows, d_wei, n = _device
+            self.n = int(n)
+            h = C.c_void_p()
+            check(ctx.lib.snpm_query_create_device(panel.h, C.c_void_p(d_rows) if d_rows else None, int(row0), self.n,
+                                                   C.c_void_p(int(d_wei)), C.byref(h)), ctx.h)
+            self.h = h
+            panel._queries.add(self)
+            ctx._children.add(self)
+            return
         wei = np.asarray(wei)
         assert wei.ndim == 2 and wei.shape[1] == 3, "SNP weights should be a np.array with  shape == n,3"
         wei = np.ascontiguousarray(wei, dtype=np.float64)
@@ -258,26 +281,48 @@ class Query(object):
         panel._queries.add(self)
         ctx._children.add(self)
 
+    @classmethod
+    def from_device(cls, panel, d_row_idx, d_wei, n, row0=0):
+        """Query whose row list (int64 [n] or None = dense from ``row0``) and weights (float64 [n, 3]) already are
+        in device memory (raw pointers); they are copied."""
+        return cls(panel, None, None, row0=row0, _device=(d_row_idx, d_wei, n))
+
     def run(self, chunk=1000, skip_hets=False, mode=MODE_EXACT, return_info=False):
         """Genotyper.genotyper accumulators: (ScoreList float64 [n_acc], NumInfoSites int64 [n_acc])."""
         ctx = self.panel.ctx
         score = np.empty(self.panel.n_acc, dtype=np.float64)
         ninfo = np.empty(self.panel.n_acc, dtype=np.int64)
-        info = np.zeros(4, dtype=np.int64)
+        info = np.zeros(4, dtype=np.int64) if return_info else None
         check(ctx.lib.snpm_query_run(self.h, int(chunk), int(bool(skip_hets)), int(mode), ptr(score), ptr(ninfo), ptr(info)),
               ctx.h)
         if return_info:
-            return score, ninfo, {"n_strict_reeval": int(info[0]), "all_integer_weights": bool(info[1])}
+            return score, ninfo, {"n_strict_reeval": int(info[0]), "all_integer_weights": bool(info[1]),
+                                  "reeval_path": int(info[2])}
         return score, ninfo
 
     def run_device(self, chunk=1000, skip_hets=False, mode=MODE_EXACT):
-        """Enqueue the scoring; returns raw device pointers (d_score f64[n_acc], d_ninfo i64[n_acc])."""
+        """Enqueue the scoring (nothing waits on the host, the certificate included); returns raw device pointers
+        (d_score f64[n_acc], d_ninfo i64[n_acc]).  ``last_reeval()`` reads the re-evaluation count afterwards."""
         ctx = self.panel.ctx
         ds, dn = C.c_void_p(), C.c_void_p()
-        info = np.zeros(4, dtype=np.int64)
         check(ctx.lib.snpm_query_run_device(self.h, int(chunk), int(bool(skip_hets)), int(mode), C.byref(ds), C.byref(dn),
-                                            ptr(info)), ctx.h)
-        return ds.value, dn.value, int(info[0])
+                                            None), ctx.h)
+        return ds.value, dn.value
+
+    def last_reeval(self):
+        """accessions the last certified run re-evaluated in reference order (synchronises)"""
+        n = C.c_int64(0)
+        check(self.panel.ctx.lib.snpm_query_last_reeval(self.h, C.byref(n)), self.panel.ctx.h)
+        return n.value
+
+    def last_kernel(self):
+        return (self.panel.ctx.lib.snpm_query_last_kernel(self.h) or b"").decode()
+
+    def run_carry(self, carry, chunk=1000, skip_hets=False, mode=MODE_EXACT, chunks_after=0):
+        """score these rows as the next SNP slab of a larger job (see ``Carry`` / ``SlabScorer``)"""
+        ctx = self.panel.ctx
+        check(ctx.lib.snpm_query_run_carry(self.h, int(chunk), int(bool(skip_hets)), int(mode), int(chunks_after), carry.h),
+              ctx.h)
 
     def bind_outputs(self, d_score, d_ninfo):
         """Write results of later runs into caller-owned device buffers (raw pointers, e.g. tensor.data_ptr())."""
@@ -327,3 +372,114 @@ class Query(object):
             self.free()
         except Exception:
             pass
+
+
+class Carry(object):
+    """Running per-accession totals of a job scored SNP slab after SNP slab (include/snpmatch_hip.h, snpm_carry_*)."""
+
+    def __init__(self, ctx, n_acc):
+        self.ctx, self.n_acc = ctx, int(n_acc)
+        h = C.c_void_p()
+        check(ctx.lib.snpm_carry_create(ctx.h, self.n_acc, C.byref(h)), ctx.h)
+        self.h = h
+        ctx._children.add(self)
+
+    def reset(self):
+        check(self.ctx.lib.snpm_carry_reset(self.h), self.ctx.h)
+
+    def bind_outputs(self, d_score, d_ninfo):
+        """keep the totals in caller-owned device buffers (raw pointers of float64 [n_acc] / int64 [n_acc])"""
+        check(self.ctx.lib.snpm_carry_bind_outputs(self.h, C.c_void_p(d_score) if d_score else None,
+                                                   C.c_void_p(d_ninfo) if d_ninfo else None), self.ctx.h)
+
+    def set_columns(self, cols):
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        check(self.ctx.lib.snpm_carry_set_columns(self.h, ptr(cols), len(cols)), self.ctx.h)
+
+    def finish(self, want_results=True):
+        """(score, ninfo, flagged accessions): flagged is empty unless the job ran in MODE_EXACT and some totals could
+        not be certified; len(flagged) > 64 is reported as a count only (``n_flagged``)."""
+        score = np.empty(self.n_acc, dtype=np.float64) if want_results else None
+        ninfo = np.empty(self.n_acc, dtype=np.int64) if want_results else None
+        cols = np.zeros(64, dtype=np.int32)
+        nf = C.c_int64(0)
+        check(self.ctx.lib.snpm_carry_finish(self.h, ptr(score), ptr(ninfo), ptr(cols), 64, C.byref(nf)), self.ctx.h)
+        self.n_flagged = nf.value
+        return score, ninfo, np.sort(cols[:min(nf.value, 64)])
+
+    def patch_from(self, cols_carry):
+        check(self.ctx.lib.snpm_carry_patch(self.h, cols_carry.h), self.ctx.h)
+
+    def device_ptrs(self):
+        ds, dn = C.c_void_p(), C.c_void_p()
+        check(self.ctx.lib.snpm_carry_device_ptrs(self.h, C.byref(ds), C.byref(dn)), self.ctx.h)
+        return ds.value, dn.value
+
+    def free(self):
+        if self.h:
+            if self.ctx.h:
+                self.ctx.lib.snpm_carry_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class SlabScorer(object):
+    """Genotyper.genotyper over a SNP axis that does not fit in HBM (core/snpmatch.py:207-233 for a panel scored slab
+    by slab).  ``slabs`` is a list of row counts; ``load(k, panel)`` must leave slab k in rows [0, slabs[k]) of
+    ``panel`` (upload, file, generator); ``weights(k)`` returns the float64 [slabs[k], 3] weights of its rows (a numpy
+    array, or a raw device pointer when ``device_weights``).  Every slab but the last holds a multiple of ``chunk``
+    rows.  ``run`` returns (ScoreList, NumInfoSites, info); in MODE_EXACT the accessions whose total the certificate
+    cannot vouch for are re-scored in reference order by streaming the slabs a second time."""
+
+    def __init__(self, panel, slabs, load, weights, chunk=1000, skip_hets=False, device_weights=False):
+        self.panel, self.slabs, self.load, self.weights = panel, [int(s) for s in slabs], load, weights
+        self.chunk, self.skip, self.device_weights = int(chunk), bool(skip_hets), device_weights
+        assert all(s % self.chunk == 0 for s in self.slabs[:-1]), "every slab but the last must hold a multiple of chunk rows"
+        assert max(self.slabs) <= panel.n_snp
+        self.queries = [None] * len(self.slabs)         # kept: a second pass reuses them
+        self.carry = Carry(panel.ctx, panel.n_acc)
+
+    def _query(self, k):
+        if self.queries[k] is None:
+            w = self.weights(k)
+            self.queries[k] = (Query.from_device(self.panel, None, w, self.slabs[k]) if self.device_weights
+                               else Query(self.panel, None, w))
+        return self.queries[k]
+
+    def _after(self, k):
+        return sum(-(-s // self.chunk) for s in self.slabs[k + 1:])
+
+    def _pass(self, carry, mode):
+        for k in range(len(self.slabs)):
+            self.load(k, self.panel)
+            self._query(k).run_carry(carry, self.chunk, self.skip, mode, self._after(k))
+
+    def run(self, mode=MODE_EXACT):
+        self.carry.reset()
+        self._pass(self.carry, mode)
+        score, ninfo, flagged = self.carry.finish()
+        info = {"n_strict_reeval": int(self.carry.n_flagged), "second_pass": False}
+        if self.carry.n_flagged > 0:
+            info["second_pass"] = True
+            if self.carry.n_flagged <= 64:
+                cols = Carry(self.panel.ctx, self.panel.n_acc)
+                cols.set_columns(flagged)
+                self._pass(cols, MODE_STRICT)
+                self.carry.patch_from(cols)
+                cols.free()
+            else:                                   # many exact-integer totals: everything in reference order
+                self.carry.reset()
+                self._pass(self.carry, MODE_STRICT)
+            score, ninfo, _ = self.carry.finish()
+        return score, ninfo, info
+
+    def free(self):
+        for q in self.queries:
+            if q is not None:
+                q.free()
+        self.carry.free()

@@ -71,3 +71,37 @@ def planted_sample(rng, planted_col, err=0.02, frac_pl=0.8):
     flip = rng.random(len(codes)) < err
     codes[flip] = rng.choice(np.array([0, 1, 2], dtype=np.int8), size=int(flip.sum()))
     return codes, sample_weights(rng, codes, frac_pl)
+
+
+def exp_table():
+    """exp(-k / 10), k = 0..255, as this host's libm rounds it: the weights a PL of k yields (core/parsers.py:147-150)"""
+    return np.exp(np.arange(256, dtype=np.float64) / (-10.0))
+
+
+def sample_weights_twin(seed, snp0, n, planted, err=0.02, frac_pl=0.8):
+    """numpy twin of the device sample generator k_synth_sample (snpm_sample_synthetic): float64 [n, 3]"""
+    err_pm, pl_pm = int(round(err * 1000)), int(round(frac_pl * 1000))
+    with np.errstate(over="ignore"):
+        s = np.arange(n, dtype=np.uint64) + np.uint64(snp0)
+        hq = _splitmix64(_splitmix64(np.uint64(seed) ^ (s * np.uint64(0xD6E8FEB86659FD93))) + np.uint64(planted // 4))
+        u = ((hq >> np.uint64(16 * (planted % 4))) & np.uint64(0xFFFF)).astype(np.int64)
+        code = np.where(u < 3277, 255, np.where(u < 42598, 0, np.where(u < 64225, 1, 2))).astype(np.int64)
+        h = _splitmix64(_splitmix64((np.uint64(seed) ^ np.uint64(0x5851F42D4C957F2D)) + s * np.uint64(0x9FB21C651E98DF25)))
+        h2 = _splitmix64(h + np.uint64(0x2545F4914F6CDD1D))
+        code = np.where(code == 255, (h & np.uint64(1)).astype(np.int64), code)
+        flip = ((h >> np.uint64(8)) & np.uint64(0xFFFFFF)).astype(np.int64) % 1000 < err_pm
+        code = np.where(flip, ((h >> np.uint64(40)) & np.uint64(0xFFFF)).astype(np.int64) % 3, code)
+        called = np.where(code == 0, 0, np.where(code == 2, 1, 2))
+        is_pl = (h2 & np.uint64(0xFFFFFF)).astype(np.int64) % 1000 < pl_pm
+        pa = 1 + ((h2 >> np.uint64(24)) & np.uint64(0xFFFF)).astype(np.int64) % 255
+        pb = 1 + ((h2 >> np.uint64(40)) & np.uint64(0xFFFF)).astype(np.int64) % 255
+    tab = exp_table()
+    rows = np.arange(n)
+    wei = np.zeros((n, 3))
+    wei[rows, called] = 1.0
+    pl = np.zeros((n, 3))
+    pl[rows, called] = tab[0]
+    pl[rows, (called + 1) % 3] = tab[pa]
+    pl[rows, (called + 2) % 3] = tab[pb]
+    wei[is_pl] = pl[is_pl]
+    return wei

@@ -25,7 +25,8 @@ t0 = time.perf_counter()
 K = 5
 nre = 0
 for _ in range(K):
-    nre += q.run_device(1000, False, mode)[2]
+    q.run_device(1000, False, mode)
+    nre += q.last_reeval()
 ctx.synchronize()
 dt = (time.perf_counter() - t0) / K * 1e3
 print("wall ms/step %.3f  re-evaluated columns/step %.1f" % (dt, nre / K))

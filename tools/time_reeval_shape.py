@@ -19,8 +19,9 @@ for mode, name in ((engine.MODE_FAST, "fast"), (engine.MODE_EXACT, "exact")):
     ctx.profile(True); ctx.profile_reset()
     t0 = time.perf_counter()
     for i in range(5):
-        _, _, nre = q.run_device(1000, False, mode)
+        q.run_device(1000, False, mode)
     ctx.synchronize()
+    nre = q.last_reeval()
     dt = (time.perf_counter() - t0) / 5 * 1e3
     parts = {kk: ctx.profile_read(kk) for kk in ("fast", "reduce", "strict", "scan")}
     ctx.profile(False)
