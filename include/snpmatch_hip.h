@@ -223,6 +223,14 @@ int snpm_intersect_sorted_search(const int64_t *a, int64_t na, const int64_t *b,
 /* Genotype.identify_segregating_snps on the resident panel (core/snp_genotype.py:188-211, used by --refine):
    mask [n_snp] (host, uint8) = 1 where the informative calls of accessions cols[0..ncols) are not all equal. */
 int snpm_panel_segregating(snpm_panel *panel, const int32_t *cols, int64_t ncols, uint8_t *mask);
+/* the same scan for an accession-SHARDED DB (ncols may be 0): besides the local mask, first [n_snp] receives the
+   first informative call of the listed local accessions in every row (0xFF = none); a row segregates when some
+   rank's mask is set or two ranks report different calls (snpmatch_amd.dist) */
+int snpm_panel_segregating_first(snpm_panel *panel, const int32_t *cols, int64_t ncols, uint8_t *mask, uint8_t *first);
+/* calls of the listed accessions at the query's matched rows, codes [ncols, n] (uint8: 0 ref, 1 alt, 2 het, 3 other
+   code, 0xFF missing; host): the g_acc.snps[:, i] column reads of the reference (core/csmatch.py:116-117), used to
+   bring the columns of an accession-sharded DB together for the in-silico crosses */
+int snpm_query_gather_columns(snpm_query *query, const int32_t *acc_idx, int ncols, uint8_t *codes);
 /* CrossIdentifier.match_insilico_f1s (core/csmatch.py:115-125): every pair (i < j, in the order of
    itertools.combinations) of the n_sel (<= 32) accessions acc_idx is crossed in silico over the query's
    matched SNPs.  Per pair: "alt" SNPs (both calls 1) take W[:, 2], "ref" SNPs (both 0) take W[:, 0], SNPs

@@ -36,7 +36,7 @@ SYMBOLS = [
     "snpm_vcf_parse", "snpm_vcf_dims", "snpm_vcf_fill", "snpm_vcf_sample_name", "snpm_vcf_free",
     "snpm_debug_stream_read", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
     "snpm_panel_fill_synthetic_rows", "snpm_sample_synthetic", "snpm_query_create_device", "snpm_query_last_reeval",
-    "snpm_query_last_kernel", "snpm_carry_create", "snpm_carry_reset", "snpm_carry_free", "snpm_carry_set_columns", "snpm_carry_bind_outputs",
+    "snpm_query_last_kernel", "snpm_carry_create", "snpm_carry_reset", "snpm_carry_free", "snpm_carry_set_columns", "snpm_carry_bind_outputs", "snpm_panel_segregating_first", "snpm_query_gather_columns",
     "snpm_query_run_carry", "snpm_carry_finish", "snpm_carry_patch", "snpm_carry_device_ptrs",
 ]
 
@@ -110,6 +110,8 @@ def load():
     lib.snpm_intersect_sorted.argtypes = [p, i64, p, i64, p, p, C.POINTER(i64)]
     lib.snpm_panel_segregating.argtypes = [p, p, i64, p]
     lib.snpm_query_f1_pairs.argtypes = [p, p, ci, p, p]
+    lib.snpm_panel_segregating_first.argtypes = [p, p, i64, p, p]
+    lib.snpm_query_gather_columns.argtypes = [p, p, ci, p]
     lib.snpm_intersect_sorted_search.argtypes = [p, i64, p, i64, p, p, C.POINTER(i64)]
     lib.snpm_vcf_parse.argtypes = [C.c_char_p, ci, pp]
     lib.snpm_vcf_dims.argtypes = [p, C.POINTER(i64), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]

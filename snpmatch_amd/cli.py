@@ -98,7 +98,13 @@ def main(argv=None):
         parser.print_help()
         return 0
     try:
+        from . import dist
+        job = dist.init_from_env()       # under torch.distributed.run: accession-sharded over the ranks' GPUs
         args['func'](args)
+        if job is not None:
+            import torch.distributed as td
+            td.barrier()
+            td.destroy_process_group()
         return 0
     except KeyboardInterrupt:
         return 0

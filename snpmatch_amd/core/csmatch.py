@@ -26,6 +26,7 @@ from . import parsers
 from . import snp_genotype  # noqa: F401  (part of the reference's module surface)
 from . import snpmatch
 from .. import _lib
+from .. import dist
 from .. import engine
 
 log = logging.getLogger(__name__)
@@ -108,7 +109,8 @@ class CrossIdentifier(object):
         self.inputs, self.g = inputs, g
         self.genome = genomes.Genome(genome_id)
         self.binLen = binLen
-        self.output_id = output_id
+        job = dist.job()             # accession-sharded run: rank 0 writes, the other ranks use a scratch prefix
+        self.output_id = job.output_prefix(output_id) if job else output_id
         self.error_rate = identity_error_rate
         self._skip_db_hets = skip_db_hets
         if run_identifier:
@@ -149,6 +151,10 @@ class CrossIdentifier(object):
         query = engine.Query(self.g.panel(), db_rows, self.inputs.wei[sample_rows, ])
         w_score, w_ninfo, tot_score, tot_ninfo = query.run_windows(offsets, self._skip_db_hets)
         query.free()
+        job = dist.job()
+        if job is not None:          # per-window and total results of this rank's accessions -> whole arrays everywhere
+            w_score, w_ninfo = job.gather_windows(w_score, w_ninfo, n_acc)
+            tot_score, tot_ninfo = job.gather_scores(tot_score, tot_ninfo, n_acc)
 
         accs = np.asarray(self.g.accessions)[shown]
         self.windows_data = pd.DataFrame(columns=list(_report.WINDOW_COLUMNS))
@@ -183,7 +189,23 @@ class CrossIdentifier(object):
         # all pairs in one device call (k_f1_*): per pair np.sum(W[alt, 2]) + np.sum(W[ref, 0]) + np.sum(W[het, 1])
         # with numpy's summation order, so the float scores printed below carry the reference's digits
         query = engine.Query(self.g.panel(), db_rows, self.inputs.wei[sample_rows, ])
-        extra_s, extra_n = query.f1_pairs(best)
+        job = dist.job()
+        if job is None:
+            extra_s, extra_n = query.f1_pairs(best)
+        else:
+            # the ten columns live on different GPUs: every rank reads the ones it holds at the matched rows, a
+            # byte-sum over ranks brings them together, and the crosses run on that ten-column panel
+            a0, a1 = self.g._shard
+            mine = np.flatnonzero((best >= a0) & (best < a1))
+            codes = np.zeros((len(best), len(db_rows)), dtype=np.uint8)
+            if len(mine):
+                codes[mine] = query.gather_columns(best[mine] - a0)
+            codes = job.sum_bytes(codes)
+            small = engine.Panel.from_host(self.g.panel().ctx, np.ascontiguousarray(codes.T).view(np.int8))
+            q10 = engine.Query(small, None, self.inputs.wei[sample_rows, ])
+            extra_s, extra_n = q10.f1_pairs(np.arange(len(best)))
+            q10.free()
+            small.free()
         query.free()
         extra_a = [self.g.accessions[i] + "x" + self.g.accessions[j] for i, j in itertools.combinations(best, 2)]
         if extra_a:
@@ -212,7 +234,7 @@ def convert_int64(o):
 
 def potatoCrossIdentifier(args):
     """entry point of ``snpmatch cross`` (args as for inbred plus genome, binLen)"""
-    inputs = parsers.ParseInputs(inFile=args['inFile'], logDebug=args['logDebug'])
+    inputs = snpmatch.parse_inputs_once(args['inFile'], args['logDebug'])
     log.info("loading genotype files!")
     g = snp_genotype.Genotype(args['hdf5File'], args['hdf5accFile'])
     log.info("running cross identifier!")

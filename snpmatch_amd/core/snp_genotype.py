@@ -126,14 +126,21 @@ class Genotype(object):
         """The DB matrix resident in HBM (created on first use; slabs go through pinned staging).
         ``packed`` (default: environment SNPMATCH_PACKED=1) stores 2 bits per call instead of a byte --
         same results, a quarter of the HBM; DBs with codes other than -1/0/1/2 stay int8."""
-        from .. import engine
+        from .. import dist, engine
         if self._panel is None or self._panel.h is None:
             ctx = ctx or engine.default_context()
             if packed is None:
                 packed = os.environ.get("SNPMATCH_PACKED", "0") not in ("", "0")
             npy = getattr(self.g, "npy_path", None)          # native flat panel: file -> pinned slabs -> HBM
-            make = (lambda pk: engine.Panel.from_npy(ctx, npy, packed=pk)) if npy else \
-                   (lambda pk: engine.Panel.from_host(ctx, self.g.snps, packed=pk))
+            job = dist.job()
+            self._shard = job.bounds(len(self.accessions)) if job else None
+            if self._shard is not None:
+                # accession-sharded job (one process per GPU): this rank holds columns [a0, a1) of every SNP row
+                assert self._shard[1] > self._shard[0], "more ranks than accession quads: this rank's shard is empty"
+                make = lambda pk: engine.Panel.from_host(ctx, self.g.snps, packed=pk, cols=self._shard)  # noqa: E731
+            else:
+                make = (lambda pk: engine.Panel.from_npy(ctx, npy, packed=pk)) if npy else \
+                       (lambda pk: engine.Panel.from_host(ctx, self.g.snps, packed=pk))
             if packed:
                 try:
                     self._panel = make(True)
@@ -230,6 +237,20 @@ class Genotype(object):
         if len(accs_ix) > (len(self.accessions) / 2):
             return None
         if self._panel is not None and self._panel.h is not None:
+            shard = getattr(self, "_shard", None)
+            if shard is not None:
+                # accession-sharded: every rank scans the listed accessions it holds; a row segregates when some
+                # rank saw two different calls, or two ranks saw different ones
+                from .. import dist
+                accs_ix = np.asarray(accs_ix)
+                local = accs_ix[(accs_ix >= shard[0]) & (accs_ix < shard[1])] - shard[0]
+                mask, first = self._panel.segregating_first(local)
+                both = dist.job().all_gather_bytes(np.stack([mask, first]))          # [world, 2, n_snp]
+                firsts = both[:, 1, :]
+                seen = firsts != 0xFF
+                lo = np.where(seen, firsts, 255).min(axis=0)
+                hi = np.where(seen, firsts, 0).max(axis=0)
+                return np.where(both[:, 0, :].any(axis=0) | (seen.any(axis=0) & (lo != hi)))[0]
             # the DB is resident in HBM: one device scan over the listed columns
             return np.where(self._panel.segregating_rows(accs_ix))[0]
         n_snps = self.g.positions.shape[0]

@@ -22,6 +22,7 @@ import numpy as np
 from . import _report
 from . import parsers
 from . import snp_genotype
+from .. import dist
 from .. import engine
 
 log = logging.getLogger(__name__)
@@ -144,7 +145,8 @@ class Genotyper(object):
     def __init__(self, inputs, g, outFile, run_genotyper=True, skip_db_hets=False, chunk_size=1000):
         assert type(g) is snp_genotype.Genotype, "provide a snp_genotype.Genotype class for genotypes"
         inputs.filter_chr_names()
-        self.inputs, self.g, self.outFile = inputs, g, outFile
+        job = dist.job()             # accession-sharded run: rank 0 writes, the other ranks use a scratch prefix
+        self.inputs, self.g, self.outFile = inputs, g, (job.output_prefix(outFile) if job else outFile)
         self.chunk_size = chunk_size
         self._skip_db_hets = skip_db_hets
         self.num_lines = len(g.g.accessions)
@@ -173,6 +175,9 @@ class Genotyper(object):
         query = engine.Query(self.g.panel(), db_rows, self.inputs.wei[sample_rows, ])
         scores, ninfo = query.run(self.chunk_size, self._skip_db_hets, engine.MODE_EXACT)
         query.free()
+        job = dist.job()
+        if job is not None:          # this rank scored its accession shard: one all-gather makes the vectors whole
+            scores, ninfo = job.gather_scores(scores, ninfo, self.num_lines)
         log.info("Done analysing %s positions", n_matched)
         overlap = get_fraction(n_matched, len(self.inputs.pos))
         accs = self.g.g.accessions
@@ -219,9 +224,19 @@ def getHeterozygosity(snpGT, outFile='default'):
     return het
 
 
+def parse_inputs_once(in_file, log_debug):
+    """ParseInputs writes a cache next to the input: in an accession-sharded job rank 0 parses, the others load its cache"""
+    job = dist.job()
+    if job is None:
+        return parsers.ParseInputs(inFile=in_file, logDebug=log_debug)
+    inputs = parsers.ParseInputs(inFile=in_file, logDebug=log_debug) if job.is_writer else None
+    job.barrier()
+    return inputs if inputs is not None else parsers.ParseInputs(inFile=in_file, logDebug=log_debug)
+
+
 def potatoGenotyper(args):
     """entry point of ``snpmatch inbred`` (args: inFile, hdf5File, hdf5accFile, outFile, logDebug, refine, skip_db_hets)"""
-    inputs = parsers.ParseInputs(inFile=args['inFile'], logDebug=args['logDebug'])
+    inputs = parse_inputs_once(args['inFile'], args['logDebug'])
     log.info("loading database files")
     g = snp_genotype.Genotype(args['hdf5File'], args['hdf5accFile'])
     log.info("running genotyper!")

@@ -2052,27 +2052,73 @@ int snpm_intersect_sorted_search(const int64_t *a, int64_t na, const int64_t *b,
     return SNPM_OK;
 }
 
-// identify_segregating_snps on the resident panel: mask [n_snp] (host, uint8)
-int snpm_panel_segregating(snpm_panel *p, const int32_t *cols, int64_t ncols, uint8_t *mask)
+// identify_segregating_snps on the resident panel: mask [n_snp] (host, uint8); first (may be NULL): the first
+// informative call of the listed accessions per row (0xFF = none), for accession-sharded DBs
+static int panel_segregating(snpm_panel *p, const int32_t *cols, int64_t ncols, uint8_t *mask, uint8_t *first)
 {
     CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
-    CHECK_ARG(ctx, ncols >= 1 && cols && mask, "provide an np array for list of indices to be considered");
+    CHECK_ARG(ctx, ncols >= 0 && (ncols == 0 || cols) && mask, "provide an np array for list of indices to be considered");
     for (int64_t i = 0; i < ncols; ++i) CHECK_ARG(ctx, cols[i] >= 0 && cols[i] < p->n_acc, "accession index outside the panel");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = wait_upload(p);
     if (rc) return rc;
     if (p->n_snp == 0) return SNPM_OK;
-    if ((rc = ensure(ctx, ctx->ws_cols, (size_t)ncols * sizeof(int32_t)))) return rc;
-    if ((rc = ensure(ctx, ctx->ws_tmp_ninfo, (size_t)p->n_snp))) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_cols.p, cols, (size_t)ncols * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = ensure(ctx, ctx->ws_cols, (size_t)std::max<int64_t>(ncols, 1) * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_tmp_ninfo, (size_t)p->n_snp * 2))) return rc;
+    if (ncols > 0)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->ws_cols.p, cols, (size_t)ncols * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    uint8_t *d_mask = (uint8_t *)ctx->ws_tmp_ninfo.p, *d_first = d_mask + p->n_snp;
     hipLaunchKernelGGL(k_segregating, dim3((unsigned)((p->n_snp + 255) / 256)), dim3(256), 0, ctx->stream, p->d, p->pitch,
-                       p->packed, p->n_snp, (const int32_t *)ctx->ws_cols.p, (int)ncols, (uint8_t *)ctx->ws_tmp_ninfo.p);
+                       p->packed, p->n_snp, (const int32_t *)ctx->ws_cols.p, (int)ncols, d_mask, first ? d_first : (uint8_t *)nullptr);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(mask, ctx->ws_tmp_ninfo.p, (size_t)p->n_snp, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(mask, d_mask, (size_t)p->n_snp, hipMemcpyDeviceToHost, ctx->stream));
+    if (first) HIPCHK(ctx, hipMemcpyAsync(first, d_first, (size_t)p->n_snp, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SNPM_OK;
 }
+
+int snpm_panel_segregating(snpm_panel *p, const int32_t *cols, int64_t ncols, uint8_t *mask)
+{
+    if (p && p->ctx) CHECK_ARG(p->ctx, ncols >= 1, "provide an np array for list of indices to be considered");
+    return panel_segregating(p, cols, ncols, mask, nullptr);
+}
+
+int snpm_panel_segregating_first(snpm_panel *p, const int32_t *cols, int64_t ncols, uint8_t *mask, uint8_t *first)
+{
+    if (!first) return SNPM_ERR_BADARG;
+    return panel_segregating(p, cols, ncols, mask, first);
+}
+
+// calls of the listed accessions at the query's matched rows: codes [ncols, n] (uint8: 0 ref, 1 alt, 2 het, 3 other,
+// 0xFF missing), host.  The g_acc.snps[:, i] reads of the reference (core/csmatch.py:116-117) for accession-sharded
+// DBs: a rank hands the columns it holds to the rank that crosses them in silico.
+int snpm_query_gather_columns(snpm_query *q, const int32_t *acc_idx, int ncols, uint8_t *codes)
+try {
+    CHECK_QUERY(q);
+    snpm_panel *p = q->panel;
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, ncols >= 0 && ncols <= 4096, "between 0 and 4096 columns");
+    if (ncols == 0 || q->n == 0) return SNPM_OK;
+    CHECK_ARG(ctx, acc_idx && codes, "NULL argument");
+    for (int i = 0; i < ncols; ++i) CHECK_ARG(ctx, acc_idx[i] >= 0 && acc_idx[i] < p->n_acc, "accession index outside the panel");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = wait_upload(p);
+    if (rc) return rc;
+    const int64_t n = q->n;
+    const int64_t stride = (n + 255) / 256 * 256;
+    if ((rc = ensure(ctx, ctx->ws_cols, (size_t)ncols * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_tmp_ninfo, (size_t)ncols * (size_t)stride))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_cols.p, acc_idx, (size_t)ncols * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_f1_gather, dim3((unsigned)(stride / 256)), dim3(256), 0, ctx->stream, p->d, p->pitch, p->packed,
+                       (const int64_t *)q->d_row_idx, q->row0, n, (const int32_t *)ctx->ws_cols.p, ncols,
+                       (uint8_t *)ctx->ws_tmp_ninfo.p, stride);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpy2DAsync(codes, (size_t)n, ctx->ws_tmp_ninfo.p, (size_t)stride, (size_t)n, (size_t)ncols,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SNPM_OK;
+} SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
 
 // match_insilico_f1s (core/csmatch.py:115-125) on the resident panel: scores of all pairs of the selected
 // accessions over the query's rows, in numpy's summation order (k_f1_* in snpm_kernels.hpp)

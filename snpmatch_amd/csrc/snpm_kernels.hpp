@@ -1837,7 +1837,8 @@ __global__ void k_binom_identity(const double *__restrict__ x, const int64_t *__
 // --refine support (identify_segregating_snps, core/snp_genotype.py:188-211): mask[row] = 1 when the
 // informative (non-negative) calls of the listed accessions in that SNP row are not all identical.
 __global__ void k_segregating(const int8_t *__restrict__ db, int64_t pitch, int packed, int64_t n_snp,
-                              const int32_t *__restrict__ cols, int ncols, uint8_t *__restrict__ mask)
+                              const int32_t *__restrict__ cols, int ncols, uint8_t *__restrict__ mask,
+                              uint8_t *__restrict__ first_out)
 {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_snp) return;
@@ -1850,6 +1851,9 @@ __global__ void k_segregating(const int8_t *__restrict__ db, int64_t pitch, int 
         else if (b != first) seg = 1;
     }
     mask[r] = (uint8_t)seg;
+    // accession-sharded DBs: the first informative call (0xFF = none) lets the ranks decide together whether the
+    // row segregates among columns that live on different GPUs
+    if (first_out) first_out[r] = (uint8_t)(first < 0 ? 0xFF : first);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -105,3 +105,114 @@ def sharded_window_scores(score_local_fn, n_acc, n_win, world, rank, device="cpu
     def full(t):          # [world * n_win, per] -> [n_win, world * per] -> accession order
         return t.reshape(world, n_win, sh.per).permute(1, 0, 2).reshape(n_win, world * sh.per).cpu().numpy()[:, idx]
     return full(all_s), full(all_n)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# The accession-sharded job as the product path sees it (Genotype.panel, Genotyper, CrossIdentifier).
+class Job(object):
+    """One process per GPU; this rank holds accessions [a0, a1) of every DB it opens.  Created by ``init_from_env``
+    (CLI under torch.distributed.run) or ``attach`` (a caller that initialised torch.distributed itself)."""
+
+    def __init__(self, world, rank, group=None, device="cpu"):
+        self.world, self.rank, self.group, self.device = int(world), int(rank), group, device
+        self._tmp = None
+
+    @property
+    def is_writer(self):
+        return self.rank == 0
+
+    def bounds(self, n_acc):
+        b, _ = shard_bounds(n_acc, self.world)
+        return b[self.rank]
+
+    def barrier(self):
+        import torch.distributed as dist
+        dist.barrier(group=self.group)
+
+    def output_prefix(self, prefix):
+        """rank 0 writes the result files; the other ranks run the same code against a private scratch prefix"""
+        if self.is_writer or prefix is None:
+            return prefix
+        import os
+        import tempfile
+        if self._tmp is None:
+            self._tmp = tempfile.mkdtemp(prefix="snpmatch_rank%d_" % self.rank)
+        return os.path.join(self._tmp, os.path.basename(prefix))
+
+    def gather_scores(self, score_loc, ninfo_loc, n_acc):
+        """local (score, ninfo) of this rank's accessions -> the full vectors on every rank (ONE all-gather each)"""
+        sh = AccessionShards(n_acc, self.world, self.rank, self.device, self.group)
+        assert len(score_loc) == sh.n_local, "local results do not match this rank's accession shard"
+        sh.set_local(score_loc, ninfo_loc)
+        fs, fn = sh.gather()
+        return sh.unpad(fs), sh.unpad(fn)
+
+    def gather_windows(self, score_loc, ninfo_loc, n_acc):
+        n_win = score_loc.shape[0]
+        return sharded_window_scores(lambda a0, a1: (score_loc, ninfo_loc), n_acc, n_win, self.world, self.rank,
+                                     self.device, self.group)
+
+    def all_gather_bytes(self, arr):
+        """uint8 array of the same shape on every rank -> [world, ...] on every rank"""
+        import torch
+        import torch.distributed as dist
+        loc = torch.as_tensor(np.ascontiguousarray(arr, dtype=np.uint8), device=self.device)
+        out = torch.empty((self.world,) + tuple(loc.shape), dtype=torch.uint8, device=self.device)
+        dist.all_gather_into_tensor(out, loc, group=self.group)
+        return out.cpu().numpy()
+
+    def sum_bytes(self, arr):
+        """element-wise sum over ranks of a uint8 array (each element is non-zero on at most one rank)"""
+        import torch
+        import torch.distributed as dist
+        t = torch.as_tensor(np.ascontiguousarray(arr, dtype=np.uint8), device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+
+_job = None
+
+
+def job():
+    """the active accession-sharded job, or None in a single-process run"""
+    return _job
+
+
+def attach(group=None, device="cpu"):
+    """Use the caller's torch.distributed process group for the product path (every rank must call it)."""
+    global _job
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    _job = Job(world, rank, group, device) if world > 1 else None
+    return _job
+
+
+def detach():
+    global _job
+    _job = None
+
+
+def init_from_env(backend=None):
+    """CLI entry under ``python -m torch.distributed.run``: WORLD_SIZE > 1 starts the process group (backend nccl =
+    RCCL when a GPU per rank is visible, else gloo) and pins this rank's default context to LOCAL_RANK."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    import torch
+    import torch.distributed as dist
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = os.environ.get("SNPMATCH_DIST_BACKEND", "nccl" if torch.cuda.device_count() >= world else "gloo")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29544")
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dev = "cpu"
+        if torch.cuda.device_count() < world:
+            os.environ["SNPMATCH_DEVICE"] = "0"         # rehearsal on a one-GPU box: every rank on device 0
+        dist.init_process_group("gloo")
+    return attach(None, dev)

@@ -177,12 +177,15 @@ class Panel(object):
         ctx._children.add(self)
 
     @classmethod
-    def from_host(cls, ctx, snps, slab_rows=1 << 16, packed=False):
-        """Upload an array-like [n_snp, n_acc] (numpy array, memmap or h5py dataset) slab by slab."""
+    def from_host(cls, ctx, snps, slab_rows=1 << 16, packed=False, cols=None):
+        """Upload an array-like [n_snp, n_acc] (numpy array, memmap or h5py dataset) slab by slab; ``cols`` = (a0, a1)
+        keeps only that accession range (this rank's shard of an accession-sharded job)."""
         n_snp, n_acc = snps.shape
-        p = cls(ctx, n_snp, n_acc, packed=packed)
+        a0, a1 = (0, n_acc) if cols is None else cols
+        p = cls(ctx, n_snp, a1 - a0, packed=packed)
         for r0 in range(0, n_snp, slab_rows):
-            slab = np.ascontiguousarray(snps[r0:r0 + slab_rows], dtype=np.int8)
+            slab = np.ascontiguousarray(snps[r0:r0 + slab_rows, a0:a1] if cols is not None else snps[r0:r0 + slab_rows],
+                                        dtype=np.int8)
             p.upload_rows(r0, slab)  # returns once `slab` is repacked into the pinned staging buffers and the
         return p                     # copies are enqueued; scoring calls wait for them on the device
 
@@ -229,6 +232,14 @@ class Panel(object):
         mask = np.zeros(self.n_snp, dtype=np.uint8)
         check(self.ctx.lib.snpm_panel_segregating(self.h, ptr(cols), len(cols), ptr(mask)), self.ctx.h)
         return mask
+
+    def segregating_first(self, cols):
+        """(mask, first) for an accession-sharded DB: local mask and the first informative call per row (0xFF: none)"""
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        mask = np.zeros(self.n_snp, dtype=np.uint8)
+        first = np.full(self.n_snp, 0xFF, dtype=np.uint8)
+        check(self.ctx.lib.snpm_panel_segregating_first(self.h, ptr(cols), len(cols), ptr(mask), ptr(first)), self.ctx.h)
+        return mask, first
 
     def stream_read(self):
         """PMC calibration: read every panel byte once; returns the byte count."""
@@ -348,6 +359,13 @@ class Query(object):
         check(ctx.lib.snpm_query_run_windows(self.h, ptr(win_off), n_win, int(bool(skip_hets)), ptr(score), ptr(ninfo),
                                              ptr(ts) if totals else None, ptr(tn) if totals else None), ctx.h)
         return score, ninfo, ts, tn
+
+    def gather_columns(self, acc_idx):
+        """calls of accessions ``acc_idx`` at the matched rows: uint8 [len(acc_idx), n] (0xFF = missing)"""
+        acc_idx = np.ascontiguousarray(acc_idx, dtype=np.int32)
+        out = np.full((len(acc_idx), self.n), 0xFF, dtype=np.uint8)
+        check(self.panel.ctx.lib.snpm_query_gather_columns(self.h, ptr(acc_idx), len(acc_idx), ptr(out)), self.panel.ctx.h)
+        return out
 
     def f1_pairs(self, acc_idx):
         """In-silico crosses of every pair of ``acc_idx`` (order of itertools.combinations) over the query's
