@@ -156,10 +156,11 @@ class Job(object):
         """uint8 array of the same shape on every rank -> [world, ...] on every rank"""
         import torch
         import torch.distributed as dist
-        loc = torch.as_tensor(np.ascontiguousarray(arr, dtype=np.uint8), device=self.device)
-        out = torch.empty((self.world,) + tuple(loc.shape), dtype=torch.uint8, device=self.device)
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        loc = torch.as_tensor(arr.reshape(-1), device=self.device)
+        out = torch.empty(self.world * loc.numel(), dtype=torch.uint8, device=self.device)
         dist.all_gather_into_tensor(out, loc, group=self.group)
-        return out.cpu().numpy()
+        return out.cpu().numpy().reshape((self.world,) + arr.shape)
 
     def sum_bytes(self, arr):
         """element-wise sum over ranks of a uint8 array (each element is non-zero on at most one rank)"""
