@@ -156,6 +156,29 @@ int snpm_query_error_bound(snpm_query *query, int64_t chunk, double *bound);
 int snpm_query_run_windows(snpm_query *query, const int64_t *win_off, int64_t n_win, int skip_hets,
                            double *score, int64_t *ninfo, double *tot_score, int64_t *tot_ninfo);
 
+/* The same window loop at streaming speed (one segmented fast pass over all windows + the certificate per
+   (window, accession) and for the totals; uncertain entries are re-scored in reference order): int(score), ninfo and
+   the totals' counts are bit-exact, fp64 window scores agree with the reference's to ~1e-12 relative (likelihoods
+   well inside the 1e-6 of north_star).  snpm_query_run_windows above is the byte-identical mode.
+   info (may be NULL) int64 [4]: [0] (window, accession) pairs re-scored, [1] totals re-scored, [2] 1 = fell back to
+   the strict pass (more uncertain entries than the sparse tiers take). */
+int snpm_query_run_windows_fast(snpm_query *query, const int64_t *win_off, int64_t n_win, int skip_hets,
+                                double *score, int64_t *ninfo, double *tot_score, int64_t *tot_ninfo, int64_t *info);
+
+/* ---------------------------------------------------------------- many samples per call */
+/* B samples against one resident panel.  The reference scores one sample per process (core/snpmatch.py:256-268); here
+   sample b owns entries [sample_off[b], sample_off[b+1]) of the concatenated row list (int64, panel rows matched by the
+   sample = commonSNPs[0]) and weights (float64 [N,3] = inputs.wei[commonSNPs[1]]); device_inputs != 0: both are DEVICE
+   pointers.  One launch scores all samples (sample on the grid), the certificate runs per (sample, accession) on the
+   device, likelihood rows [B, n_acc] come from one launch (scores truncated first, as GenotyperOutput does), results
+   return in one copy.  Outputs (host, may be NULL; lik and lrt both or neither): score / ninfo / lik / lrt [B, n_acc].
+   mode as snpm_query_run: EXACT = int(score) and ninfo bit-exact per sample.
+   info (may be NULL) int64 [4]: [0] (sample, accession) pairs re-scored in reference order, [1] 1 = every sample went
+   through the strict pass (more uncertain pairs than the sparse tier takes). */
+int snpm_score_batch(snpm_panel *panel, int64_t n_samples, const int64_t *sample_off, const void *row_idx, const void *wei,
+                     int device_inputs, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo,
+                     double *lik, double *lrt, int64_t *info);
+
 /* ---------------------------------------------------------------- jobs larger than HBM: SNP slab after SNP slab */
 /* The reference walks the whole SNP axis in `chunk`-row pieces and adds every piece onto ScoreList / NumInfoSites
    (core/snpmatch.py:218-225).  When the panel does not fit in HBM the caller loads (or regenerates) one SNP slab

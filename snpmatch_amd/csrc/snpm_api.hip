@@ -63,6 +63,8 @@ struct snpm_ctx {
     Buf ws_part_score, ws_part_miss, ws_seg_score, ws_seg_miss, ws_seg_off, ws_cols, ws_tmp_score, ws_tmp_ninfo, ws_flags;
     Buf ws_lik_y, ws_lik_n, ws_lik_l, ws_lik_r;
     Buf ws_wprops, ws_epart;            // partial sums of k_wprops / k_eref
+    Buf ws_seg_desc, ws_eseg, ws_pairs, ws_pair_sums, ws_bscore, ws_bninfo, ws_blut, ws_brows, ws_bw;   // segmented / batched scoring
+    std::vector<int64_t> h_seg_desc;    // host image of ws_seg_desc (kept until the next segmented call)
     // device buffers of freed queries, kept for the next query (hipMalloc / hipFree cost more than a small query's run)
     struct Cached { void *p; size_t cap; };
     std::vector<Cached> qcache;
@@ -758,11 +760,12 @@ int run_strict_chain(snpm_query *q, int skip, int64_t chunk, const int *gate, co
 // Sparse tier: reference-order chunk sums of the accessions listed on the device (d_cols, *d_ncols <= REEVAL_CAP;
 // the kernels do nothing for other counts) -> ws_seg_score [n_seg, REEVAL_CAP] -> chain of additions ->
 // ws_tmp_score [REEVAL_CAP].  carry (may be NULL): compact totals of earlier slabs, continued by the chain.
-int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_cols, const int *d_ncols, const double *carry)
+int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_cols, const int *d_ncols, const double *carry,
+                      const int64_t *d_seg_off = nullptr, int64_t n_seg_explicit = 0)
 {
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
-    const int64_t n_seg = (q->n + chunk - 1) / chunk;
+    const int64_t n_seg = d_seg_off ? n_seg_explicit : (q->n + chunk - 1) / chunk;
     const int64_t ld = REEVAL_CAP;
     int rc = ensure(ctx, ctx->ws_seg_score, (size_t)std::max<int64_t>(n_seg, 1) * ld * sizeof(double));
     if (rc) return rc;
@@ -780,7 +783,7 @@ int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_c
             q->reeval_path = 1;
 #define LAUNCH_SPARSE_T(S, G)                                                                                      \
     hipLaunchKernelGGL((k_strict_sparse_T<S, G>), sgrid, dim3(256), 0, ctx->stream, p->dT, p->pitchT, q->d_row_idx, \
-                       q->row0, q->d_w, (const int64_t *)nullptr, chunk, q->n, n_seg, d_cols, d_ncols, REEVAL_CAP, \
+                       q->row0, q->d_w, d_seg_off, chunk, q->n, n_seg, d_cols, d_ncols, REEVAL_CAP, \
                        (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld)
             if (skip) {
                 if (gather) LAUNCH_SPARSE_T(true, true); else LAUNCH_SPARSE_T(true, false);
@@ -792,7 +795,7 @@ int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_c
             q->reeval_path = 2;
 #define LAUNCH_SPARSE(S, G)                                                                                        \
     hipLaunchKernelGGL((k_strict_sparse<S, G>), sgrid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->packed, q->d_row_idx, \
-                       q->row0, q->d_w, (const int64_t *)nullptr, chunk, q->n, n_seg, d_cols, d_ncols, REEVAL_CAP, \
+                       q->row0, q->d_w, d_seg_off, chunk, q->n, n_seg, d_cols, d_ncols, REEVAL_CAP, \
                        (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld)
             if (skip) {
                 if (gather) LAUNCH_SPARSE(true, true); else LAUNCH_SPARSE(true, false);
@@ -807,6 +810,163 @@ int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_c
     hipLaunchKernelGGL(k_scan_few, dim3(1), dim3(256), 0, ctx->stream, (const double *)ctx->ws_seg_score.p, n_seg, ld,
                        d_ncols, REEVAL_CAP, (double *)ctx->ws_tmp_score.p, carry);
     HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+// ---- segmented scoring: many row ranges of one matched list in one launch (batches of samples, windows) -----------
+struct SegJob {
+    snpm_panel *p = nullptr;
+    const int64_t *d_row_idx = nullptr;     // device; NULL = dense rows row0 + r
+    int64_t row0 = 0, n_total = 0;
+    const double *d_w = nullptr, *d_lut = nullptr;      // device [n_total, 3] / [n_total, 4]
+    const int64_t *seg_off = nullptr;       // HOST [n_seg + 1], non-decreasing, inside [0, n_total]
+    int64_t n_seg = 0;
+    int64_t chunk = 1000;                   // rows per matchGTsAccs call of the reference inside a segment
+    int skip = 0;
+    bool certify = true;
+    double *d_score = nullptr;              // device outputs [n_seg, ldo]
+    int64_t *d_ninfo = nullptr;
+    int64_t ldo = 0;
+    // filled by run_segmented
+    int64_t kmax = 1;
+    int cap = 0;
+    const int64_t *d_seg_off = nullptr;
+};
+
+constexpr int SEG_PAIR_CAP = 32768;
+
+int *seg_pair_count(snpm_ctx *ctx) { return (int *)ctx->ws_pairs.p; }
+int32_t *seg_pairs(snpm_ctx *ctx) { return (int32_t *)((char *)ctx->ws_pairs.p + 16); }
+
+template <int BPL, bool NT>
+static int launch_fast_seg(snpm_ctx *ctx, const SegJob &j, dim3 grid, dim3 block, int64_t n_parts, const int64_t *d_desc)
+{
+    snpm_panel *p = j.p;
+    const bool gather = j.d_row_idx != nullptr;
+    ProfScope ps(ctx, PK_FAST);
+#define LAUNCH_SEG(S, G)                                                                                          \
+    hipLaunchKernelGGL((k_fast<BPL, S, G, NT, true>), grid, block, 0, ctx->stream, p->d, p->pitch, j.d_row_idx, j.row0,    \
+                       n_parts, j.d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, d_desc)
+    if (j.skip) {
+        if (gather) LAUNCH_SEG(true, true); else LAUNCH_SEG(true, false);
+    } else {
+        if (gather) LAUNCH_SEG(false, true); else LAUNCH_SEG(false, false);
+    }
+#undef LAUNCH_SEG
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+// fast pass over every segment + ordered reduce + (certify) the list of (segment, accession) pairs whose int(score) is
+// not proven, their reference-order re-evaluation and the patch.  Everything is enqueued; nothing waits.
+static int run_segmented(snpm_ctx *ctx, SegJob &j)
+{
+    snpm_panel *p = j.p;
+    const int64_t n_seg = j.n_seg;
+    if (n_seg == 0) return SNPM_OK;
+    const int bpl = p->packed ? 4 : 4;          // int8: a dword per lane; packed: the one-byte-per-lane instantiation (4 accessions)
+    FastGeom g0 = fast_geom(ctx, p->n_acc, TILE_ROWS, 2, bpl, TILE_ROWS);
+    // parts: contiguous runs of <= EPOCH_TILES tiles inside one segment; enough of them to fill the chip twice over
+    int64_t total_tiles = 0, kmax = 1;
+    for (int64_t s = 0; s < n_seg; ++s) {
+        const int64_t len = j.seg_off[s + 1] - j.seg_off[s];
+        total_tiles += (len + TILE_ROWS - 1) / TILE_ROWS;
+        kmax = std::max<int64_t>(kmax, (len + j.chunk - 1) / j.chunk);
+    }
+    const int64_t want_blocks = (int64_t)ctx->n_cu * 8 / std::max<int64_t>(1, g0.n_colblocks);
+    const int64_t tiles_per_part = std::max<int64_t>(2, std::min<int64_t>(EPOCH_TILES, (total_tiles + want_blocks - 1) / std::max<int64_t>(1, want_blocks)));
+    std::vector<int64_t> &h = ctx->h_seg_desc;      // [seg_off | slot0 | part_desc]; stays alive until the copy is done
+    h.clear();
+    h.insert(h.end(), j.seg_off, j.seg_off + n_seg + 1);
+    const size_t o_slot0 = h.size();
+    h.resize(h.size() + (size_t)n_seg + 1);
+    const size_t o_desc = h.size();
+    int64_t n_parts = 0;
+    for (int64_t s = 0; s < n_seg; ++s) {
+        h[o_slot0 + (size_t)s] = n_parts;
+        const int64_t r0 = j.seg_off[s], r1 = j.seg_off[s + 1];
+        for (int64_t r = r0; r < r1; r += tiles_per_part * TILE_ROWS) {
+            h.push_back(r);
+            h.push_back(std::min<int64_t>(r1, r + tiles_per_part * TILE_ROWS));
+            h.push_back(n_parts++);
+        }
+    }
+    h[o_slot0 + (size_t)n_seg] = n_parts;
+    int rc = ensure(ctx, ctx->ws_seg_desc, h.size() * sizeof(int64_t));
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_seg_desc.p, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    const int64_t *d_seg_off = (const int64_t *)ctx->ws_seg_desc.p;
+    const int64_t *d_slot0 = d_seg_off + o_slot0;
+    const int64_t *d_desc = d_seg_off + o_desc;
+    j.d_seg_off = d_seg_off;
+    j.kmax = kmax;
+    j.cap = (int)std::max<int64_t>(64, std::min<int64_t>(SEG_PAIR_CAP, (int64_t(8) << 20) / kmax));
+    rc = ensure(ctx, ctx->ws_part_score, (size_t)std::max<int64_t>(n_parts, 1) * p->ld * sizeof(double));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->ws_part_miss, (size_t)std::max<int64_t>(n_parts, 1) * p->ld * sizeof(uint32_t));
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->ws_pairs, 16 + (size_t)SEG_PAIR_CAP * 2 * sizeof(int32_t));
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemsetAsync(seg_pair_count(ctx), 0, sizeof(int), ctx->stream));
+    if (j.certify) {
+        rc = ensure(ctx, ctx->ws_eseg, (size_t)n_seg * sizeof(double));
+        if (rc) return rc;
+        // fast-pass additions a term passes through: its part (<= tiles_per_part tiles) + the parts of its segment
+        const int64_t max_parts = (kmax * j.chunk / (tiles_per_part * TILE_ROWS)) + 2;
+        hipLaunchKernelGGL(k_eseg, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_w, d_seg_off, j.chunk,
+                           tiles_per_part * TILE_ROWS + max_parts + 2, (double *)ctx->ws_eseg.p);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    if (n_parts > 0) {
+        const unsigned gy = (unsigned)std::min<int64_t>(n_parts, 65535);
+        const unsigned gz = (unsigned)((n_parts + gy - 1) / gy);
+        dim3 grid((unsigned)g0.n_colblocks, gy, gz), block(WAVE * g0.wpb);
+        const bool nt = ctx->nt_loads != 0;
+        if (p->packed) rc = nt ? launch_fast_seg<1, true>(ctx, j, grid, block, n_parts, d_desc) : launch_fast_seg<1, false>(ctx, j, grid, block, n_parts, d_desc);
+        else rc = nt ? launch_fast_seg<4, true>(ctx, j, grid, block, n_parts, d_desc) : launch_fast_seg<4, false>(ctx, j, grid, block, n_parts, d_desc);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(ctx, PK_REDUCE);
+        const int thr = 64;
+        for (int64_t s0 = 0; s0 < n_seg; s0 += 65535) {
+            const int64_t ns = std::min<int64_t>(65535, n_seg - s0);
+            hipLaunchKernelGGL(k_reduce_seg, dim3((unsigned)((p->n_acc + thr - 1) / thr), (unsigned)ns), dim3(thr), 0, ctx->stream,
+                               (const double *)ctx->ws_part_score.p, (const uint32_t *)ctx->ws_part_miss.p, d_slot0 + s0,
+                               d_seg_off + s0, p->ld, p->n_acc, j.d_score + s0 * j.ldo, j.d_ninfo + s0 * j.ldo, j.ldo,
+                               j.certify ? (const double *)ctx->ws_eseg.p + s0 : (const double *)nullptr, ctx->debug_reeval,
+                               seg_pairs(ctx), seg_pair_count(ctx), j.cap);
+            HIPCHK(ctx, hipGetLastError());
+        }
+    }
+    if (!j.certify) return SNPM_OK;
+    // NOTE: pairs of a later reduce slab carry segment indices relative to s0 only when n_seg > 65535 (never in practice:
+    // guarded by the callers), so pair segment ids are absolute here.
+    rc = ensure(ctx, ctx->ws_pair_sums, (size_t)j.cap * (size_t)kmax * sizeof(double));
+    if (rc) return rc;
+    const bool gather = j.d_row_idx != nullptr;
+    {
+        ProfScope ps(ctx, PK_STRICT);
+        dim3 grid((unsigned)((kmax + 255) / 256), (unsigned)j.cap);
+#define LAUNCH_PAIRS(S, G)                                                                                        \
+    hipLaunchKernelGGL((k_strict_pairs<S, G>), grid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->packed, j.d_row_idx,     \
+                       j.row0, j.d_w, d_seg_off, j.chunk, (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), \
+                       j.cap, kmax, (double *)ctx->ws_pair_sums.p)
+        if (j.skip) {
+            if (gather) LAUNCH_PAIRS(true, true); else LAUNCH_PAIRS(true, false);
+        } else {
+            if (gather) LAUNCH_PAIRS(false, true); else LAUNCH_PAIRS(false, false);
+        }
+#undef LAUNCH_PAIRS
+        HIPCHK(ctx, hipGetLastError());
+    }
+    {
+        ProfScope ps(ctx, PK_SCAN);
+        hipLaunchKernelGGL(k_scan_pairs, dim3((unsigned)j.cap), dim3(64), 0, ctx->stream, (const double *)ctx->ws_pair_sums.p,
+                           d_seg_off, j.chunk, (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), j.cap, kmax,
+                           j.d_score, j.ldo);
+        HIPCHK(ctx, hipGetLastError());
+    }
     return SNPM_OK;
 }
 
@@ -1040,7 +1200,9 @@ int snpm_destroy(snpm_ctx *ctx)
         for (auto &c : ctx->qcache) (void)hipFree(c.p);
         Buf *bufs[] = {&ctx->ws_stage_dev, &ctx->ws_flags2, &ctx->ws_grp_score, &ctx->ws_grp_miss, &ctx->ws_part_score, &ctx->ws_part_miss, &ctx->ws_seg_score, &ctx->ws_seg_miss, &ctx->ws_seg_off,
                        &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
-                       &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r, &ctx->ws_wprops, &ctx->ws_epart};
+                       &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r, &ctx->ws_wprops, &ctx->ws_epart,
+                       &ctx->ws_seg_desc, &ctx->ws_eseg, &ctx->ws_pairs, &ctx->ws_pair_sums, &ctx->ws_bscore, &ctx->ws_bninfo,
+                       &ctx->ws_blut, &ctx->ws_brows, &ctx->ws_bw};
         for (Buf *b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -1674,6 +1836,216 @@ try {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return SNPM_OK;
 } SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
+
+// CrossIdentifier.window_genotyper at streaming speed: one segmented fast pass over all windows, then the
+// certificate per (window, accession) -- pairs whose int(score) is not proven are re-scored in reference order and
+// patched in -- and once more for the totals.  snps_match = int(score), snps_info and the totals' counts are
+// bit-exact; fp64 window scores are within the per-window bound (~1e-12) of the reference's, likelihoods follow at
+// that relative accuracy.  snpm_query_run_windows stays the mode whose fp64 scores carry the reference's bits.
+int snpm_query_run_windows_fast(snpm_query *q, const int64_t *win_off, int64_t n_win, int skip_hets, double *score,
+                                int64_t *ninfo, double *tot_score, int64_t *tot_ninfo, int64_t *info)
+try {
+    CHECK_QUERY(q);
+    snpm_ctx *ctx = q->panel->ctx;
+    snpm_panel *p = q->panel;
+    CHECK_ARG(ctx, n_win >= 0 && win_off != nullptr, "window offsets missing");
+    CHECK_ARG(ctx, n_win <= 65535, "at most 65535 windows per call");
+    int64_t maxlen = 1;
+    for (int64_t w = 0; w < n_win; ++w) {
+        CHECK_ARG(ctx, win_off[w] <= win_off[w + 1], "window offsets must be non-decreasing");
+        maxlen = std::max(maxlen, win_off[w + 1] - win_off[w]);
+    }
+    CHECK_ARG(ctx, win_off[0] >= 0 && win_off[n_win] <= q->n, "window offsets outside the matched list");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (info) info[0] = info[1] = info[2] = info[3] = 0;
+    if (n_win == 0) return snpm_query_run_windows(q, win_off, n_win, skip_hets, score, ninfo, tot_score, tot_ninfo);
+    int rc = wait_upload(p);
+    if (rc) return rc;
+    const int skip = skip_hets ? 1 : 0;
+    rc = ensure_lut(q, skip);
+    if (rc) return rc;
+    const size_t na = (size_t)p->n_acc;
+    if ((rc = ensure(ctx, ctx->ws_bscore, (size_t)n_win * na * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_bninfo, (size_t)n_win * na * sizeof(int64_t)))) return rc;
+    q->count_valid = false;
+    SegJob j;
+    j.p = p;
+    j.d_row_idx = q->d_row_idx;
+    j.row0 = q->row0;
+    j.n_total = q->n;
+    j.d_w = q->d_w;
+    j.d_lut = q->d_lut;
+    j.seg_off = win_off;
+    j.n_seg = n_win;
+    j.chunk = maxlen;                          // a window is ONE matchGTsAccs call
+    j.skip = skip;
+    j.certify = true;
+    j.d_score = (double *)ctx->ws_bscore.p;
+    j.d_ninfo = (int64_t *)ctx->ws_bninfo.p;
+    j.ldo = p->n_acc;
+    rc = run_segmented(ctx, j);
+    if (rc) return rc;
+    // totals in window order, certified against the reference's chain over its own (bit-different) window scores
+    rc = ensure(ctx, ctx->ws_flags, 64);
+    if (rc) return rc;
+    double *d_etot = (double *)((char *)ctx->ws_flags.p + 8);
+    hipLaunchKernelGGL(k_tot_seg, dim3((unsigned)((p->n_acc + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double *)ctx->ws_bscore.p, (const int64_t *)ctx->ws_bninfo.p, n_win, p->n_acc, p->n_acc,
+                       q->d_score, q->d_ninfo, (const double *)ctx->ws_eseg.p, d_etot);
+    HIPCHK(ctx, hipGetLastError());
+    const double u = 1.1102230246251565e-16;
+    const double m = (double)(n_win + 2);
+    const double e_extra = q->all_integer ? 0.0 : 2.0 * q->wsum * (m * u / (1.0 - m * u)) * 1.0000001;
+    HIPCHK(ctx, hipMemsetAsync(q->cert_count(), 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_carry_flag, dim3((unsigned)((p->n_acc + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const double *)q->d_score, p->n_acc, (const double *)d_etot, e_extra, ctx->debug_reeval,
+                       q->cert_cols(), q->cert_count(), REEVAL_CAP);
+    HIPCHK(ctx, hipGetLastError());
+    rc = run_strict_sparse(q, skip, maxlen, q->cert_cols(), q->cert_count(), nullptr, j.d_seg_off, n_win);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_patch, dim3(1), dim3(REEVAL_CAP), 0, ctx->stream, (const double *)ctx->ws_tmp_score.p,
+                       (const int32_t *)q->cert_cols(), (const int *)q->cert_count(), REEVAL_CAP, q->d_score);
+    HIPCHK(ctx, hipGetLastError());
+    rc = ensure_pinned(ctx, 64);
+    if (rc) return rc;
+    int *h_cnt = (int *)ctx->h_pinned;
+    HIPCHK(ctx, hipMemcpyAsync(h_cnt, seg_pair_count(ctx), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_cnt + 1, q->cert_count(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (score) HIPCHK(ctx, hipMemcpyAsync(score, ctx->ws_bscore.p, (size_t)n_win * na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (ninfo) HIPCHK(ctx, hipMemcpyAsync(ninfo, ctx->ws_bninfo.p, (size_t)n_win * na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (tot_score) HIPCHK(ctx, hipMemcpyAsync(tot_score, q->d_score, na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (tot_ninfo) HIPCHK(ctx, hipMemcpyAsync(tot_ninfo, q->d_ninfo, na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int n_pairs = h_cnt[0], n_tot = h_cnt[1];
+    if (info) { info[0] = n_pairs; info[1] = n_tot; }
+    if (n_pairs > j.cap || n_tot > REEVAL_CAP) {
+        // more uncertain results than the sparse tiers take: every window in reference order
+        if (info) info[2] = 1;
+        return snpm_query_run_windows(q, win_off, n_win, skip_hets, score, ninfo, tot_score, tot_ninfo);
+    }
+    return SNPM_OK;
+} SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
+
+// Many samples against one resident panel in ONE call (the reference scores one sample per process,
+// core/snpmatch.py:256-268): sample b owns entries [sample_off[b], sample_off[b+1]) of the concatenated matched-row list
+// and weights.  One segmented fast pass (sample = segment), certificate per (sample, accession), reference-order
+// re-evaluation of the flagged pairs, one likelihood launch with a row per sample, one copy back.
+int snpm_score_batch(snpm_panel *p, int64_t n_samples, const int64_t *sample_off, const void *row_idx, const void *wei,
+                     int device_inputs, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo,
+                     double *lik, double *lrt, int64_t *info)
+try {
+    CHECK_PANEL(p);
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, n_samples >= 0 && n_samples <= 65535 && sample_off, "between 0 and 65535 samples per call");
+    CHECK_ARG(ctx, chunk >= 1, "chunk must be >= 1");
+    CHECK_ARG(ctx, mode == SNPM_MODE_EXACT || mode == SNPM_MODE_STRICT || mode == SNPM_MODE_FAST, "unknown mode");
+    if (info) info[0] = info[1] = info[2] = info[3] = 0;
+    if (n_samples == 0) return SNPM_OK;
+    CHECK_ARG(ctx, sample_off[0] == 0, "sample offsets start at 0");
+    for (int64_t b = 0; b < n_samples; ++b) CHECK_ARG(ctx, sample_off[b] <= sample_off[b + 1], "sample offsets must be non-decreasing");
+    const int64_t N = sample_off[n_samples];
+    CHECK_ARG(ctx, N == 0 || (row_idx && wei), "please provide same number of positions for both sample and db");
+    CHECK_ARG(ctx, (lik == nullptr) == (lrt == nullptr), "ask for both likelihood outputs or neither");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = wait_upload(p);
+    if (rc) return rc;
+    const int skip = skip_hets ? 1 : 0;
+    const size_t NN = (size_t)std::max<int64_t>(N, 1);
+    const size_t na = (size_t)p->n_acc, B = (size_t)n_samples;
+    if ((rc = ensure(ctx, ctx->ws_brows, (NN + PREFETCH_PAD_ROWS) * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_blut, NN * 4 * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_bscore, B * na * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_bninfo, B * na * sizeof(int64_t)))) return rc;
+    const double *d_w = nullptr;
+    if (device_inputs) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->ws_brows.p, row_idx, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+        d_w = (const double *)wei;
+    } else {
+        const int64_t *rows = (const int64_t *)row_idx;
+        for (int64_t i = 0; i < N; ++i)
+            if (rows[i] < 0 || rows[i] >= p->n_snp)
+                return set_err(ctx, SNPM_ERR_BADARG, "row index %lld at %lld outside the panel (n_snp %lld)",
+                               (long long)rows[i], (long long)i, (long long)p->n_snp);
+        if ((rc = ensure(ctx, ctx->ws_bw, NN * 3 * sizeof(double)))) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->ws_brows.p, row_idx, (size_t)N * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->ws_bw.p, wei, (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        d_w = (const double *)ctx->ws_bw.p;
+    }
+    HIPCHK(ctx, hipMemsetAsync((int64_t *)ctx->ws_brows.p + N, 0, PREFETCH_PAD_ROWS * sizeof(int64_t), ctx->stream));
+    if (N > 0) {
+        ProfScope ps(ctx, PK_LUT);
+        hipLaunchKernelGGL(k_build_lut, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_w,
+                           (double *)ctx->ws_blut.p, N, skip);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    SegJob j;
+    j.p = p;
+    j.d_row_idx = (const int64_t *)ctx->ws_brows.p;
+    j.n_total = N;
+    j.d_w = d_w;
+    j.d_lut = (const double *)ctx->ws_blut.p;
+    j.seg_off = sample_off;
+    j.n_seg = n_samples;
+    j.chunk = chunk;
+    j.skip = skip;
+    j.certify = (mode == SNPM_MODE_EXACT);
+    j.d_score = (double *)ctx->ws_bscore.p;
+    j.d_ninfo = (int64_t *)ctx->ws_bninfo.p;
+    j.ldo = p->n_acc;
+    // every sample through the reference-order chain (requested, or more uncertain pairs than the sparse tier takes)
+    auto strict_every_sample = [&]() -> int {
+        for (int64_t b = 0; b < n_samples; ++b) {
+            snpm_query *q = nullptr;
+            const int64_t o = sample_off[b], nb = sample_off[b + 1] - o;
+            int r = snpm_query_create_device(p, (const int64_t *)ctx->ws_brows.p + o, 0, nb, d_w + 3 * o, &q);
+            if (r) return r;
+            r = run_strict_chain(q, skip, chunk, nullptr, nullptr, nullptr, (double *)ctx->ws_bscore.p + b * na,
+                                 (int64_t *)ctx->ws_bninfo.p + b * na);
+            const std::string keep = ctx->err;
+            (void)hipStreamSynchronize(ctx->stream);
+            snpm_query_free(q);
+            if (r) { ctx->err = keep; return r; }
+        }
+        return SNPM_OK;
+    };
+    bool strict_all = (mode == SNPM_MODE_STRICT);
+    int n_pairs = 0;
+    if (strict_all) {
+        rc = strict_every_sample();
+        if (rc) return rc;
+    } else {
+        rc = run_segmented(ctx, j);
+        if (rc) return rc;
+        if (j.certify) {
+            rc = ensure_pinned(ctx, 64);
+            if (rc) return rc;
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, seg_pair_count(ctx), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            n_pairs = *(const int *)ctx->h_pinned;
+            if (n_pairs > j.cap) {
+                strict_all = true;
+                rc = strict_every_sample();
+                if (rc) return rc;
+            }
+        }
+    }
+    if (lik) {
+        if ((rc = ensure(ctx, ctx->ws_lik_l, B * na * sizeof(double)))) return rc;
+        if ((rc = ensure(ctx, ctx->ws_lik_r, B * na * sizeof(double)))) return rc;
+        int dom = 0;
+        rc = snpm_likelihood_device(ctx, ctx->ws_bscore.p, ctx->ws_bninfo.p, n_samples, p->n_acc, 1, __builtin_nan(""),
+                                    ctx->ws_lik_l.p, ctx->ws_lik_r.p, &dom);
+        if (rc) return rc;
+        if (dom) return set_err(ctx, SNPM_ERR_DOMAIN, "provided y is greater than n");
+        HIPCHK(ctx, hipMemcpyAsync(lik, ctx->ws_lik_l.p, B * na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(lrt, ctx->ws_lik_r.p, B * na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (score) HIPCHK(ctx, hipMemcpyAsync(score, ctx->ws_bscore.p, B * na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (ninfo) HIPCHK(ctx, hipMemcpyAsync(ninfo, ctx->ws_bninfo.p, B * na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (info) { info[0] = n_pairs; info[1] = (strict_all && mode != SNPM_MODE_STRICT) ? 1 : 0; }
+    return SNPM_OK;
+} SNPM_GUARD((p ? p->ctx : nullptr))
 
 // ---------------------------------------------------------------------------------------------- slab-streamed jobs
 // A panel larger than HBM is scored SNP slab after SNP slab; a snpm_carry holds the running per-accession totals

@@ -254,10 +254,15 @@ __device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[(BPL >= 
 // kernel is latency-bound and 5-wave blocks only fit 4 per CU with 6 wave slots per SIMD (measured:
 // 79-82 % of HBM peak at 80 VGPRs vs 67-70 % at 88; asking for 7 waves changes nothing -- the kernel already
 // needs only 70 VGPRs -- and 8 waves (64 VGPRs, 7 spilled) costs 1-8 %: -DSNPM_FAST_MIN_WAVES=n to re-measure)
-template <int BPL, bool SKIP, bool GATHER, bool NT>
+// SEG (segmented pass: batches of samples, windows of a cross): part p scores the CONTIGUOUS rows
+// [part_desc[3p], part_desc[3p+1]) of the (concatenated) matched list -- never more than EPOCH_TILES tiles, all inside
+// one segment -- and writes its partial sums to slot part_desc[3p+2]; k_reduce_seg adds the slots of a segment in
+// order.  Without SEG the arguments part_desc is unused and the code is the tile-interleaved pass described above.
+template <int BPL, bool SKIP, bool GATHER, bool NT, bool SEG = false>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (BPL <= 4 ? SNPM_FAST_MIN_WAVES : 1))
 k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
-       const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
+       const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
+       const int64_t *__restrict__ part_desc = nullptr)
 {
     // BPL = bytes per lane and row.  BPL == 1 is the packed panel (2 bits per call): the lane's byte holds 4
     // accessions, exactly like the 4 bytes of the int8 BPL == 4 layout, so everything downstream is shared.
@@ -276,9 +281,16 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     // a lane works when its bytes lie inside the row (pitch is a multiple of 256 B) AND its accessions inside
     // the result arrays (ld): on a packed panel 4*pitch can exceed ld, and blocks may carry spare waves
     const bool lane_on = byte0 < pitch && col0 < ld;
-    const int64_t p = blockIdx.y;
-    const int64_t P = gridDim.y;
-    const int64_t n_tiles_total = (n + TILE_ROWS - 1) / TILE_ROWS;
+    const int64_t p = SEG ? (int64_t)blockIdx.y + (int64_t)gridDim.y * blockIdx.z : (int64_t)blockIdx.y;
+    if (SEG && p >= n) return;             // SEG: n is the number of parts (grid.y * grid.z may exceed it)
+    // tiles of this block: T = T0, T0 + TS, ... < n_tiles_total; tile T = rows [rbase + T * TILE_ROWS, ...) up to rend
+    const int64_t rbase = SEG ? part_desc[3 * p] : 0;
+    const int64_t rend = SEG ? part_desc[3 * p + 1] : n;
+    const int64_t P = SEG ? 1 : (int64_t)gridDim.y;               // tile stride
+    const int64_t T0 = SEG ? 0 : p;
+    const int64_t slot0 = SEG ? part_desc[3 * p + 2] : p;         // partial slot of epoch 0 (epoch e: slot0 + e * slot_stride)
+    const int64_t slot_stride = SEG ? 1 : (int64_t)gridDim.y;
+    const int64_t n_tiles_total = (rend - rbase + TILE_ROWS - 1) / TILE_ROWS;
 
     double acc[EPL];
     uint32_t miss16[NDW * 2];               // packed 2 x u16 per register, flushed from packed u8 every tile
@@ -307,8 +319,8 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     // write this lane's partial sums to slot (epoch, part) and restart them
     auto store_partials = [&](int64_t epoch) {
         if (lane_on) {
-            double *os = out_score + (epoch * P + p) * ld + col0;
-            uint32_t *om = out_miss + (epoch * P + p) * ld + col0;
+            double *os = out_score + (slot0 + epoch * slot_stride) * ld + col0;
+            uint32_t *om = out_miss + (slot0 + epoch * slot_stride) * ld + col0;
 #pragma unroll
             for (int i = 0; i < EPL; i += 2) *reinterpret_cast<double2 *>(os + i) = make_double2(acc[i], acc[i + 1]);
 #pragma unroll
@@ -328,39 +340,39 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     };
     int64_t last_epoch = 0;
 
-    if (p < n_tiles_total) {
+    if (T0 < n_tiles_total) {
         // first LUT tile -> LDS; first group in flight
         {
-            const int64_t tr0 = p * TILE_ROWS;
-            const int rows2 = 2 * (int)((n - tr0 < TILE_ROWS) ? (n - tr0) : TILE_ROWS);
+            const int64_t tr0 = rbase + T0 * TILE_ROWS;
+            const int rows2 = 2 * (int)((rend - tr0 < TILE_ROWS) ? (rend - tr0) : TILE_ROWS);
             const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * tr0);
             double2 *dst = reinterpret_cast<double2 *>(&s_lut[0][0]);
             for (int i = tid; i < rows2; i += nthr) dst[i] = src[i];
         }
         uint32_t xa[G][NDW], xb[G][NDW];
 #pragma unroll
-        for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(p * TILE_ROWS + u), xa[u]);
+        for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rbase + T0 * TILE_ROWS + u), xa[u]);
         __syncthreads();
 
         int buf = 0;
         int tiles_in_epoch = 0;
         int64_t epoch = 0;
-        for (int64_t T = p; T < n_tiles_total; T += P, buf ^= 1) {
+        for (int64_t T = T0; T < n_tiles_total; T += P, buf ^= 1) {
             if (tiles_in_epoch == EPOCH_TILES) {
                 store_partials(epoch);
                 ++epoch;
                 tiles_in_epoch = 0;
             }
             ++tiles_in_epoch;
-            const int64_t tr0 = T * TILE_ROWS;
-            const int rows = (int)((n - tr0 < TILE_ROWS) ? (n - tr0) : TILE_ROWS);
+            const int64_t tr0 = rbase + T * TILE_ROWS;
+            const int rows = (int)((rend - tr0 < TILE_ROWS) ? (rend - tr0) : TILE_ROWS);
             const bool more = (T + P < n_tiles_total);
-            const int64_t ntr0 = more ? (T + P) * TILE_ROWS : tr0;      // my next tile (or a harmless re-read)
+            const int64_t ntr0 = more ? rbase + (T + P) * TILE_ROWS : tr0;      // my next tile (or a harmless re-read)
             // stage the next LUT tile (256 double2) in ONE register pair per thread when the block has
             // >= 256 threads; narrower blocks copy it synchronously at the end of the tile instead
             double2 pre0 = make_double2(0.0, 0.0);
             const bool staged = more && nthr >= TILE_ROWS * 2;
-            const int nrows2 = more ? 2 * (int)((n - ntr0 < TILE_ROWS) ? (n - ntr0) : TILE_ROWS) : 0;
+            const int nrows2 = more ? 2 * (int)((rend - ntr0 < TILE_ROWS) ? (rend - ntr0) : TILE_ROWS) : 0;
             if (staged && tid < nrows2) pre0 = reinterpret_cast<const double2 *>(lut + 4 * ntr0)[tid];
 
             const uint32_t lds_base =
@@ -1068,6 +1080,180 @@ __device__ __forceinline__ int code_at(const int8_t *__restrict__ db, int64_t pi
         return v == 3 ? -1 : v;
     }
     return db[prow * pitch + col];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Segmented scoring (k_fast<..., SEG>): many independent row ranges ("segments": the samples of a batch, the
+// windows of a cross) of one concatenated matched list in ONE launch.
+//   k_eseg          per segment: the certificate's error bound.  Segment s = rows [seg_off[s], seg_off[s+1]) scored by
+//                   the reference in `chunk`-row matchGTsAccs calls (a window: one call, chunk >= its length):
+//                   E_s = (sum_k s_k (len_k + 3 + K_s - k)) u / (1 - m u) + wsum_s gamma(fast adds), 0 when every
+//                   weight of the segment is an integer (any order is exact then).  One block per segment.
+//   k_reduce_seg    adds the partial slots [slot0[s], slot0[s+1]) of segment s in order -> score / ninfo [n_seg, ldo];
+//                   optional certificate: pairs (s, a) whose int(score) is not proven are appended to `pairs`.
+//   k_strict_pairs  reference-order chunk sums of the flagged pairs: block = pair, lane = chunk of its segment.
+//   k_scan_pairs    the chain of additions over a pair's chunk sums (ScoreList += chunk) and the patch.
+__global__ void __launch_bounds__(256)
+k_eseg(const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t fast_adds,
+       double *__restrict__ eseg)
+{
+    __shared__ double sm[4];
+    __shared__ int s_flag;
+    const int64_t s = blockIdx.x;
+    const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
+    const int64_t len = r1 - r0;
+    const int64_t K = (len + chunk - 1) / chunk;
+    if (threadIdx.x == 0) s_flag = 0;
+    __syncthreads();
+    double acc = 0.0, wsum = 0.0;
+    int nonint = 0;
+    for (int64_t k = 0; k < K; ++k) {
+        const int64_t c0 = r0 + k * chunk, c1 = (c0 + chunk < r1) ? c0 + chunk : r1;
+        double v = 0.0;
+        for (int64_t r = c0 + threadIdx.x; r < c1; r += 256) {
+            const double a = fabs(w[3 * r]), b = fabs(w[3 * r + 1]), c = fabs(w[3 * r + 2]);
+            v += fmax(a, fmax(b, c));
+            if (!(a == floor(a) && b == floor(b) && c == floor(c)) || !(a < 1e300 && b < 1e300 && c < 1e300)) nonint = 1;
+        }
+        v = block_sum_256(v, sm);
+        acc += v * (double)((c1 - c0) + 3 + (K - k));
+        wsum += v;
+    }
+    if (nonint) atomicOr(&s_flag, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double u = 1.1102230246251565e-16;
+        const double mmax = (double)((chunk < len ? chunk : len) + 3 + K);
+        const double mf = (double)fast_adds;
+        double e = (acc * u / (1.0 - mmax * u) + wsum * (mf * u / (1.0 - mf * u))) * 1.0000001;
+        if (!s_flag && wsum < 9.0e15) e = 0.0;
+        eseg[s] = e;
+    }
+}
+
+__global__ void k_reduce_seg(const double *__restrict__ part_score, const uint32_t *__restrict__ part_miss,
+                             const int64_t *__restrict__ slot0, const int64_t *__restrict__ seg_off, int64_t ld, int64_t n_acc,
+                             double *__restrict__ score, int64_t *__restrict__ ninfo, int64_t ldo,
+                             const double *__restrict__ eseg, int force_first, int32_t *__restrict__ pairs,
+                             int *__restrict__ count, int cap)
+{
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t sg = blockIdx.y;
+    if (a >= n_acc) return;
+    double v = 0.0;
+    int64_t m = 0;
+    for (int64_t k = slot0[sg]; k < slot0[sg + 1]; ++k) {
+        v = v + part_score[k * ld + a];
+        m += part_miss[k * ld + a];
+    }
+    score[sg * ldo + a] = v;
+    ninfo[sg * ldo + a] = (seg_off[sg + 1] - seg_off[sg]) - m;
+    if (eseg) {
+        const double E = eseg[sg];
+        const double lo = v - E, hi = v + E;
+        if (!(lo >= 0.0) || floor(lo) != floor(hi) || a < force_first) {
+            const int k = atomicAdd(count, 1);
+            if (k < cap) {
+                pairs[2 * k] = (int32_t)sg;
+                pairs[2 * k + 1] = (int32_t)a;
+            }
+        }
+    }
+}
+
+template <bool SKIP, bool GATHER>
+__global__ void __launch_bounds__(256)
+k_strict_pairs(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx, int64_t row0,
+               const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk,
+               const int32_t *__restrict__ pairs, const int *__restrict__ count, int cap, int64_t kmax,
+               double *__restrict__ sums)
+{
+    const int np = *count < cap ? *count : cap;
+    const int pr = blockIdx.y;
+    if (pr >= np) return;
+    const int64_t sg = pairs[2 * pr], col = pairs[2 * pr + 1];
+    const int64_t s0 = seg_off[sg], s1 = seg_off[sg + 1];
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r0 = s0 + k * chunk;
+    if (r0 >= s1 && !(k == 0)) return;
+    const int64_t r1 = (r0 + chunk < s1) ? r0 + chunk : s1;
+    double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
+    constexpr int U = 8;
+    int64_t r = r0;
+    for (; r + U <= r1; r += U) {
+        int b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t prow = GATHER ? row_idx[r + u] : (row0 + r + u);
+            b[u] = code_at(db, pitch, prow, col, packed);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double w0 = w[3 * (r + u) + 0], w1 = w[3 * (r + u) + 1], w2 = w[3 * (r + u) + 2];
+            a_ref = add_sel(a_ref, b[u] == 0, w0);
+            if (!SKIP) a_het = add_sel(a_het, b[u] == 2, w1);
+            a_alt = add_sel(a_alt, b[u] == 1, w2);
+        }
+    }
+    for (; r < r1; ++r) {
+        const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
+        const int b = code_at(db, pitch, prow, col, packed);
+        const double w0 = w[3 * r + 0], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
+        a_ref = add_sel(a_ref, b == 0, w0);
+        if (!SKIP) a_het = add_sel(a_het, b == 2, w1);
+        a_alt = add_sel(a_alt, b == 1, w2);
+    }
+    sums[(int64_t)pr * kmax + k] = ((0.0 + a_ref) + a_het) + a_alt;
+}
+
+// one wave per pair: lanes fetch 64 chunk sums at a time, lane 0 adds them in order; then score[seg, acc] = total
+__global__ void __launch_bounds__(64)
+k_scan_pairs(const double *__restrict__ sums, const int64_t *__restrict__ seg_off, int64_t chunk,
+             const int32_t *__restrict__ pairs, const int *__restrict__ count, int cap, int64_t kmax,
+             double *__restrict__ score, int64_t ldo)
+{
+    __shared__ double tile[64];
+    const int np = *count < cap ? *count : cap;
+    const int pr = blockIdx.x;
+    if (pr >= np) return;
+    const int64_t sg = pairs[2 * pr], col = pairs[2 * pr + 1];
+    const int64_t len = seg_off[sg + 1] - seg_off[sg];
+    int64_t K = (len + chunk - 1) / chunk;
+    if (K < 1) K = 1;                                  // an empty segment: one matchGTsAccs call on no rows
+    double s = 0.0;
+    for (int64_t k0 = 0; k0 < K; k0 += 64) {
+        if (k0 + threadIdx.x < K) tile[threadIdx.x] = sums[(int64_t)pr * kmax + k0 + threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = (int)((K - k0 < 64) ? (K - k0) : 64);
+            for (int i = 0; i < cnt; ++i) s = s + tile[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) score[sg * ldo + col] = s;
+}
+
+// totals over the segments in order (TotScoreList += ScoreList per window, core/csmatch.py:88-90) from [n_seg, ldo]
+// results; block 0 also leaves sum_s eseg[s] in etot[0] (the totals' share of the per-window bounds)
+__global__ void k_tot_seg(const double *__restrict__ score, const int64_t *__restrict__ ninfo, int64_t n_seg, int64_t ldo,
+                          int64_t n_acc, double *__restrict__ tot_score, int64_t *__restrict__ tot_ninfo,
+                          const double *__restrict__ eseg, double *__restrict__ etot)
+{
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a == 0 && eseg) {
+        double e = 0.0;
+        for (int64_t s = 0; s < n_seg; ++s) e += eseg[s];
+        etot[0] = e * 1.0000001;
+    }
+    if (a >= n_acc) return;
+    double t = 0.0;
+    int64_t m = 0;
+    for (int64_t s = 0; s < n_seg; ++s) {
+        t = t + score[s * ldo + a];
+        m += ninfo[s * ldo + a];
+    }
+    tot_score[a] = t;
+    tot_ninfo[a] = m;
 }
 
 // Rows of segment `seg`: explicit offsets (windows of a cross) or implicit `chunk`-row pieces of [0, n)

@@ -346,9 +346,24 @@ class Query(object):
         check(self.panel.ctx.lib.snpm_query_error_bound(self.h, int(chunk), C.byref(b)), self.panel.ctx.h)
         return b.value
 
-    def run_windows(self, win_off, skip_hets=False, totals=True):
-        """Per-window matchGTsAccs: (score [n_win,n_acc], ninfo [n_win,n_acc], tot_score, tot_ninfo)."""
+    def run_windows(self, win_off, skip_hets=False, totals=True, fast=False):
+        """Per-window matchGTsAccs: (score [n_win,n_acc], ninfo [n_win,n_acc], tot_score, tot_ninfo).
+        ``fast``: the segmented streaming pass with the certificate (exact counts, scores to ~1e-12) instead of the
+        reference-order pass (fp64 bits); ``self.last_windows_info`` then holds the re-evaluation counters."""
         ctx = self.panel.ctx
+        if fast:
+            win_off = np.ascontiguousarray(win_off, dtype=np.int64)
+            n_win = len(win_off) - 1
+            na = self.panel.n_acc
+            score = np.empty((n_win, na), dtype=np.float64)
+            ninfo = np.empty((n_win, na), dtype=np.int64)
+            ts = np.empty(na, dtype=np.float64)
+            tn = np.empty(na, dtype=np.int64)
+            info = np.zeros(4, dtype=np.int64)
+            check(ctx.lib.snpm_query_run_windows_fast(self.h, ptr(win_off), n_win, int(bool(skip_hets)), ptr(score), ptr(ninfo),
+                                                      ptr(ts), ptr(tn), ptr(info)), ctx.h)
+            self.last_windows_info = {"pairs_reeval": int(info[0]), "totals_reeval": int(info[1]), "strict_fallback": bool(info[2])}
+            return score, ninfo, ts, tn
         win_off = np.ascontiguousarray(win_off, dtype=np.int64)
         n_win = len(win_off) - 1
         na = self.panel.n_acc
@@ -390,6 +405,41 @@ class Query(object):
             self.free()
         except Exception:
             pass
+
+
+def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, likelihoods=True, device=None):
+    """Many samples against one resident panel in one call (snpm_score_batch).  ``samples``: list of
+    (row_idx int64 [n_b], wei float64 [n_b, 3]) pairs.  ``device`` = (d_row_idx, d_wei, offsets): the concatenated
+    inputs already in device memory (raw pointers) instead.  Returns a dict with score / ninfo (and lik / lrt)
+    arrays [B, n_acc] and the re-evaluation counters."""
+    ctx = panel.ctx
+    if device is None:
+        off = np.zeros(len(samples) + 1, dtype=np.int64)
+        for b, (rows, wei) in enumerate(samples):
+            wei = np.asarray(wei)
+            assert wei.ndim == 2 and wei.shape[1] == 3, "SNP weights should be a np.array with  shape == n,3"
+            assert len(rows) == wei.shape[0], "please provide same number of positions for both sample and db"
+            off[b + 1] = off[b] + len(rows)
+        rows = np.ascontiguousarray(np.concatenate([np.asarray(s[0], dtype=np.int64) for s in samples]) if samples
+                                    else np.zeros(0, dtype=np.int64))
+        wei = np.ascontiguousarray(np.concatenate([np.asarray(s[1], dtype=np.float64) for s in samples]) if samples
+                                   else np.zeros((0, 3)))
+        p_rows, p_wei, dev_flag = ptr(rows), ptr(wei), 0
+    else:
+        d_rows, d_wei, off = device
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        p_rows, p_wei, dev_flag = C.c_void_p(int(d_rows)), C.c_void_p(int(d_wei)), 1
+    nb, na = len(off) - 1, panel.n_acc
+    out = {"score": np.empty((nb, na), dtype=np.float64), "ninfo": np.empty((nb, na), dtype=np.int64)}
+    if likelihoods:
+        out["lik"] = np.empty((nb, na), dtype=np.float64)
+        out["lrt"] = np.empty((nb, na), dtype=np.float64)
+    info = np.zeros(4, dtype=np.int64)
+    check(ctx.lib.snpm_score_batch(panel.h, nb, ptr(off), p_rows, p_wei, dev_flag, int(chunk), int(bool(skip_hets)), int(mode),
+                                   ptr(out["score"]), ptr(out["ninfo"]), ptr(out.get("lik")), ptr(out.get("lrt")), ptr(info)),
+          ctx.h)
+    out["pairs_reeval"], out["strict_fallback"] = int(info[0]), bool(info[1])
+    return out
 
 
 class Carry(object):
