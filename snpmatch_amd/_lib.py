@@ -6,6 +6,7 @@ usable, the calls below raise.  (The CPU oracle lives in oracle/ and is test inf
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -50,11 +51,31 @@ class SnpmError(RuntimeError):
         self.msg = msg
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (soname libamdhip64.so.7) and load it by file name.  Imported
+    first, torch's runtime also serves this library (same soname); imported AFTER this library was loaded, torch would
+    bring a second HIP runtime into the process and find no GPU.  Preloading torch's copy (without importing torch)
+    makes the order irrelevant.  SNPMATCH_HIP_RUNTIME=system keeps the system runtime (processes that never use torch)."""
+    if "torch" in sys.modules or os.environ.get("SNPMATCH_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """dlopen the HIP library; raises (never falls back) when it is absent."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "%s not found: build it with ./build_lib.sh (hipcc --offload-arch=gfx950). "

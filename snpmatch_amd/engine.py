@@ -413,7 +413,15 @@ def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, li
     inputs already in device memory (raw pointers) instead.  Returns a dict with score / ninfo (and lik / lrt)
     arrays [B, n_acc] and the re-evaluation counters."""
     ctx = panel.ctx
-    if device is None:
+    if device is None and isinstance(samples, tuple):
+        # already concatenated: (row_idx int64 [N], wei float64 [N, 3], offsets int64 [B + 1])
+        rows, wei, off = samples
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        wei = np.ascontiguousarray(wei, dtype=np.float64)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        assert wei.ndim == 2 and wei.shape[1] == 3 and len(rows) == len(wei) == off[-1]
+        p_rows, p_wei, dev_flag = ptr(rows), ptr(wei), 0
+    elif device is None:
         off = np.zeros(len(samples) + 1, dtype=np.int64)
         for b, (rows, wei) in enumerate(samples):
             wei = np.asarray(wei)

@@ -35,10 +35,12 @@ for rows, wei in samples:
 dt = time.perf_counter() - t0
 print("one sample per call : %7.0f samples/s (%.3f ms per sample)" % (B / dt, dt / B * 1e3), flush=True)
 
-engine.score_batch(panel, samples[:4])
+off = np.concatenate([[0], np.cumsum([len(r) for r, _ in samples])]).astype(np.int64)
+cat = (np.concatenate([r for r, _ in samples]), np.concatenate([w for _, w in samples]), off)
+engine.score_batch(panel, cat)
 t0 = time.perf_counter()
 for _ in range(NB):
-    out = engine.score_batch(panel, samples)
+    out = engine.score_batch(panel, cat)
 dt = time.perf_counter() - t0
 print("batches of %3d, host : %7.0f samples/s (%.3f ms per sample), pairs re-evaluated per batch %d"
       % (B, B * NB / dt, dt / B / NB * 1e3, out["pairs_reeval"]), flush=True)
@@ -46,9 +48,8 @@ top = [int(np.nanargmin(out["lik"][b])) for b in range(B)]
 assert top == [b * 7 % n_acc for b in range(B)], top
 
 import torch  # noqa: E402
-off = np.concatenate([[0], np.cumsum([len(r) for r, _ in samples])]).astype(np.int64)
-d_rows = torch.as_tensor(np.concatenate([r for r, _ in samples]), device="cuda:0")
-d_wei = torch.as_tensor(np.concatenate([w for _, w in samples]), device="cuda:0")
+d_rows = torch.as_tensor(cat[0], device="cuda:0")
+d_wei = torch.as_tensor(cat[1], device="cuda:0")
 torch.cuda.synchronize()
 dev = (d_rows.data_ptr(), d_wei.data_ptr(), off)
 engine.score_batch(panel, None, device=dev)
