@@ -179,6 +179,11 @@ int snpm_score_batch(snpm_panel *panel, int64_t n_samples, const int64_t *sample
                      int device_inputs, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo,
                      double *lik, double *lrt, int64_t *info);
 
+/* pinned host memory (hipHostMalloc): batch inputs built in it go to the device at full PCIe speed without the
+   staging copy (snpm_score_batch recognises pinned pointers) */
+int snpm_host_alloc(snpm_ctx *ctx, int64_t bytes, void **out);
+int snpm_host_free(snpm_ctx *ctx, void *ptr);
+
 /* ---------------------------------------------------------------- jobs larger than HBM: SNP slab after SNP slab */
 /* The reference walks the whole SNP axis in `chunk`-row pieces and adds every piece onto ScoreList / NumInfoSites
    (core/snpmatch.py:218-225).  When the panel does not fit in HBM the caller loads (or regenerates) one SNP slab

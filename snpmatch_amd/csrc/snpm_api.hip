@@ -63,8 +63,11 @@ struct snpm_ctx {
     Buf ws_part_score, ws_part_miss, ws_seg_score, ws_seg_miss, ws_seg_off, ws_cols, ws_tmp_score, ws_tmp_ninfo, ws_flags;
     Buf ws_lik_y, ws_lik_n, ws_lik_l, ws_lik_r;
     Buf ws_wprops, ws_epart;            // partial sums of k_wprops / k_eref
-    Buf ws_seg_desc, ws_eseg, ws_pairs, ws_pair_sums, ws_bscore, ws_bninfo, ws_blut, ws_brows, ws_bw;   // segmented / batched scoring
-    std::vector<int64_t> h_seg_desc;    // host image of ws_seg_desc (kept until the next segmented call)
+    Buf ws_seg_desc, ws_eseg, ws_pairs, ws_pair_sums, ws_bscore, ws_bninfo, ws_blut, ws_brows, ws_brows32, ws_bw;   // segmented / batched scoring
+    int64_t *h_desc = nullptr;          // pinned host image of ws_seg_desc
+    size_t h_desc_cap = 0;
+    int stage_which = 0;                // next staging slab of stage_bytes
+    hipEvent_t batch_ev = nullptr;      // "this sub-batch's inputs have arrived" (copy stream -> compute stream)
     // device buffers of freed queries, kept for the next query (hipMalloc / hipFree cost more than a small query's run)
     struct Cached { void *p; size_t cap; };
     std::vector<Cached> qcache;
@@ -857,48 +860,68 @@ static int launch_fast_seg(snpm_ctx *ctx, const SegJob &j, dim3 grid, dim3 block
     return SNPM_OK;
 }
 
-// fast pass over every segment + ordered reduce + (certify) the list of (segment, accession) pairs whose int(score) is
-// not proven, their reference-order re-evaluation and the patch.  Everything is enqueued; nothing waits.
-static int run_segmented(snpm_ctx *ctx, SegJob &j)
+// Plan of a segmented pass: parts (contiguous runs of <= EPOCH_TILES tiles inside one segment), their partial slots,
+// the descriptor tables on the device.  seg_launch scores a range of segments (fast pass + ordered reduce + the
+// certificate's list of uncertain (segment, accession) pairs), seg_finish re-scores those pairs in reference order
+// and patches them in.  Everything is enqueued; nothing waits.
+struct SegPlan {
+    FastGeom g0;
+    int64_t n_parts = 0, tiles_per_part = 0;
+    std::vector<int64_t> slot0;             // host: first part / slot of every segment, [n_seg + 1]
+    const int64_t *d_slot0 = nullptr, *d_desc = nullptr;
+};
+
+static int seg_plan(snpm_ctx *ctx, SegJob &j, SegPlan &pl)
 {
     snpm_panel *p = j.p;
     const int64_t n_seg = j.n_seg;
-    if (n_seg == 0) return SNPM_OK;
-    const int bpl = p->packed ? 4 : 4;          // int8: a dword per lane; packed: the one-byte-per-lane instantiation (4 accessions)
-    FastGeom g0 = fast_geom(ctx, p->n_acc, TILE_ROWS, 2, bpl, TILE_ROWS);
-    // parts: contiguous runs of <= EPOCH_TILES tiles inside one segment; enough of them to fill the chip twice over
+    pl.g0 = fast_geom(ctx, p->n_acc, TILE_ROWS, 2, 4, TILE_ROWS);      // int8: a dword per lane; packed: a byte (4 accessions)
     int64_t total_tiles = 0, kmax = 1;
     for (int64_t s = 0; s < n_seg; ++s) {
         const int64_t len = j.seg_off[s + 1] - j.seg_off[s];
         total_tiles += (len + TILE_ROWS - 1) / TILE_ROWS;
         kmax = std::max<int64_t>(kmax, (len + j.chunk - 1) / j.chunk);
     }
-    const int64_t want_blocks = (int64_t)ctx->n_cu * 8 / std::max<int64_t>(1, g0.n_colblocks);
-    const int64_t tiles_per_part = std::max<int64_t>(2, std::min<int64_t>(EPOCH_TILES, (total_tiles + want_blocks - 1) / std::max<int64_t>(1, want_blocks)));
-    std::vector<int64_t> &h = ctx->h_seg_desc;      // [seg_off | slot0 | part_desc]; stays alive until the copy is done
-    h.clear();
-    h.insert(h.end(), j.seg_off, j.seg_off + n_seg + 1);
-    const size_t o_slot0 = h.size();
-    h.resize(h.size() + (size_t)n_seg + 1);
-    const size_t o_desc = h.size();
+    // enough parts to fill the chip a few times over
+    const int64_t want_blocks = std::max<int64_t>(1, (int64_t)ctx->n_cu * 8 / std::max<int64_t>(1, pl.g0.n_colblocks));
+    pl.tiles_per_part = std::max<int64_t>(2, std::min<int64_t>(EPOCH_TILES, (total_tiles + want_blocks - 1) / want_blocks));
+    // [seg_off | slot0 | part_desc], built in pinned memory (the copy below is asynchronous)
+    const int64_t max_parts = total_tiles / pl.tiles_per_part + n_seg + 1;
+    const size_t words = 2 * ((size_t)n_seg + 1) + 3 * (size_t)max_parts;
+    if (ctx->h_desc_cap < words * sizeof(int64_t)) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
+        ctx->h_desc = nullptr;
+        ctx->h_desc_cap = 0;
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->h_desc, std::max<size_t>(words * sizeof(int64_t), 1 << 16), hipHostMallocDefault));
+        ctx->h_desc_cap = std::max<size_t>(words * sizeof(int64_t), 1 << 16);
+    } else {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // the previous plan's copy may still read the buffer
+    }
+    int64_t *h = ctx->h_desc;
+    memcpy(h, j.seg_off, ((size_t)n_seg + 1) * sizeof(int64_t));
+    const size_t o_slot0 = (size_t)n_seg + 1, o_desc = 2 * ((size_t)n_seg + 1);
+    pl.slot0.assign((size_t)n_seg + 1, 0);
     int64_t n_parts = 0;
+    size_t w = o_desc;
     for (int64_t s = 0; s < n_seg; ++s) {
-        h[o_slot0 + (size_t)s] = n_parts;
+        pl.slot0[(size_t)s] = n_parts;
         const int64_t r0 = j.seg_off[s], r1 = j.seg_off[s + 1];
-        for (int64_t r = r0; r < r1; r += tiles_per_part * TILE_ROWS) {
-            h.push_back(r);
-            h.push_back(std::min<int64_t>(r1, r + tiles_per_part * TILE_ROWS));
-            h.push_back(n_parts++);
+        for (int64_t r = r0; r < r1; r += pl.tiles_per_part * TILE_ROWS) {
+            h[w++] = r;
+            h[w++] = std::min<int64_t>(r1, r + pl.tiles_per_part * TILE_ROWS);
+            h[w++] = n_parts++;
         }
     }
-    h[o_slot0 + (size_t)n_seg] = n_parts;
-    int rc = ensure(ctx, ctx->ws_seg_desc, h.size() * sizeof(int64_t));
+    pl.slot0[(size_t)n_seg] = n_parts;
+    memcpy(h + o_slot0, pl.slot0.data(), ((size_t)n_seg + 1) * sizeof(int64_t));
+    pl.n_parts = n_parts;
+    int rc = ensure(ctx, ctx->ws_seg_desc, w * sizeof(int64_t));
     if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_seg_desc.p, h.data(), h.size() * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    const int64_t *d_seg_off = (const int64_t *)ctx->ws_seg_desc.p;
-    const int64_t *d_slot0 = d_seg_off + o_slot0;
-    const int64_t *d_desc = d_seg_off + o_desc;
-    j.d_seg_off = d_seg_off;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_seg_desc.p, h, w * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    j.d_seg_off = (const int64_t *)ctx->ws_seg_desc.p;
+    pl.d_slot0 = j.d_seg_off + o_slot0;
+    pl.d_desc = j.d_seg_off + o_desc;
     j.kmax = kmax;
     j.cap = (int)std::max<int64_t>(64, std::min<int64_t>(SEG_PAIR_CAP, (int64_t(8) << 20) / kmax));
     rc = ensure(ctx, ctx->ws_part_score, (size_t)std::max<int64_t>(n_parts, 1) * p->ld * sizeof(double));
@@ -909,49 +932,61 @@ static int run_segmented(snpm_ctx *ctx, SegJob &j)
     if (rc) return rc;
     HIPCHK(ctx, hipMemsetAsync(seg_pair_count(ctx), 0, sizeof(int), ctx->stream));
     if (j.certify) {
-        rc = ensure(ctx, ctx->ws_eseg, (size_t)n_seg * sizeof(double));
+        rc = ensure(ctx, ctx->ws_eseg, (size_t)std::max<int64_t>(n_seg, 1) * sizeof(double));
         if (rc) return rc;
+        rc = ensure(ctx, ctx->ws_pair_sums, (size_t)j.cap * (size_t)kmax * sizeof(double));
+        if (rc) return rc;
+    }
+    return SNPM_OK;
+}
+
+static int seg_launch(snpm_ctx *ctx, const SegJob &j, const SegPlan &pl, int64_t s0, int64_t s1)
+{
+    snpm_panel *p = j.p;
+    if (s1 <= s0) return SNPM_OK;
+    int rc;
+    if (j.certify) {
         // fast-pass additions a term passes through: its part (<= tiles_per_part tiles) + the parts of its segment
-        const int64_t max_parts = (kmax * j.chunk / (tiles_per_part * TILE_ROWS)) + 2;
-        hipLaunchKernelGGL(k_eseg, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_w, d_seg_off, j.chunk,
-                           tiles_per_part * TILE_ROWS + max_parts + 2, (double *)ctx->ws_eseg.p);
+        const int64_t seg_parts = (j.kmax * j.chunk) / (pl.tiles_per_part * TILE_ROWS) + 2;
+        hipLaunchKernelGGL(k_eseg, dim3((unsigned)(s1 - s0)), dim3(256), 0, ctx->stream, j.d_w, j.d_seg_off, j.chunk,
+                           pl.tiles_per_part * TILE_ROWS + seg_parts + 2, (double *)ctx->ws_eseg.p, s0);
         HIPCHK(ctx, hipGetLastError());
     }
-    if (n_parts > 0) {
-        const unsigned gy = (unsigned)std::min<int64_t>(n_parts, 65535);
-        const unsigned gz = (unsigned)((n_parts + gy - 1) / gy);
-        dim3 grid((unsigned)g0.n_colblocks, gy, gz), block(WAVE * g0.wpb);
+    const int64_t p0 = pl.slot0[(size_t)s0], p1 = pl.slot0[(size_t)s1];
+    if (p1 > p0) {
+        const int64_t np = p1 - p0;
+        const unsigned gy = (unsigned)std::min<int64_t>(np, 65535);
+        const unsigned gz = (unsigned)((np + gy - 1) / gy);
+        dim3 grid((unsigned)pl.g0.n_colblocks, gy, gz), block(WAVE * pl.g0.wpb);
         const bool nt = ctx->nt_loads != 0;
-        if (p->packed) rc = nt ? launch_fast_seg<1, true>(ctx, j, grid, block, n_parts, d_desc) : launch_fast_seg<1, false>(ctx, j, grid, block, n_parts, d_desc);
-        else rc = nt ? launch_fast_seg<4, true>(ctx, j, grid, block, n_parts, d_desc) : launch_fast_seg<4, false>(ctx, j, grid, block, n_parts, d_desc);
+        const int64_t *desc = pl.d_desc + 3 * p0;
+        if (p->packed) rc = nt ? launch_fast_seg<1, true>(ctx, j, grid, block, np, desc) : launch_fast_seg<1, false>(ctx, j, grid, block, np, desc);
+        else rc = nt ? launch_fast_seg<4, true>(ctx, j, grid, block, np, desc) : launch_fast_seg<4, false>(ctx, j, grid, block, np, desc);
         if (rc) return rc;
     }
-    {
-        ProfScope ps(ctx, PK_REDUCE);
-        const int thr = 64;
-        for (int64_t s0 = 0; s0 < n_seg; s0 += 65535) {
-            const int64_t ns = std::min<int64_t>(65535, n_seg - s0);
-            hipLaunchKernelGGL(k_reduce_seg, dim3((unsigned)((p->n_acc + thr - 1) / thr), (unsigned)ns), dim3(thr), 0, ctx->stream,
-                               (const double *)ctx->ws_part_score.p, (const uint32_t *)ctx->ws_part_miss.p, d_slot0 + s0,
-                               d_seg_off + s0, p->ld, p->n_acc, j.d_score + s0 * j.ldo, j.d_ninfo + s0 * j.ldo, j.ldo,
-                               j.certify ? (const double *)ctx->ws_eseg.p + s0 : (const double *)nullptr, ctx->debug_reeval,
-                               seg_pairs(ctx), seg_pair_count(ctx), j.cap);
-            HIPCHK(ctx, hipGetLastError());
-        }
-    }
-    if (!j.certify) return SNPM_OK;
-    // NOTE: pairs of a later reduce slab carry segment indices relative to s0 only when n_seg > 65535 (never in practice:
-    // guarded by the callers), so pair segment ids are absolute here.
-    rc = ensure(ctx, ctx->ws_pair_sums, (size_t)j.cap * (size_t)kmax * sizeof(double));
-    if (rc) return rc;
+    ProfScope ps(ctx, PK_REDUCE);
+    const int thr = 64;
+    hipLaunchKernelGGL(k_reduce_seg, dim3((unsigned)((p->n_acc + thr - 1) / thr), (unsigned)(s1 - s0)), dim3(thr), 0, ctx->stream,
+                       (const double *)ctx->ws_part_score.p, (const uint32_t *)ctx->ws_part_miss.p, pl.d_slot0, j.d_seg_off,
+                       p->ld, p->n_acc, j.d_score, j.d_ninfo, j.ldo,
+                       j.certify ? (const double *)ctx->ws_eseg.p : (const double *)nullptr, ctx->debug_reeval,
+                       seg_pairs(ctx), seg_pair_count(ctx), j.cap, s0);
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+static int seg_finish(snpm_ctx *ctx, const SegJob &j)
+{
+    snpm_panel *p = j.p;
+    if (!j.certify || j.n_seg == 0) return SNPM_OK;
     const bool gather = j.d_row_idx != nullptr;
     {
         ProfScope ps(ctx, PK_STRICT);
-        dim3 grid((unsigned)((kmax + 255) / 256), (unsigned)j.cap);
+        dim3 grid((unsigned)((j.kmax + 255) / 256), (unsigned)j.cap);
 #define LAUNCH_PAIRS(S, G)                                                                                        \
     hipLaunchKernelGGL((k_strict_pairs<S, G>), grid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->packed, j.d_row_idx,     \
-                       j.row0, j.d_w, d_seg_off, j.chunk, (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), \
-                       j.cap, kmax, (double *)ctx->ws_pair_sums.p)
+                       j.row0, j.d_w, j.d_seg_off, j.chunk, (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), \
+                       j.cap, j.kmax, (double *)ctx->ws_pair_sums.p)
         if (j.skip) {
             if (gather) LAUNCH_PAIRS(true, true); else LAUNCH_PAIRS(true, false);
         } else {
@@ -960,14 +995,104 @@ static int run_segmented(snpm_ctx *ctx, SegJob &j)
 #undef LAUNCH_PAIRS
         HIPCHK(ctx, hipGetLastError());
     }
-    {
-        ProfScope ps(ctx, PK_SCAN);
-        hipLaunchKernelGGL(k_scan_pairs, dim3((unsigned)j.cap), dim3(64), 0, ctx->stream, (const double *)ctx->ws_pair_sums.p,
-                           d_seg_off, j.chunk, (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), j.cap, kmax,
-                           j.d_score, j.ldo);
-        HIPCHK(ctx, hipGetLastError());
+    ProfScope ps(ctx, PK_SCAN);
+    hipLaunchKernelGGL(k_scan_pairs, dim3((unsigned)j.cap), dim3(64), 0, ctx->stream, (const double *)ctx->ws_pair_sums.p,
+                       j.d_seg_off, j.chunk, (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), j.cap, j.kmax,
+                       j.d_score, j.ldo);
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
+static int run_segmented(snpm_ctx *ctx, SegJob &j)
+{
+    if (j.n_seg == 0) return SNPM_OK;
+    SegPlan pl;
+    int rc = seg_plan(ctx, j, pl);
+    if (!rc) rc = seg_launch(ctx, j, pl, 0, j.n_seg);
+    if (!rc) rc = seg_finish(ctx, j);
+    return rc;
+}
+
+// Host bytes -> device through the double-buffered pinned staging slabs on the copy stream (the slab is filled by a few
+// threads while the previous one is in flight); memory the caller pinned itself goes straight to hipMemcpyAsync.
+static int ensure_stage(snpm_ctx *ctx)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (!ctx->stage[i]) {
+            hipError_t e = hipHostMalloc(&ctx->stage[i], snpm_ctx::kStageBytes, hipHostMallocDefault);
+            if (e != hipSuccess) return set_err(ctx, SNPM_ERR_OOM, "hipHostMalloc staging failed: %s", hipGetErrorString(e));
+            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
+        }
     }
     return SNPM_OK;
+}
+
+void parallel_copy(snpm_ctx *ctx, int8_t *dst, const int8_t *src, size_t n);
+
+static int stage_bytes(snpm_ctx *ctx, void *d_dst, const void *h_src, size_t nbytes, bool src_pinned)
+{
+    if (nbytes == 0) return SNPM_OK;
+    if (src_pinned) {
+        HIPCHK(ctx, hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        return SNPM_OK;
+    }
+    for (size_t o = 0; o < nbytes; o += snpm_ctx::kStageBytes) {
+        const size_t piece = std::min(snpm_ctx::kStageBytes, nbytes - o);
+        const int which = ctx->stage_which;
+        ctx->stage_which ^= 1;
+        if (ctx->stage_busy[which]) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->stage_done[which]));
+            ctx->stage_busy[which] = false;
+        }
+        parallel_copy(ctx, (int8_t *)ctx->stage[which], (const int8_t *)h_src + o, piece);
+        HIPCHK(ctx, hipMemcpyAsync((char *)d_dst + o, ctx->stage[which], piece, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIPCHK(ctx, hipEventRecord(ctx->stage_done[which], ctx->copy_stream));
+        ctx->stage_busy[which] = true;
+    }
+    return SNPM_OK;
+}
+
+// n int64 row indices (n * 4 bytes <= one slab) -> int32 on the device; values that do not fit become -1
+static int stage_rows32(snpm_ctx *ctx, int32_t *d_dst, const int64_t *h_src, int64_t n)
+{
+    if (n == 0) return SNPM_OK;
+    const int which = ctx->stage_which;
+    ctx->stage_which ^= 1;
+    if (ctx->stage_busy[which]) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->stage_done[which]));
+        ctx->stage_busy[which] = false;
+    }
+    int32_t *slab = (int32_t *)ctx->stage[which];
+    const int nthreads = (int)std::min<int64_t>(ctx->stage_threads, std::max<int64_t>(1, n >> 18));
+    auto narrow = [=](int64_t a, int64_t b) {
+        for (int64_t i = a; i < b; ++i) {
+            const int64_t v = h_src[i];
+            slab[i] = (v >= 0 && v <= 0x7fffffff) ? (int32_t)v : -1;
+        }
+    };
+    if (nthreads <= 1) {
+        narrow(0, n);
+    } else {
+        std::vector<std::thread> pool;
+        const int64_t per = (n + nthreads - 1) / nthreads;
+        for (int t = 0; t < nthreads; ++t)
+            if (t * per < n) pool.emplace_back(narrow, t * per, std::min<int64_t>(n, (t + 1) * per));
+        for (auto &th : pool) th.join();
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d_dst, slab, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->copy_stream));
+    HIPCHK(ctx, hipEventRecord(ctx->stage_done[which], ctx->copy_stream));
+    ctx->stage_busy[which] = true;
+    return SNPM_OK;
+}
+
+static bool host_pointer_is_pinned(const void *ptr)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
 }
 
 // number of accessions the last certified run flagged (synchronises the stream)
@@ -1064,7 +1189,7 @@ static int stage_rows(snpm_panel *p, int64_t row0, int64_t nrows, Fill fill)
 }
 
 // copy n bytes with a few threads (one memcpy stream is ~15 GB/s, well under what PCIe gen5 x16 takes)
-static void parallel_copy(snpm_ctx *ctx, int8_t *dst, const int8_t *src, size_t n)
+void parallel_copy(snpm_ctx *ctx, int8_t *dst, const int8_t *src, size_t n)
 {
     const int nthreads = (int)std::min<size_t>((size_t)ctx->stage_threads, std::max<size_t>(1, n >> 20));
     if (nthreads <= 1) {
@@ -1202,10 +1327,12 @@ int snpm_destroy(snpm_ctx *ctx)
                        &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
                        &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r, &ctx->ws_wprops, &ctx->ws_epart,
                        &ctx->ws_seg_desc, &ctx->ws_eseg, &ctx->ws_pairs, &ctx->ws_pair_sums, &ctx->ws_bscore, &ctx->ws_bninfo,
-                       &ctx->ws_blut, &ctx->ws_brows, &ctx->ws_bw};
+                       &ctx->ws_blut, &ctx->ws_brows, &ctx->ws_brows32, &ctx->ws_bw};
         for (Buf *b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+        if (ctx->h_desc) (void)hipHostFree(ctx->h_desc);
+        if (ctx->batch_ev) (void)hipEventDestroy(ctx->batch_ev);
         for (int i = 0; i < 2; ++i) {
             if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
             if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
@@ -1956,31 +2083,25 @@ try {
     if ((rc = ensure(ctx, ctx->ws_blut, NN * 4 * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->ws_bscore, B * na * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, ctx->ws_bninfo, B * na * sizeof(int64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_flags2, sizeof(int)))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->ws_flags2.p, 0, sizeof(int), ctx->stream));
+    int64_t *d_rows = (int64_t *)ctx->ws_brows.p;
     const double *d_w = nullptr;
     if (device_inputs) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->ws_brows.p, row_idx, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(d_rows, row_idx, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
         d_w = (const double *)wei;
     } else {
-        const int64_t *rows = (const int64_t *)row_idx;
-        for (int64_t i = 0; i < N; ++i)
-            if (rows[i] < 0 || rows[i] >= p->n_snp)
-                return set_err(ctx, SNPM_ERR_BADARG, "row index %lld at %lld outside the panel (n_snp %lld)",
-                               (long long)rows[i], (long long)i, (long long)p->n_snp);
         if ((rc = ensure(ctx, ctx->ws_bw, NN * 3 * sizeof(double)))) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->ws_brows.p, row_idx, (size_t)N * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->ws_bw.p, wei, (size_t)N * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = ensure(ctx, ctx->ws_brows32, NN * sizeof(int32_t)))) return rc;
         d_w = (const double *)ctx->ws_bw.p;
     }
-    HIPCHK(ctx, hipMemsetAsync((int64_t *)ctx->ws_brows.p + N, 0, PREFETCH_PAD_ROWS * sizeof(int64_t), ctx->stream));
-    if (N > 0) {
-        ProfScope ps(ctx, PK_LUT);
-        hipLaunchKernelGGL(k_build_lut, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, d_w,
-                           (double *)ctx->ws_blut.p, N, skip);
-        HIPCHK(ctx, hipGetLastError());
-    }
+    // the scoring kernel prefetches (never scores) a few row-list entries past a part: every entry it can reach must be
+    // a row of THIS panel before the first launch -- also the ones whose upload is still on its way
+    if (device_inputs) HIPCHK(ctx, hipMemsetAsync(d_rows + N, 0, PREFETCH_PAD_ROWS * sizeof(int64_t), ctx->stream));
+    else HIPCHK(ctx, hipMemsetAsync(d_rows, 0, ((size_t)N + PREFETCH_PAD_ROWS) * sizeof(int64_t), ctx->stream));
     SegJob j;
     j.p = p;
-    j.d_row_idx = (const int64_t *)ctx->ws_brows.p;
+    j.d_row_idx = d_rows;
     j.n_total = N;
     j.d_w = d_w;
     j.d_lut = (const double *)ctx->ws_blut.p;
@@ -1992,12 +2113,25 @@ try {
     j.d_score = (double *)ctx->ws_bscore.p;
     j.d_ninfo = (int64_t *)ctx->ws_bninfo.p;
     j.ldo = p->n_acc;
+    // rows [r0, r1) of the concatenated inputs are on the device (or on their way, ordered before what follows):
+    // sanitise the row list, build the LUT rows
+    auto prepare_rows = [&](int64_t r0, int64_t r1, const int32_t *rows32) -> int {
+        if (r1 <= r0) return SNPM_OK;
+        const int64_t n = r1 - r0;
+        hipLaunchKernelGGL(k_check_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_rows + r0, rows32, n,
+                           p->n_snp, (int *)ctx->ws_flags2.p);
+        ProfScope ps(ctx, PK_LUT);
+        hipLaunchKernelGGL(k_build_lut, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_w + 3 * r0,
+                           (double *)ctx->ws_blut.p + 4 * r0, n, skip);
+        HIPCHK(ctx, hipGetLastError());
+        return SNPM_OK;
+    };
     // every sample through the reference-order chain (requested, or more uncertain pairs than the sparse tier takes)
     auto strict_every_sample = [&]() -> int {
         for (int64_t b = 0; b < n_samples; ++b) {
             snpm_query *q = nullptr;
             const int64_t o = sample_off[b], nb = sample_off[b + 1] - o;
-            int r = snpm_query_create_device(p, (const int64_t *)ctx->ws_brows.p + o, 0, nb, d_w + 3 * o, &q);
+            int r = snpm_query_create_device(p, d_rows + o, 0, nb, d_w + 3 * o, &q);
             if (r) return r;
             r = run_strict_chain(q, skip, chunk, nullptr, nullptr, nullptr, (double *)ctx->ws_bscore.p + b * na,
                                  (int64_t *)ctx->ws_bninfo.p + b * na);
@@ -2009,12 +2143,58 @@ try {
         return SNPM_OK;
     };
     bool strict_all = (mode == SNPM_MODE_STRICT);
+    SegPlan pl;
+    if (!strict_all) {
+        rc = seg_plan(ctx, j, pl);
+        if (rc) return rc;
+    }
+    if (device_inputs) {
+        rc = prepare_rows(0, N, nullptr);
+        if (!rc && !strict_all) rc = seg_launch(ctx, j, pl, 0, n_samples);
+        if (rc) return rc;
+    } else {
+        // Host inputs: the batch is cut into runs of samples of about one staging slab; while run k is scored, run
+        // k + 1 travels over PCIe on the copy stream and the host fills the slab of run k + 2.
+        rc = ensure_stage(ctx);
+        if (rc) return rc;
+        if (!ctx->batch_ev) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->batch_ev, hipEventDisableTiming));
+        if (!ctx->compute_mark) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->compute_mark, hipEventDisableTiming));
+        // the device arenas may still be read by the previous call's kernels: the copy stream waits for them
+        HIPCHK(ctx, hipEventRecord(ctx->compute_mark, ctx->stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->compute_mark, 0));
+        const bool pinned = N > 0 && host_pointer_is_pinned(row_idx) && host_pointer_is_pinned(wei);
+        const int64_t rows_per_run = std::max<int64_t>(1, (int64_t)(snpm_ctx::kStageBytes / 32));
+        int64_t s0 = 0;
+        while (s0 < n_samples) {
+            int64_t s1 = s0 + 1;
+            while (s1 < n_samples && sample_off[s1 + 1] - sample_off[s0] <= rows_per_run) ++s1;
+            const int64_t r0 = sample_off[s0], r1 = sample_off[s1];
+            // the row list crosses PCIe as int32 (the link is what bounds a batch: 28 instead of 32 bytes per matched SNP);
+            // it is narrowed while the staging slab is filled and widened again by k_check_rows
+            const int32_t *rows32 = nullptr;
+            if (!pinned && r1 - r0 <= rows_per_run) {
+                rc = stage_rows32(ctx, (int32_t *)ctx->ws_brows32.p + r0, (const int64_t *)row_idx + r0, r1 - r0);
+                rows32 = (const int32_t *)ctx->ws_brows32.p + r0;
+            } else {
+                rc = stage_bytes(ctx, d_rows + r0, (const int64_t *)row_idx + r0, (size_t)(r1 - r0) * sizeof(int64_t), pinned);
+            }
+            if (!rc) rc = stage_bytes(ctx, (double *)ctx->ws_bw.p + 3 * r0, (const double *)wei + 3 * r0,
+                                      (size_t)(r1 - r0) * 3 * sizeof(double), pinned);
+            if (rc) return rc;
+            HIPCHK(ctx, hipEventRecord(ctx->batch_ev, ctx->copy_stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_ev, 0));
+            rc = prepare_rows(r0, r1, rows32);
+            if (!rc && !strict_all) rc = seg_launch(ctx, j, pl, s0, s1);
+            if (rc) return rc;
+            s0 = s1;
+        }
+    }
     int n_pairs = 0;
     if (strict_all) {
         rc = strict_every_sample();
         if (rc) return rc;
     } else {
-        rc = run_segmented(ctx, j);
+        rc = seg_finish(ctx, j);
         if (rc) return rc;
         if (j.certify) {
             rc = ensure_pinned(ctx, 64);
@@ -2042,7 +2222,11 @@ try {
     }
     if (score) HIPCHK(ctx, hipMemcpyAsync(score, ctx->ws_bscore.p, B * na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (ninfo) HIPCHK(ctx, hipMemcpyAsync(ninfo, ctx->ws_bninfo.p, B * na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = ensure_pinned(ctx, 64))) return rc;
+    int *h_bad = (int *)ctx->h_pinned + 8;
+    HIPCHK(ctx, hipMemcpyAsync(h_bad, ctx->ws_flags2.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*h_bad) return set_err(ctx, SNPM_ERR_BADARG, "a row index lies outside the panel (n_snp %lld)", (long long)p->n_snp);
     if (info) { info[0] = n_pairs; info[1] = (strict_all && mode != SNPM_MODE_STRICT) ? 1 : 0; }
     return SNPM_OK;
 } SNPM_GUARD((p ? p->ctx : nullptr))
@@ -2592,6 +2776,30 @@ int snpm_debug_stream_read(snpm_panel *p, int64_t *bytes_read)
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (bytes_read) *bytes_read = n_dwords * 4;
+    return SNPM_OK;
+}
+
+// pinned host memory for callers that want their batch inputs to travel at full PCIe speed without the staging copy
+int snpm_host_alloc(snpm_ctx *ctx, int64_t bytes, void **out)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    CHECK_ARG(ctx, out != nullptr && bytes >= 0, "bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, (size_t)std::max<int64_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) return set_err(ctx, SNPM_ERR_OOM, "hipHostMalloc of %lld bytes failed: %s", (long long)bytes, hipGetErrorString(e));
+    return SNPM_OK;
+}
+
+int snpm_host_free(snpm_ctx *ctx, void *ptr)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    if (ptr && hip_alive()) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipHostFree(ptr);
+    }
     return SNPM_OK;
 }
 

@@ -144,6 +144,23 @@ k_efinish(const double *__restrict__ partial, int n_partial, int64_t n, int64_t 
     }
 }
 
+// row lists that arrive without a host pass over them (batches): entries outside the panel are replaced by row 0 --
+// no kernel ever reads outside the panel -- and reported through *bad (the call then fails after its synchronisation).
+// src32 != NULL: the list crossed PCIe as int32 (half the bytes; -1 stands for any value that does not fit) and is
+// widened into `rows` here.
+__global__ void k_check_rows(int64_t *__restrict__ rows, const int32_t *__restrict__ src32, int64_t n, int64_t n_snp,
+                             int *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t r = src32 ? (int64_t)src32[i] : rows[i];
+    if (r < 0 || r >= n_snp) {
+        r = 0;
+        atomicOr(bad, 1);
+    }
+    rows[i] = r;
+}
+
 // ------------------------------------------------------------------------------------------------
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1095,11 +1112,11 @@ __device__ __forceinline__ int code_at(const int8_t *__restrict__ db, int64_t pi
 //   k_scan_pairs    the chain of additions over a pair's chunk sums (ScoreList += chunk) and the patch.
 __global__ void __launch_bounds__(256)
 k_eseg(const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t fast_adds,
-       double *__restrict__ eseg)
+       double *__restrict__ eseg, int64_t seg_base)
 {
     __shared__ double sm[4];
     __shared__ int s_flag;
-    const int64_t s = blockIdx.x;
+    const int64_t s = blockIdx.x + seg_base;
     const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
     const int64_t len = r1 - r0;
     const int64_t K = (len + chunk - 1) / chunk;
@@ -1135,10 +1152,10 @@ __global__ void k_reduce_seg(const double *__restrict__ part_score, const uint32
                              const int64_t *__restrict__ slot0, const int64_t *__restrict__ seg_off, int64_t ld, int64_t n_acc,
                              double *__restrict__ score, int64_t *__restrict__ ninfo, int64_t ldo,
                              const double *__restrict__ eseg, int force_first, int32_t *__restrict__ pairs,
-                             int *__restrict__ count, int cap)
+                             int *__restrict__ count, int cap, int64_t seg_base)
 {
     const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t sg = blockIdx.y;
+    const int64_t sg = blockIdx.y + seg_base;
     if (a >= n_acc) return;
     double v = 0.0;
     int64_t m = 0;

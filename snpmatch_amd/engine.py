@@ -24,6 +24,7 @@ class Context(object):
         self.h = h
         self.device_id = int(device_id)
         self._children = weakref.WeakSet()      # panels and queries: freed before the context
+        self._pinned = []                       # pinned host blocks handed out by pinned_empty
         # every context is closed before the interpreter (and with it the HIP runtime) goes down, also when the
         # script ends with an exception; the weak reference keeps the hook from pinning the object.  The library
         # tolerates the other order too (snpm_destroy orphans live panels / queries, include/snpmatch_hip.h).
@@ -40,6 +41,9 @@ class Context(object):
             for k in kids:
                 if isinstance(k, (Panel, Carry)):
                     k.free()
+            for blk in self._pinned:
+                self.lib.snpm_host_free(self.h, blk)
+            self._pinned = []
             self.lib.snpm_destroy(self.h)
             self.h = None
             try:
@@ -135,6 +139,17 @@ class Context(object):
         check(self.lib.snpm_sample_synthetic(self.h, C.c_uint64(int(seed)), int(snp0), int(n), int(planted),
                                              int(round(err * 1000)), int(round(frac_pl * 1000)), ptr(tab),
                                              C.c_void_p(int(d_wei))), self.h)
+
+    def pinned_empty(self, shape, dtype):
+        """numpy array in pinned host memory (hipHostMalloc): inputs of ``score_batch`` built here skip the staging copy.
+        The memory is released with the context."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        h = C.c_void_p()
+        check(self.lib.snpm_host_alloc(self.h, n, C.byref(h)), self.h)
+        self._pinned.append(h)
+        buf = (C.c_char * max(n, 1)).from_address(h.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def binom_identity(self, x, n, error_rate=0.0005, pthres=0.05, return_sf=False):
         x = np.ascontiguousarray(x, dtype=np.float64)

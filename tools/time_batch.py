@@ -44,6 +44,15 @@ for _ in range(NB):
 dt = time.perf_counter() - t0
 print("batches of %3d, host : %7.0f samples/s (%.3f ms per sample), pairs re-evaluated per batch %d"
       % (B, B * NB / dt, dt / B / NB * 1e3, out["pairs_reeval"]), flush=True)
+pin = (ctx.pinned_empty(cat[0].shape, np.int64), ctx.pinned_empty(cat[1].shape, np.float64), off)
+pin[0][:] = cat[0]
+pin[1][:] = cat[1]
+engine.score_batch(panel, pin)
+t0 = time.perf_counter()
+for _ in range(NB):
+    out = engine.score_batch(panel, pin)
+dt = time.perf_counter() - t0
+print("batches of %3d, pinned: %7.0f samples/s (%.3f ms per sample)" % (B, B * NB / dt, dt / B / NB * 1e3), flush=True)
 top = [int(np.nanargmin(out["lik"][b])) for b in range(B)]
 assert top == [b * 7 % n_acc for b in range(B)], top
 
