@@ -179,6 +179,15 @@ int snpm_score_batch(snpm_panel *panel, int64_t n_samples, const int64_t *sample
                      int device_inputs, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo,
                      double *lik, double *lrt, int64_t *info);
 
+/* The same with dictionary-coded weights, wei[r, c] = table[codes[r, c]] (codes uint16 [N, 3], table float64
+   [table_len <= 65536], host; codes >= table_len read 0.0): for samples whose weights are exp(-PL/10) of integer PLs
+   (core/parsers.py:141-151) the caller fills the table with its own libm, the device weights then carry the bits the
+   fp64 path would have received, and 6 + 4 instead of 24 + 8 bytes per matched SNP cross PCIe (the link bounds a batch
+   from host memory). */
+int snpm_score_batch_coded(snpm_panel *panel, int64_t n_samples, const int64_t *sample_off, const int64_t *row_idx,
+                           const uint16_t *codes, const double *table, int64_t table_len, int64_t chunk, int skip_hets,
+                           int mode, double *score, int64_t *ninfo, double *lik, double *lrt, int64_t *info);
+
 /* pinned host memory (hipHostMalloc): batch inputs built in it go to the device at full PCIe speed without the
    staging copy (snpm_score_batch recognises pinned pointers) */
 int snpm_host_alloc(snpm_ctx *ctx, int64_t bytes, void **out);

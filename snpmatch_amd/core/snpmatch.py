@@ -224,6 +224,32 @@ def getHeterozygosity(snpGT, outFile='default'):
     return het
 
 
+def genotype_batch(inputs_list, g, out_files, skip_db_hets=False, chunk_size=1000):
+    """``Genotyper`` for many samples against one DB in ONE device call (the reference starts a process per sample,
+    :256-268): every sample's positions are intersected with the DB on the host, all of them are scored by one segmented
+    launch with the per-sample certificate (``engine.score_batch``), and each sample gets the files ``Genotyper`` writes
+    (``<out>.scores.txt``, ``<out>.matches.json``).  Returns the list of ``GenotyperOutput``."""
+    assert type(g) is snp_genotype.Genotype, "provide a snp_genotype.Genotype class for genotypes"
+    assert len(inputs_list) == len(out_files)
+    samples, common = [], []
+    for inputs in inputs_list:
+        inputs.filter_chr_names()
+        db_rows, sample_rows = g.get_positions_idxs(inputs.chrs, inputs.pos)
+        common.append((db_rows, sample_rows))
+        samples.append((db_rows, inputs.wei[sample_rows, ]))
+    res = engine.score_batch(g.panel(), samples, chunk_size, skip_db_hets, engine.MODE_EXACT, likelihoods=False)
+    results = []
+    for b, inputs in enumerate(inputs_list):
+        n_matched = len(common[b][0])
+        out = GenotyperOutput(g.g.accessions, res["score"][b], res["ninfo"][b], get_fraction(n_matched, len(inputs.pos)),
+                              n_matched, inputs.dp)
+        out.print_out_table(out_files[b] + '.scores.txt')
+        out.print_json_output(out_files[b] + ".matches.json")
+        getHeterozygosity(inputs.gt[common[b][1]], out_files[b] + ".matches.json")
+        results.append(out)
+    return results
+
+
 def parse_inputs_once(in_file, log_debug):
     """ParseInputs writes a cache next to the input: in an accession-sharded job rank 0 parses, the others load its cache"""
     job = dist.job()

@@ -63,7 +63,7 @@ struct snpm_ctx {
     Buf ws_part_score, ws_part_miss, ws_seg_score, ws_seg_miss, ws_seg_off, ws_cols, ws_tmp_score, ws_tmp_ninfo, ws_flags;
     Buf ws_lik_y, ws_lik_n, ws_lik_l, ws_lik_r;
     Buf ws_wprops, ws_epart;            // partial sums of k_wprops / k_eref
-    Buf ws_seg_desc, ws_eseg, ws_pairs, ws_pair_sums, ws_bscore, ws_bninfo, ws_blut, ws_brows, ws_brows32, ws_bw;   // segmented / batched scoring
+    Buf ws_seg_desc, ws_eseg, ws_pairs, ws_pair_sums, ws_bscore, ws_bninfo, ws_blut, ws_brows, ws_brows32, ws_bw, ws_bcodes;   // segmented / batched scoring
     int64_t *h_desc = nullptr;          // pinned host image of ws_seg_desc
     size_t h_desc_cap = 0;
     int stage_which = 0;                // next staging slab of stage_bytes
@@ -1327,7 +1327,7 @@ int snpm_destroy(snpm_ctx *ctx)
                        &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
                        &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r, &ctx->ws_wprops, &ctx->ws_epart,
                        &ctx->ws_seg_desc, &ctx->ws_eseg, &ctx->ws_pairs, &ctx->ws_pair_sums, &ctx->ws_bscore, &ctx->ws_bninfo,
-                       &ctx->ws_blut, &ctx->ws_brows, &ctx->ws_brows32, &ctx->ws_bw};
+                       &ctx->ws_blut, &ctx->ws_brows, &ctx->ws_brows32, &ctx->ws_bw, &ctx->ws_bcodes};
         for (Buf *b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
@@ -2057,10 +2057,10 @@ try {
 // core/snpmatch.py:256-268): sample b owns entries [sample_off[b], sample_off[b+1]) of the concatenated matched-row list
 // and weights.  One segmented fast pass (sample = segment), certificate per (sample, accession), reference-order
 // re-evaluation of the flagged pairs, one likelihood launch with a row per sample, one copy back.
-int snpm_score_batch(snpm_panel *p, int64_t n_samples, const int64_t *sample_off, const void *row_idx, const void *wei,
-                     int device_inputs, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo,
-                     double *lik, double *lrt, int64_t *info)
-try {
+static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sample_off, const void *row_idx, const void *wei,
+                            const uint16_t *codes, const double *table, int64_t table_len, int device_inputs, int64_t chunk, int skip_hets,
+                            int mode, double *score, int64_t *ninfo, double *lik, double *lrt, int64_t *info)
+{
     CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
     CHECK_ARG(ctx, n_samples >= 0 && n_samples <= 65535 && sample_off, "between 0 and 65535 samples per call");
@@ -2071,7 +2071,7 @@ try {
     CHECK_ARG(ctx, sample_off[0] == 0, "sample offsets start at 0");
     for (int64_t b = 0; b < n_samples; ++b) CHECK_ARG(ctx, sample_off[b] <= sample_off[b + 1], "sample offsets must be non-decreasing");
     const int64_t N = sample_off[n_samples];
-    CHECK_ARG(ctx, N == 0 || (row_idx && wei), "please provide same number of positions for both sample and db");
+    CHECK_ARG(ctx, N == 0 || (row_idx && (wei || (codes && table))), "please provide same number of positions for both sample and db");
     CHECK_ARG(ctx, (lik == nullptr) == (lrt == nullptr), "ask for both likelihood outputs or neither");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = wait_upload(p);
@@ -2093,6 +2093,13 @@ try {
     } else {
         if ((rc = ensure(ctx, ctx->ws_bw, NN * 3 * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->ws_brows32, NN * sizeof(int32_t)))) return rc;
+        if (codes) {
+            if ((rc = ensure(ctx, ctx->ws_bcodes, NN * 3 * sizeof(uint16_t) + 65536 * sizeof(double) + 64))) return rc;
+            // the table travels first (ordered before every expansion kernel on the compute stream)
+            HIPCHK(ctx, hipMemsetAsync(ctx->ws_bcodes.p, 0, 65536 * sizeof(double), ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(ctx->ws_bcodes.p, table, (size_t)table_len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));      // `table` is the caller's
+        }
         d_w = (const double *)ctx->ws_bw.p;
     }
     // the scoring kernel prefetches (never scores) a few row-list entries past a part: every entry it can reach must be
@@ -2162,7 +2169,8 @@ try {
         // the device arenas may still be read by the previous call's kernels: the copy stream waits for them
         HIPCHK(ctx, hipEventRecord(ctx->compute_mark, ctx->stream));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->compute_mark, 0));
-        const bool pinned = N > 0 && host_pointer_is_pinned(row_idx) && host_pointer_is_pinned(wei);
+        const bool pinned_codes = codes && N > 0 && host_pointer_is_pinned(codes);
+        const bool pinned = N > 0 && host_pointer_is_pinned(row_idx) && (codes ? pinned_codes : host_pointer_is_pinned(wei));
         const int64_t rows_per_run = std::max<int64_t>(1, (int64_t)(snpm_ctx::kStageBytes / 32));
         int64_t s0 = 0;
         while (s0 < n_samples) {
@@ -2178,11 +2186,20 @@ try {
             } else {
                 rc = stage_bytes(ctx, d_rows + r0, (const int64_t *)row_idx + r0, (size_t)(r1 - r0) * sizeof(int64_t), pinned);
             }
-            if (!rc) rc = stage_bytes(ctx, (double *)ctx->ws_bw.p + 3 * r0, (const double *)wei + 3 * r0,
-                                      (size_t)(r1 - r0) * 3 * sizeof(double), pinned);
+            uint16_t *d_codes = codes ? (uint16_t *)((char *)ctx->ws_bcodes.p + 65536 * sizeof(double)) : nullptr;
+            if (!rc && codes) rc = stage_bytes(ctx, d_codes + 3 * r0, codes + 3 * r0, (size_t)(r1 - r0) * 3 * sizeof(uint16_t), pinned_codes);
+            else if (!rc) rc = stage_bytes(ctx, (double *)ctx->ws_bw.p + 3 * r0, (const double *)wei + 3 * r0,
+                                           (size_t)(r1 - r0) * 3 * sizeof(double), pinned);
             if (rc) return rc;
             HIPCHK(ctx, hipEventRecord(ctx->batch_ev, ctx->copy_stream));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_ev, 0));
+            if (codes && r1 > r0) {      // weights of these rows from their codes (3 B per matched SNP crossed PCIe)
+                const int64_t n3 = (r1 - r0) * 3;
+                hipLaunchKernelGGL(k_expand_codes, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   (const uint16_t *)d_codes + 3 * r0, (const double *)ctx->ws_bcodes.p, n3,
+                                   (double *)ctx->ws_bw.p + 3 * r0);
+                HIPCHK(ctx, hipGetLastError());
+            }
             rc = prepare_rows(r0, r1, rows32);
             if (!rc && !strict_all) rc = seg_launch(ctx, j, pl, s0, s1);
             if (rc) return rc;
@@ -2229,6 +2246,28 @@ try {
     if (*h_bad) return set_err(ctx, SNPM_ERR_BADARG, "a row index lies outside the panel (n_snp %lld)", (long long)p->n_snp);
     if (info) { info[0] = n_pairs; info[1] = (strict_all && mode != SNPM_MODE_STRICT) ? 1 : 0; }
     return SNPM_OK;
+}
+
+int snpm_score_batch(snpm_panel *p, int64_t n_samples, const int64_t *sample_off, const void *row_idx, const void *wei,
+                     int device_inputs, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo,
+                     double *lik, double *lrt, int64_t *info)
+try {
+    return score_batch_impl(p, n_samples, sample_off, row_idx, wei, nullptr, nullptr, 0, device_inputs, chunk, skip_hets, mode,
+                            score, ninfo, lik, lrt, info);
+} SNPM_GUARD((p ? p->ctx : nullptr))
+
+// The same batch with DICTIONARY-CODED weights: wei[r, c] = table[codes[r, c]] (codes uint16 [N, 3], table float64
+// [table_len <= 65536], both host; codes >= table_len read 0.0).  A VCF sample's weights are exp(-PL/10) of integer PLs
+// (core/parsers.py:141-151): the caller computes the table entries with its own libm (numpy), so the device weights carry
+// exactly the bits the fp64 path would have received, while 6 + 4 instead of 24 + 8 bytes per matched SNP cross PCIe --
+// the link is what bounds a batch from host memory.
+int snpm_score_batch_coded(snpm_panel *p, int64_t n_samples, const int64_t *sample_off, const int64_t *row_idx,
+                           const uint16_t *codes, const double *table, int64_t table_len, int64_t chunk, int skip_hets,
+                           int mode, double *score, int64_t *ninfo, double *lik, double *lrt, int64_t *info)
+try {
+    if (p && p->ctx) CHECK_ARG(p->ctx, codes && table && table_len >= 1 && table_len <= 65536, "codes and a table of 1..65536 entries are required");
+    return score_batch_impl(p, n_samples, sample_off, row_idx, nullptr, codes, table, table_len, 0, chunk, skip_hets, mode, score,
+                            ninfo, lik, lrt, info);
 } SNPM_GUARD((p ? p->ctx : nullptr))
 
 // ---------------------------------------------------------------------------------------------- slab-streamed jobs

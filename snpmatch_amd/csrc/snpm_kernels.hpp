@@ -161,6 +161,14 @@ __global__ void k_check_rows(int64_t *__restrict__ rows, const int32_t *__restri
     rows[i] = r;
 }
 
+// dictionary-coded weights (batches from VCFs whose PLs are small integers): wei[i] = table[codes[i]], i over n * 3
+__global__ void k_expand_codes(const uint16_t *__restrict__ codes, const double *__restrict__ table, int64_t n3,
+                               double *__restrict__ wei)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3) wei[i] = table[codes[i]];
+}
+
 // ------------------------------------------------------------------------------------------------
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

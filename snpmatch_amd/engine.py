@@ -422,17 +422,40 @@ class Query(object):
             pass
 
 
-def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, likelihoods=True, device=None):
+def weight_codes(wei, table):
+    """uint16 codes [n, 3] with table[codes] == wei bit for bit, or None when some weight is not in ``table``
+    (float64 [<= 65536], e.g. ``pl_table()``).  A binary search per weight on the host; parsers that still hold the
+    integer PLs produce the codes directly instead (code = PL)."""
+    wei = np.ascontiguousarray(wei, dtype=np.float64)
+    order = np.argsort(table, kind="stable")
+    pos = np.searchsorted(table[order], wei.ravel())
+    pos[pos >= len(order)] = len(order) - 1
+    codes = order[pos].astype(np.uint16)
+    if not np.array_equal(table[codes].view(np.uint64), wei.ravel().view(np.uint64)):
+        return None
+    return codes.reshape(wei.shape)
+
+
+def pl_table(n=8192):
+    """table[k] = exp(-k / 10) for PL k = 0 .. n - 1 as numpy rounds it (what ParseInputs computes from a VCF's PL field,
+    core/parsers.py:147-150).  exp underflows to exactly 0.0 from k = 7451 on, so the last entries double as the zeros
+    of hard-call rows (code n - 1)."""
+    return np.exp(np.arange(n, dtype=np.float64) / (-10))
+
+
+def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, likelihoods=True, device=None, table=None):
     """Many samples against one resident panel in one call (snpm_score_batch).  ``samples``: list of
-    (row_idx int64 [n_b], wei float64 [n_b, 3]) pairs.  ``device`` = (d_row_idx, d_wei, offsets): the concatenated
+    (row_idx int64 [n_b], wei float64 [n_b, 3]) pairs.  With ``table`` (float64 [256]) the second element of a sample is
+    uint16 codes [n_b, 3] instead, wei = table[codes] (snpm_score_batch_coded: 10 instead of 32 bytes per SNP over PCIe).  ``device`` = (d_row_idx, d_wei, offsets): the concatenated
     inputs already in device memory (raw pointers) instead.  Returns a dict with score / ninfo (and lik / lrt)
     arrays [B, n_acc] and the re-evaluation counters."""
     ctx = panel.ctx
+    wdtype = np.float64 if table is None else np.uint16
     if device is None and isinstance(samples, tuple):
-        # already concatenated: (row_idx int64 [N], wei float64 [N, 3], offsets int64 [B + 1])
+        # already concatenated: (row_idx int64 [N], wei float64 [N, 3] (or codes uint8 [N, 3]), offsets int64 [B + 1])
         rows, wei, off = samples
         rows = np.ascontiguousarray(rows, dtype=np.int64)
-        wei = np.ascontiguousarray(wei, dtype=np.float64)
+        wei = np.ascontiguousarray(wei, dtype=wdtype)
         off = np.ascontiguousarray(off, dtype=np.int64)
         assert wei.ndim == 2 and wei.shape[1] == 3 and len(rows) == len(wei) == off[-1]
         p_rows, p_wei, dev_flag = ptr(rows), ptr(wei), 0
@@ -445,8 +468,8 @@ def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, li
             off[b + 1] = off[b] + len(rows)
         rows = np.ascontiguousarray(np.concatenate([np.asarray(s[0], dtype=np.int64) for s in samples]) if samples
                                     else np.zeros(0, dtype=np.int64))
-        wei = np.ascontiguousarray(np.concatenate([np.asarray(s[1], dtype=np.float64) for s in samples]) if samples
-                                   else np.zeros((0, 3)))
+        wei = np.ascontiguousarray(np.concatenate([np.asarray(s[1], dtype=wdtype) for s in samples]) if samples
+                                   else np.zeros((0, 3), dtype=wdtype))
         p_rows, p_wei, dev_flag = ptr(rows), ptr(wei), 0
     else:
         d_rows, d_wei, off = device
@@ -458,9 +481,17 @@ def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, li
         out["lik"] = np.empty((nb, na), dtype=np.float64)
         out["lrt"] = np.empty((nb, na), dtype=np.float64)
     info = np.zeros(4, dtype=np.int64)
-    check(ctx.lib.snpm_score_batch(panel.h, nb, ptr(off), p_rows, p_wei, dev_flag, int(chunk), int(bool(skip_hets)), int(mode),
-                                   ptr(out["score"]), ptr(out["ninfo"]), ptr(out.get("lik")), ptr(out.get("lrt")), ptr(info)),
-          ctx.h)
+    if table is not None:
+        assert device is None, "coded weights come from host memory"
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        assert table.ndim == 1 and 1 <= len(table) <= 65536
+        check(ctx.lib.snpm_score_batch_coded(panel.h, nb, ptr(off), p_rows, p_wei, ptr(table), len(table), int(chunk), int(bool(skip_hets)),
+                                             int(mode), ptr(out["score"]), ptr(out["ninfo"]), ptr(out.get("lik")),
+                                             ptr(out.get("lrt")), ptr(info)), ctx.h)
+    else:
+        check(ctx.lib.snpm_score_batch(panel.h, nb, ptr(off), p_rows, p_wei, dev_flag, int(chunk), int(bool(skip_hets)), int(mode),
+                                       ptr(out["score"]), ptr(out["ninfo"]), ptr(out.get("lik")), ptr(out.get("lrt")), ptr(info)),
+              ctx.h)
     out["pairs_reeval"], out["strict_fallback"] = int(info[0]), bool(info[1])
     return out
 

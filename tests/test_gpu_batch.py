@@ -165,3 +165,51 @@ def test_fast_windows_certified_against_strict(packed):
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
     ctx.close()
+
+
+def test_coded_weights_batch_equals_fp64_batch():
+    """weights sent as uint16 dictionary codes (exp(-PL/10) table from numpy) give the fp64 path's bits"""
+    ctx = make_ctx()
+    rng = np.random.default_rng(31)
+    n_snp, n_acc = 50_000, 257
+    db = rand_db(rng, n_snp, n_acc)
+    panel = engine.Panel.from_host(ctx, db)
+    samples = mixed_samples(rng, db, 12)
+    tab = engine.pl_table()
+    coded = []
+    for rows, wei in samples:
+        c = engine.weight_codes(wei, tab)
+        assert c is not None and c.dtype == np.uint16
+        coded.append((rows, c))
+    want = engine.score_batch(panel, samples, 1000, False, engine.MODE_EXACT)
+    got = engine.score_batch(panel, coded, 1000, False, engine.MODE_EXACT, table=tab)
+    for k in ("score", "ninfo", "lik", "lrt"):
+        assert np.array_equal(got[k].view(np.uint64), want[k].view(np.uint64)), k
+    assert got["pairs_reeval"] == want["pairs_reeval"]
+    assert engine.weight_codes(np.array([[0.3, 1.0, 0.0]]), tab) is None          # 0.3 is no exp(-k/10)
+    # a row index outside the panel is reported, not read
+    bad = [(np.array([1, 2, n_snp], dtype=np.int64), np.ones((3, 3)))]
+    with pytest.raises(AssertionError, match="outside the panel"):
+        engine.score_batch(panel, bad)
+    ctx.close()
+
+
+def test_batch_genotyper_writes_the_single_sample_files(tmp_path, golden_dir):
+    """snpmatch.genotype_batch: the files of Genotyper for every sample, from one batched call"""
+    from snpmatch_amd.core import parsers, snp_genotype, snpmatch
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    g = snp_genotype.Genotype.from_arrays(toy["snps"], toy["accs"], toy["positions"], toy["chrs"], toy["regions"])
+    rng = np.random.default_rng(2)
+    inputs, outs = [], []
+    for b in range(5):
+        keep = np.sort(rng.choice(len(toy["s_pos"]), size=len(toy["s_pos"]) - 100 * b, replace=False))
+        inp = parsers.ParseInputs("")
+        inp.load_snp_info(toy["s_chrs"][keep], toy["s_pos"][keep], toy["s_gt"][keep], toy["s_wei"][keep], toy["s_dp"])
+        inputs.append(inp)
+        outs.append(str(tmp_path / ("batch%d" % b)))
+    snpmatch.genotype_batch(inputs, g, outs)
+    for b, inp in enumerate(inputs):
+        single = str(tmp_path / ("single%d" % b))
+        snpmatch.Genotyper(inp, g, single, run_genotyper=True)
+        for ext in (".scores.txt", ".matches.json"):
+            assert open(outs[b] + ext).read() == open(single + ext).read(), (b, ext)
