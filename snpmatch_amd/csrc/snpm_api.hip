@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <new>
@@ -85,7 +86,7 @@ struct snpm_ctx {
     int strict4 = 1;           // dense strict scoring with 4 columns per lane (SNPM_STRICT4=0: one column per lane)
     int debug_max_parts = 0;   // SNPM_DEBUG_MAX_PARTS=k: cap the parts of the fast pass (tests of multi-epoch parts)
     int debug_reeval = 0;   // SNPM_DEBUG_REEVAL=k: also re-evaluate accessions 0..k-1 (to time that path)
-    int stage_threads = 4;  // host threads repacking rows into the pinned staging slabs
+    int stage_threads = 8;  // host threads repacking rows into the pinned staging slabs
     int nt_loads = 1;      // panel bytes are read once: non-temporal loads (+5-8% measured)
     int64_t f1_slab_bytes = int64_t(2) << 30;   // SNPM_F1_SLAB_BYTES: compacted-weight scratch of the in-silico crosses
     int full_occupancy = 0;   // SNPM_FULL_OCCUPANCY=1: as many resident blocks as the occupancy API allows
@@ -2150,11 +2151,16 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
         return SNPM_OK;
     };
     bool strict_all = (mode == SNPM_MODE_STRICT);
+    const bool trace = getenv("SNPM_BATCH_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    double t_stage = 0, t_launch = 0;
     SegPlan pl;
     if (!strict_all) {
         rc = seg_plan(ctx, j, pl);
         if (rc) return rc;
     }
+    const double t_planned = now();
     if (device_inputs) {
         rc = prepare_rows(0, N, nullptr);
         if (!rc && !strict_all) rc = seg_launch(ctx, j, pl, 0, n_samples);
@@ -2171,7 +2177,10 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
         HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->compute_mark, 0));
         const bool pinned_codes = codes && N > 0 && host_pointer_is_pinned(codes);
         const bool pinned = N > 0 && host_pointer_is_pinned(row_idx) && (codes ? pinned_codes : host_pointer_is_pinned(wei));
-        const int64_t rows_per_run = std::max<int64_t>(1, (int64_t)(snpm_ctx::kStageBytes / 32));
+        // a run = what one staging slab takes of the widest per-row item (24 B of fp64 weights, 6 B of codes), but about a
+        // quarter of the batch at most, so that uploads and launches overlap without the launches becoming small
+        const int64_t slab_rows = (int64_t)(snpm_ctx::kStageBytes / (codes ? 8 : 32));
+        const int64_t rows_per_run = std::max<int64_t>(1, std::min<int64_t>(slab_rows, std::max<int64_t>(N / 4 + 1, 262144)));
         int64_t s0 = 0;
         while (s0 < n_samples) {
             int64_t s1 = s0 + 1;
@@ -2180,6 +2189,7 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
             // the row list crosses PCIe as int32 (the link is what bounds a batch: 28 instead of 32 bytes per matched SNP);
             // it is narrowed while the staging slab is filled and widened again by k_check_rows
             const int32_t *rows32 = nullptr;
+            const double ts0 = now();
             if (!pinned && r1 - r0 <= rows_per_run) {
                 rc = stage_rows32(ctx, (int32_t *)ctx->ws_brows32.p + r0, (const int64_t *)row_idx + r0, r1 - r0);
                 rows32 = (const int32_t *)ctx->ws_brows32.p + r0;
@@ -2193,6 +2203,8 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
             if (rc) return rc;
             HIPCHK(ctx, hipEventRecord(ctx->batch_ev, ctx->copy_stream));
             HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->batch_ev, 0));
+            const double ts1 = now();
+            t_stage += ts1 - ts0;
             if (codes && r1 > r0) {      // weights of these rows from their codes (3 B per matched SNP crossed PCIe)
                 const int64_t n3 = (r1 - r0) * 3;
                 hipLaunchKernelGGL(k_expand_codes, dim3((unsigned)((n3 + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -2203,9 +2215,11 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
             rc = prepare_rows(r0, r1, rows32);
             if (!rc && !strict_all) rc = seg_launch(ctx, j, pl, s0, s1);
             if (rc) return rc;
+            t_launch += now() - ts1;
             s0 = s1;
         }
     }
+    const double t_enqueued = now();
     int n_pairs = 0;
     if (strict_all) {
         rc = strict_every_sample();
@@ -2243,6 +2257,9 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     int *h_bad = (int *)ctx->h_pinned + 8;
     HIPCHK(ctx, hipMemcpyAsync(h_bad, ctx->ws_flags2.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (trace)
+        fprintf(stderr, "[snpm batch] plan %.3f ms, enqueue %.3f ms (staging %.3f, launches %.3f), finish+likelihood+copy back %.3f ms\n",
+                t_planned - t_begin, t_enqueued - t_planned, t_stage, t_launch, now() - t_enqueued);
     if (*h_bad) return set_err(ctx, SNPM_ERR_BADARG, "a row index lies outside the panel (n_snp %lld)", (long long)p->n_snp);
     if (info) { info[0] = n_pairs; info[1] = (strict_all && mode != SNPM_MODE_STRICT) ? 1 : 0; }
     return SNPM_OK;
