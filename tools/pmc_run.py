@@ -13,8 +13,10 @@ n_snp = int(os.environ.get("PMC_N_SNP", "6250000"))
 ctx = engine.Context(0)
 panel = engine.Panel(ctx, n_snp, n_acc)
 panel.fill_synthetic(bench.SEED)
-wei = bench.make_sample(n_snp, bench.SEED, bench.PLANTED)
-q = engine.Query(panel, None, wei)
+import torch  # noqa: E402
+wei = torch.empty((n_snp, 3), dtype=torch.float64, device="cuda:0")
+ctx.sample_synthetic(bench.SEED, 0, n_snp, bench.PLANTED, wei.data_ptr())
+q = engine.Query.from_device(panel, None, wei.data_ptr(), n_snp)
 for _ in range(2):
     print("calib bytes", panel.stream_read())
 for _ in range(3):
