@@ -16,6 +16,7 @@ more device call (``k_f1_*``, numpy's summation order).
 import itertools
 import json
 import logging
+import os
 
 import numpy as np
 import pandas as pd
@@ -149,7 +150,11 @@ class CrossIdentifier(object):
         n_matched = int(offsets[-1])
 
         query = engine.Query(self.g.panel(), db_rows, self.inputs.wei[sample_rows, ])
-        w_score, w_ninfo, tot_score, tot_ninfo = query.run_windows(offsets, self._skip_db_hets)
+        # default: every window in reference order (fp64 window scores with the reference's bits -> byte-identical
+        # windowscore.txt).  SNPMATCH_CROSS_FAST=1: the segmented streaming pass with the certificate -- snps_match,
+        # snps_info and the totals identical, float scores / likelihoods equal to ~1e-12 relative.
+        fast = os.environ.get("SNPMATCH_CROSS_FAST", "0") not in ("", "0")
+        w_score, w_ninfo, tot_score, tot_ninfo = query.run_windows(offsets, self._skip_db_hets, fast=fast)
         query.free()
         job = dist.job()
         if job is not None:          # per-window and total results of this rank's accessions -> whole arrays everywhere
