@@ -1576,15 +1576,12 @@ int snpm_panel_fill_synthetic_rows(snpm_panel *p, uint64_t seed, int64_t snp0, i
     if (rc) return rc;
     ProfScope ps(ctx, PK_SYNTH);
     const int thr = 256;
+    const unsigned gy = (unsigned)std::min<int64_t>(nrows, 2048);
     if (p->packed) {
-        const int64_t total = nrows * p->pitch;
-        const unsigned blocks = (unsigned)std::min<int64_t>((total + thr - 1) / thr, (int64_t)ctx->n_cu * 32);
-        hipLaunchKernelGGL(k_synth_packed, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->stream,
+        hipLaunchKernelGGL(k_synth_packed, dim3((unsigned)((p->pitch + thr - 1) / thr), gy), dim3(thr), 0, ctx->stream,
                            (uint8_t *)p->d + row0 * p->pitch, p->pitch, nrows, p->n_acc, seed, snp0, acc0);
     } else {
-        const int64_t total = nrows * (p->pitch / 4);
-        const unsigned blocks = (unsigned)std::min<int64_t>((total + thr - 1) / thr, (int64_t)ctx->n_cu * 32);
-        hipLaunchKernelGGL(k_synth, dim3(std::max(1u, blocks)), dim3(thr), 0, ctx->stream,
+        hipLaunchKernelGGL(k_synth, dim3((unsigned)((p->pitch / 4 + thr - 1) / thr), gy), dim3(thr), 0, ctx->stream,
                            (uint32_t *)(p->d + row0 * p->pitch), p->pitch, nrows, p->n_acc, seed, snp0, acc0);
     }
     HIPCHK(ctx, hipGetLastError());

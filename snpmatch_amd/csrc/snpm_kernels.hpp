@@ -1919,24 +1919,57 @@ __host__ __device__ __forceinline__ uint32_t synth_quad(uint64_t seed, uint64_t 
     return out;
 }
 
-__global__ void k_synth(uint32_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n_acc, uint64_t seed,
-                        int64_t snp0, int64_t acc0)
+// grid.x = blocks of 256 accession quads, grid.y = row lanes (a block walks rows blockIdx.y, + gridDim.y, ...): the
+// row's hash is wave-uniform (scalar unit), a thread pays one splitmix64 per quad and no index division.
+__device__ __forceinline__ uint32_t synth_quad_row(uint64_t row_hash, uint64_t acc_quad)
+{
+    const uint64_t h = splitmix64(row_hash + acc_quad);
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t u = (uint32_t)(h >> (16 * j)) & 0xffffu;
+        const uint32_t c = u < 3277u ? 0xffu : (u < 42598u ? 0u : (u < 64225u ? 1u : 2u));
+        out |= c << (8 * j);
+    }
+    return out;
+}
+
+__global__ void __launch_bounds__(256)
+k_synth(uint32_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n_acc, uint64_t seed,
+        int64_t snp0, int64_t acc0)
 {
     // acc0 must be a multiple of 4 so that a shard sees the same quads as the full panel
     const int64_t quads_per_row = pitch / 4;
-    const int64_t total = n_snp * quads_per_row;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) {
-        const int64_t row = i / quads_per_row;
-        const int64_t q = i - row * quads_per_row;
-        uint32_t v = synth_quad(seed, (uint64_t)(snp0 + row), (uint64_t)((acc0 >> 2) + q));
-        const int64_t c = q * 4;
-        if (c + 4 > n_acc) {       // pad bytes are "missing"
-            for (int j = 0; j < 4; ++j)
-                if (c + j >= n_acc) v |= 0xffu << (8 * j);
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= quads_per_row) return;
+    const int64_t c = q * 4;
+    uint32_t pad = 0;                    // pad bytes are "missing"
+    for (int j = 0; j < 4; ++j)
+        if (c + j >= n_acc) pad |= 0xffu << (8 * j);
+    for (int64_t row = blockIdx.y; row < n_snp; row += gridDim.y) {
+        const uint64_t rh = splitmix64(seed ^ ((uint64_t)(snp0 + row) * 0xD6E8FEB86659FD93ull));
+        db[row * quads_per_row + q] = synth_quad_row(rh, (uint64_t)((acc0 >> 2) + q)) | pad;
+    }
+}
+
+// packed counterpart of k_synth: the same values, one byte (= one accession quad) per thread and row
+__global__ void __launch_bounds__(256)
+k_synth_packed(uint8_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n_acc, uint64_t seed,
+               int64_t snp0, int64_t acc0)
+{
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= pitch) return;
+    for (int64_t row = blockIdx.y; row < n_snp; row += gridDim.y) {
+        const uint64_t rh = splitmix64(seed ^ ((uint64_t)(snp0 + row) * 0xD6E8FEB86659FD93ull));
+        const uint32_t v = synth_quad_row(rh, (uint64_t)((acc0 >> 2) + q));
+        uint32_t out = 0;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint32_t c = (v >> (8 * f)) & 0xffu;                      // 0, 1, 2 or 0xff
+            const bool pad = (q * 4 + f) >= n_acc;
+            out |= ((c == 0xffu || pad) ? 3u : c) << (2 * f);
         }
-        db[i] = v;
+        db[row * pitch + q] = (uint8_t)out;
     }
 }
 
@@ -1970,28 +2003,6 @@ __global__ void k_synth_sample(uint64_t seed, int64_t snp0, int64_t n, int64_t p
     wei[3 * r] = w[0];
     wei[3 * r + 1] = w[1];
     wei[3 * r + 2] = w[2];
-}
-
-// packed counterpart of k_synth: the same values, one byte (= one accession quad) per thread step
-__global__ void k_synth_packed(uint8_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n_acc, uint64_t seed,
-                               int64_t snp0, int64_t acc0)
-{
-    const int64_t total = n_snp * pitch;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) {
-        const int64_t row = i / pitch;
-        const int64_t q = i - row * pitch;
-        const uint32_t v = synth_quad(seed, (uint64_t)(snp0 + row), (uint64_t)((acc0 >> 2) + q));
-        uint32_t out = 0;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            const uint32_t c = (v >> (8 * f)) & 0xffu;                      // 0, 1, 2 or 0xff
-            const bool pad = (q * 4 + f) >= n_acc;
-            out |= ((c == 0xffu || pad) ? 3u : c) << (2 * f);
-        }
-        db[i] = (uint8_t)out;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
