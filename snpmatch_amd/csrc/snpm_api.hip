@@ -686,17 +686,18 @@ int launch_strict_dense(snpm_query *q, int skip, const int64_t *d_seg_off, int64
         // 4 columns per lane (one dword of an int8 panel, one byte of a packed panel)
         const int64_t lanes = (ncols + 3) / 4;
         const int t4 = lanes >= 256 ? 256 : (lanes > 64 ? 128 : 64);
-        dim3 grid4((unsigned)n_seg, (unsigned)((lanes + t4 - 1) / t4));
+        // a gated launch (the certificate's dense tier) usually has nothing to do: a bounded grid that walks the segments
+        dim3 grid4((unsigned)(gate ? std::min<int64_t>(n_seg, 2048) : n_seg), (unsigned)((lanes + t4 - 1) / t4));
         ProfScope ps(ctx, PK_STRICT);
 #define LAUNCH_STRICT4(S, G)                                                                                     \
     do {                                                                                                         \
         if (p->packed)                                                                                           \
             hipLaunchKernelGGL((k_strict4<S, G, true>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
-                               q->d_w, seg_off, chunk, q->n, seg0, ncols, (double *)ctx->ws_seg_score.p,         \
+                               q->d_w, seg_off, chunk, q->n, seg0, n_seg, ncols, (double *)ctx->ws_seg_score.p,  \
                                (uint32_t *)ctx->ws_seg_miss.p, ld, gate, REEVAL_CAP);                            \
         else                                                                                                     \
             hipLaunchKernelGGL((k_strict4<S, G, false>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
-                               q->d_w, seg_off, chunk, q->n, seg0, ncols, (double *)ctx->ws_seg_score.p,         \
+                               q->d_w, seg_off, chunk, q->n, seg0, n_seg, ncols, (double *)ctx->ws_seg_score.p,  \
                                (uint32_t *)ctx->ws_seg_miss.p, ld, gate, REEVAL_CAP);                            \
     } while (0)
         if (skip) {
@@ -709,11 +710,11 @@ int launch_strict_dense(snpm_query *q, int skip, const int64_t *d_seg_off, int64
         return SNPM_OK;
     }
     const int thr = ncols > 128 ? 256 : (ncols > 64 ? 128 : 64);
-    dim3 grid((unsigned)n_seg, (unsigned)((ncols + thr - 1) / thr));
+    dim3 grid((unsigned)(gate ? std::min<int64_t>(n_seg, 2048) : n_seg), (unsigned)((ncols + thr - 1) / thr));
     ProfScope ps(ctx, PK_STRICT);
 #define LAUNCH_STRICT(S, G)                                                                                       \
     hipLaunchKernelGGL((k_strict<S, G>), grid, dim3(thr), 0, ctx->stream, p->d, p->pitch, p->packed, q->d_row_idx, q->row0,  \
-                       q->d_w, seg_off, chunk, q->n, seg0, (const int32_t *)nullptr, ncols,                       \
+                       q->d_w, seg_off, chunk, q->n, seg0, n_seg, (const int32_t *)nullptr, ncols,                \
                        (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld, gate, REEVAL_CAP)
     if (skip) {
         if (gather) LAUNCH_STRICT(true, true); else LAUNCH_STRICT(true, false);
@@ -780,7 +781,7 @@ int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_c
     const bool gather = q->d_row_idx != nullptr;
     const int64_t total = n_seg * ld;
     if (total > 0) {
-        dim3 sgrid((unsigned)((total + 255) / 256));
+        dim3 sgrid((unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)ctx->n_cu * 8));     // grid-stride over (segment, column)
         const bool use_T = !q->transient_panel && q->n >= ctx->acc_major_min_rows && p->dT_state == 1;
         ProfScope ps(ctx, PK_STRICT);
         if (use_T) {

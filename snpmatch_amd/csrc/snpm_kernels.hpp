@@ -1310,14 +1310,16 @@ template <bool SKIP, bool GATHER>
 __global__ void __launch_bounds__(256)
 k_strict(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx, int64_t row0,
          const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
-         const int32_t *__restrict__ cols, int64_t ncols, double *__restrict__ out_score,
+         int64_t n_seg, const int32_t *__restrict__ cols, int64_t ncols, double *__restrict__ out_score,
          uint32_t *__restrict__ out_miss, int64_t ld, const int *__restrict__ gate, int gate_cap)
 {
     if (dense_tier_off(gate, gate_cap)) return;
-    const int64_t seg = blockIdx.x;          // output row; the segment itself is seg0 + seg when the pieces are implicit
     const int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
     if (i >= ncols) return;
     const int64_t col = cols ? (int64_t)cols[i] : i;
+    // seg = output row (the segment itself is seg0 + seg when the pieces are implicit); a gated launch uses a
+    // bounded grid and walks the segments, so that a launch that has nothing to do costs a few microseconds
+    for (int64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {
     int64_t r0, r1;
     seg_bounds(seg_off, chunk, n, seg_off ? seg : seg0 + seg, r0, r1);
     double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
@@ -1350,6 +1352,7 @@ k_strict(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t
     }
     out_score[seg * ld + i] = ((0.0 + a_ref) + a_het) + a_alt;
     out_miss[seg * ld + i] = miss;
+    }
 }
 
 // Dense strict kernel: 4 adjacent accession columns per lane (int8 panel: one dword per row; packed panel: one
@@ -1360,13 +1363,13 @@ template <bool SKIP, bool GATHER, bool PACKED>
 __global__ void __launch_bounds__(256)
 k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
           const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
-          int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
+          int64_t n_seg, int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
           const int *__restrict__ gate, int gate_cap)
 {
     if (dense_tier_off(gate, gate_cap)) return;
-    const int64_t seg = blockIdx.x;
     const int64_t c0 = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) * 4;
     if (c0 >= ncols) return;                 // pitch is a multiple of 256: the dword / byte of an active lane is inside the row
+    for (int64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {          // one pass unless the launch is gated (see k_strict)
     int64_t r0, r1;
     seg_bounds(seg_off, chunk, n, seg_off ? seg : seg0 + seg, r0, r1);
     double a_ref[4] = {0.0, 0.0, 0.0, 0.0}, a_het[4] = {0.0, 0.0, 0.0, 0.0}, a_alt[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1422,6 +1425,7 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
             out_miss[seg * ld + c0 + j] = miss[j] + ((miss8 >> (8 * j)) & 0xffu);
         }
     }
+    }
 }
 
 // Strict segment sums for a SHORT list of columns (the accessions SNPM_MODE_EXACT has to re-evaluate):
@@ -1437,8 +1441,7 @@ k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, int packed, const 
 {
     const int64_t ncols = *d_ncols;           // flagged accessions (device-side count): sparse tier only
     if (ncols > cap) return;
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_seg * ncols) return;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_seg * ncols; id += (int64_t)gridDim.x * blockDim.x) {
     const int64_t seg = id / ncols;
     const int64_t i = id - seg * ncols;
     const int64_t col = cols[i];
@@ -1475,6 +1478,7 @@ k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, int packed, const 
     }
     out_score[seg * ld + i] = ((0.0 + a_ref) + a_het) + a_alt;
     out_miss[seg * ld + i] = miss;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1575,8 +1579,7 @@ k_strict_sparse_T(const uint8_t *__restrict__ dT, int64_t pitchT, const int64_t 
 {
     const int64_t ncols = *d_ncols;
     if (ncols > cap) return;
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_seg * ncols) return;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < n_seg * ncols; id += (int64_t)gridDim.x * blockDim.x) {
     const int64_t seg = id / ncols;
     const int64_t i = id - seg * ncols;
     const uint8_t *colp = dT + (int64_t)cols[i] * pitchT;
@@ -1584,7 +1587,10 @@ k_strict_sparse_T(const uint8_t *__restrict__ dT, int64_t pitchT, const int64_t 
     seg_bounds(seg_off, chunk, n, seg, r0, r1);
     double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
     uint32_t miss = 0;
-    constexpr int U = 8;
+#ifndef SNPM_SPARSE_T_U
+#define SNPM_SPARSE_T_U 8
+#endif
+    constexpr int U = SNPM_SPARSE_T_U;      // rows whose code bytes are in flight per lane
     int64_t r = r0;
     for (; r + U <= r1; r += U) {
         int b[U];
@@ -1613,6 +1619,7 @@ k_strict_sparse_T(const uint8_t *__restrict__ dT, int64_t pitchT, const int64_t 
     }
     out_score[seg * ld + i] = ((0.0 + a_ref) + a_het) + a_alt;
     out_miss[seg * ld + i] = miss;
+    }
 }
 
 // total[i] = (((0 + s0) + s1) + ...) over the segments in order; ninfo[i] = n_rows - sum(miss).
