@@ -120,3 +120,39 @@ def test_config3_last_rank_shard_1236_x_50M():
 def test_config4_per_gpu_slab_12500_x_16M():
     """the per-GPU slab of configs[4] (100k x 100M over 8 GPUs: 12 500 accessions x <= 16M SNPs, 200 GB)"""
     check_shape(16_000_000, 12_500, 0, planted=417, oracle_quads=[0, 416], ninfo_quads=[0, 12_496])
+
+
+def test_slab_streamed_job_equals_resident_10000_x_12M():
+    """bench-shaped slab streaming at scale: 10 000 accessions x 12M SNPs scored as two 6M-SNP slabs regenerated on the
+    device (carry, certificate over the totals, second pass for the flagged and the two forced accessions) against the
+    same panel resident in one piece: certified counts equal, strict totals bit-identical (the chain continues across
+    slabs), three slabs of uneven size as well; device-generated sample weights."""
+    import torch
+    ctx = reeval_context()
+    try:
+        n_snp, n_acc, planted = 12_000_000, 10_000, 417
+        wei = torch.empty((n_snp, 3), dtype=torch.float64, device="cuda:0")
+        ctx.sample_synthetic(SEED, 0, n_snp, planted, wei.data_ptr())
+        resident = engine.Panel(ctx, n_snp, n_acc)
+        resident.fill_synthetic(SEED)
+        q = engine.Query.from_device(resident, None, wei.data_ptr(), n_snp)
+        se, ne = q.run(1000, False, engine.MODE_EXACT)
+        ss, ns = q.run(1000, False, engine.MODE_STRICT)
+        assert np.array_equal(ne, ns) and np.array_equal(se.astype(np.int64), ss.astype(np.int64))
+        q.free()
+        for slabs in ([6_000_000, 6_000_000], [5_000_000, 5_000_000, 2_000_000]):
+            starts = np.concatenate([[0], np.cumsum(slabs)])
+            buf = engine.Panel(ctx, max(slabs), n_acc)
+            sc = engine.SlabScorer(buf, slabs, lambda k, p: p.fill_synthetic(SEED, snp0=int(starts[k]), row0=0, nrows=slabs[k]),
+                                   lambda k: wei[int(starts[k]):].data_ptr(), device_weights=True)
+            s1, n1, info = sc.run(engine.MODE_EXACT)
+            assert info["second_pass"] and 2 <= info["n_strict_reeval"] <= 64
+            assert np.array_equal(n1, ne) and np.array_equal(s1.astype(np.int64), se.astype(np.int64))
+            assert np.array_equal(bits(s1[:2]), bits(ss[:2]))                  # re-scored in reference order across the slabs
+            s2, n2, _ = sc.run(engine.MODE_STRICT)
+            assert np.array_equal(bits(s2), bits(ss)) and np.array_equal(n2, ns)
+            sc.free()
+            buf.free()
+        assert int(np.argmax(se / ne)) == planted
+    finally:
+        ctx.close()
