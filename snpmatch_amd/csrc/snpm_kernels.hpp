@@ -20,11 +20,20 @@
 //              sums per segment, core/snpmatch.py:85-87).  Used for cross windows, for SNPM_MODE_STRICT and to
 //              re-evaluate the few accessions the fast pass cannot certify (sparse variants; _T reads the
 //              accession-major packed copy built by k_pack_transpose).
-//   k_scan / k_scan_few  sequential accumulation of segment sums (ScoreList += chunk, core/snpmatch.py:224).
+//   k_scan / k_scan_few  sequential accumulation of segment sums (ScoreList += chunk, core/snpmatch.py:224), with an
+//              optional carry-in (totals of earlier SNP slabs).
+//   k_fast<..., SEG>  the same fast pass over many independent row ranges (samples of a batch, windows of a cross) in one
+//              launch; k_reduce_seg / k_eseg / k_strict_pairs / k_scan_pairs: per-segment reduce, error bound, and the
+//              reference-order re-evaluation of the (segment, accession) pairs the certificate flags.
+//   certificate  k_wprops (weight properties), k_eref / k_efinish (reference-order error bound on the device),
+//              flag_if_uncertain inside k_reduce / k_carry_flag; the re-evaluation kernels read the flag count on the
+//              device and leave at once when their tier has nothing to do (dense_tier_off, *d_ncols).
+//   k_carry_add / k_carry_flag / k_tot_seg  running totals of slab-streamed jobs, totals over windows.
 //   k_likelihood  likeliTest + nanmin + ratio on device (core/snpmatch.py:40-55,106-117).
 //   k_binom_identity  np_test_identity (core/snpmatch.py:57-72).   k_segregating  --refine support.
 //   k_f1_*     in-silico F1 scores in numpy's summation order (core/csmatch.py:115-125).
-//   k_build_lut, k_repitch_canon / k_pack_rows / k_unpack_rows (upload / download), k_synth*, k_seg_pack,
+//   k_build_lut, k_repitch_canon / k_pack_rows / k_unpack_rows (upload / download), k_pack_transpose[_packed]
+//   (accession-major copies), k_synth* / k_synth_sample (benchmark data), k_check_rows, k_expand_codes, k_seg_pack,
 //   k_patch, k_calib_read: small helpers.
 #pragma once
 #include <hip/hip_runtime.h>
