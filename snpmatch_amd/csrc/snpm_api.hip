@@ -950,8 +950,14 @@ static int seg_launch(snpm_ctx *ctx, const SegJob &j, const SegPlan &pl, int64_t
     if (j.certify) {
         // fast-pass additions a term passes through: its part (<= tiles_per_part tiles) + the parts of its segment
         const int64_t seg_parts = (j.kmax * j.chunk) / (pl.tiles_per_part * TILE_ROWS) + 2;
-        hipLaunchKernelGGL(k_eseg, dim3((unsigned)(s1 - s0)), dim3(256), 0, ctx->stream, j.d_w, j.d_seg_off, j.chunk,
-                           pl.tiles_per_part * TILE_ROWS + seg_parts + 2, (double *)ctx->ws_eseg.p, s0);
+        const int npart = (int)((j.kmax + 3) / 4);
+        rc = ensure(ctx, ctx->ws_epart, (size_t)(s1 - s0) * (size_t)npart * 3 * sizeof(double));
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_eseg_part, dim3((unsigned)npart, (unsigned)(s1 - s0)), dim3(256), 0, ctx->stream, j.d_w,
+                           j.d_seg_off, j.chunk, s0, npart, (double *)ctx->ws_epart.p);
+        hipLaunchKernelGGL(k_eseg_finish, dim3((unsigned)(s1 - s0)), dim3(256), 0, ctx->stream,
+                           (const double *)ctx->ws_epart.p, j.d_seg_off, j.chunk,
+                           pl.tiles_per_part * TILE_ROWS + seg_parts + 2, s0, npart, (double *)ctx->ws_eseg.p);
         HIPCHK(ctx, hipGetLastError());
     }
     const int64_t p0 = pl.slot0[(size_t)s0], p1 = pl.slot0[(size_t)s1];

@@ -23,7 +23,7 @@
 //   k_scan / k_scan_few  sequential accumulation of segment sums (ScoreList += chunk, core/snpmatch.py:224), with an
 //              optional carry-in (totals of earlier SNP slabs).
 //   k_fast<..., SEG>  the same fast pass over many independent row ranges (samples of a batch, windows of a cross) in one
-//              launch; k_reduce_seg / k_eseg / k_strict_pairs / k_scan_pairs: per-segment reduce, error bound, and the
+//              launch; k_reduce_seg / k_eseg_part + k_eseg_finish / k_strict_pairs / k_scan_pairs: per-segment reduce, error bound, and the
 //              reference-order re-evaluation of the (segment, accession) pairs the certificate flags.
 //   certificate  k_wprops (weight properties), k_eref / k_efinish (reference-order error bound on the device),
 //              flag_if_uncertain inside k_reduce / k_carry_flag; the re-evaluation kernels read the flag count on the
@@ -1119,7 +1119,7 @@ __device__ __forceinline__ int code_at(const int8_t *__restrict__ db, int64_t pi
 // ------------------------------------------------------------------------------------------------
 // Segmented scoring (k_fast<..., SEG>): many independent row ranges ("segments": the samples of a batch, the
 // windows of a cross) of one concatenated matched list in ONE launch.
-//   k_eseg          per segment: the certificate's error bound.  Segment s = rows [seg_off[s], seg_off[s+1]) scored by
+//   k_eseg_*        per segment: the certificate's error bound.  Segment s = rows [seg_off[s], seg_off[s+1]) scored by
 //                   the reference in `chunk`-row matchGTsAccs calls (a window: one call, chunk >= its length):
 //                   E_s = (sum_k s_k (len_k + 3 + K_s - k)) u / (1 - m u) + wsum_s gamma(fast adds), 0 when every
 //                   weight of the segment is an integer (any order is exact then).  One block per segment.
@@ -1127,40 +1127,76 @@ __device__ __forceinline__ int code_at(const int8_t *__restrict__ db, int64_t pi
 //                   optional certificate: pairs (s, a) whose int(score) is not proven are appended to `pairs`.
 //   k_strict_pairs  reference-order chunk sums of the flagged pairs: block = pair, lane = chunk of its segment.
 //   k_scan_pairs    the chain of additions over a pair's chunk sums (ScoreList += chunk) and the patch.
+// two steps so that long segments (a 200k-row sample = 200 chunks) do not run on one block: a WAVE per chunk, four chunks
+// per block, partial[(seg * npart + blockIdx.x) * 3 + {0, 1, 2}] = {sum_k s_k * factor_k, sum_k s_k, non-integer flag};
+// the finish kernel adds a segment's partials in a fixed order (the bound is the same in every run).
 __global__ void __launch_bounds__(256)
-k_eseg(const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t fast_adds,
-       double *__restrict__ eseg, int64_t seg_base)
+k_eseg_part(const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t seg_base, int npart,
+            double *__restrict__ partial)
 {
-    __shared__ double sm[4];
-    __shared__ int s_flag;
-    const int64_t s = blockIdx.x + seg_base;
+    __shared__ double sm[4][3];
+    const int64_t s = blockIdx.y + seg_base;
     const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
     const int64_t len = r1 - r0;
     const int64_t K = (len + chunk - 1) / chunk;
-    if (threadIdx.x == 0) s_flag = 0;
-    __syncthreads();
-    double acc = 0.0, wsum = 0.0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * 4 + wave;
+    double v = 0.0;
     int nonint = 0;
-    for (int64_t k = 0; k < K; ++k) {
-        const int64_t c0 = r0 + k * chunk, c1 = (c0 + chunk < r1) ? c0 + chunk : r1;
-        double v = 0.0;
-        for (int64_t r = c0 + threadIdx.x; r < c1; r += 256) {
+    int64_t c0 = 0, c1 = 0;
+    if (k < K) {
+        c0 = r0 + k * chunk;
+        c1 = (c0 + chunk < r1) ? c0 + chunk : r1;
+        for (int64_t r = c0 + lane; r < c1; r += 64) {
             const double a = fabs(w[3 * r]), b = fabs(w[3 * r + 1]), c = fabs(w[3 * r + 2]);
             v += fmax(a, fmax(b, c));
             if (!(a == floor(a) && b == floor(b) && c == floor(c)) || !(a < 1e300 && b < 1e300 && c < 1e300)) nonint = 1;
         }
-        v = block_sum_256(v, sm);
-        acc += v * (double)((c1 - c0) + 3 + (K - k));
-        wsum += v;
     }
-    if (nonint) atomicOr(&s_flag, 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v += __shfl_xor(v, o);
+        nonint |= __shfl_xor(nonint, o);
+    }
+    if (lane == 0) {
+        sm[wave][0] = (k < K) ? v * (double)((c1 - c0) + 3 + (K - k)) : 0.0;
+        sm[wave][1] = v;
+        sm[wave][2] = (double)nonint;
+    }
     __syncthreads();
+    if (threadIdx.x < 3) {
+        const int q = threadIdx.x;
+        const double t = (q == 2) ? fmax(fmax(sm[0][2], sm[1][2]), fmax(sm[2][2], sm[3][2]))
+                                  : ((sm[0][q] + sm[1][q]) + sm[2][q]) + sm[3][q];
+        partial[((int64_t)blockIdx.y * npart + blockIdx.x) * 3 + q] = t;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_eseg_finish(const double *__restrict__ partial, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t fast_adds,
+              int64_t seg_base, int npart, double *__restrict__ eseg)
+{
+    __shared__ double sm[4];
+    const int64_t s = blockIdx.x + seg_base;
+    const int64_t len = seg_off[s + 1] - seg_off[s];
+    const int64_t K = (len + chunk - 1) / chunk;
+    const int np = (int)((K + 3) / 4);                  // blocks of k_eseg_part that held chunks of this segment
+    const double *p = partial + (int64_t)blockIdx.x * npart * 3;
+    double acc = 0.0, wsum = 0.0, flag = 0.0;
+    for (int i = threadIdx.x; i < np && i < npart; i += 256) {
+        acc += p[3 * i];
+        wsum += p[3 * i + 1];
+        flag = fmax(flag, p[3 * i + 2]);
+    }
+    acc = block_sum_256(acc, sm);
+    wsum = block_sum_256(wsum, sm);
+    flag = block_sum_256(flag, sm);
     if (threadIdx.x == 0) {
         const double u = 1.1102230246251565e-16;
         const double mmax = (double)((chunk < len ? chunk : len) + 3 + K);
         const double mf = (double)fast_adds;
         double e = (acc * u / (1.0 - mmax * u) + wsum * (mf * u / (1.0 - mf * u))) * 1.0000001;
-        if (!s_flag && wsum < 9.0e15) e = 0.0;
+        if (flag == 0.0 && wsum < 9.0e15) e = 0.0;
         eseg[s] = e;
     }
 }
