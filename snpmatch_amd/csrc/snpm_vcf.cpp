@@ -87,22 +87,6 @@ inline bool parse_double(const char *p, size_t n, double *v)
     return true;
 }
 
-int read_all(const char *path, std::string &data)
-{
-    gzFile f = gzopen(path, "rb");          // transparently reads plain text as well
-    if (!f) return SNPM_ERR_BADARG;
-    (void)gzbuffer(f, 1u << 20);
-    std::vector<char> buf(4u << 20);
-    for (;;) {
-        const int got = gzread(f, buf.data(), (unsigned)buf.size());
-        if (got < 0) { gzclose(f); return SNPM_ERR_STATE; }
-        if (got == 0) break;
-        data.append(buf.data(), (size_t)got);
-    }
-    gzclose(f);
-    return SNPM_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -112,17 +96,16 @@ extern "C" {
 int snpm_vcf_parse(const char *path, int sample_index, snpm_vcf **out)
 try {
     if (!path || !out || sample_index < 0 || sample_index > 4000) return SNPM_ERR_BADARG;
-    std::string data;
-    int rc = read_all(path, data);
-    if (rc) return rc;
     std::unique_ptr<snpm_vcf> v(new snpm_vcf());
     v->chr_off.push_back(0);
     v->gt_off.push_back(0);
-    const char *s = data.data(), *end = s + data.size();
     constexpr int MAXF = 4096;
     std::vector<Field> f(MAXF);
     Field keys[64], vals[64], nums[4];
     bool ok = true;
+    // every line of [s, end): the file is consumed block by block (4 MiB of decompressed text at a time, the records
+    // kept are a few dozen bytes each), never held in memory as a whole
+    auto consume = [&](const char *s, const char *end) {
     while (s < end && ok) {
         const char *nl = (const char *)memchr(s, '\n', (size_t)(end - s));
         const char *e = nl ? nl : end;
@@ -210,6 +193,38 @@ try {
         v->pl.push_back(pl[1]);
         v->pl.push_back(pl[2]);
     }
+    };
+    gzFile gz = gzopen(path, "rb");          // transparently reads plain text as well
+    if (!gz) return SNPM_ERR_BADARG;
+    struct Closer { gzFile f; ~Closer() { gzclose(f); } } closer{gz};
+    (void)gzbuffer(gz, 1u << 20);
+    std::vector<char> buf(4u << 20);
+    std::string carry;                       // the unfinished last line of the previous block
+    for (;;) {
+        const int got = gzread(gz, buf.data(), (unsigned)buf.size());
+        if (got < 0) return SNPM_ERR_STATE;
+        if (got == 0) break;
+        const char *b = buf.data(), *be = b + got;
+        const char *last_nl = nullptr;
+        for (const char *q = be; q > b; --q)
+            if (q[-1] == '\n') { last_nl = q - 1; break; }
+        if (!last_nl) {                      // no line ends in this block
+            carry.append(b, (size_t)got);
+            if (carry.size() > (64u << 20)) return SNPM_ERR_STATE;     // a 64 MiB line: not ours to interpret
+            continue;
+        }
+        if (!carry.empty()) {
+            const char *first_nl = (const char *)memchr(b, '\n', (size_t)(be - b));
+            carry.append(b, (size_t)(first_nl + 1 - b));
+            consume(carry.data(), carry.data() + carry.size());
+            carry.clear();
+            b = first_nl + 1;
+        }
+        if (ok && b <= last_nl) consume(b, last_nl + 1);
+        carry.assign(last_nl + 1, (size_t)(be - (last_nl + 1)));
+        if (!ok) break;
+    }
+    if (ok && !carry.empty()) consume(carry.data(), carry.data() + carry.size());
     if (!ok) return SNPM_ERR_STATE;
     *out = v.release();
     return SNPM_OK;

@@ -87,6 +87,35 @@ int main(int argc, char **argv)
         (void)parse_and_fill(path, 3);                              // a sample column that does not exist
         (void)parse_and_fill(write_file((std::string(c.first) + ".gz").c_str(), c.second, true), 0);
     }
+    {   // a file several read blocks long (lines straddle the 4 MiB blocks of the streaming reader), plain and gzip
+        std::string big = head;
+        for (int i = 0; i < 150000; ++i) {
+            char line[160];
+            snprintf(line, sizeof(line), "Chr%d\t%d\t.\tA\tT\t50\tPASS\tDP=%d;AF=0.5\tGT:AD:PL\t%s:3,4:%d,0,%d\n", 1 + i % 5, 100 + 7 * i,
+                     i % 90, (i % 3) ? "0/1" : "1/1", 10 + i % 200, 20 + i % 100);
+            big += line;
+        }
+        for (int gz = 0; gz < 2; ++gz) {
+            const std::string path = write_file(gz ? "big.vcf.gz" : "big.vcf", big, gz != 0);
+            snpm_vcf *bv = nullptr;
+            const int r = snpm_vcf_parse(path.c_str(), 0, &bv);
+            int64_t k = 0;
+            int cw = 0, gw = 0, fl = 0, ns = 0;
+            long long possum = 0, dpsum = 0;
+            double plsum = 0;
+            if (r == SNPM_OK) {
+                snpm_vcf_dims(bv, &k, &cw, &gw, &fl, &ns);
+                std::vector<char> chr((size_t)k * cw + 1), gt((size_t)k * gw + 1);
+                std::vector<int64_t> pos((size_t)k + 1), dp((size_t)k + 1);
+                std::vector<double> pl((size_t)k * 3 + 1);
+                snpm_vcf_fill(bv, chr.data(), pos.data(), gt.data(), pl.data(), dp.data());
+                for (int64_t i = 0; i < k; ++i) { possum += pos[(size_t)i]; dpsum += dp[(size_t)i]; plsum += pl[(size_t)i * 3] + pl[(size_t)i * 3 + 2]; }
+                snpm_vcf_free(bv);
+            }
+            printf("big_%s rc=%d records=%lld bytes=%zu possum=%lld dpsum=%lld plsum=%.0f\n", gz ? "gz" : "plain", r, (long long)k,
+                   big.size(), possum, dpsum, plsum);
+        }
+    }
     snpm_vcf *v = nullptr;
     printf("missing_file rc=%d\n", snpm_vcf_parse((tmpdir + "/does_not_exist.vcf").c_str(), 0, &v));
     printf("bad_args rc=%d %d\n", snpm_vcf_parse(nullptr, 0, &v), snpm_vcf_parse(vcf.c_str(), -1, &v));

@@ -30,6 +30,15 @@ def test_host_sources_under_asan_and_ubsan(tmp_path, golden_dir):
     assert r.stdout.strip().endswith("done")
     assert lines["sample_vcf"] == "rc=0 records=10000"               # /root/reference/sample_files: 10 000 records
     assert lines["intersect"].startswith("rounds=400 not_increasing rc=-4 -4 -4 empty rc=0")
+    # 150 000 records, ~9 MB of text: lines straddle the reader's 4 MiB blocks; sums of POS / DP / PL pin the content
+    n = 150000
+    want = "rc=0 records=%d" % n
+    possum = sum(100 + 7 * i for i in range(n))
+    dpsum = sum(i % 90 for i in range(n))
+    plsum = sum((10 + i % 200) + (20 + i % 100) for i in range(n))
+    for key in ("big_plain", "big_gz"):
+        assert lines[key].startswith(want), lines[key]
+        assert "possum=%d dpsum=%d plsum=%d" % (possum, dpsum, plsum) in lines[key], lines[key]
     # the unsanitised library agrees on what it accepts and what it hands back to the Python reader
     sys.path.insert(0, ROOT)
     from snpmatch_amd import _lib
