@@ -47,6 +47,9 @@ namespace snpm {
 #ifndef SNPM_FAST_MIN_WAVES
 #define SNPM_FAST_MIN_WAVES 6
 #endif
+#ifndef SNPM_STRICT_EXEC
+#define SNPM_STRICT_EXEC 1              // k_strict4 (int8 panels) adds under EXEC masks (v_cmpx); 0: selects 1.0 / 0.0 multipliers (8 % slower)
+#endif
 constexpr int WAVE = 64;
 constexpr int TILE_ROWS = 128;          // rows per LDS LUT tile (4 KiB); also the SWAR counter flush period (<= 255)
 constexpr int LUT_ROW_BYTES = 32;       // 4 x fp64
@@ -1420,16 +1423,49 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
     double a_ref[4] = {0.0, 0.0, 0.0, 0.0}, a_het[4] = {0.0, 0.0, 0.0, 0.0}, a_alt[4] = {0.0, 0.0, 0.0, 0.0};
     uint32_t miss8 = 0, miss[4] = {0, 0, 0, 0};
     int since_flush = 0;
+#if SNPM_STRICT_EXEC
+    const uint64_t exec_all = __builtin_amdgcn_read_exec();       // the lanes of this wave that own columns
+    uint32_t k0 = 0u, k1 = 1u, k2 = 2u;                            // class codes in VGPRs (SDWA takes no literals)
+    asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2));
+#endif
     auto one_row = [&](uint32_t x, int64_t r) {
         const double w0 = w[3 * r + 0], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
         // (skipping the classes whose weight is zero -- two of three on a hard-call row -- was tried in round 2: the
         // scalar branches cost more than the additions they save, 30.8 instead of 17.1 ms on 10k x 6.25M)
+#if SNPM_STRICT_EXEC
+        if constexpr (!PACKED) {
+            // EXEC-masked additions: v_cmpx selects the lanes whose call is this class (byte select inside the compare),
+            // one v_add_f64 with the row's weight from scalar registers runs on exactly those lanes, EXEC is restored:
+            // 1 + 2 VALU issue slots per class instead of 1 + 1 + 2 (no select), one scalar move more.
+#define STRICT_CLASS(ACC, CODE_REG, WREG, SEL)                                                              \
+    asm volatile("v_cmpx_eq_u32_sdwa vcc, %[x], %[c] src0_sel:" SEL " src1_sel:DWORD\n\t"                   \
+                 "v_add_f64 %[a], %[a], %[w]\n\t"                                                          \
+                 "s_mov_b64 exec, %[sv]"                                                                     \
+                 : [a] "+v"(ACC)                                                                             \
+                 : [x] "v"(x), [c] "v"(CODE_REG), [w] "s"(WREG), [sv] "s"(exec_all)                          \
+                 : "vcc")
+#define STRICT_COLUMN(J, SEL)                                                                               \
+    do {                                                                                                    \
+        STRICT_CLASS(a_ref[J], k0, w0, SEL);                                                                \
+        if (!SKIP) STRICT_CLASS(a_het[J], k2, w1, SEL);                                                     \
+        STRICT_CLASS(a_alt[J], k1, w2, SEL);                                                                \
+    } while (0)
+            STRICT_COLUMN(0, "BYTE_0");
+            STRICT_COLUMN(1, "BYTE_1");
+            STRICT_COLUMN(2, "BYTE_2");
+            STRICT_COLUMN(3, "BYTE_3");
+#undef STRICT_COLUMN
+#undef STRICT_CLASS
+        } else
+#endif
+        {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t b = PACKED ? ((x >> (2 * j)) & 3u) : ((x >> (8 * j)) & 0xffu);
             a_ref[j] = add_if(a_ref[j], b == 0u, w0);
             if (!SKIP) a_het[j] = add_if(a_het[j], b == 2u, w1);
             a_alt[j] = add_if(a_alt[j], b == 1u, w2);
+        }
         }
         if (PACKED) {     // code 3 (or 2 / 3 with skip_hets): one bit per call, spread to one byte per call
             const uint32_t m = SKIP ? ((x >> 1) & 0x55u) : (x & (x >> 1) & 0x55u);
