@@ -47,6 +47,9 @@ namespace snpm {
 #ifndef SNPM_FAST_MIN_WAVES
 #define SNPM_FAST_MIN_WAVES 6
 #endif
+#ifndef SNPM_STRICT_BATCH
+#define SNPM_STRICT_BATCH 8             // rows per prefetch batch of k_strict4 (two batches in flight)
+#endif
 #ifndef SNPM_STRICT_EXEC
 #define SNPM_STRICT_EXEC 1              // k_strict4 (int8 panels) adds under EXEC masks (v_cmpx); 0: selects 1.0 / 0.0 multipliers (8 % slower)
 #endif
@@ -1484,17 +1487,34 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
         return PACKED ? (uint32_t) * reinterpret_cast<const uint8_t *>(ptr) : *reinterpret_cast<const uint32_t *>(ptr);
     };
     const int8_t *colp = db + (PACKED ? c0 / 4 : c0);
-    int64_t r = r0;
-    for (; r + 4 <= r1; r += 4) {
-        uint32_t x[4];
+    // Batches of SB rows, two register sets: the next batch is requested before the current one is scored, so a wave
+    // keeps up to 2 * SB row loads in flight (with 4 per wave the kernel sat at its bytes-in-flight limit, ~4 TB/s,
+    // whatever the arithmetic cost).
+    constexpr int SB = SNPM_STRICT_BATCH;
+    auto load_batch = [&](uint32_t (&x)[SB], int64_t rb) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t prow = GATHER ? row_idx[r + u] : (row0 + r + u);
+        for (int u = 0; u < SB; ++u) {
+            const int64_t prow = GATHER ? row_idx[rb + u] : (row0 + rb + u);
             x[u] = load(colp + prow * pitch);
         }
+    };
+    auto score_batch = [&](const uint32_t (&x)[SB], int64_t rb) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) one_row(x[u], r + u);
+        for (int u = 0; u < SB; ++u) one_row(x[u], rb + u);
+    };
+    int64_t r = r0;
+    const int64_t nb = (r1 - r0) / SB;
+    uint32_t xa[SB], xb[SB];
+    if (nb > 0) load_batch(xa, r0);
+    for (int64_t b = 0; b < nb; b += 2) {
+        if (b + 1 < nb) load_batch(xb, r0 + (b + 1) * SB);
+        score_batch(xa, r0 + b * SB);
+        if (b + 1 < nb) {
+            if (b + 2 < nb) load_batch(xa, r0 + (b + 2) * SB);
+            score_batch(xb, r0 + (b + 1) * SB);
+        }
     }
+    r = r0 + nb * SB;
     for (; r < r1; ++r) {
         const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
         one_row(load(colp + prow * pitch), r);
