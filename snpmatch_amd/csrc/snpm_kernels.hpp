@@ -1431,8 +1431,7 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
     uint32_t k0 = 0u, k1 = 1u, k2 = 2u;                            // class codes in VGPRs (SDWA takes no literals)
     asm volatile("" : "+v"(k0), "+v"(k1), "+v"(k2));
 #endif
-    auto one_row = [&](uint32_t x, int64_t r) {
-        const double w0 = w[3 * r + 0], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
+    auto one_row = [&](uint32_t x, double w0, double w1, double w2) {
         // (skipping the classes whose weight is zero -- two of three on a hard-call row -- was tried in round 2: the
         // scalar branches cost more than the additions they save, 30.8 instead of 17.1 ms on 10k x 6.25M)
 #if SNPM_STRICT_EXEC
@@ -1440,6 +1439,38 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
             // EXEC-masked additions: v_cmpx selects the lanes whose call is this class (byte select inside the compare),
             // one v_add_f64 with the row's weight from scalar registers runs on exactly those lanes, EXEC is restored:
             // 1 + 2 VALU issue slots per class instead of 1 + 1 + 2 (no select), one scalar move more.
+#if SNPM_STRICT_EXEC == 2
+            // the whole row in ONE asm statement: plain compares on pre-extracted bytes with the class as an inline constant;
+            // between separate asm statements the compiler pads every EXEC restore with an s_nop, and the scalar unit is
+            // the bound of this kernel
+            const uint32_t b0_ = x & 0xffu, b1_ = (x >> 8) & 0xffu, b2_ = (x >> 16) & 0xffu, b3_ = x >> 24;
+#define ROW_CLASS(A, C, B, W) "v_cmpx_eq_u32_e32 vcc, " C ", %[" B "]\n\tv_add_f64 %[" A "], %[" A "], %[" W "]\n\ts_mov_b64 exec, %[sv]\n\t"
+            if constexpr (SKIP) {
+                asm volatile(ROW_CLASS("r0", "0", "b0", "w0") ROW_CLASS("l0", "1", "b0", "w2")
+                             ROW_CLASS("r1", "0", "b1", "w0") ROW_CLASS("l1", "1", "b1", "w2")
+                             ROW_CLASS("r2", "0", "b2", "w0") ROW_CLASS("l2", "1", "b2", "w2")
+                             ROW_CLASS("r3", "0", "b3", "w0") ROW_CLASS("l3", "1", "b3", "w2")
+                             : [r0] "+v"(a_ref[0]), [l0] "+v"(a_alt[0]), [r1] "+v"(a_ref[1]), [l1] "+v"(a_alt[1]),
+                               [r2] "+v"(a_ref[2]), [l2] "+v"(a_alt[2]), [r3] "+v"(a_ref[3]), [l3] "+v"(a_alt[3])
+                             : [b0] "v"(b0_), [b1] "v"(b1_), [b2] "v"(b2_), [b3] "v"(b3_), [w0] "s"(w0), [w2] "s"(w2),
+                               [sv] "s"(exec_all)
+                             : "vcc");
+            } else {
+                asm volatile(ROW_CLASS("r0", "0", "b0", "w0") ROW_CLASS("h0", "2", "b0", "w1") ROW_CLASS("l0", "1", "b0", "w2")
+                             ROW_CLASS("r1", "0", "b1", "w0") ROW_CLASS("h1", "2", "b1", "w1") ROW_CLASS("l1", "1", "b1", "w2")
+                             ROW_CLASS("r2", "0", "b2", "w0") ROW_CLASS("h2", "2", "b2", "w1") ROW_CLASS("l2", "1", "b2", "w2")
+                             ROW_CLASS("r3", "0", "b3", "w0") ROW_CLASS("h3", "2", "b3", "w1") ROW_CLASS("l3", "1", "b3", "w2")
+                             : [r0] "+v"(a_ref[0]), [h0] "+v"(a_het[0]), [l0] "+v"(a_alt[0]), [r1] "+v"(a_ref[1]),
+                               [h1] "+v"(a_het[1]), [l1] "+v"(a_alt[1]), [r2] "+v"(a_ref[2]), [h2] "+v"(a_het[2]),
+                               [l2] "+v"(a_alt[2]), [r3] "+v"(a_ref[3]), [h3] "+v"(a_het[3]), [l3] "+v"(a_alt[3])
+                             : [b0] "v"(b0_), [b1] "v"(b1_), [b2] "v"(b2_), [b3] "v"(b3_), [w0] "s"(w0), [w1] "s"(w1),
+                               [w2] "s"(w2), [sv] "s"(exec_all)
+                             : "vcc");
+            }
+#undef ROW_CLASS
+#define STRICT_COLUMN(J, SEL) do { } while (0)
+#define STRICT_CLASS(A, B, C, D)
+#else
 #define STRICT_CLASS(ACC, CODE_REG, WREG, SEL)                                                              \
     asm volatile("v_cmpx_eq_u32_sdwa vcc, %[x], %[c] src0_sel:" SEL " src1_sel:DWORD\n\t"                   \
                  "v_add_f64 %[a], %[a], %[w]\n\t"                                                          \
@@ -1453,6 +1484,7 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
         if (!SKIP) STRICT_CLASS(a_het[J], k2, w1, SEL);                                                     \
         STRICT_CLASS(a_alt[J], k1, w2, SEL);                                                                \
     } while (0)
+#endif
             STRICT_COLUMN(0, "BYTE_0");
             STRICT_COLUMN(1, "BYTE_1");
             STRICT_COLUMN(2, "BYTE_2");
@@ -1499,8 +1531,13 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
         }
     };
     auto score_batch = [&](const uint32_t (&x)[SB], int64_t rb) {
+        // the batch's weights first (wave-uniform: a few wide scalar loads, one wait), then the rows: with a scalar load
+        // and a wait per row the waves spent 62 % of their cycles parked in s_waitcnt (SQ_WAIT_ANY)
+        double wb[SB * 3];
 #pragma unroll
-        for (int u = 0; u < SB; ++u) one_row(x[u], rb + u);
+        for (int i = 0; i < SB * 3; ++i) wb[i] = w[3 * rb + i];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) one_row(x[u], wb[3 * u], wb[3 * u + 1], wb[3 * u + 2]);
     };
     int64_t r = r0;
     const int64_t nb = (r1 - r0) / SB;
@@ -1517,7 +1554,7 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
     r = r0 + nb * SB;
     for (; r < r1; ++r) {
         const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
-        one_row(load(colp + prow * pitch), r);
+        one_row(load(colp + prow * pitch), w[3 * r], w[3 * r + 1], w[3 * r + 2]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
