@@ -919,8 +919,13 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
 
     if (p < n_tiles_total) {
         uint32_t xa[G], xb[G];
+        // the eight weight bytes of a group (one scalar dwordx2) travel with the group's rows, one group ahead: loaded at
+        // the top of the group they were waited for at once, before any row could be classified
+        auto wbits8 = [&](int64_t r) -> uint64_t { return *reinterpret_cast<const uint64_t *>(wbits + r); };
+        uint64_t wa8, wb8;
 #pragma unroll
         for (int u = 0; u < G; ++u) xa[u] = load(p * TR + u);
+        wa8 = wbits8(p * TR);
 
         int tiles_in_epoch = 0;
         int64_t epoch = 0;
@@ -938,10 +943,10 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
             const int full_groups = rows / G;
 
             // 8 rows: classify, then both bit vectors into their bit-sliced counters with carry-save adders
-#define BITS_GROUP(X, R0)                                                                           \
+#define BITS_GROUP(X, W8)                                                                           \
     do {                                                                                            \
         _Pragma("unroll") for (int u_ = 0; u_ < G; ++u_) asm volatile("" : "+v"((X)[u_]));         \
-        const uint64_t wb8_ = *reinterpret_cast<const uint64_t *>(wbits + (R0));                   \
+        const uint64_t wb8_ = (W8);                                                                 \
         uint32_t hb_[8], mb_[8];                                                                    \
         _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_)                                            \
             classify((X)[u_], (uint32_t)(wb8_ >> (8 * u_)) & 0xffu, hb_[u_], mb_[u_]);              \
@@ -966,13 +971,15 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
                 const int64_t rafter = (g + 2 < TR / G) ? rnext + G : ntr0;
 #pragma unroll
                 for (int u = 0; u < G; ++u) xb[u] = load(rnext + u);
-                BITS_GROUP(xa, tr0 + (int64_t)g * G);
+                wb8 = wbits8(rnext);
+                BITS_GROUP(xa, wa8);
 #pragma unroll
                 for (int u = 0; u < G; ++u) xa[u] = load(rafter + u);
-                BITS_GROUP(xb, rnext);
+                wa8 = wbits8(rafter);
+                BITS_GROUP(xb, wb8);
             }
             if (g < full_groups) {                               // odd group count: only in the last tile of all
-                BITS_GROUP(xa, tr0 + (int64_t)g * G);
+                BITS_GROUP(xa, wa8);
             }
 #undef BITS_GROUP
             for (int r = full_groups * G; r < rows; ++r) {      // at most G-1 rows: last tile of all
