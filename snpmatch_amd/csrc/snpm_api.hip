@@ -105,6 +105,8 @@ struct snpm_panel {
     int64_t ld = 0;                     // accessions per row rounded up to 256: leading dimension of result arrays
     int packed = 0;                     // 0 = int8 (one byte per call), 1 = 2 bits per call (4 accessions per byte)
     int8_t *d = nullptr;
+    int *d_other = nullptr;             // int8 panels: 1 once an upload stored a call code > 2 ("other": informative, matches no
+                                        // class), else 0; lives behind the rows in the same allocation.  k_strict4 reads it.
     hipEvent_t uploaded = nullptr;      // last upload / fill enqueued on copy_stream
     bool upload_pending = false;
     // accession-major packed copy (2 bits per call), built on first use by the exactness re-evaluation
@@ -694,11 +696,11 @@ int launch_strict_dense(snpm_query *q, int skip, const int64_t *d_seg_off, int64
         if (p->packed)                                                                                           \
             hipLaunchKernelGGL((k_strict4<S, G, true>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
                                q->d_w, seg_off, chunk, q->n, seg0, n_seg, ncols, (double *)ctx->ws_seg_score.p,  \
-                               (uint32_t *)ctx->ws_seg_miss.p, ld, gate, REEVAL_CAP);                            \
+                               (uint32_t *)ctx->ws_seg_miss.p, ld, (const int *)nullptr, gate, REEVAL_CAP);      \
         else                                                                                                     \
             hipLaunchKernelGGL((k_strict4<S, G, false>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
                                q->d_w, seg_off, chunk, q->n, seg0, n_seg, ncols, (double *)ctx->ws_seg_score.p,  \
-                               (uint32_t *)ctx->ws_seg_miss.p, ld, gate, REEVAL_CAP);                            \
+                               (uint32_t *)ctx->ws_seg_miss.p, ld, (const int *)p->d_other, gate, REEVAL_CAP);   \
     } while (0)
         if (skip) {
             if (gather) LAUNCH_STRICT4(true, true); else LAUNCH_STRICT4(true, false);
@@ -1171,7 +1173,7 @@ static int stage_rows(snpm_panel *p, int64_t row0, int64_t nrows, Fill fill)
         if (!p->packed) {
             const int64_t total = nr * (p->pitch / 4);
             hipLaunchKernelGGL(k_repitch_canon, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream,
-                               scratch, spitch, nr, p->n_acc, (uint32_t *)(p->d + (row0 + r) * p->pitch), p->pitch);
+                               scratch, spitch, nr, p->n_acc, (uint32_t *)(p->d + (row0 + r) * p->pitch), p->pitch, p->d_other);
         } else {
             const int64_t total = nr * p->pitch;
             hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream, scratch,
@@ -1302,6 +1304,7 @@ static void orphan_panel(snpm_panel *p, bool use_hip)
         if (p->uploaded) (void)hipEventDestroy(p->uploaded);
     }
     p->d = nullptr;
+    p->d_other = nullptr;
     p->dT = nullptr;
     p->uploaded = nullptr;
     p->ctx = nullptr;
@@ -1390,17 +1393,26 @@ try {
     p->ld = ((n_acc + 255) / 256) * 256;
     p->pitch = packed ? (((n_acc + 3) / 4 + 255) / 256) * 256 : p->ld;
     // PREFETCH_PAD_ROWS extra rows: the fast pass prefetches (and never scores) a few rows past a part
-    size_t bytes = (size_t)(n_snp + PREFETCH_PAD_ROWS) * (size_t)p->pitch;
+    const size_t row_bytes = (size_t)(n_snp + PREFETCH_PAD_ROWS) * (size_t)p->pitch;
+    const size_t bytes = row_bytes + 256;                            // + the flag word d_other
     hipError_t e = hipMalloc((void **)&p->d, bytes);
     if (e != hipSuccess) {
         delete p;
         return set_err(ctx, SNPM_ERR_OOM, "hipMalloc of %zu panel bytes failed: %s", bytes, hipGetErrorString(e));
+    }
+    p->d_other = (int *)(p->d + row_bytes);
+    if (hipMemsetAsync(p->d_other, 0, sizeof(int), ctx->copy_stream) != hipSuccess) {
+        (void)hipFree(p->d);
+        delete p;
+        return set_err(ctx, SNPM_ERR_HIP, "hipMemsetAsync failed");
     }
     if (hipEventCreateWithFlags(&p->uploaded, hipEventDisableTiming) != hipSuccess) {
         (void)hipFree(p->d);
         delete p;
         return set_err(ctx, SNPM_ERR_HIP, "hipEventCreate failed");
     }
+    (void)hipEventRecord(p->uploaded, ctx->copy_stream);             // the flag word is cleared before anything reads it
+    p->upload_pending = true;
     ctx->panels.push_back(p);
     *out = p;
     return SNPM_OK;

@@ -1417,16 +1417,14 @@ k_strict(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t
 // byte = four 2-bit calls), same arithmetic and order as k_strict (three sequential per-category sums per column
 // and segment).
 //   grid.x = segment, grid.y = blocks of blockDim.x lanes x 4 columns;  out_* [n_seg, ld]
-template <bool SKIP, bool GATHER, bool PACKED>
-__global__ void __launch_bounds__(256)
-k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
-          const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
-          int64_t n_seg, int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
-          const int *__restrict__ gate, int gate_cap)
+//   MASKS (int8 panels whose calls are all in {0, 1, 2, missing}): two compares per call instead of three, see below.
+template <bool SKIP, bool GATHER, bool PACKED, bool MASKS>
+__device__ __forceinline__ void
+strict4_segments(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
+                 const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
+                 int64_t n_seg, int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
+                 int64_t c0)
 {
-    if (dense_tier_off(gate, gate_cap)) return;
-    const int64_t c0 = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) * 4;
-    if (c0 >= ncols) return;                 // pitch is a multiple of 256: the dword / byte of an active lane is inside the row
     for (int64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {          // one pass unless the launch is gated (see k_strict)
     int64_t r0, r1;
     seg_bounds(seg_off, chunk, n, seg_off ? seg : seg0 + seg, r0, r1);
@@ -1446,38 +1444,6 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
             // EXEC-masked additions: v_cmpx selects the lanes whose call is this class (byte select inside the compare),
             // one v_add_f64 with the row's weight from scalar registers runs on exactly those lanes, EXEC is restored:
             // 1 + 2 VALU issue slots per class instead of 1 + 1 + 2 (no select), one scalar move more.
-#if SNPM_STRICT_EXEC == 2
-            // the whole row in ONE asm statement: plain compares on pre-extracted bytes with the class as an inline constant;
-            // between separate asm statements the compiler pads every EXEC restore with an s_nop, and the scalar unit is
-            // the bound of this kernel
-            const uint32_t b0_ = x & 0xffu, b1_ = (x >> 8) & 0xffu, b2_ = (x >> 16) & 0xffu, b3_ = x >> 24;
-#define ROW_CLASS(A, C, B, W) "v_cmpx_eq_u32_e32 vcc, " C ", %[" B "]\n\tv_add_f64 %[" A "], %[" A "], %[" W "]\n\ts_mov_b64 exec, %[sv]\n\t"
-            if constexpr (SKIP) {
-                asm volatile(ROW_CLASS("r0", "0", "b0", "w0") ROW_CLASS("l0", "1", "b0", "w2")
-                             ROW_CLASS("r1", "0", "b1", "w0") ROW_CLASS("l1", "1", "b1", "w2")
-                             ROW_CLASS("r2", "0", "b2", "w0") ROW_CLASS("l2", "1", "b2", "w2")
-                             ROW_CLASS("r3", "0", "b3", "w0") ROW_CLASS("l3", "1", "b3", "w2")
-                             : [r0] "+v"(a_ref[0]), [l0] "+v"(a_alt[0]), [r1] "+v"(a_ref[1]), [l1] "+v"(a_alt[1]),
-                               [r2] "+v"(a_ref[2]), [l2] "+v"(a_alt[2]), [r3] "+v"(a_ref[3]), [l3] "+v"(a_alt[3])
-                             : [b0] "v"(b0_), [b1] "v"(b1_), [b2] "v"(b2_), [b3] "v"(b3_), [w0] "s"(w0), [w2] "s"(w2),
-                               [sv] "s"(exec_all)
-                             : "vcc");
-            } else {
-                asm volatile(ROW_CLASS("r0", "0", "b0", "w0") ROW_CLASS("h0", "2", "b0", "w1") ROW_CLASS("l0", "1", "b0", "w2")
-                             ROW_CLASS("r1", "0", "b1", "w0") ROW_CLASS("h1", "2", "b1", "w1") ROW_CLASS("l1", "1", "b1", "w2")
-                             ROW_CLASS("r2", "0", "b2", "w0") ROW_CLASS("h2", "2", "b2", "w1") ROW_CLASS("l2", "1", "b2", "w2")
-                             ROW_CLASS("r3", "0", "b3", "w0") ROW_CLASS("h3", "2", "b3", "w1") ROW_CLASS("l3", "1", "b3", "w2")
-                             : [r0] "+v"(a_ref[0]), [h0] "+v"(a_het[0]), [l0] "+v"(a_alt[0]), [r1] "+v"(a_ref[1]),
-                               [h1] "+v"(a_het[1]), [l1] "+v"(a_alt[1]), [r2] "+v"(a_ref[2]), [h2] "+v"(a_het[2]),
-                               [l2] "+v"(a_alt[2]), [r3] "+v"(a_ref[3]), [h3] "+v"(a_het[3]), [l3] "+v"(a_alt[3])
-                             : [b0] "v"(b0_), [b1] "v"(b1_), [b2] "v"(b2_), [b3] "v"(b3_), [w0] "s"(w0), [w1] "s"(w1),
-                               [w2] "s"(w2), [sv] "s"(exec_all)
-                             : "vcc");
-            }
-#undef ROW_CLASS
-#define STRICT_COLUMN(J, SEL) do { } while (0)
-#define STRICT_CLASS(A, B, C, D)
-#else
 #define STRICT_CLASS(ACC, CODE_REG, WREG, SEL)                                                              \
     asm volatile("v_cmpx_eq_u32_sdwa vcc, %[x], %[c] src0_sel:" SEL " src1_sel:DWORD\n\t"                   \
                  "v_add_f64 %[a], %[a], %[w]\n\t"                                                          \
@@ -1485,18 +1451,55 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
                  : [a] "+v"(ACC)                                                                             \
                  : [x] "v"(x), [c] "v"(CODE_REG), [w] "s"(WREG), [sv] "s"(exec_all)                          \
                  : "vcc")
+            // MASKS: two compares per call instead of three -- G = {1, 2} (signed byte > 0), U = {0, 1} (unsigned byte < 2);
+            // ref = U & ~G, het = G & ~U, alt = U & G are scalar operations that write EXEC directly.  A call code 3
+            // ("other": informative, matches no class) would land in the het class, so this form runs only on panels
+            // that hold none (snpm_panel::d_other, raised by the upload kernel).
+#define STRICT_COLUMN_MASKS(J, SEL)                                                                         \
+    do {                                                                                                    \
+        uint64_t mg, mu;                                                                                    \
+        if (!SKIP)                                                                                          \
+            asm volatile("v_cmp_gt_i32_sdwa %[g], sext(%[x]), %[k0] src0_sel:" SEL " src1_sel:DWORD\n\t"     \
+                         "v_cmp_lt_u32_sdwa %[u], %[x], %[k2] src0_sel:" SEL " src1_sel:DWORD\n\t"           \
+                         "s_andn2_b64 exec, %[u], %[g]\n\t"                                                 \
+                         "v_add_f64 %[ar], %[ar], %[w0]\n\t"                                                \
+                         "s_andn2_b64 exec, %[g], %[u]\n\t"                                                 \
+                         "v_add_f64 %[ah], %[ah], %[w1]\n\t"                                                \
+                         "s_and_b64 exec, %[u], %[g]\n\t"                                                   \
+                         "v_add_f64 %[aa], %[aa], %[w2]\n\t"                                                \
+                         "s_mov_b64 exec, %[sv]"                                                             \
+                         : [ar] "+v"(a_ref[J]), [ah] "+v"(a_het[J]), [aa] "+v"(a_alt[J]), [g] "=&s"(mg), [u] "=&s"(mu) \
+                         : [x] "v"(x), [k0] "v"(k0), [k2] "v"(k2), [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2),   \
+                           [sv] "s"(exec_all)                                                                \
+                         : "scc");                                                                           \
+        else                                                                                                \
+            asm volatile("v_cmp_gt_i32_sdwa %[g], sext(%[x]), %[k0] src0_sel:" SEL " src1_sel:DWORD\n\t"     \
+                         "v_cmp_lt_u32_sdwa %[u], %[x], %[k2] src0_sel:" SEL " src1_sel:DWORD\n\t"           \
+                         "s_andn2_b64 exec, %[u], %[g]\n\t"                                                 \
+                         "v_add_f64 %[ar], %[ar], %[w0]\n\t"                                                \
+                         "s_and_b64 exec, %[u], %[g]\n\t"                                                   \
+                         "v_add_f64 %[aa], %[aa], %[w2]\n\t"                                                \
+                         "s_mov_b64 exec, %[sv]"                                                             \
+                         : [ar] "+v"(a_ref[J]), [aa] "+v"(a_alt[J]), [g] "=&s"(mg), [u] "=&s"(mu)             \
+                         : [x] "v"(x), [k0] "v"(k0), [k2] "v"(k2), [w0] "s"(w0), [w2] "s"(w2), [sv] "s"(exec_all) \
+                         : "scc");                                                                           \
+    } while (0)
 #define STRICT_COLUMN(J, SEL)                                                                               \
     do {                                                                                                    \
-        STRICT_CLASS(a_ref[J], k0, w0, SEL);                                                                \
-        if (!SKIP) STRICT_CLASS(a_het[J], k2, w1, SEL);                                                     \
-        STRICT_CLASS(a_alt[J], k1, w2, SEL);                                                                \
+        if constexpr (MASKS) {                                                                              \
+            STRICT_COLUMN_MASKS(J, SEL);                                                                    \
+        } else {                                                                                            \
+            STRICT_CLASS(a_ref[J], k0, w0, SEL);                                                            \
+            if (!SKIP) STRICT_CLASS(a_het[J], k2, w1, SEL);                                                 \
+            STRICT_CLASS(a_alt[J], k1, w2, SEL);                                                            \
+        }                                                                                                   \
     } while (0)
-#endif
             STRICT_COLUMN(0, "BYTE_0");
             STRICT_COLUMN(1, "BYTE_1");
             STRICT_COLUMN(2, "BYTE_2");
             STRICT_COLUMN(3, "BYTE_3");
 #undef STRICT_COLUMN
+#undef STRICT_COLUMN_MASKS
 #undef STRICT_CLASS
         } else
 #endif
@@ -1515,17 +1518,22 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
         } else {
             miss8 += SKIP ? (((x >> 7) | ((x >> 1) & ~x)) & 0x01010101u) : ((x >> 7) & 0x01010101u);
         }
-        if (++since_flush == 255) {
+    };
+    // the byte counters of miss8 take 255 rows: callers announce the rows they are about to score
+    auto flush_before = [&](int rows) {
+        if (since_flush + rows > 255) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) miss[j] += (miss8 >> (8 * j)) & 0xffu;
             miss8 = 0;
             since_flush = 0;
         }
+        since_flush += rows;
     };
     auto load = [&](const int8_t *ptr) -> uint32_t {
         return PACKED ? (uint32_t) * reinterpret_cast<const uint8_t *>(ptr) : *reinterpret_cast<const uint32_t *>(ptr);
     };
-    const int8_t *colp = db + (PACKED ? c0 / 4 : c0);
+    // row address = wave-uniform row base + the lane's 32-bit offset (global_load with a scalar base: no address VALU)
+    const uint32_t coff = (uint32_t)(PACKED ? c0 / 4 : c0);
     int64_t r = r0;
     if constexpr (!PACKED && SNPM_STRICT_EXEC) {
         // Batches of SB rows, two register sets: the next batch is requested before the current one is scored (up to
@@ -1535,7 +1543,7 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
                 const int64_t prow = GATHER ? row_idx[rb + u] : (row0 + rb + u);
-                x[u] = load(colp + prow * pitch);
+                x[u] = load(db + prow * pitch + coff);
             }
         };
         auto score_batch = [&](const uint32_t (&x)[SB], int64_t rb) {
@@ -1544,6 +1552,7 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
             double wb[SB * 3];
 #pragma unroll
             for (int i = 0; i < SB * 3; ++i) wb[i] = w[3 * rb + i];
+            flush_before(SB);
 #pragma unroll
             for (int u = 0; u < SB; ++u) one_row(x[u], wb[3 * u], wb[3 * u + 1], wb[3 * u + 2]);
         };
@@ -1567,15 +1576,17 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t prow = GATHER ? row_idx[r + u] : (row0 + r + u);
-                x[u] = load(colp + prow * pitch);
+                x[u] = load(db + prow * pitch + coff);
             }
+            flush_before(4);
 #pragma unroll
             for (int u = 0; u < 4; ++u) one_row(x[u], w[3 * (r + u)], w[3 * (r + u) + 1], w[3 * (r + u) + 2]);
         }
     }
     for (; r < r1; ++r) {
         const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
-        one_row(load(colp + prow * pitch), w[3 * r], w[3 * r + 1], w[3 * r + 2]);
+        flush_before(1);
+        one_row(load(db + prow * pitch + coff), w[3 * r], w[3 * r + 1], w[3 * r + 2]);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1585,6 +1596,28 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
         }
     }
     }
+}
+
+//   other_codes: the int8 panel's flag "a call code > 2 was stored" (nullptr for packed panels)
+template <bool SKIP, bool GATHER, bool PACKED>
+__global__ void __launch_bounds__(256)
+k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
+          const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
+          int64_t n_seg, int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
+          const int *__restrict__ other_codes, const int *__restrict__ gate, int gate_cap)
+{
+    if (dense_tier_off(gate, gate_cap)) return;
+    const int64_t c0 = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) * 4;
+    if (c0 >= ncols) return;                 // pitch is a multiple of 256: the dword / byte of an active lane is inside the row
+    if constexpr (!PACKED && SNPM_STRICT_EXEC) {
+        if (*other_codes == 0) {             // wave-uniform
+            strict4_segments<SKIP, GATHER, false, true>(db, pitch, row_idx, row0, w, seg_off, chunk, n, seg0, n_seg, ncols,
+                                                        out_score, out_miss, ld, c0);
+            return;
+        }
+    }
+    strict4_segments<SKIP, GATHER, PACKED, false>(db, pitch, row_idx, row0, w, seg_off, chunk, n, seg0, n_seg, ncols,
+                                                  out_score, out_miss, ld, c0);
 }
 
 // Strict segment sums for a SHORT list of columns (the accessions SNPM_MODE_EXACT has to re-evaluate):
@@ -2030,9 +2063,10 @@ __global__ void k_pack_rows(const int8_t *__restrict__ src, int64_t src_pitch, i
 }
 
 // int8 panel upload: tightly staged rows (row stride src_pitch) -> panel rows (256-B pitch), codes
-// canonicalised on the way (negative -> 0xFF, > 2 -> 3), pad bytes = 0xFF.  One thread per destination dword.
+// canonicalised on the way (negative -> 0xFF, > 2 -> 3, which raises *other_codes), pad bytes = 0xFF.  One thread per
+// destination dword.
 __global__ void k_repitch_canon(const int8_t *__restrict__ src, int64_t src_pitch, int64_t nrows, int64_t n_acc,
-                                uint32_t *__restrict__ dst, int64_t dst_pitch)
+                                uint32_t *__restrict__ dst, int64_t dst_pitch, int *__restrict__ other_codes)
 {
     const int64_t dwords_per_row = dst_pitch / 4;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2047,6 +2081,7 @@ __global__ void k_repitch_canon(const int8_t *__restrict__ src, int64_t src_pitc
         const uint32_t c = v < 0 ? 0xffu : (v > 2 ? 3u : (uint32_t)v);
         out |= c << (8 * j);
     }
+    if ((out & (out >> 1) & ~(out >> 7)) & 0x01010101u) atomicOr(other_codes, 1);     // a byte == 3 (k_strict4 needs to know)
     dst[r * dwords_per_row + d] = out;
 }
 
