@@ -1417,13 +1417,34 @@ k_strict(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t
 // byte = four 2-bit calls), same arithmetic and order as k_strict (three sequential per-category sums per column
 // and segment).
 //   grid.x = segment, grid.y = blocks of blockDim.x lanes x 4 columns;  out_* [n_seg, ld]
-//   MASKS (int8 panels whose calls are all in {0, 1, 2, missing}): two compares per call instead of three, see below.
+//   MASKS: two compares per call instead of three (int8 panels whose calls are all in {0, 1, 2, missing}, and packed
+//   panels, whose row byte goes through a 256-entry table of compare-ready bits), see below.
+
+// Table entry of a packed row byte e (four 2-bit calls) for the MASKS form: per call j two predicates,
+// G = call in {alt, het} and U = call in {ref, alt}, each at the SIGN bit of a byte (the SDWA compare picks the byte and
+// sign-extends it): .x holds calls 0, 1 (bytes G0 U0 G1 U1), .y calls 2, 3; .z = one byte per call, 1 where the call
+// counts as missing (code 3, or 2 / 3 with skip_hets), calls 0, 1; .w the same for calls 2, 3: .z + .w is the increment of
+// the packed missing counters.
+template <bool SKIP>
+__device__ __forceinline__ uint4 strict_lut_entry(uint32_t e)
+{
+    uint32_t d[2] = {0u, 0u}, m[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t code = (e >> (2 * j)) & 3u;
+        const uint32_t g = (code == 1u || code == 2u) ? 0x80u : 0u, u = (code < 2u) ? 0x80u : 0u;
+        d[j >> 1] |= (g | (u << 8)) << (16 * (j & 1));
+        m[j >> 1] |= (uint32_t)(SKIP ? code >= 2u : code == 3u) << (8 * j);
+    }
+    return make_uint4(d[0], d[1], m[0], m[1]);      // all four words are used: one ds_read_b128 (a b96 takes twice the cycles)
+}
+
 template <bool SKIP, bool GATHER, bool PACKED, bool MASKS>
 __device__ __forceinline__ void
 strict4_segments(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
                  const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
                  int64_t n_seg, int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
-                 int64_t c0)
+                 int64_t c0, const uint4 *lut)
 {
     for (int64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {          // one pass unless the launch is gated (see k_strict)
     int64_t r0, r1;
@@ -1440,7 +1461,47 @@ strict4_segments(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         // (skipping the classes whose weight is zero -- two of three on a hard-call row -- was tried in round 2: the
         // scalar branches cost more than the additions they save, 30.8 instead of 17.1 ms on 10k x 6.25M)
 #if SNPM_STRICT_EXEC
-        if constexpr (!PACKED) {
+        uint32_t lut_miss = 0;
+        if constexpr (PACKED && MASKS) {
+            // packed row byte -> table entry (one ds_read_b128), then per call two sign tests that give the scalar masks
+            // G and U; ref = U & ~G, het = G & ~U, alt = U & G are written to EXEC by scalar instructions and one
+            // v_add_f64 runs under each: 8 + 12 + 2 VALU per row of 4 calls (the select form below takes about 50)
+            const uint4 e = lut[x];
+            lut_miss = e.z + e.w;
+#define STRICT_COLUMN_LUT(J, P, SELG, SELU)                                                                 \
+    do {                                                                                                    \
+        uint64_t mg, mu;                                                                                    \
+        if (!SKIP)                                                                                          \
+            asm volatile("v_cmp_lt_i32_sdwa %[g], sext(%[x]), %[k0] src0_sel:" SELG " src1_sel:DWORD\n\t"    \
+                         "v_cmp_lt_i32_sdwa %[u], sext(%[x]), %[k0] src0_sel:" SELU " src1_sel:DWORD\n\t"    \
+                         "s_andn2_b64 exec, %[u], %[g]\n\t"                                                 \
+                         "v_add_f64 %[ar], %[ar], %[w0]\n\t"                                                \
+                         "s_andn2_b64 exec, %[g], %[u]\n\t"                                                 \
+                         "v_add_f64 %[ah], %[ah], %[w1]\n\t"                                                \
+                         "s_and_b64 exec, %[u], %[g]\n\t"                                                   \
+                         "v_add_f64 %[aa], %[aa], %[w2]\n\t"                                                \
+                         "s_mov_b64 exec, %[sv]"                                                             \
+                         : [ar] "+v"(a_ref[J]), [ah] "+v"(a_het[J]), [aa] "+v"(a_alt[J]), [g] "=&s"(mg), [u] "=&s"(mu) \
+                         : [x] "v"(P), [k0] "v"(k0), [w0] "s"(w0), [w1] "s"(w1), [w2] "s"(w2), [sv] "s"(exec_all) \
+                         : "scc");                                                                           \
+        else                                                                                                \
+            asm volatile("v_cmp_lt_i32_sdwa %[g], sext(%[x]), %[k0] src0_sel:" SELG " src1_sel:DWORD\n\t"    \
+                         "v_cmp_lt_i32_sdwa %[u], sext(%[x]), %[k0] src0_sel:" SELU " src1_sel:DWORD\n\t"    \
+                         "s_andn2_b64 exec, %[u], %[g]\n\t"                                                 \
+                         "v_add_f64 %[ar], %[ar], %[w0]\n\t"                                                \
+                         "s_and_b64 exec, %[u], %[g]\n\t"                                                   \
+                         "v_add_f64 %[aa], %[aa], %[w2]\n\t"                                                \
+                         "s_mov_b64 exec, %[sv]"                                                             \
+                         : [ar] "+v"(a_ref[J]), [aa] "+v"(a_alt[J]), [g] "=&s"(mg), [u] "=&s"(mu)             \
+                         : [x] "v"(P), [k0] "v"(k0), [w0] "s"(w0), [w2] "s"(w2), [sv] "s"(exec_all)           \
+                         : "scc");                                                                           \
+    } while (0)
+            STRICT_COLUMN_LUT(0, e.x, "BYTE_0", "BYTE_1");
+            STRICT_COLUMN_LUT(1, e.x, "BYTE_2", "BYTE_3");
+            STRICT_COLUMN_LUT(2, e.y, "BYTE_0", "BYTE_1");
+            STRICT_COLUMN_LUT(3, e.y, "BYTE_2", "BYTE_3");
+#undef STRICT_COLUMN_LUT
+        } else if constexpr (!PACKED) {
             // EXEC-masked additions: v_cmpx selects the lanes whose call is this class (byte select inside the compare),
             // one v_add_f64 with the row's weight from scalar registers runs on exactly those lanes, EXEC is restored:
             // 1 + 2 VALU issue slots per class instead of 1 + 1 + 2 (no select), one scalar move more.
@@ -1512,6 +1573,11 @@ strict4_segments(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             a_alt[j] = add_if(a_alt[j], b == 1u, w2);
         }
         }
+#if SNPM_STRICT_EXEC
+        if (PACKED && MASKS) {
+            miss8 += lut_miss;
+        } else
+#endif
         if (PACKED) {     // code 3 (or 2 / 3 with skip_hets): one bit per call, spread to one byte per call
             const uint32_t m = SKIP ? ((x >> 1) & 0x55u) : (x & (x >> 1) & 0x55u);
             miss8 += (m * 0x41041u) & 0x01010101u;
@@ -1535,7 +1601,7 @@ strict4_segments(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     // row address = wave-uniform row base + the lane's 32-bit offset (global_load with a scalar base: no address VALU)
     const uint32_t coff = (uint32_t)(PACKED ? c0 / 4 : c0);
     int64_t r = r0;
-    if constexpr (!PACKED && SNPM_STRICT_EXEC) {
+    if constexpr ((!PACKED || MASKS) && SNPM_STRICT_EXEC) {
         // Batches of SB rows, two register sets: the next batch is requested before the current one is scored (up to
         // 2 * SB row loads in flight per wave), and the batch's weights arrive in a few wide scalar loads.
         constexpr int SB = SNPM_STRICT_BATCH;
@@ -1569,8 +1635,8 @@ strict4_segments(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         }
         r = r0 + nb * SB;
     } else {
-        // packed panels (select form): round 1's loop -- four rows requested, then scored (the batched form above is slower
-        // here: 24.5 vs 18.5 ms on 10 000 x 6.25M)
+        // select form: round 1's loop -- four rows requested, then scored (the batched form above is slower with it:
+        // 24.5 vs 18.5 ms on a packed 10 000 x 6.25M panel)
         for (; r + 4 <= r1; r += 4) {
             uint32_t x[4];
 #pragma unroll
@@ -1608,16 +1674,25 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
 {
     if (dense_tier_off(gate, gate_cap)) return;
     const int64_t c0 = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) * 4;
+    if constexpr (PACKED && SNPM_STRICT_EXEC) {
+        __shared__ uint4 s_lut[256];
+        for (uint32_t e = threadIdx.x; e < 256u; e += blockDim.x) s_lut[e] = strict_lut_entry<SKIP>(e);
+        __syncthreads();
+        if (c0 >= ncols) return;
+        strict4_segments<SKIP, GATHER, true, true>(db, pitch, row_idx, row0, w, seg_off, chunk, n, seg0, n_seg, ncols,
+                                                   out_score, out_miss, ld, c0, s_lut);
+        return;
+    }
     if (c0 >= ncols) return;                 // pitch is a multiple of 256: the dword / byte of an active lane is inside the row
     if constexpr (!PACKED && SNPM_STRICT_EXEC) {
         if (*other_codes == 0) {             // wave-uniform
             strict4_segments<SKIP, GATHER, false, true>(db, pitch, row_idx, row0, w, seg_off, chunk, n, seg0, n_seg, ncols,
-                                                        out_score, out_miss, ld, c0);
+                                                        out_score, out_miss, ld, c0, nullptr);
             return;
         }
     }
     strict4_segments<SKIP, GATHER, PACKED, false>(db, pitch, row_idx, row0, w, seg_off, chunk, n, seg0, n_seg, ncols,
-                                                  out_score, out_miss, ld, c0);
+                                                  out_score, out_miss, ld, c0, nullptr);
 }
 
 // Strict segment sums for a SHORT list of columns (the accessions SNPM_MODE_EXACT has to re-evaluate):
