@@ -373,6 +373,18 @@ def main():
         parity = bool(np.array_equal(gn, cn) and np.array_equal(np.array(gs, dtype=int), np.array(cs, dtype=int)))
         q2.free()
 
+    # what a kernel that only READS this slab reaches on this GPU (k_calib_read: 4 B per lane, non-temporal, no
+    # arithmetic): the practical ceiling next to the 8 TB/s of the data sheet
+    ceiling = None
+    if rank == 0 and not args.packed:
+        ts = []
+        for i in range(5):
+            t0 = time.perf_counter()
+            nbytes = panel.stream_read()          # synchronises
+            if i >= 2:
+                ts.append(time.perf_counter() - t0)
+        ceiling = nbytes / min(ts) / 1e9
+
     if rank == 0:
         comparisons = float(n_snp) * n_acc * args.steps
         kname = queries[0].last_kernel() or ("k_strict4" if kernel == "strict" else "k_fast")
@@ -411,7 +423,10 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes * passes / max(launches, 1), "algorithmic_bytes_per_pass": alg_bytes,
                          "shape": "%d accessions x %d SNPs" % (n_loc, rows_dom),
                          "all_slabs_frac": (all_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if all_ms > 0 else None,
-                         "end_to_end_frac": float(n_snp) * row_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "end_to_end_frac": float(n_snp) * row_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                         "read_only_kernel": {"kernel": "k_calib_read", "achieved": ceiling,
+                                              "frac": ceiling / HBM_PEAK_GBS if ceiling else None,
+                                              "this_kernel_over_read_only": achieved / ceiling if ceiling else None}},
             "cpu_baseline": cpu,
             "end_to_end": end_to_end,
             "checks": {"top_hit_is_planted": result_ok, "counts_match_cpu_port": parity,

@@ -347,7 +347,8 @@ int pick_bpl(snpm_ctx *ctx, int64_t n_acc)
     return 4;
 }
 
-FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint, int bpl, int tile_rows = TILE_ROWS)
+FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint, int bpl, int tile_rows = TILE_ROWS,
+                   int wpb_fixed = 0)
 {
     FastGeom g;
     g.bpl = bpl;
@@ -355,6 +356,8 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     g.n_wc = std::max<int64_t>(1, (n_acc + span - 1) / span);
     if (ctx->force_wpb >= 1 && ctx->force_wpb <= MAX_WAVES_PER_BLOCK) {
         g.wpb = (int)std::min<int64_t>(ctx->force_wpb, g.n_wc);
+    } else if (wpb_fixed > 0) {
+        g.wpb = (int)std::min<int64_t>(wpb_fixed, g.n_wc);
     } else if (g.n_wc <= 8) {
         g.wpb = (int)g.n_wc;
     } else {
@@ -567,18 +570,21 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     const bool p16 = p->packed && !ctx->packed_byte;
     const int bpl = p16 ? 16 : (p->packed ? 4 : pick_bpl(ctx, p->n_acc));
     const int tile_rows = p16 ? P16_TILE_ROWS : TILE_ROWS;
-    FastGeom g0 = fast_geom(ctx, p->n_acc, q->n, 2, bpl, tile_rows);   // wpb does not depend on occupancy
+    const bool bits = p16 && q->hard01 && ctx->bits_path;      // counts instead of weighted sums
+    // k_fast_bits has no LDS tile and no barrier: one wave per block fills every wave slot of a CU evenly (measured on the
+    // packed 10k x 50M panel: 22.4 ms with 1- or 2-wave blocks, 26.9 ms with the 5-wave blocks of the LUT kernels, 30.7 with 3)
+    const int wpb_fixed = bits ? 1 : 0;
+    FastGeom g0 = fast_geom(ctx, p->n_acc, q->n, 2, bpl, tile_rows, wpb_fixed);   // wpb does not depend on occupancy
     int occ = 0;
     const bool nt = ctx->nt_loads != 0;
     const int thr = WAVE * g0.wpb;
-    const bool bits = p16 && q->hard01 && ctx->bits_path;      // counts instead of weighted sums
     if (bits) (void)launch_bits(q, g0, skip, gather, nt, &occ, thr);
     else if (p16) (void)launch_p16(q, g0, skip, gather, nt, &occ, thr);
     else if (p->packed) occ = nt ? occ_b<1, true>(skip, gather, thr) : occ_b<1, false>(skip, gather, thr);
     else if (bpl == 16) occ = nt ? occ_b<16, true>(skip, gather, thr) : occ_b<16, false>(skip, gather, thr);
     else if (bpl == 8) occ = nt ? occ_b<8, true>(skip, gather, thr) : occ_b<8, false>(skip, gather, thr);
     else occ = nt ? occ_b<4, true>(skip, gather, thr) : occ_b<4, false>(skip, gather, thr);
-    FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl, tile_rows);
+    FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl, tile_rows, wpb_fixed);
     if (geom_out) *geom_out = g;
     q->last_kernel = bits ? "k_fast_bits" : (p16 ? "k_fast_packed16" : "k_fast");
     rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_slots * p->ld * sizeof(double));

@@ -216,6 +216,13 @@ template <int NDW, bool SKIP, int U>
 __device__ __forceinline__ void fast_row(const uint32_t (&x)[NDW], uint32_t group_base, uint32_t roff4,
                                          double (&acc)[NDW * 4], uint32_t (&miss8)[NDW])
 {
+#ifdef SNPM_FAST_PATTERN_ONLY
+    // diagnostic build: k_fast's loads, geometry and barriers without its arithmetic (what the access pattern alone reaches)
+#pragma unroll
+    for (int k = 0; k < NDW; ++k) miss8[k] ^= x[k];
+    (void)group_base; (void)roff4; (void)acc;
+    return;
+#endif
     double w[NDW * 4];
 #pragma unroll
     for (int k = 0; k < NDW; ++k) {
@@ -965,6 +972,14 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
         c_ = m8 & t8_;  m8 ^= t8_;  d_ = m16 & c_;  m16 ^= c_;  c_ = m32 & d_;  m32 ^= d_;  m64 ^= c_; \
     } while (0)
 
+#ifdef SNPM_FAST_PATTERN_ONLY       // diagnostic build: the loads and the loop structure without the arithmetic
+#undef BITS_GROUP
+#define BITS_GROUP(X, W8)                                                                           \
+    do {                                                                                            \
+        _Pragma("unroll") for (int u_ = 0; u_ < G; ++u_) h1 ^= (X)[u_];                             \
+        m1 ^= (uint32_t)(W8);                                                                       \
+    } while (0)
+#endif
             int g = 0;
             for (; g + 2 <= full_groups; g += 2) {
                 const int64_t rnext = tr0 + (int64_t)(g + 1) * G;
