@@ -83,6 +83,7 @@ struct snpm_ctx {
     int parts_mult = 1;
     int use_acc_major = 1;  // keep an accession-major packed copy (+25 % memory) for contiguous re-evaluation reads
     int64_t acc_major_min_rows = 1000000;   // ... once a query is long enough for the strided path to hurt
+    int packed_q4 = 1;         // packed panels, PL weights: four-row tables (k_fast_packed_q4); SNPM_P16_Q4=0: k_fast_packed16
     int strict4 = 1;           // dense strict scoring with 4 columns per lane (SNPM_STRICT4=0: one column per lane)
     int debug_max_parts = 0;   // SNPM_DEBUG_MAX_PARTS=k: cap the parts of the fast pass (tests of multi-epoch parts)
     int debug_reeval = 0;   // SNPM_DEBUG_REEVAL=k: also re-evaluate accessions 0..k-1 (to time that path)
@@ -429,17 +430,24 @@ int launch_p16_t(snpm_query *q, const FastGeom &g, int *occ_out, int threads)
 {
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
+    const bool q4 = ctx->packed_q4 != 0;
     if (occ_out) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_packed16<SKIP, GATHER, NT>, threads, 0) != hipSuccess) nb = 0;
+        hipError_t e = q4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_packed_q4<SKIP, GATHER, NT>, threads, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_packed16<SKIP, GATHER, NT>, threads, 0);
+        if (e != hipSuccess) nb = 0;
         *occ_out = nb;
         return SNPM_OK;
     }
     dim3 grid((unsigned)g.n_colblocks, (unsigned)g.n_parts);
     dim3 block(WAVE * g.wpb);
     ProfScope ps(ctx, PK_FAST);
-    hipLaunchKernelGGL((k_fast_packed16<SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx,
-                       q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
+    if (q4)
+        hipLaunchKernelGGL((k_fast_packed_q4<SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx,
+                           q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
+    else
+        hipLaunchKernelGGL((k_fast_packed16<SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx,
+                           q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }
@@ -569,11 +577,13 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     // one-byte-per-lane instantiation of k_fast stays selectable (SNPM_PACKED_BYTE=1) for comparison
     const bool p16 = p->packed && !ctx->packed_byte;
     const int bpl = p16 ? 16 : (p->packed ? 4 : pick_bpl(ctx, p->n_acc));
-    const int tile_rows = p16 ? P16_TILE_ROWS : TILE_ROWS;
     const bool bits = p16 && q->hard01 && ctx->bits_path;      // counts instead of weighted sums
+    const int tile_rows = p16 ? ((!bits && ctx->packed_q4) ? Q4_TILE_ROWS : P16_TILE_ROWS) : TILE_ROWS;
     // k_fast_bits has no LDS tile and no barrier: one wave per block fills every wave slot of a CU evenly (measured on the
     // packed 10k x 50M panel: 22.4 ms with 1- or 2-wave blocks, 26.9 ms with the 5-wave blocks of the LUT kernels, 30.7 with 3)
-    const int wpb_fixed = bits ? 1 : 0;
+    // k_fast_packed_q4: 4-wave blocks (one wave per SIMD; 35.9 ms against 38.5 with 5-wave blocks on 10 000 accessions,
+    // although 2 of its 12 waves there only help to build the tables)
+    const int wpb_fixed = bits ? 1 : ((p16 && ctx->packed_q4) ? 4 : 0);
     FastGeom g0 = fast_geom(ctx, p->n_acc, q->n, 2, bpl, tile_rows, wpb_fixed);   // wpb does not depend on occupancy
     int occ = 0;
     const bool nt = ctx->nt_loads != 0;
@@ -1279,6 +1289,7 @@ try {
     if (const char *s = getenv("SNPM_ACC_MAJOR_MIN_ROWS")) ctx->acc_major_min_rows = atoll(s);
     if (const char *s = getenv("SNPM_DEBUG_REEVAL")) ctx->debug_reeval = atoi(s);
     if (const char *s = getenv("SNPM_STRICT4")) ctx->strict4 = atoi(s);
+    if (const char *s = getenv("SNPM_P16_Q4")) ctx->packed_q4 = atoi(s);
     if (const char *s = getenv("SNPM_DEBUG_MAX_PARTS")) ctx->debug_max_parts = atoi(s);
     if (const char *s = getenv("SNPM_STAGE_THREADS")) ctx->stage_threads = std::max(1, atoi(s));
     *out = ctx;
@@ -1824,7 +1835,7 @@ try {
     const double eref = *(const double *)ctx->h_pinned;
     const bool p16 = q->panel->packed && !ctx->packed_byte;
     const int bpl = p16 ? 16 : (q->panel->packed ? 4 : pick_bpl(ctx, q->panel->n_acc));
-    FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl, p16 ? P16_TILE_ROWS : TILE_ROWS);   // occ 1 -> longest parts -> largest bound
+    FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl, p16 ? std::min(P16_TILE_ROWS, Q4_TILE_ROWS) : TILE_ROWS);   // occ 1, short tiles -> longest parts -> largest bound
     *bound = eref + efast_bound(q, g);
     return SNPM_OK;
 } SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))

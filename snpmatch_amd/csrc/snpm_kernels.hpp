@@ -44,6 +44,9 @@ namespace snpm {
 #ifndef SNPM_P16_MIN_WAVES
 #define SNPM_P16_MIN_WAVES 4
 #endif
+#ifndef SNPM_Q4_MIN_WAVES
+#define SNPM_Q4_MIN_WAVES 4
+#endif
 #ifndef SNPM_FAST_MIN_WAVES
 #define SNPM_FAST_MIN_WAVES 6
 #endif
@@ -805,6 +808,253 @@ k_fast_packed16(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__r
     store_partials(last_epoch);
 }
 #undef P16_CSA
+
+// ------------------------------------------------------------------------------------------------
+// Fast pass on a PACKED panel, FOUR ROWS PER LOOKUP (k_fast_packed_q4).
+//   k_fast_packed16 above issues one 16-byte LDS read and two additions per two comparisons and is bound by the LDS
+//   array and the fp64 adder together (51 ms on the packed 10k x 50M panel; its loads alone take 22 ms).  Here the
+//   block builds, per group of four rows, a 256-entry table  entry[c0 | c1 << 2 | c2 << 4 | c3 << 6] =
+//   ((lut[r][c0] + lut[r+1][c1]) + lut[r+2][c2]) + lut[r+3][c3]  (2 KiB per four rows), and a lane scores four rows of
+//   one accession with ONE 8-byte LDS read and ONE addition.  The index byte of every accession comes from a 4 x 16
+//   transpose of the rows' 2-bit fields (24 integer operations per 64 comparisons: fields -> nibbles -> bytes).
+//   The pre-added entries only change the summation tree of the fast pass (every term still passes through fewer
+//   additions than efast_bound assumes); the reference-order paths never use this kernel.
+//   Rows past the end of the matched list read as table rows of 0.0 and as call code 0 (not missing).
+//   Geometry, tile-interleaved parts, epochs, missing counters and outputs are those of k_fast_packed16.
+constexpr int Q4_TILE_ROWS = 64;        // 16 four-row tables x 2 KiB = 32 KiB of LDS per block
+constexpr int Q4_G = 8;                 // rows per prefetch group (two tables)
+static_assert(Q4_TILE_ROWS % (2 * Q4_G) == 0 && Q4_TILE_ROWS <= 127, "two register sets per iteration; 7-bit missing counters per tile");
+
+#define Q4_CSA(H, L, A, B, C)             \
+    do {                                  \
+        const uint32_t u_ = (A) ^ (B);    \
+        const uint32_t h_ = ((A) & (B)) | (u_ & (C)); \
+        (L) = u_ ^ (C);                   \
+        (H) = h_;                         \
+    } while (0)
+
+template <bool SKIP, bool GATHER, bool NT>
+__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, SNPM_Q4_MIN_WAVES)
+k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
+                 const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
+{
+    constexpr int G = Q4_G;
+    constexpr int TR = Q4_TILE_ROWS;
+    constexpr int NQ = TR / 4;
+    __shared__ __attribute__((aligned(256))) double s_tab[NQ * 256];
+    __shared__ __attribute__((aligned(16))) double s_l4[TR * 4];       // the tile's 4-entry LUT rows (table build only)
+
+    const int tid = threadIdx.x;
+    const int nthr = blockDim.x;
+    const int64_t byte0 = ((int64_t)blockIdx.x * nthr + tid) * 4;      // 4 bytes = 16 accessions per lane and row
+    const int64_t col0 = byte0 * 4;
+    const bool lane_on = byte0 < pitch && col0 < ld;
+    const bool wave_on = __any(lane_on) != 0;           // wave-uniform
+    const int64_t p = blockIdx.y;
+    const int64_t P = gridDim.y;
+    const int64_t n_tiles_total = (n + TR - 1) / TR;
+
+    double acc[16];
+    uint32_t miss16[8];                 // miss16[d]: accession d (low half) and d + 8 (high half)
+    uint32_t p1 = 0, p2 = 0, p4 = 0, p8 = 0, p16 = 0, p32 = 0, p64 = 0;   // bit-sliced counts of the current tile
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) miss16[i] = 0;
+
+    const uint32_t lane_off = lane_on ? (uint32_t)byte0 : 0u;
+    auto load = [&](int64_t rr) -> uint32_t {
+        const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
+        const int8_t *rowbase = db + prow * pitch;
+        uint32_t off = lane_off;
+        asm volatile("" : "+v"(off));                     // keeps the saddr form of the load (see k_fast)
+        const uint32_t *ptr = reinterpret_cast<const uint32_t *>(rowbase + off);
+        return NT ? __builtin_nontemporal_load(ptr) : *ptr;
+    };
+    auto missing_bits = [](uint32_t x) -> uint32_t {
+        return SKIP ? ((x >> 1) & 0x55555555u) : (x & (x >> 1) & 0x55555555u);
+    };
+    // tables of one tile from its LUT rows in s_l4
+    auto build_tables = [&]() {
+        // one thread per (table, c0, c1, c2): the three-row prefix once, then the four entries that differ in c3
+        for (int i = tid; i < NQ * 64; i += nthr) {
+            const double *L = s_l4 + 16 * (i >> 6);
+            const int e = i & 63;
+            const double pre3 = (L[e & 3] + L[4 + ((e >> 2) & 3)]) + L[8 + (e >> 4)];
+            const double2 l3a = *reinterpret_cast<const double2 *>(L + 12), l3b = *reinterpret_cast<const double2 *>(L + 14);
+            double *dst = s_tab + 256 * (i >> 6) + e;
+            dst[0] = pre3 + l3a.x;
+            dst[64] = pre3 + l3a.y;
+            dst[128] = pre3 + l3b.x;
+            dst[192] = pre3 + l3b.y;
+        }
+    };
+    auto flush_planes = [&]() {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            uint32_t c = (p1 >> (2 * d)) & 0x00010001u;
+            c += ((p2 >> (2 * d)) & 0x00010001u) << 1;
+            c += ((p4 >> (2 * d)) & 0x00010001u) << 2;
+            c += ((p8 >> (2 * d)) & 0x00010001u) << 3;
+            c += ((p16 >> (2 * d)) & 0x00010001u) << 4;
+            c += ((p32 >> (2 * d)) & 0x00010001u) << 5;
+            c += ((p64 >> (2 * d)) & 0x00010001u) << 6;
+            miss16[d] += c;
+        }
+        p1 = p2 = p4 = p8 = p16 = p32 = p64 = 0;
+    };
+    auto store_partials = [&](int64_t epoch) {
+        if (lane_on) {
+            double *os = out_score + (epoch * P + p) * ld + col0;
+            uint32_t *om = out_miss + (epoch * P + p) * ld + col0;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) *reinterpret_cast<double2 *>(os + i) = make_double2(acc[i], acc[i + 1]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {                 // accessions 8k .. 8k+7
+                uint4 a, b;
+                a.x = k ? (miss16[0] >> 16) : (miss16[0] & 0xffffu);
+                a.y = k ? (miss16[1] >> 16) : (miss16[1] & 0xffffu);
+                a.z = k ? (miss16[2] >> 16) : (miss16[2] & 0xffffu);
+                a.w = k ? (miss16[3] >> 16) : (miss16[3] & 0xffffu);
+                b.x = k ? (miss16[4] >> 16) : (miss16[4] & 0xffffu);
+                b.y = k ? (miss16[5] >> 16) : (miss16[5] & 0xffffu);
+                b.z = k ? (miss16[6] >> 16) : (miss16[6] & 0xffffu);
+                b.w = k ? (miss16[7] >> 16) : (miss16[7] & 0xffffu);
+                *reinterpret_cast<uint4 *>(om + 8 * k) = a;
+                *reinterpret_cast<uint4 *>(om + 8 * k + 4) = b;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) miss16[i] = 0;
+    };
+    // four rows of 16 accessions against one table: index bytes by a transpose of the rows' 2-bit fields
+    //   e01 nibble k = accession 2k, rows 0-1;  o01 nibble k = accession 2k+1;  then nibbles -> bytes:
+    //   w[0] byte m = accession 4m, w[1] byte m = accession 4m+1, w[2]: 4m+2, w[3]: 4m+3
+    // (an index with the calls' low bits in bits 0-3 -- ref and alt entries of all four rows in distinct LDS banks -- costs
+    // the same 24 operations and measured 8 % SLOWER: the pass is bound by instruction issue, not by the LDS array)
+    auto score_quad = [&](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, const double *tab) {
+        const uint32_t M3 = 0x33333333u, MF = 0x0F0F0F0Fu;
+        const uint32_t e01 = (x0 & M3) | ((x1 & M3) << 2), o01 = ((x0 >> 2) & M3) | (x1 & ~M3);
+        const uint32_t e23 = (x2 & M3) | ((x3 & M3) << 2), o23 = ((x2 >> 2) & M3) | (x3 & ~M3);
+        uint32_t w[4];
+        w[0] = (e01 & MF) | ((e23 & MF) << 4);
+        w[1] = (o01 & MF) | ((o23 & MF) << 4);
+        w[2] = ((e01 >> 4) & MF) | (e23 & ~MF);
+        w[3] = ((o01 >> 4) & MF) | (o23 & ~MF);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                     // eight lookups in flight, then their additions
+            double t[8];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[4 * m + j] = tab[(w[j] >> (8 * (2 * h + m))) & 0xffu];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) acc[8 * h + c] += t[c];
+        }
+    };
+    // the 8 missing-bit words of a group into the bit-sliced counters
+    auto count_group = [&](const uint32_t (&x)[G]) {
+        uint32_t t2a, t2b, t4a, t4b, t8;
+        Q4_CSA(t2a, p1, p1, missing_bits(x[0]), missing_bits(x[1]));
+        Q4_CSA(t2b, p1, p1, missing_bits(x[2]), missing_bits(x[3]));
+        Q4_CSA(t4a, p2, p2, t2a, t2b);
+        Q4_CSA(t2a, p1, p1, missing_bits(x[4]), missing_bits(x[5]));
+        Q4_CSA(t2b, p1, p1, missing_bits(x[6]), missing_bits(x[7]));
+        Q4_CSA(t4b, p2, p2, t2a, t2b);
+        Q4_CSA(t8, p4, p4, t4a, t4b);
+        uint32_t c = p8 & t8;  p8 ^= t8;
+        uint32_t d = p16 & c;  p16 ^= c;
+        c = p32 & d;           p32 ^= d;
+        p64 ^= c;
+    };
+    auto score_group = [&](uint32_t (&x)[G], int gi) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) asm volatile("" : "+v"(x[u]));       // the group's rows become visible here, not earlier
+        score_quad(x[0], x[1], x[2], x[3], s_tab + (2 * gi) * 256);
+        score_quad(x[4], x[5], x[6], x[7], s_tab + (2 * gi + 1) * 256);
+        count_group(x);
+    };
+    // LUT rows of the tile that starts at matched row tr: TR * 4 doubles, one per thread (0.0 past the end of the list);
+    // blocks with fewer than TR * 4 threads copy the rest synchronously
+    auto fetch_l4 = [&](int64_t tr, bool on) -> double {
+        return (on && tid < TR * 4 && tr + (tid >> 2) < n) ? lut[4 * tr + tid] : 0.0;
+    };
+    auto store_l4 = [&](int64_t tr, double pre) {
+        if (tid < TR * 4) s_l4[tid] = pre;
+        for (int i = tid + nthr; i < TR * 4; i += nthr) s_l4[i] = (tr + (i >> 2) < n) ? lut[4 * tr + i] : 0.0;
+    };
+    int64_t last_epoch = 0;
+
+    if (p < n_tiles_total) {
+        // two register sets of G rows (a third one, 16 to 24 row loads in flight per lane, measured no gain)
+        uint32_t xa[G], xb[G];
+        {
+            const double pre = fetch_l4(p * TR, true);
+            const int rows0 = (int)((n - p * TR < TR) ? (n - p * TR) : TR);
+#pragma unroll
+            for (int u = 0; u < G; ++u) xa[u] = (wave_on && u < rows0) ? load(p * TR + u) : 0u;
+            store_l4(p * TR, pre);
+        }
+        __syncthreads();
+        build_tables();
+        __syncthreads();
+
+        int tiles_in_epoch = 0;
+        int64_t epoch = 0;
+        for (int64_t T = p; T < n_tiles_total; T += P) {
+            if (tiles_in_epoch == EPOCH_TILES) {
+                store_partials(epoch);
+                ++epoch;
+                tiles_in_epoch = 0;
+            }
+            ++tiles_in_epoch;
+            const int64_t tr0 = T * TR;
+            const int rows = (int)((n - tr0 < TR) ? (n - tr0) : TR);
+            const bool more = (T + P < n_tiles_total);
+            const int64_t ntr0 = more ? (T + P) * TR : tr0;        // my next tile (or a harmless re-read)
+            const double pre = fetch_l4(ntr0, more);               // waited for at the end of this tile
+
+            if (!wave_on) {
+                // a wave whose lanes all lie past the last accession only helps to build the tables
+            } else if (rows == TR) {
+#pragma unroll
+                for (int g = 0; g < TR / G; g += 2) {
+                    const int64_t rnext = tr0 + (int64_t)(g + 1) * G;
+                    // the group after the pair: inside this tile, or the first group of my next tile (a partial last tile
+                    // is followed by PREFETCH_PAD_ROWS >= G readable rows)
+                    const int64_t rafter = (g + 2 < TR / G) ? rnext + G : ntr0;
+#pragma unroll
+                    for (int u = 0; u < G; ++u) xb[u] = load(rnext + u);
+                    score_group(xa, g);
+#pragma unroll
+                    for (int u = 0; u < G; ++u) xa[u] = load(rafter + u);
+                    score_group(xb, g + 1);
+                }
+            } else {
+                // the partial last tile of the whole list (nothing follows it): group by group, rows past the end read as 0
+                for (int g = 0; g * G < rows; ++g) {
+#pragma unroll
+                    for (int u = 0; u < G; ++u) xb[u] = (g * G + u < rows) ? load(tr0 + g * G + u) : 0u;
+#pragma unroll
+                    for (int u = 0; u < G; ++u) asm volatile("" : "+v"(xb[u]));
+                    score_quad(xb[0], xb[1], xb[2], xb[3], s_tab + (2 * g) * 256);
+                    score_quad(xb[4], xb[5], xb[6], xb[7], s_tab + (2 * g + 1) * 256);
+                    count_group(xb);
+                }
+            }
+            flush_planes();
+            if (more) store_l4(ntr0, pre);
+            __syncthreads();                      // every wave is done with this tile's tables; s_l4 holds the next rows
+            if (more) build_tables();
+            __syncthreads();
+        }
+        last_epoch = epoch;
+    }
+    store_partials(last_epoch);
+}
+#undef Q4_CSA
 
 // ------------------------------------------------------------------------------------------------
 // Fast pass for HARD-CALL samples on a packed panel: every weight is 0 or 1 (BED input, VCF without PL:
