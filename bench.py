@@ -376,7 +376,7 @@ def main():
     # what a kernel that only READS this slab reaches on this GPU (k_calib_read: 4 B per lane, non-temporal, no
     # arithmetic): the practical ceiling next to the 8 TB/s of the data sheet
     ceiling = None
-    if rank == 0 and not args.packed:
+    if rank == 0:
         ts = []
         for i in range(5):
             t0 = time.perf_counter()

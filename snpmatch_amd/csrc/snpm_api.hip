@@ -83,7 +83,6 @@ struct snpm_ctx {
     int parts_mult = 1;
     int use_acc_major = 1;  // keep an accession-major packed copy (+25 % memory) for contiguous re-evaluation reads
     int64_t acc_major_min_rows = 1000000;   // ... once a query is long enough for the strided path to hurt
-    int packed_q4 = 1;         // packed panels, PL weights: four-row tables (k_fast_packed_q4); SNPM_P16_Q4=0: k_fast_packed16
     int strict4 = 1;           // dense strict scoring with 4 columns per lane (SNPM_STRICT4=0: one column per lane)
     int debug_max_parts = 0;   // SNPM_DEBUG_MAX_PARTS=k: cap the parts of the fast pass (tests of multi-epoch parts)
     int debug_reeval = 0;   // SNPM_DEBUG_REEVAL=k: also re-evaluate accessions 0..k-1 (to time that path)
@@ -91,8 +90,8 @@ struct snpm_ctx {
     int nt_loads = 1;      // panel bytes are read once: non-temporal loads (+5-8% measured)
     int64_t f1_slab_bytes = int64_t(2) << 30;   // SNPM_F1_SLAB_BYTES: compacted-weight scratch of the in-silico crosses
     int full_occupancy = 0;   // SNPM_FULL_OCCUPANCY=1: as many resident blocks as the occupancy API allows
-    int bits_path = 1;     // SNPM_BITS=0: hard-call samples on packed panels go through k_fast_packed16 like any other
-    int packed_byte = 0;   // SNPM_PACKED_BYTE=1: packed panels through the one-byte-per-lane k_fast instead of k_fast_packed16
+    int bits_path = 1;     // SNPM_BITS=0: hard-call samples on packed panels go through k_fast_packed_q4 like any other
+    int packed_byte = 0;   // SNPM_PACKED_BYTE=1: packed panels through the one-byte-per-lane k_fast instead of k_fast_packed_q4
     // live panels of this context: snpm_destroy releases their device memory and orphans them (and their
     // queries), so that a panel / query handle freed AFTER its context is a harmless host-side delete
     std::vector<snpm_panel *> panels;
@@ -424,30 +423,23 @@ int launch_fast_b(snpm_query *q, const FastGeom &g, bool skip, bool gather)
     return gather ? launch_fast_t<BPL, false, true, NT>(q, g) : launch_fast_t<BPL, false, false, NT>(q, g);
 }
 
-// packed panels, 16 accessions per lane (k_fast_packed16)
+// packed panels, 16 accessions per lane (k_fast_packed_q4)
 template <bool SKIP, bool GATHER, bool NT>
 int launch_p16_t(snpm_query *q, const FastGeom &g, int *occ_out, int threads)
 {
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
-    const bool q4 = ctx->packed_q4 != 0;
     if (occ_out) {
         int nb = 0;
-        hipError_t e = q4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_packed_q4<SKIP, GATHER, NT>, threads, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_packed16<SKIP, GATHER, NT>, threads, 0);
-        if (e != hipSuccess) nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_packed_q4<SKIP, GATHER, NT>, threads, 0) != hipSuccess) nb = 0;
         *occ_out = nb;
         return SNPM_OK;
     }
     dim3 grid((unsigned)g.n_colblocks, (unsigned)g.n_parts);
     dim3 block(WAVE * g.wpb);
     ProfScope ps(ctx, PK_FAST);
-    if (q4)
-        hipLaunchKernelGGL((k_fast_packed_q4<SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx,
-                           q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
-    else
-        hipLaunchKernelGGL((k_fast_packed16<SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx,
-                           q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
+    hipLaunchKernelGGL((k_fast_packed_q4<SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx,
+                       q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }
@@ -573,17 +565,17 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     int rc = ensure_lut(q, skip);
     if (rc) return rc;
     const bool gather = q->d_row_idx != nullptr;
-    // packed panels: 16 accessions (one dword) per lane and row, pair-table lookups (k_fast_packed16); the older
+    // packed panels: 16 accessions (one dword) per lane and row, four rows per table lookup (k_fast_packed_q4); the older
     // one-byte-per-lane instantiation of k_fast stays selectable (SNPM_PACKED_BYTE=1) for comparison
     const bool p16 = p->packed && !ctx->packed_byte;
     const int bpl = p16 ? 16 : (p->packed ? 4 : pick_bpl(ctx, p->n_acc));
     const bool bits = p16 && q->hard01 && ctx->bits_path;      // counts instead of weighted sums
-    const int tile_rows = p16 ? ((!bits && ctx->packed_q4) ? Q4_TILE_ROWS : P16_TILE_ROWS) : TILE_ROWS;
+    const int tile_rows = p16 ? (bits ? P16_TILE_ROWS : Q4_TILE_ROWS) : TILE_ROWS;
     // k_fast_bits has no LDS tile and no barrier: one wave per block fills every wave slot of a CU evenly (measured on the
     // packed 10k x 50M panel: 22.4 ms with 1- or 2-wave blocks, 26.9 ms with the 5-wave blocks of the LUT kernels, 30.7 with 3)
     // k_fast_packed_q4: 4-wave blocks (one wave per SIMD; 35.9 ms against 38.5 with 5-wave blocks on 10 000 accessions,
     // although 2 of its 12 waves there only help to build the tables)
-    const int wpb_fixed = bits ? 1 : ((p16 && ctx->packed_q4) ? 4 : 0);
+    const int wpb_fixed = bits ? 1 : (p16 ? 4 : 0);
     FastGeom g0 = fast_geom(ctx, p->n_acc, q->n, 2, bpl, tile_rows, wpb_fixed);   // wpb does not depend on occupancy
     int occ = 0;
     const bool nt = ctx->nt_loads != 0;
@@ -596,7 +588,7 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     else occ = nt ? occ_b<4, true>(skip, gather, thr) : occ_b<4, false>(skip, gather, thr);
     FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl, tile_rows, wpb_fixed);
     if (geom_out) *geom_out = g;
-    q->last_kernel = bits ? "k_fast_bits" : (p16 ? "k_fast_packed16" : "k_fast");
+    q->last_kernel = bits ? "k_fast_bits" : (p16 ? "k_fast_packed_q4" : "k_fast");
     rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_slots * p->ld * sizeof(double));
     if (rc) return rc;
     rc = ensure(ctx, ctx->ws_part_miss, (size_t)g.n_slots * p->ld * sizeof(uint32_t));
@@ -1289,7 +1281,6 @@ try {
     if (const char *s = getenv("SNPM_ACC_MAJOR_MIN_ROWS")) ctx->acc_major_min_rows = atoll(s);
     if (const char *s = getenv("SNPM_DEBUG_REEVAL")) ctx->debug_reeval = atoi(s);
     if (const char *s = getenv("SNPM_STRICT4")) ctx->strict4 = atoi(s);
-    if (const char *s = getenv("SNPM_P16_Q4")) ctx->packed_q4 = atoi(s);
     if (const char *s = getenv("SNPM_DEBUG_MAX_PARTS")) ctx->debug_max_parts = atoi(s);
     if (const char *s = getenv("SNPM_STAGE_THREADS")) ctx->stage_threads = std::max(1, atoi(s));
     *out = ctx;

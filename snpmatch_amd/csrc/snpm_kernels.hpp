@@ -11,7 +11,7 @@
 //              (byte & 3); every element costs one ds_read_b64 + one v_add_f64 instead of three
 //              compare/select pairs.  Missing counts are SWAR (packed u8 lanes).  Partials per part
 //              are written once; k_reduce adds them in part order (deterministic, no atomics).
-//   k_fast_packed16  the fast pass on a 2-bit packed panel: 16 accessions per lane, pair-table lookups
+//   k_fast_packed_q4 the fast pass on a 2-bit packed panel: 16 accessions per lane, four rows per table lookup
 //              (one ds_read_b128 + two v_add_f64 per two comparisons), bit-sliced missing counts, LDS reads
 //              issued and waited for by hand.
 //   k_fast_bits  hard-call samples (all weights 0 or 1) on a packed panel: bit-plane boolean scoring and
@@ -500,337 +500,35 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
 #undef SCORE_ROW
 
 // ------------------------------------------------------------------------------------------------
-// Fast pass on a PACKED panel (2 bits per call), 16 accessions per lane.
-//   The one-byte-per-lane instantiation above spends ~5.5 VALU operations per comparison and is VALU-bound at
-//   a quarter of the HBM rate.  Here a lane loads a dword per SNP row (16 calls; a wave covers 1024 accessions
-//   with 256 contiguous bytes, the access shape of the int8 kernel) and scores them TWO AT A TIME: the LDS
-//   tile holds, per row, a 16-entry pair table  entry[c_lo | c_hi << 2] = (lut[c_lo], lut[c_hi])  (2 x fp64,
-//   256 B per row, built by the block from the row's 4-entry LUT), so a nibble of the dword is the table
-//   index: its LDS address is built by one v_perm_b32 (as in k_fast), then one ds_read_b128 and two v_add_f64
-//   per two comparisons.
+// Fast pass on a PACKED panel (2 bits per call): 16 accessions per lane, FOUR ROWS PER LOOKUP (k_fast_packed_q4).
+//   The one-byte-per-lane instantiation of k_fast spends ~5.5 VALU operations per comparison and is VALU-bound at a
+//   quarter of the HBM rate.  Here a lane loads a dword per SNP row (16 calls; a wave covers 1024 accessions with 256
+//   contiguous bytes, the access shape of the int8 kernel), and the block builds, per group of four rows, a 256-entry
+//   table  entry[c0 | c1 << 2 | c2 << 4 | c3 << 6] = ((lut[r][c0] + lut[r+1][c1]) + lut[r+2][c2]) + lut[r+3][c3]
+//   (2 KiB per four rows), so that a lane scores four rows of one accession with ONE 8-byte LDS read and ONE addition.
+//   The index byte of every accession comes from a 4 x 16 transpose of the rows' 2-bit fields (24 integer operations
+//   per 64 comparisons: fields -> nibbles -> bytes).
+//   (Round 1-2's k_fast_packed16 looked up pairs of accessions of ONE row, a 16-byte read and two additions per two
+//   comparisons: 51 ms on the packed 10k x 50M panel, this kernel 36 ms, the loads alone 22 ms.)
+//   The pre-added entries only change the summation tree of the fast pass (every term still passes through fewer
+//   additions than efast_bound assumes); the reference-order paths never use this kernel.
+//   Rows past the end of the matched list read as table rows of 0.0 and as call code 0 (not missing).
 //   Missing calls (code 3, or 2/3 with skip_hets) are one bit per call after  x & (x >> 1) & 0x55555555;
 //   the 16 per-accession counts are kept bit-sliced (planes 1, 2, 4 ... 64) and updated for 8 rows at a time
 //   with carry-save adders (3 operations each), i.e. ~0.4 operations per comparison instead of one.
 //   Geometry, tile-interleaved parts, epochs and the prefetch pipeline are those of k_fast.
-constexpr int P16_TILE_ROWS = 64;       // rows per LDS pair-table tile (16 KiB)
-constexpr int P16_G = 8;                // rows per prefetch group
-typedef __attribute__((address_space(3))) const f64x2_t lds_cpair;
-
-#define P16_CSA(H, L, A, B, C)            \
-    do {                                  \
-        const uint32_t u_ = (A) ^ (B);    \
-        const uint32_t h_ = ((A) & (B)) | (u_ & (C)); \
-        (L) = u_ ^ (C);                   \
-        (H) = h_;                         \
-    } while (0)
-
-template <bool SKIP, bool GATHER, bool NT>
-__global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, SNPM_P16_MIN_WAVES)
-k_fast_packed16(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
-                const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
-{
-    constexpr int G = P16_G;
-    constexpr int TR = P16_TILE_ROWS;
-    __shared__ __attribute__((aligned(256))) f64x2_t s_pair[2][TR * 16];
-
-    const int tid = threadIdx.x;
-    const int nthr = blockDim.x;
-    const int64_t byte0 = ((int64_t)blockIdx.x * nthr + tid) * 4;      // 4 bytes = 16 accessions per lane and row
-    const int64_t col0 = byte0 * 4;
-    const bool lane_on = byte0 < pitch && col0 < ld;
-    const int64_t p = blockIdx.y;
-    const int64_t P = gridDim.y;
-    const int64_t n_tiles_total = (n + TR - 1) / TR;
-
-    double acc[16];
-    uint32_t miss16[8];                 // miss16[d]: accession d (low half) and d + 8 (high half)
-    uint32_t p1 = 0, p2 = 0, p4 = 0, p8 = 0, p16 = 0, p32 = 0, p64 = 0;   // bit-sliced counts of the current tile
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) miss16[i] = 0;
-
-    const uint32_t lane_off = lane_on ? (uint32_t)byte0 : 0u;
-    auto row_ptr = [&](int64_t rr) -> const uint32_t * {
-        const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
-        const int8_t *rowbase = db + prow * pitch;
-        uint32_t off = lane_off;
-        asm volatile("" : "+v"(off));                     // keeps the saddr form of the load (see k_fast)
-        return reinterpret_cast<const uint32_t *>(rowbase + off);
-    };
-    auto load = [&](int64_t rr) -> uint32_t {
-        return NT ? __builtin_nontemporal_load(row_ptr(rr)) : *row_ptr(rr);
-    };
-    auto missing_bits = [](uint32_t x) -> uint32_t {
-        return SKIP ? ((x >> 1) & 0x55555555u) : (x & (x >> 1) & 0x55555555u);
-    };
-    // pair table of one tile: entry (r, e) = (lut[r][e & 3], lut[r][e >> 2])
-    auto fill_pairs = [&](int buf, int64_t tr0) {
-        const int rows = (int)((n - tr0 < TR) ? (n - tr0) : TR);
-        for (int i = tid; i < rows * 16; i += nthr) {
-            const double *L = lut + 4 * (tr0 + (i >> 4));
-            f64x2_t v;
-            v.x = L[i & 3];
-            v.y = L[(i >> 2) & 3];
-            s_pair[buf][i] = v;
-        }
-    };
-    auto flush_planes = [&]() {
-#pragma unroll
-        for (int d = 0; d < 8; ++d) {
-            uint32_t c = (p1 >> (2 * d)) & 0x00010001u;
-            c += ((p2 >> (2 * d)) & 0x00010001u) << 1;
-            c += ((p4 >> (2 * d)) & 0x00010001u) << 2;
-            c += ((p8 >> (2 * d)) & 0x00010001u) << 3;
-            c += ((p16 >> (2 * d)) & 0x00010001u) << 4;
-            c += ((p32 >> (2 * d)) & 0x00010001u) << 5;
-            c += ((p64 >> (2 * d)) & 0x00010001u) << 6;
-            miss16[d] += c;
-        }
-        p1 = p2 = p4 = p8 = p16 = p32 = p64 = 0;
-    };
-    auto store_partials = [&](int64_t epoch) {
-        if (lane_on) {
-            double *os = out_score + (epoch * P + p) * ld + col0;
-            uint32_t *om = out_miss + (epoch * P + p) * ld + col0;
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) *reinterpret_cast<double2 *>(os + i) = make_double2(acc[i], acc[i + 1]);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {                 // accessions 8k .. 8k+7
-                uint4 a, b;
-                a.x = k ? (miss16[0] >> 16) : (miss16[0] & 0xffffu);
-                a.y = k ? (miss16[1] >> 16) : (miss16[1] & 0xffffu);
-                a.z = k ? (miss16[2] >> 16) : (miss16[2] & 0xffffu);
-                a.w = k ? (miss16[3] >> 16) : (miss16[3] & 0xffffu);
-                b.x = k ? (miss16[4] >> 16) : (miss16[4] & 0xffffu);
-                b.y = k ? (miss16[5] >> 16) : (miss16[5] & 0xffffu);
-                b.z = k ? (miss16[6] >> 16) : (miss16[6] & 0xffffu);
-                b.w = k ? (miss16[7] >> 16) : (miss16[7] & 0xffffu);
-                *reinterpret_cast<uint4 *>(om + 8 * k) = a;
-                *reinterpret_cast<uint4 *>(om + 8 * k + 4) = b;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) miss16[i] = 0;
-    };
-    int64_t last_epoch = 0;
-
-    if (p < n_tiles_total) {
-        fill_pairs(0, p * TR);
-        uint32_t xa[G], xb[G];
-#pragma unroll
-        for (int u = 0; u < G; ++u) xa[u] = load(p * TR + u);
-        __syncthreads();
-
-        int buf = 0;
-        int tiles_in_epoch = 0;
-        int64_t epoch = 0;
-        for (int64_t T = p; T < n_tiles_total; T += P, buf ^= 1) {
-            if (tiles_in_epoch == EPOCH_TILES) {
-                store_partials(epoch);
-                ++epoch;
-                tiles_in_epoch = 0;
-            }
-            ++tiles_in_epoch;
-            const int64_t tr0 = T * TR;
-            const int rows = (int)((n - tr0 < TR) ? (n - tr0) : TR);
-            const bool more = (T + P < n_tiles_total);
-            const int64_t ntr0 = more ? (T + P) * TR : tr0;
-            const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) f64x2_t *)(&s_pair[buf][0]);
-            const int full_groups = rows / G;
-            // the next tile's 4-entry LUT rows (64 x 4 doubles) are requested now, one double per thread, and
-            // expanded into the pair table at the end of the tile without touching global memory again
-            const bool staged = more && nthr >= TR * 4;
-            double pre = 0.0;
-            if (staged && tid < TR * 4 && ntr0 + (tid >> 2) < n) pre = lut[4 * ntr0 + tid];
-
-            // One row = 8 pair lookups in two half-row sets: A = nibbles 0-3 (accumulators 0-7), B = nibbles 4-7.
-            // The LDS reads are issued from inline asm and waited for by hand (cf. k_scan_few): the compiler
-            // would serialise "read, wait, add".  Steady state inside a group: both sets of the next row are
-            // requested before the additions of the current one retire, so with A(4 reads) older than B(4 reads)
-            // in flight, lgkmcnt(4) means "A has arrived" (LDS returns in order; scalar loads in between only make
-            // the wait more conservative).  Nothing stays in flight across groups.
-#define P16_ADDR(X, GBASE)                                                                           \
-    const uint32_t xe_ = ((X) << 4) & 0xF0F0F0F0u, xo_ = (X) & 0xF0F0F0F0u;  /* idx * 16, one per byte */ \
-    (void)xe_; (void)xo_
-#define P16_PERM(SRC, GBASE, J) __builtin_amdgcn_perm((SRC), (GBASE), 0x0c0c0100u | (uint32_t)(4 + (J)))
-#define P16_ISSUE(S, A0, A1, A2, A3, OFF)                                                            \
-    asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\t"                \
-                 "ds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8"                    \
-                 : "=&v"(S##0), "=&v"(S##1), "=&v"(S##2), "=&v"(S##3)                                \
-                 : "v"(A0), "v"(A1), "v"(A2), "v"(A3), "n"(OFF))
-#define P16_ISSUE_A(X, GBASE, OFF)                                                                   \
-    do {                                                                                             \
-        P16_ADDR(X, GBASE);                                                                          \
-        const uint32_t q0_ = P16_PERM(xe_, GBASE, 0), q1_ = P16_PERM(xo_, GBASE, 0);                 \
-        const uint32_t q2_ = P16_PERM(xe_, GBASE, 1), q3_ = P16_PERM(xo_, GBASE, 1);                 \
-        P16_ISSUE(a, q0_, q1_, q2_, q3_, OFF);                                                       \
-    } while (0)
-#define P16_ISSUE_B(X, GBASE, OFF)                                                                   \
-    do {                                                                                             \
-        P16_ADDR(X, GBASE);                                                                          \
-        const uint32_t q0_ = P16_PERM(xe_, GBASE, 2), q1_ = P16_PERM(xo_, GBASE, 2);                 \
-        const uint32_t q2_ = P16_PERM(xe_, GBASE, 3), q3_ = P16_PERM(xo_, GBASE, 3);                 \
-        P16_ISSUE(b, q0_, q1_, q2_, q3_, OFF);                                                       \
-    } while (0)
-#define P16_WAIT(S, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(S##0), "+v"(S##1), "+v"(S##2), "+v"(S##3))
-#define P16_ADD(S, E0)                                                                               \
-    do {                                                                                             \
-        acc[(E0) + 0] += (S##0).x; acc[(E0) + 1] += (S##0).y; acc[(E0) + 2] += (S##1).x; acc[(E0) + 3] += (S##1).y; \
-        acc[(E0) + 4] += (S##2).x; acc[(E0) + 5] += (S##2).y; acc[(E0) + 6] += (S##3).x; acc[(E0) + 7] += (S##3).y; \
-    } while (0)
-            // the row in flight retires, row XR (table at GBASE + OFF) is requested
-#define P16_STEP(XR, GBASE, OFF)                                                                     \
-    do {                                                                                             \
-        P16_WAIT(a, 4); P16_ADD(a, 0); P16_ISSUE_A(XR, GBASE, OFF);                                  \
-        P16_WAIT(b, 4); P16_ADD(b, 8); P16_ISSUE_B(XR, GBASE, OFF);                                  \
-    } while (0)
-#define P16_DRAIN()                                                                                  \
-    do {                                                                                             \
-        P16_WAIT(a, 4); P16_ADD(a, 0); P16_WAIT(b, 0); P16_ADD(b, 8);                                \
-    } while (0)
-            // the rows of a group become visible to the compiler at this point, not earlier: without it the
-            // compiler hoists work on rows that were just requested and waits for HBM in the middle of a group
-#define P16_FENCE(X) _Pragma("unroll") for (int u_ = 0; u_ < G; ++u_) asm volatile("" : "+v"((X)[u_]))
-            // the 8 missing-bit words of a group into the bit-sliced counters (pure VALU work: placed where it
-            // overlaps the LDS latency of the first / last reads of a group)
-#define P16_COUNT(X)                                                                                 \
-    do {                                                                                             \
-        uint32_t t2a_, t2b_, t4a_, t4b_, t8_;                                                        \
-        P16_CSA(t2a_, p1, p1, missing_bits((X)[0]), missing_bits((X)[1]));                           \
-        P16_CSA(t2b_, p1, p1, missing_bits((X)[2]), missing_bits((X)[3]));                           \
-        P16_CSA(t4a_, p2, p2, t2a_, t2b_);                                                           \
-        P16_CSA(t2a_, p1, p1, missing_bits((X)[4]), missing_bits((X)[5]));                           \
-        P16_CSA(t2b_, p1, p1, missing_bits((X)[6]), missing_bits((X)[7]));                           \
-        P16_CSA(t4b_, p2, p2, t2a_, t2b_);                                                           \
-        P16_CSA(t8_, p4, p4, t4a_, t4b_);                                                            \
-        uint32_t c_ = p8 & t8_;  p8 ^= t8_;                                                          \
-        uint32_t d_ = p16 & c_;  p16 ^= c_;                                                          \
-        c_ = p32 & d_;           p32 ^= d_;                                                          \
-        p64 ^= c_;                                                                                   \
-    } while (0)
-            // one group of 8 rows on its own (odd group count: last tile of all)
-#define P16_GROUP(X, GI)                                                                             \
-    do {                                                                                             \
-        const uint32_t gb_ = lds_base + (uint32_t)(GI) * (uint32_t)(G * 256);                        \
-        P16_FENCE(X);                                                                                \
-        f64x2_t a0, a1, a2, a3, b0, b1, b2, b3;                                                      \
-        P16_ISSUE_A((X)[0], gb_, 0); P16_ISSUE_B((X)[0], gb_, 0);                                    \
-        P16_COUNT(X);                                                                                \
-        P16_STEP((X)[1], gb_, 256); P16_STEP((X)[2], gb_, 512); P16_STEP((X)[3], gb_, 768);          \
-        P16_STEP((X)[4], gb_, 1024); P16_STEP((X)[5], gb_, 1280); P16_STEP((X)[6], gb_, 1536);       \
-        P16_STEP((X)[7], gb_, 1792);                                                                 \
-        P16_DRAIN();                                                                                 \
-    } while (0)
-            // a single row (tail of the very last tile)
-#define P16_ROW1(X, RBASE)                                                                           \
-    do {                                                                                             \
-        f64x2_t a0, a1, a2, a3, b0, b1, b2, b3;                                                      \
-        P16_ISSUE_A(X, RBASE, 0); P16_ISSUE_B(X, RBASE, 0);                                          \
-        P16_WAIT(a, 4); P16_ADD(a, 0); P16_WAIT(b, 0); P16_ADD(b, 8);                                \
-    } while (0)
-
-            int g = 0;
-            for (; g + 2 <= full_groups; g += 2) {
-                const int64_t rnext = tr0 + (int64_t)(g + 1) * G;
-                const int64_t rafter = (g + 2 < TR / G) ? rnext + G : ntr0;
-                // 16 rows with the LDS pipeline running through: group g (rows in xa) while group g+1 is requested
-                // from HBM into xb, then group g+1 while the group after it is requested into xa
-#pragma unroll
-                for (int u = 0; u < G; ++u) xb[u] = load(rnext + u);
-                const uint32_t gb = lds_base + (uint32_t)g * (uint32_t)(G * 256);
-                f64x2_t a0, a1, a2, a3, b0, b1, b2, b3;
-                P16_FENCE(xa);
-                P16_ISSUE_A(xa[0], gb, 0); P16_ISSUE_B(xa[0], gb, 0);
-                P16_COUNT(xa);
-                P16_STEP(xa[1], gb, 256); P16_STEP(xa[2], gb, 512); P16_STEP(xa[3], gb, 768);
-                P16_STEP(xa[4], gb, 1024); P16_STEP(xa[5], gb, 1280); P16_STEP(xa[6], gb, 1536);
-                P16_STEP(xa[7], gb, 1792);
-                P16_FENCE(xb);
-                P16_STEP(xb[0], gb, 2048);
-#pragma unroll
-                for (int u = 0; u < G; ++u) xa[u] = load(rafter + u);
-                P16_STEP(xb[1], gb, 2304); P16_STEP(xb[2], gb, 2560); P16_STEP(xb[3], gb, 2816);
-                P16_STEP(xb[4], gb, 3072); P16_STEP(xb[5], gb, 3328); P16_STEP(xb[6], gb, 3584);
-                P16_STEP(xb[7], gb, 3840);
-                P16_COUNT(xb);
-                P16_DRAIN();
-            }
-            if (g < full_groups) {                               // odd group count: only in the last tile of all
-                P16_GROUP(xa, g);
-            }
-            for (int r = full_groups * G; r < rows; ++r) {      // at most G-1 rows: last tile of all
-                const uint32_t x = load(tr0 + r);
-                const uint32_t rb = lds_base + (uint32_t)r * 256u;
-                P16_ROW1(x, rb);
-                uint32_t c = missing_bits(x), t;                 // ripple-carry add of one word
-                t = p1 & c; p1 ^= c; c = t;
-                t = p2 & c; p2 ^= c; c = t;
-                t = p4 & c; p4 ^= c; c = t;
-                t = p8 & c; p8 ^= c; c = t;
-                t = p16 & c; p16 ^= c; c = t;
-                t = p32 & c; p32 ^= c; c = t;
-                p64 ^= c;
-            }
-#undef P16_GROUP
-#undef P16_ROW1
-#undef P16_STEP
-#undef P16_DRAIN
-#undef P16_FENCE
-#undef P16_COUNT
-#undef P16_ADD
-#undef P16_WAIT
-#undef P16_ISSUE_A
-#undef P16_ISSUE_B
-#undef P16_ISSUE
-#undef P16_PERM
-#undef P16_ADDR
-            flush_planes();
-            if (staged) {
-                if (tid < TR * 4) {      // thread (row r, c): entries c + 4 j = (lut[r][c], lut[r][j]), lut[r][j] from its quad
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f64x2_t v;
-                        v.x = pre;
-                        v.y = __shfl(pre, (tid & (WAVE - 1) & ~3) + j);
-                        s_pair[buf ^ 1][(tid >> 2) * 16 + (tid & 3) + 4 * j] = v;
-                    }
-                }
-            } else if (more) {
-                fill_pairs(buf ^ 1, ntr0);
-            }
-            __syncthreads();
-        }
-        last_epoch = epoch;
-    }
-    store_partials(last_epoch);
-}
-#undef P16_CSA
-
-// ------------------------------------------------------------------------------------------------
-// Fast pass on a PACKED panel, FOUR ROWS PER LOOKUP (k_fast_packed_q4).
-//   k_fast_packed16 above issues one 16-byte LDS read and two additions per two comparisons and is bound by the LDS
-//   array and the fp64 adder together (51 ms on the packed 10k x 50M panel; its loads alone take 22 ms).  Here the
-//   block builds, per group of four rows, a 256-entry table  entry[c0 | c1 << 2 | c2 << 4 | c3 << 6] =
-//   ((lut[r][c0] + lut[r+1][c1]) + lut[r+2][c2]) + lut[r+3][c3]  (2 KiB per four rows), and a lane scores four rows of
-//   one accession with ONE 8-byte LDS read and ONE addition.  The index byte of every accession comes from a 4 x 16
-//   transpose of the rows' 2-bit fields (24 integer operations per 64 comparisons: fields -> nibbles -> bytes).
-//   The pre-added entries only change the summation tree of the fast pass (every term still passes through fewer
-//   additions than efast_bound assumes); the reference-order paths never use this kernel.
-//   Rows past the end of the matched list read as table rows of 0.0 and as call code 0 (not missing).
-//   Geometry, tile-interleaved parts, epochs, missing counters and outputs are those of k_fast_packed16.
+constexpr int P16_TILE_ROWS = 64;       // rows per tile of k_fast_bits (no LDS; the flush period of its bit-sliced counters)
+constexpr int P16_G = 8;                // rows per prefetch group of k_fast_bits
 constexpr int Q4_TILE_ROWS = 64;        // 16 four-row tables x 2 KiB = 32 KiB of LDS per block
 constexpr int Q4_G = 8;                 // rows per prefetch group (two tables)
 static_assert(Q4_TILE_ROWS % (2 * Q4_G) == 0 && Q4_TILE_ROWS <= 127, "two register sets per iteration; 7-bit missing counters per tile");
 
-#define Q4_CSA(H, L, A, B, C)             \
-    do {                                  \
-        const uint32_t u_ = (A) ^ (B);    \
-        const uint32_t h_ = ((A) & (B)) | (u_ & (C)); \
-        (L) = u_ ^ (C);                   \
-        (H) = h_;                         \
+// carry-save adder of three bit vectors: two v_bitop3_b32 (majority 0xE8, parity 0x96)
+#define Q4_CSA(H, L, A, B, C)                                                   \
+    do {                                                                        \
+        const uint32_t a_ = (A), b_ = (B), c_ = (C);                            \
+        (H) = __builtin_amdgcn_bitop3_b32(a_, b_, c_, 0xE8);                    \
+        (L) = __builtin_amdgcn_bitop3_b32(a_, b_, c_, 0x96);                    \
     } while (0)
 
 template <bool SKIP, bool GATHER, bool NT>
@@ -863,6 +561,8 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     for (int i = 0; i < 8; ++i) miss16[i] = 0;
 
     const uint32_t lane_off = lane_on ? (uint32_t)byte0 : 0u;
+    uint32_t three = 3u;                                   // shift count of the table index (SDWA takes no literal)
+    asm volatile("" : "+v"(three));
     auto load = [&](int64_t rr) -> uint32_t {
         const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
         const int8_t *rowbase = db + prow * pitch;
@@ -872,7 +572,7 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         return NT ? __builtin_nontemporal_load(ptr) : *ptr;
     };
     auto missing_bits = [](uint32_t x) -> uint32_t {
-        return SKIP ? ((x >> 1) & 0x55555555u) : (x & (x >> 1) & 0x55555555u);
+        return SKIP ? ((x >> 1) & 0x55555555u) : __builtin_amdgcn_bitop3_b32(x, x >> 1, 0x55555555u, 0x80);
     };
     // tables of one tile from its LUT rows in s_l4
     auto build_tables = [&]() {
@@ -935,24 +635,40 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     // (an index with the calls' low bits in bits 0-3 -- ref and alt entries of all four rows in distinct LDS banks -- costs
     // the same 24 operations and measured 8 % SLOWER: the pass is bound by instruction issue, not by the LDS array)
     auto score_quad = [&](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, const double *tab) {
+        // the pass is bound by VALU issue: every step below is pinned to the one instruction it needs (the compiler expands
+        // the merges into and / and / or and the byte extractions into shift + and: 6.2 instead of 4.2 VALU per lookup)
         const uint32_t M3 = 0x33333333u, MF = 0x0F0F0F0Fu;
-        const uint32_t e01 = (x0 & M3) | ((x1 & M3) << 2), o01 = ((x0 >> 2) & M3) | (x1 & ~M3);
-        const uint32_t e23 = (x2 & M3) | ((x3 & M3) << 2), o23 = ((x2 >> 2) & M3) | (x3 & ~M3);
+        auto bfi = [](uint32_t m, uint32_t a, uint32_t b) -> uint32_t {        // (a & m) | (b & ~m)
+            uint32_t d;
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(m), "v"(a), "v"(b));
+            return d;
+        };
+        const uint32_t e01 = bfi(M3, x0, x1 << 2), o01 = bfi(M3, x0 >> 2, x1);
+        const uint32_t e23 = bfi(M3, x2, x3 << 2), o23 = bfi(M3, x2 >> 2, x3);
         uint32_t w[4];
-        w[0] = (e01 & MF) | ((e23 & MF) << 4);
-        w[1] = (o01 & MF) | ((o23 & MF) << 4);
-        w[2] = ((e01 >> 4) & MF) | (e23 & ~MF);
-        w[3] = ((o01 >> 4) & MF) | (o23 & ~MF);
+        w[0] = bfi(MF, e01, e23 << 4);
+        w[1] = bfi(MF, o01, o23 << 4);
+        w[2] = bfi(MF, e01 >> 4, e23);
+        w[3] = bfi(MF, o01 >> 4, o23);
+        const char *tabc = reinterpret_cast<const char *>(tab);
+#define Q4_IDX(D, W, SEL)                                                                                             \
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL              \
+        : "=v"(D) : "v"(three), "v"(W))
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                     // eight lookups in flight, then their additions
+            uint32_t a8[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                 // byte 2h of w[j] -> accession 8h + j, byte 2h+1 -> 8h + 4 + j
+                if (h == 0) { Q4_IDX(a8[j], w[j], "BYTE_0"); Q4_IDX(a8[4 + j], w[j], "BYTE_1"); }
+                else        { Q4_IDX(a8[j], w[j], "BYTE_2"); Q4_IDX(a8[4 + j], w[j], "BYTE_3"); }
+            }
             double t[8];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[4 * m + j] = tab[(w[j] >> (8 * (2 * h + m))) & 0xffu];
+            for (int c = 0; c < 8; ++c) t[c] = *reinterpret_cast<const double *>(tabc + a8[c]);
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[8 * h + c] += t[c];
         }
+#undef Q4_IDX
     };
     // the 8 missing-bit words of a group into the bit-sliced counters
     auto count_group = [&](const uint32_t (&x)[G]) {
@@ -1063,9 +779,9 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
 //     lo = x & 0x5555..., hi = (x >> 1) & 0x5555...      (code = lo + 2 hi: 0 ref, 1 alt, 2 het, 3 missing)
 // a call scores when  (~lo & ~hi & R_ref) | (lo & ~hi & R_alt) | (~lo & hi & R_het),  R_c = 0x5555... or 0 from the
 // row's three weight bits (wave-uniform, scalar registers), and is missing when lo & hi (or hi with skip_hets).
-// Both bit vectors are counted per accession with the bit-sliced carry-save scheme of k_fast_packed16, flushed
+// Both bit vectors are counted per accession with the bit-sliced carry-save scheme of k_fast_packed_q4, flushed
 // into 16-bit counters every 64 rows.  ~1.1 integer operations and 0.25 B per comparison, no LDS, no barriers.
-// Geometry (16 accessions per lane, tile-interleaved parts, epochs, prefetch pipeline) as k_fast_packed16;
+// Geometry (16 accessions per lane, tile-interleaved parts, epochs, prefetch pipeline) as k_fast_packed_q4;
 // partial scores are written as fp64 counts so that the reduce kernels are shared.  wbits[r] = ref | het << 1 |
 // alt << 2 for query row r, padded to a multiple of 8 entries.
 #define BITS_CSA(H, L, A, B, C)           \

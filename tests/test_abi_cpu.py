@@ -61,7 +61,7 @@ def test_product_never_imports_oracle():
 
 
 def test_inline_asm_lds_reads_stay_untouched_until_waited_for(tmp_path):
-    """k_fast_packed16 / k_scan_few issue ds_read_b128 from inline asm and wait with counted s_waitcnt; the
+    """k_scan_few issues ds_read_b128 from inline asm and waits with counted s_waitcnt; the
     compiler does not know those registers are in flight.  Compile the device code to ISA and verify that nothing
     touches a destination register between its read and the wait that covers it (tools/check_inflight_regs.py)."""
     import shutil

@@ -273,6 +273,36 @@ def test_upload_roundtrip_and_canonical_codes(ctx):
     assert np.array_equal(bits(s), bits(ws)) and np.array_equal(ni, wn)
 
 
+@pytest.mark.parametrize("skip", [False, True])
+def test_reference_order_kernel_takes_both_forms(ctx, skip):
+    """k_strict4 scores panels whose calls are all in {-1, 0, 1, 2} with two compares per call and falls back to three
+    when an upload stored a call code > 2 (informative, matches no class: core/snpmatch.py:78-88 compares with 0, 1, 2
+    only).  The same panel first without, then with such calls -- the flag is raised by the second upload and stays."""
+    rng = np.random.default_rng(11)
+    n, n_acc = 5003, 1300
+    db = rng.choice(np.array([-1, 0, 1, 2], dtype=np.int8), size=(n, n_acc), p=[0.05, 0.6, 0.3, 0.05])
+    wei = rand_wei(rng, n)
+    panel = engine.Panel.from_host(ctx, db)
+    q = engine.Query(panel, None, wei)
+    s, ni = q.run(1000, skip, engine.MODE_STRICT)
+    ws, wn = c_oracle.genotyper(db, None, wei, 1000, skip)
+    assert np.array_equal(bits(s), bits(ws)) and np.array_equal(ni, wn)
+    db[17:4000:7, 3::5] = 3
+    db[4001, :] = 127
+    panel.upload_rows(0, db)
+    s, ni = q.run(1000, skip, engine.MODE_STRICT)
+    ws, wn = c_oracle.genotyper(db, None, wei, 1000, skip)
+    assert np.array_equal(bits(s), bits(ws)) and np.array_equal(ni, wn)
+    se, ne = q.run(1000, skip, engine.MODE_EXACT)
+    assert np.array_equal(ne, wn) and np.array_equal(np.array(se, dtype=np.int64), np.array(ws, dtype=np.int64))
+    # overwriting the rows with clean calls keeps the (conservative) flag: results stay the reference's
+    db[db > 2] = 0
+    panel.upload_rows(0, db)
+    s, ni = q.run(1000, skip, engine.MODE_STRICT)
+    ws, wn = c_oracle.genotyper(db, None, wei, 1000, skip)
+    assert np.array_equal(bits(s), bits(ws)) and np.array_equal(ni, wn)
+
+
 # ------------------------------------------------------------------ size-independent properties at scale
 def test_large_panel_properties(ctx):
     """10k accessions x 1M SNPs (10 GB) generated on the device: every informative element matches

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static check of the kernels that issue LDS reads from inline asm (k_fast_packed16, k_scan_few): between a
+"""Static check of the kernels that issue LDS reads from inline asm (k_scan_few): between a
 ds_read_b128 and the s_waitcnt that covers it, no other instruction may touch its destination registers (the
 compiler does not know they are in flight).  Input: the gfx950 .s file written by SNPM_SAVE_TEMPS=1 ./build_lib.sh.
 LDS reads return in order, so after `s_waitcnt lgkmcnt(N)` at most the N most recent reads are still pending
@@ -30,7 +30,7 @@ for line in open(path):
     if m:
         name, pending = m.group(1), []
         continue
-    if name is None or not ("k_fast_packed16" in name or "k_scan_few" in name):
+    if name is None or not ("k_scan_few" in name):
         continue
     t = line.strip()
     if not t or t.startswith((";", ".", "//")) or t.endswith(":"):
