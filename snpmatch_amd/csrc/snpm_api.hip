@@ -89,6 +89,7 @@ struct snpm_ctx {
     int stage_threads = 8;  // host threads repacking rows into the pinned staging slabs
     int nt_loads = 1;      // panel bytes are read once: non-temporal loads (+5-8% measured)
     int64_t f1_slab_bytes = int64_t(2) << 30;   // SNPM_F1_SLAB_BYTES: compacted-weight scratch of the in-silico crosses
+    int occ_cap = 0;          // SNPM_OCC_CAP=n: at most n resident blocks per CU in the fast pass (experiments)
     int full_occupancy = 0;   // SNPM_FULL_OCCUPANCY=1: as many resident blocks as the occupancy API allows
     int bits_path = 1;     // SNPM_BITS=0: hard-call samples on packed panels go through k_fast_packed_q4 like any other
     int packed_byte = 0;   // SNPM_PACKED_BYTE=1: packed panels through the one-byte-per-lane k_fast instead of k_fast_packed_q4
@@ -386,6 +387,7 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     if (bpl == 4 && tile_rows == TILE_ROWS && occ_blocks_hint > 0 && !ctx->full_occupancy && (g.wpb == 4 || g.wpb == 5) &&
         n * pitch_bytes >= (int64_t(32) << 30))
         occ = std::min(occ, std::max(3, 18 / g.wpb));
+    if (ctx->occ_cap > 0) occ = std::min(occ, ctx->occ_cap);
     int64_t resident = (int64_t)ctx->n_cu * occ * std::max(1, ctx->parts_mult);
     int64_t n_parts = std::max<int64_t>(1, resident / g.n_colblocks);
     const int64_t n_tiles = std::max<int64_t>(1, (n + tile_rows - 1) / tile_rows);
@@ -1276,6 +1278,7 @@ try {
     if (const char *s = getenv("SNPM_PACKED_BYTE")) ctx->packed_byte = atoi(s);
     if (const char *s = getenv("SNPM_BITS")) ctx->bits_path = atoi(s);
     if (const char *s = getenv("SNPM_FULL_OCCUPANCY")) ctx->full_occupancy = atoi(s);
+    if (const char *s = getenv("SNPM_OCC_CAP")) ctx->occ_cap = atoi(s);
     if (const char *s = getenv("SNPM_F1_SLAB_BYTES")) ctx->f1_slab_bytes = std::max<int64_t>(1, atoll(s));
     if (const char *s = getenv("SNPM_ACC_MAJOR")) ctx->use_acc_major = atoi(s);
     if (const char *s = getenv("SNPM_ACC_MAJOR_MIN_ROWS")) ctx->acc_major_min_rows = atoll(s);

@@ -47,6 +47,9 @@ namespace snpm {
 #ifndef SNPM_Q4_MIN_WAVES
 #define SNPM_Q4_MIN_WAVES 4
 #endif
+#ifndef SNPM_FAST_G
+#define SNPM_FAST_G 4                   // rows per prefetch group of the int8 fast pass (two groups in flight)
+#endif
 #ifndef SNPM_FAST_MIN_WAVES
 #define SNPM_FAST_MIN_WAVES 6
 #endif
@@ -321,7 +324,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     constexpr int EPL = PACKED ? 4 : BPL;   // accessions (= accumulators) per lane
     // rows per prefetch group: 4 (G*32 B = half a 256-B LUT block) for int8; 8 (a whole block) for the packed
     // layout, whose 64-B-per-wave row loads need twice as many in flight to cover the HBM latency
-    constexpr int G = PACKED ? 8 : 4;     // (8-row groups for int8 spill at the 80-VGPR budget and measured no gain)
+    constexpr int G = PACKED ? 8 : SNPM_FAST_G;     // (8-row groups for int8 spill at the 80-VGPR budget and measured no gain)
     __shared__ __attribute__((aligned(256))) double s_lut[2][TILE_ROWS * 4];
 
     const int tid = threadIdx.x;
@@ -423,7 +426,9 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
             double2 pre0 = make_double2(0.0, 0.0);
             const bool staged = more && nthr >= TILE_ROWS * 2;
             const int nrows2 = more ? 2 * (int)((rend - ntr0 < TILE_ROWS) ? (rend - ntr0) : TILE_ROWS) : 0;
+#if !defined(SNPM_FAST_PATTERN_ONLY) || SNPM_FAST_PATTERN_ONLY != 2
             if (staged && tid < nrows2) pre0 = reinterpret_cast<const double2 *>(lut + 4 * ntr0)[tid];
+#endif
 
             const uint32_t lds_base =
                 (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)(&s_lut[buf][0]);
@@ -438,8 +443,10 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
         const uint32_t roff4_ = roff_ * 0x01010101u;                                        \
         SCORE_ROW(0, (X)[0], gbase_, roff4_, roff_);                                        \
         SCORE_ROW(1, (X)[1], gbase_, roff4_, roff_);                                        \
-        SCORE_ROW(2, (X)[2], gbase_, roff4_, roff_);                                        \
-        SCORE_ROW(3, (X)[3], gbase_, roff4_, roff_);                                        \
+        if constexpr (G > 2) {                                                              \
+            SCORE_ROW(2, (X)[G > 2 ? 2 : 0], gbase_, roff4_, roff_);                        \
+            SCORE_ROW(3, (X)[G > 2 ? 3 : 0], gbase_, roff4_, roff_);                        \
+        }                                                                                   \
         if constexpr (G > 4) {                                                              \
             SCORE_ROW(4, (X)[G > 4 ? 4 : 0], gbase_, roff4_, roff_);                        \
             SCORE_ROW(5, (X)[G > 4 ? 5 : 0], gbase_, roff4_, roff_);                        \
@@ -480,6 +487,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
                 miss16[2 * k + 1] += (miss8[k] >> 8) & 0x00ff00ffu;   // bytes 1 and 3
                 miss8[k] = 0;
             }
+#if !defined(SNPM_FAST_PATTERN_ONLY) || SNPM_FAST_PATTERN_ONLY != 2
             if (more) {
                 double2 *dst = reinterpret_cast<double2 *>(&s_lut[buf ^ 1][0]);
                 if (staged) {
@@ -490,6 +498,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
                 }
             }
             __syncthreads();
+#endif
         }
         last_epoch = epoch;
     }
