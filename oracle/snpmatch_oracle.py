@@ -181,6 +181,26 @@ def get_common_positions(chr1, pos1, chr2, pos2):
 
 
 # --------------------------------------------------------------------------- a7 (windows)
+def segregating_rows(snps, accs_ix, block=1 << 16):
+    """DB rows on which the listed accessions segregate, as `snpmatch inbred --refine` selects them
+    (core/snp_genotype.py:188-211 with segregting_snps :378-383): per row the calls of those accessions as floats,
+    negative -> NaN, sorted; run = (#equal neighbours) + 1, info = #non-NaN; kept where run / info < 1 and info > 0
+    (i.e. at least two different informative calls).  None when more than half of all accessions are listed (:193)."""
+    accs_ix = np.asarray(accs_ix)
+    if len(accs_ix) > snps.shape[1] / 2:
+        return None
+    run = np.zeros(0, dtype=int)
+    info = np.zeros(0, dtype=int)
+    for j in range(0, snps.shape[0], block):                     # :199-203 walks the DB in blocks
+        t = np.array(snps[j:j + block, :][:, accs_ix], dtype=float)
+        t[t < 0] = np.nan                                         # :379
+        t = np.sort(t, axis=1)                                    # :380
+        info = np.append(info, np.sum(~np.isnan(t), axis=1))      # :381
+        run = np.append(run, np.nansum(t[:, 1:] == t[:, :-1], axis=1) + 1)     # :382
+    div = np.divide(run, info, out=np.zeros(len(run)), where=info != 0)         # :206
+    return np.setdiff1d(np.where(div < 1)[0], np.where(info == 0)[0])            # :207-208
+
+
 def bins_echr(real_chrlen, chr_pos, bin_len, rel_ix):
     """``get_bins_echr`` (core/genomes.py:111-127) as a list, same walk."""
     out = []

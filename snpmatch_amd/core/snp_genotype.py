@@ -196,28 +196,28 @@ class Genotype(object):
 
     @staticmethod
     def get_common_positions(input_1_chr, input_1_pos, input_2_chr, input_2_pos):
-        """core/snp_genotype.py:46-68: chromosomes in the order of input 1, per chromosome the
-        positions present in both inputs (inputs sorted and unique per chromosome)."""
+        """Rows of input 1 and of input 2 whose (chromosome, position) occurs in both, chromosomes in the order in
+        which input 1 first names them (the contract of core/snp_genotype.py:46-68; 'Chr1' / 'chr1' / '1' are one
+        chromosome).  Each side is grouped once (one stable sort of its chromosome index); a chromosome both sides
+        hold is intersected by the native sorted merge when both position lists are strictly increasing, otherwise by
+        the membership masks the reference builds (np.isin with assume_unique, quirks on repeated positions included)."""
         assert len(input_1_chr) == len(input_1_pos), "Both chromosome and position array provided should be of same length"
         assert len(input_2_chr) == len(input_2_pos), "Both chromosome and position array provided should be of same length"
-        in1 = parsers.ParseInputs("")
-        in1.load_snp_info(snpCHR=input_1_chr, snpPOS=input_1_pos, snpGT="", snpWEI=np.nan, DPmean=0)
-        in1.filter_chr_names()
-        in2 = parsers.ParseInputs("")
-        in2.load_snp_info(snpCHR=input_2_chr, snpPOS=input_2_pos, snpGT="", snpWEI=np.nan, DPmean=0)
-        in2.filter_chr_names()
-        common = np.intersect1d(in1.g_chrs_ids, in2.g_chrs_ids)
-        common = in1.g_chrs_ids[np.where(np.isin(in1.g_chrs_ids, common))[0]]
-        idx1 = np.zeros(0, dtype=int)
-        idx2 = np.zeros(0, dtype=int)
-        for cid in common:
-            ix1 = np.where(in1.g_chrs == cid)[0]
-            ix2 = np.where(in2.g_chrs == cid)[0]
-            p1 = np.array(in1.pos[ix1], dtype=int)
-            p2 = np.array(in2.pos[ix2], dtype=int)
-            idx1 = np.append(idx1, ix1[np.where(np.isin(p1, p2, assume_unique=True))[0]])
-            idx2 = np.append(idx2, ix2[np.where(np.isin(p2, p1, assume_unique=True))[0]])
-        return (idx1, idx2)
+        side1, side2 = _rows_by_chromosome(input_1_chr, input_1_pos), _rows_by_chromosome(input_2_chr, input_2_pos)
+        hits1, hits2 = [np.zeros(0, dtype=int)], [np.zeros(0, dtype=int)]
+        for cid in side1.order:
+            if cid not in side2.rows:
+                continue
+            rows1, rows2 = side1.rows[cid], side2.rows[cid]
+            pos1, pos2 = side1.pos[rows1], side2.pos[rows2]
+            merged = _lib.intersect_sorted(pos1, pos2)
+            if merged is not None:
+                hits1.append(rows1[merged[0]])
+                hits2.append(rows2[merged[1]])
+            else:
+                hits1.append(rows1[np.isin(pos1, pos2, assume_unique=True)])
+                hits2.append(rows2[np.isin(pos2, pos1, assume_unique=True)])
+        return (np.concatenate(hits1).astype(int), np.concatenate(hits2).astype(int))
 
     def get_matching_accs_ix(self, accs, return_np=False):
         acc_ix = []
@@ -231,48 +231,47 @@ class Genotype(object):
     # ------------------------------------------------------------------ --refine support
     def identify_segregating_snps(self, accs_ix):
         """DB rows where the given accessions do not all carry the same informative call
-        (core/snp_genotype.py:188-211, segregting_snps :378-383)."""
+        (core/snp_genotype.py:188-211, segregting_snps :378-383) -- scanned on the device, where the DB lives."""
         assert type(accs_ix) is np.ndarray, "provide an np array for list of indices to be considered"
         assert len(accs_ix) > 1, "polymorphism happens in more than 1 line"
         if len(accs_ix) > (len(self.accessions) / 2):
             return None
-        if self._panel is not None and self._panel.h is not None:
-            shard = getattr(self, "_shard", None)
-            if shard is not None:
-                # accession-sharded: every rank scans the listed accessions it holds; a row segregates when some
-                # rank saw two different calls, or two ranks saw different ones
-                from .. import dist
-                accs_ix = np.asarray(accs_ix)
-                local = accs_ix[(accs_ix >= shard[0]) & (accs_ix < shard[1])] - shard[0]
-                mask, first = self._panel.segregating_first(local)
-                both = dist.job().all_gather_bytes(np.stack([mask, first]))          # [world, 2, n_snp]
-                firsts = both[:, 1, :]
-                seen = firsts != 0xFF
-                lo = np.where(seen, firsts, 255).min(axis=0)
-                hi = np.where(seen, firsts, 0).max(axis=0)
-                return np.where(both[:, 0, :].any(axis=0) | (seen.any(axis=0) & (lo != hi)))[0]
-            # the DB is resident in HBM: one device scan over the listed columns
-            return np.where(self._panel.segregating_rows(accs_ix))[0]
-        n_snps = self.g.positions.shape[0]
-        seg_counts = np.zeros(0, dtype=int)
-        total_counts = np.zeros(0, dtype=int)
-        snps = self.g.snps
-        for j in range(0, n_snps, 1 << 16):
-            t = np.array(snps[j:j + (1 << 16), :][:, accs_ix], dtype=float)
-            s, r = segregting_snps(t)
-            seg_counts = np.append(seg_counts, s)
-            total_counts = np.append(total_counts, r)
-        div_counts = np.divide(seg_counts, total_counts, out=np.zeros(len(seg_counts)), where=total_counts != 0)
-        seg_ix = np.setdiff1d(np.where(div_counts < 1)[0], np.where(total_counts == 0)[0])
-        return seg_ix
+        panel = self.panel()                       # resident after the genome-wide pass; uploaded now otherwise
+        shard = getattr(self, "_shard", None)
+        if shard is not None:
+            # accession-sharded: every rank scans the listed accessions it holds; a row segregates when some
+            # rank saw two different calls, or two ranks saw different ones
+            from .. import dist
+            accs_ix = np.asarray(accs_ix)
+            local = accs_ix[(accs_ix >= shard[0]) & (accs_ix < shard[1])] - shard[0]
+            mask, first = panel.segregating_first(local)
+            both = dist.job().all_gather_bytes(np.stack([mask, first]))          # [world, 2, n_snp]
+            firsts = both[:, 1, :]
+            seen = firsts != 0xFF
+            lo = np.where(seen, firsts, 255).min(axis=0)
+            hi = np.where(seen, firsts, 0).max(axis=0)
+            return np.where(both[:, 0, :].any(axis=0) | (seen.any(axis=0) & (lo != hi)))[0]
+        return np.where(panel.segregating_rows(accs_ix))[0]        # one device scan over the listed columns (k_segregating)
 
 
-def segregting_snps(t):
-    """per row: (size of the longest run after sorting = #equal-neighbour pairs + 1, #informative);
-    core/snp_genotype.py:378-383."""
-    t = np.array(t, dtype=float)
-    t[t < 0] = np.nan
-    t = np.sort(t, axis=1)
-    t_r_sum = np.sum(~np.isnan(t), axis=1)
-    t_sum = np.nansum(t[:, 1:] == t[:, :-1], axis=1) + 1
-    return (t_sum, t_r_sum)
+class _ChromosomeRows(object):
+    """One side of a position intersection: ``order`` = chromosome ids as first named, ``rows[id]`` = its row numbers
+    in input order, ``pos`` = all positions as integers."""
+    __slots__ = ("order", "rows", "pos")
+
+
+def _rows_by_chromosome(chrs, pos):
+    ins = parsers.ParseInputs("")
+    ins.load_snp_info(snpCHR=chrs, snpPOS=pos, snpGT="", snpWEI=np.nan, DPmean=0)
+    ins.filter_chr_names()
+    side = _ChromosomeRows()
+    side.order = [str(c) for c in ins.g_chrs_ids.tolist()]
+    side.pos = np.asarray(ins.pos).astype(int)
+    side.rows = {}
+    if len(side.order):
+        names, inv = np.unique(ins.g_chrs, return_inverse=True)
+        by_name = np.argsort(inv, kind="stable")                      # rows grouped by chromosome, input order kept
+        ends = np.cumsum(np.bincount(inv, minlength=len(names)))
+        for k, name in enumerate(names.tolist()):
+            side.rows[str(name)] = by_name[(ends[k - 1] if k else 0):ends[k]]
+    return side

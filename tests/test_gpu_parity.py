@@ -434,13 +434,14 @@ def test_segregating_rows_on_device(ctx):
     db = rand_db(rng, 70000, 40)
     db[:, 5] = db[:, 4]                       # identical pair: segregating only where one of them is missing? no: never
     g = snp_genotype.Genotype.from_arrays(db, ["a%d" % i for i in range(40)], np.arange(1, 70001), ["1"], [(0, 70000)])
-    want = g.identify_segregating_snps(np.array([4, 5]))            # host path (panel not resident yet)
-    assert len(want) == 0
-    want = g.identify_segregating_snps(np.array([1, 4, 9, 17]))
+    assert len(orc.segregating_rows(db, np.array([4, 5]))) == 0
     panel = g.panel(ctx)
+    assert len(g.identify_segregating_snps(np.array([4, 5]))) == 0
+    want = orc.segregating_rows(db, np.array([1, 4, 9, 17]))
     got = np.where(panel.segregating_rows(np.array([1, 4, 9, 17])))[0]
     assert np.array_equal(got, want) and len(got) > 1000
-    assert np.array_equal(g.identify_segregating_snps(np.array([1, 4, 9, 17])), want)      # device path now
+    assert np.array_equal(g.identify_segregating_snps(np.array([1, 4, 9, 17])), want)
+    assert g.identify_segregating_snps(np.arange(21)) is None and orc.segregating_rows(db, np.arange(21)) is None
 
 
 def test_exact_mode_on_accession_major_copy():

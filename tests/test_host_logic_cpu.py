@@ -3,6 +3,7 @@ native panel format, drop-in import path."""
 import os
 
 import numpy as np
+import pytest
 
 from oracle import snpmatch_oracle as orc
 from snpmatch_amd.core import genomes, parsers, snp_genotype
@@ -132,10 +133,20 @@ def test_segregating_snps():
     snps = np.array([[0, 0, 0, 1], [0, 1, -1, 0], [-1, -1, -1, 0], [1, 1, 1, 1], [2, 1, 1, 0], [0, -1, 0, 1]], dtype=np.int8)
     g = snp_genotype.Genotype.from_arrays(np.repeat(snps, 3, axis=1), ["a%d" % i for i in range(12)],
                                           np.arange(1, 7), ["1"], [(0, 6)])
-    # accessions 0,1,2 are copies of column 0; 3,4,5 of column 1 -> rows where col0 != col1 (both informative)
-    seg = g.identify_segregating_snps(np.array([0, 3]))
-    assert seg.tolist() == [1, 4]
     assert g.identify_segregating_snps(np.arange(7)) is None          # more than half of the lines
+    db = np.repeat(snps, 3, axis=1)
+    assert orc.segregating_rows(db, np.array([0, 3])).tolist() == [1, 4] and orc.segregating_rows(db, np.arange(7)) is None
+    # accessions 0,1,2 are copies of column 0; 3,4,5 of column 1 -> rows where col0 != col1 (both informative).
+    # The scan runs on the device (k_segregating); without one the call fails loudly, nothing is computed on the host.
+    import ctypes as C
+    from snpmatch_amd import _lib
+    n = C.c_int(0)
+    _lib.load().snpm_device_count(C.byref(n))
+    if n.value > 0:
+        assert g.identify_segregating_snps(np.array([0, 3])).tolist() == [1, 4]
+    else:
+        with pytest.raises(Exception):
+            g.identify_segregating_snps(np.array([0, 3]))
 
 
 def test_native_panel_roundtrip(golden_dir, tmp_path):
