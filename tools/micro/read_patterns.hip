@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(256) k_read(const T *__restrict__ p, long n, u
 
 // k_fast's shape: a block of W waves owns W*256 contiguous bytes of every row of a tile; rows are `pitch` apart
 template <int U, bool NT>
-__global__ void __launch_bounds__(512) k_rows(const unsigned *__restrict__ p, long pitch_dw, long nrows, long tile_rows, unsigned *out)
+__global__ void __launch_bounds__(1024) k_rows(const unsigned *__restrict__ p, long pitch_dw, long nrows, long tile_rows, unsigned *out)
 {
     const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;     // dword column
     if (col >= pitch_dw) return;
@@ -142,6 +142,7 @@ int main(int argc, char **argv)
         printf("row tiles, pipelined  %d-wave blocks  groups of %d (<= %d in flight)  %s  %d blocks/CU : %7.3f ms  %6.0f GB/s\n", W, G, 2 * G, \
                NT ? "nt" : "  ", OCC, ms, nrows * 10240.0 / ms / 1e6);                                         \
     } while (0)
+    ROWS(4, true, 16, 1); ROWS(4, true, 16, 2); ROWS(8, true, 16, 1); ROWS(4, true, 10, 2); ROWS(4, true, 10, 3); ROWS(2, true, 16, 2);
     ROWS_DB(4, true, 8, 3); ROWS_DB(4, true, 8, 2); ROWS_DB(2, true, 8, 3); ROWS_DB(2, true, 8, 4); ROWS_DB(1, true, 8, 3); ROWS_DB(4, true, 4, 4);
     return 0;
 }
