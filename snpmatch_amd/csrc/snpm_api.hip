@@ -575,9 +575,12 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     const int tile_rows = p16 ? (bits ? P16_TILE_ROWS : Q4_TILE_ROWS) : TILE_ROWS;
     // k_fast_bits has no LDS tile and no barrier: one wave per block fills every wave slot of a CU evenly (measured on the
     // packed 10k x 50M panel: 22.4 ms with 1- or 2-wave blocks, 26.9 ms with the 5-wave blocks of the LUT kernels, 30.7 with 3)
-    // k_fast_packed_q4: 4-wave blocks (one wave per SIMD; 35.9 ms against 38.5 with 5-wave blocks on 10 000 accessions,
-    // although 2 of its 12 waves there only help to build the tables)
-    const int wpb_fixed = bits ? 1 : (p16 ? 4 : 0);
+    // k_fast_packed_q4: 4-wave blocks (one wave per SIMD; 33.5 ms against 34.5 with 5-wave blocks on 10 000 accessions,
+    // although 2 of its 12 waves there only help to build the tables; 2- and 3-wave blocks 40-41 ms) -- except for panels
+    // of exactly five waves (4097-5120 accessions): one 5-wave block instead of two 4-wave blocks with three idle waves
+    // (17.5 against 23.4 ms on 5000 x 50M)
+    const int64_t p16_waves = (p->n_acc + 1023) / 1024;
+    const int wpb_fixed = bits ? 1 : (p16 ? (p16_waves == 5 ? 5 : 4) : 0);
     FastGeom g0 = fast_geom(ctx, p->n_acc, q->n, 2, bpl, tile_rows, wpb_fixed);   // wpb does not depend on occupancy
     int occ = 0;
     const bool nt = ctx->nt_loads != 0;

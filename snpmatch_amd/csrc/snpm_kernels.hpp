@@ -44,6 +44,9 @@ namespace snpm {
 #ifndef SNPM_P16_MIN_WAVES
 #define SNPM_P16_MIN_WAVES 4
 #endif
+#ifndef SNPM_Q4_BITIDX
+#define SNPM_Q4_BITIDX 0                // k_fast_packed_q4: 1 = table index with the calls' low bits in bits 0-3 (fewer LDS bank conflicts, 8 more VALU per 64 comparisons)
+#endif
 #ifndef SNPM_Q4_MIN_WAVES
 #define SNPM_Q4_MIN_WAVES 4
 #endif
@@ -591,11 +594,21 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             const int e = i & 63;
             const double pre3 = (L[e & 3] + L[4 + ((e >> 2) & 3)]) + L[8 + (e >> 4)];
             const double2 l3a = *reinterpret_cast<const double2 *>(L + 12), l3b = *reinterpret_cast<const double2 *>(L + 14);
+#if SNPM_Q4_BITIDX
+            const int c0 = e & 3, c1 = (e >> 2) & 3, c2 = e >> 4;
+            const int eb = (c0 & 1) | ((c1 & 1) << 1) | ((c2 & 1) << 2) | ((c0 >> 1) << 4) | ((c1 >> 1) << 5) | ((c2 >> 1) << 6);
+            double *dst = s_tab + 256 * (i >> 6) + eb;
+            dst[0] = pre3 + l3a.x;          // c3 = 0
+            dst[8] = pre3 + l3a.y;          // c3 = 1: bit 3
+            dst[128] = pre3 + l3b.x;        // c3 = 2: bit 7
+            dst[136] = pre3 + l3b.y;        // c3 = 3
+#else
             double *dst = s_tab + 256 * (i >> 6) + e;
             dst[0] = pre3 + l3a.x;
             dst[64] = pre3 + l3a.y;
             dst[128] = pre3 + l3b.x;
             dst[192] = pre3 + l3b.y;
+#endif
         }
     };
     auto flush_planes = [&]() {
@@ -652,8 +665,21 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(m), "v"(a), "v"(b));
             return d;
         };
+#if SNPM_Q4_BITIDX
+        // index byte = low bits of the four calls in bits 0-3, high bits in bits 4-7 (one transpose stage more): the LDS
+        // bank of an entry is its index mod 32, so entries that differ only in ref / alt calls never share a bank.
+        // With the field index below 63 % of the LDS-array cycles are bank-conflict cycles (SQ_LDS_BANK_CONFLICT /
+        // SQ_LDS_IDX_ACTIVE, profiles/r02b_sq_fast_packed_q4.txt) -- and yet this form is not faster: 31.9 vs 32.0 ms on
+        // 10 000 accessions, 5.9 vs 5.2 ms on 1135: the eight extra VALU instructions cost what the conflicts cost.
+        const uint32_t M1 = 0x55555555u;
+        const uint32_t l01 = bfi(M1, x0, x1 << 1), h01 = bfi(M1, x0 >> 1, x1);
+        const uint32_t l23 = bfi(M1, x2, x3 << 1), h23 = bfi(M1, x2 >> 1, x3);
+        const uint32_t e01 = bfi(M3, l01, l23 << 2), o01 = bfi(M3, l01 >> 2, l23);      // nibbles [lo0 lo1 lo2 lo3]
+        const uint32_t e23 = bfi(M3, h01, h23 << 2), o23 = bfi(M3, h01 >> 2, h23);      // nibbles [hi0 hi1 hi2 hi3]
+#else
         const uint32_t e01 = bfi(M3, x0, x1 << 2), o01 = bfi(M3, x0 >> 2, x1);
         const uint32_t e23 = bfi(M3, x2, x3 << 2), o23 = bfi(M3, x2 >> 2, x3);
+#endif
         uint32_t w[4];
         w[0] = bfi(MF, e01, e23 << 4);
         w[1] = bfi(MF, o01, o23 << 4);

@@ -10,7 +10,7 @@ from snpmatch_amd import engine  # noqa: E402
 
 n_acc, n_snp = 10000, 2_000_000
 ctx = engine.Context(0)
-panel = engine.Panel(ctx, n_snp, n_acc)
+panel = engine.Panel(ctx, n_snp, n_acc, packed=os.environ.get("PMC_PACKED", "0") == "1")
 panel.fill_synthetic(bench.SEED)
 wei = torch.empty((n_snp, 3), dtype=torch.float64, device="cuda:0")
 ctx.sample_synthetic(bench.SEED, 0, n_snp, bench.PLANTED, wei.data_ptr())
