@@ -7,7 +7,9 @@ properties plus the C oracle on a few whole columns:
   * 12 500 accessions x 16M SNPs int8 (200 GB): the per-GPU slab of configs[4] (the accession-major copy does
     not fit beside it, so the re-evaluation takes the SNP-major path).
 
-Both contexts run with SNPM_DEBUG_REEVAL=2: accessions 0 and 1 are re-evaluated in reference order in every
+A third case holds the WHOLE 10 000 x 50M job on one GPU as a 2-bit packed panel.
+
+All contexts run with SNPM_DEBUG_REEVAL=2: accessions 0 and 1 are re-evaluated in reference order in every
 certified run, so k_pack_transpose + k_strict_sparse_T (or the strided k_strict_sparse) + k_scan_few + k_patch
 execute at full length whether or not the certificate flags anything.  Reference: core/snpmatch.py:207-233.
 """
@@ -44,10 +46,10 @@ def reeval_context():
         del os.environ["SNPM_DEBUG_REEVAL"]
 
 
-def check_shape(n_snp, n_acc, acc0, planted, oracle_quads, ninfo_quads):
+def check_shape(n_snp, n_acc, acc0, planted, oracle_quads, ninfo_quads, packed=False):
     ctx = reeval_context()
     try:
-        panel = engine.Panel(ctx, n_snp, n_acc)
+        panel = engine.Panel(ctx, n_snp, n_acc, packed=packed)
         panel.fill_synthetic(SEED, 0, acc0)
         # (1) all-ones weights: every informative call matches exactly one class -> score == ninfo (fast and
         #     certified mode agree; integer weights need no re-evaluation)
@@ -120,6 +122,13 @@ def test_config3_last_rank_shard_1236_x_50M():
 def test_config4_per_gpu_slab_12500_x_16M():
     """the per-GPU slab of configs[4] (100k x 100M over 8 GPUs: 12 500 accessions x <= 16M SNPs, 200 GB)"""
     check_shape(16_000_000, 12_500, 0, planted=417, oracle_quads=[0, 416], ninfo_quads=[0, 12_496])
+
+
+def test_config3_whole_job_on_one_gpu_packed_10000_x_50M():
+    """the whole configs[3] job resident on ONE GPU as a 2-bit packed panel (125 GB, plus its accession-major copy): the
+    four-rows-per-lookup fast pass (k_fast_packed_q4) with its certificate, the bit-parallel hard-call pass (k_fast_bits),
+    the table-driven reference-order kernel (k_strict4 on packed rows) over all 50M SNPs, forced re-evaluations"""
+    check_shape(50_000_000, 10_000, 0, planted=417, oracle_quads=[416], ninfo_quads=[0, 9996], packed=True)
 
 
 def test_slab_streamed_job_equals_resident_10000_x_12M():
