@@ -92,7 +92,6 @@ struct snpm_ctx {
     int occ_cap = 0;          // SNPM_OCC_CAP=n: at most n resident blocks per CU in the fast pass (experiments)
     int full_occupancy = 0;   // SNPM_FULL_OCCUPANCY=1: as many resident blocks as the occupancy API allows
     int bits_path = 1;     // SNPM_BITS=0: hard-call samples on packed panels go through k_fast_packed_q4 like any other
-    int packed_byte = 0;   // SNPM_PACKED_BYTE=1: packed panels through the one-byte-per-lane k_fast instead of k_fast_packed_q4
     // live panels of this context: snpm_destroy releases their device memory and orphans them (and their
     // queries), so that a panel / query handle freed AFTER its context is a harmless host-side delete
     std::vector<snpm_panel *> panels;
@@ -425,6 +424,9 @@ int launch_fast_b(snpm_query *q, const FastGeom &g, bool skip, bool gather)
     return gather ? launch_fast_t<BPL, false, true, NT>(q, g) : launch_fast_t<BPL, false, false, NT>(q, g);
 }
 
+// block shape of k_fast_packed_q4 (a wave covers 1024 accessions): see run_fast
+static int q4_waves_per_block(int64_t n_acc) { return (n_acc + 1023) / 1024 == 5 ? 5 : 4; }
+
 // packed panels, 16 accessions per lane (k_fast_packed_q4)
 template <bool SKIP, bool GATHER, bool NT>
 int launch_p16_t(snpm_query *q, const FastGeom &g, int *occ_out, int threads)
@@ -567,10 +569,9 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     int rc = ensure_lut(q, skip);
     if (rc) return rc;
     const bool gather = q->d_row_idx != nullptr;
-    // packed panels: 16 accessions (one dword) per lane and row, four rows per table lookup (k_fast_packed_q4); the older
-    // one-byte-per-lane instantiation of k_fast stays selectable (SNPM_PACKED_BYTE=1) for comparison
-    const bool p16 = p->packed && !ctx->packed_byte;
-    const int bpl = p16 ? 16 : (p->packed ? 4 : pick_bpl(ctx, p->n_acc));
+    // packed panels: 16 accessions (one dword) per lane and row, four rows per table lookup (k_fast_packed_q4)
+    const bool p16 = p->packed != 0;
+    const int bpl = p16 ? 16 : pick_bpl(ctx, p->n_acc);
     const bool bits = p16 && q->hard01 && ctx->bits_path;      // counts instead of weighted sums
     const int tile_rows = p16 ? (bits ? P16_TILE_ROWS : Q4_TILE_ROWS) : TILE_ROWS;
     // k_fast_bits has no LDS tile and no barrier: one wave per block fills every wave slot of a CU evenly (measured on the
@@ -579,15 +580,13 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     // although 2 of its 12 waves there only help to build the tables; 2- and 3-wave blocks 40-41 ms) -- except for panels
     // of exactly five waves (4097-5120 accessions): one 5-wave block instead of two 4-wave blocks with three idle waves
     // (17.5 against 23.4 ms on 5000 x 50M)
-    const int64_t p16_waves = (p->n_acc + 1023) / 1024;
-    const int wpb_fixed = bits ? 1 : (p16 ? (p16_waves == 5 ? 5 : 4) : 0);
+    const int wpb_fixed = bits ? 1 : (p16 ? q4_waves_per_block(p->n_acc) : 0);
     FastGeom g0 = fast_geom(ctx, p->n_acc, q->n, 2, bpl, tile_rows, wpb_fixed);   // wpb does not depend on occupancy
     int occ = 0;
     const bool nt = ctx->nt_loads != 0;
     const int thr = WAVE * g0.wpb;
     if (bits) (void)launch_bits(q, g0, skip, gather, nt, &occ, thr);
     else if (p16) (void)launch_p16(q, g0, skip, gather, nt, &occ, thr);
-    else if (p->packed) occ = nt ? occ_b<1, true>(skip, gather, thr) : occ_b<1, false>(skip, gather, thr);
     else if (bpl == 16) occ = nt ? occ_b<16, true>(skip, gather, thr) : occ_b<16, false>(skip, gather, thr);
     else if (bpl == 8) occ = nt ? occ_b<8, true>(skip, gather, thr) : occ_b<8, false>(skip, gather, thr);
     else occ = nt ? occ_b<4, true>(skip, gather, thr) : occ_b<4, false>(skip, gather, thr);
@@ -618,7 +617,6 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
         }
         if (bits) rc = launch_bits(q, g, skip, gather, nt, nullptr, thr);
         else if (p16) rc = launch_p16(q, g, skip, gather, nt, nullptr, thr);
-        else if (p->packed) rc = nt ? launch_fast_b<1, true>(q, g, skip, gather) : launch_fast_b<1, false>(q, g, skip, gather);
         else if (bpl == 16) rc = nt ? launch_fast_b<16, true>(q, g, skip, gather) : launch_fast_b<16, false>(q, g, skip, gather);
         else if (bpl == 8) rc = nt ? launch_fast_b<8, true>(q, g, skip, gather) : launch_fast_b<8, false>(q, g, skip, gather);
         else rc = nt ? launch_fast_b<4, true>(q, g, skip, gather) : launch_fast_b<4, false>(q, g, skip, gather);
@@ -858,6 +856,25 @@ constexpr int SEG_PAIR_CAP = 32768;
 int *seg_pair_count(snpm_ctx *ctx) { return (int *)ctx->ws_pairs.p; }
 int32_t *seg_pairs(snpm_ctx *ctx) { return (int32_t *)((char *)ctx->ws_pairs.p + 16); }
 
+template <bool NT>
+static int launch_q4_seg(snpm_ctx *ctx, const SegJob &j, dim3 grid, dim3 block, int64_t n_parts, const int64_t *d_desc)
+{
+    snpm_panel *p = j.p;
+    const bool gather = j.d_row_idx != nullptr;
+    ProfScope ps(ctx, PK_FAST);
+#define LAUNCH_SEG(S, G)                                                                                          \
+    hipLaunchKernelGGL((k_fast_packed_q4<S, G, NT, true>), grid, block, 0, ctx->stream, p->d, p->pitch, j.d_row_idx, j.row0, \
+                       n_parts, j.d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, d_desc)
+    if (j.skip) {
+        if (gather) LAUNCH_SEG(true, true); else LAUNCH_SEG(true, false);
+    } else {
+        if (gather) LAUNCH_SEG(false, true); else LAUNCH_SEG(false, false);
+    }
+#undef LAUNCH_SEG
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
 template <int BPL, bool NT>
 static int launch_fast_seg(snpm_ctx *ctx, const SegJob &j, dim3 grid, dim3 block, int64_t n_parts, const int64_t *d_desc)
 {
@@ -892,7 +909,10 @@ static int seg_plan(snpm_ctx *ctx, SegJob &j, SegPlan &pl)
 {
     snpm_panel *p = j.p;
     const int64_t n_seg = j.n_seg;
-    pl.g0 = fast_geom(ctx, p->n_acc, TILE_ROWS, 2, 4, TILE_ROWS);      // int8: a dword per lane; packed: a byte (4 accessions)
+    // int8: a dword (4 accessions) per lane, k_fast<4, SEG>; packed: a dword (16 accessions) per lane, k_fast_packed_q4<SEG>
+    const bool q4 = p->packed != 0;
+    pl.g0 = q4 ? fast_geom(ctx, p->n_acc, TILE_ROWS, 2, 16, TILE_ROWS, q4_waves_per_block(p->n_acc))
+               : fast_geom(ctx, p->n_acc, TILE_ROWS, 2, 4, TILE_ROWS);
     int64_t total_tiles = 0, kmax = 1;
     for (int64_t s = 0; s < n_seg; ++s) {
         const int64_t len = j.seg_off[s + 1] - j.seg_off[s];
@@ -983,7 +1003,7 @@ static int seg_launch(snpm_ctx *ctx, const SegJob &j, const SegPlan &pl, int64_t
         dim3 grid((unsigned)pl.g0.n_colblocks, gy, gz), block(WAVE * pl.g0.wpb);
         const bool nt = ctx->nt_loads != 0;
         const int64_t *desc = pl.d_desc + 3 * p0;
-        if (p->packed) rc = nt ? launch_fast_seg<1, true>(ctx, j, grid, block, np, desc) : launch_fast_seg<1, false>(ctx, j, grid, block, np, desc);
+        if (p->packed) rc = nt ? launch_q4_seg<true>(ctx, j, grid, block, np, desc) : launch_q4_seg<false>(ctx, j, grid, block, np, desc);
         else rc = nt ? launch_fast_seg<4, true>(ctx, j, grid, block, np, desc) : launch_fast_seg<4, false>(ctx, j, grid, block, np, desc);
         if (rc) return rc;
     }
@@ -1278,7 +1298,6 @@ try {
     if (const char *s = getenv("SNPM_PARTS_MULT")) ctx->parts_mult = std::max(1, atoi(s));
     if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
     if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
-    if (const char *s = getenv("SNPM_PACKED_BYTE")) ctx->packed_byte = atoi(s);
     if (const char *s = getenv("SNPM_BITS")) ctx->bits_path = atoi(s);
     if (const char *s = getenv("SNPM_FULL_OCCUPANCY")) ctx->full_occupancy = atoi(s);
     if (const char *s = getenv("SNPM_OCC_CAP")) ctx->occ_cap = atoi(s);
@@ -1830,8 +1849,8 @@ try {
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, q->cert_eref(), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const double eref = *(const double *)ctx->h_pinned;
-    const bool p16 = q->panel->packed && !ctx->packed_byte;
-    const int bpl = p16 ? 16 : (q->panel->packed ? 4 : pick_bpl(ctx, q->panel->n_acc));
+    const bool p16 = q->panel->packed != 0;
+    const int bpl = p16 ? 16 : pick_bpl(ctx, q->panel->n_acc);
     FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl, p16 ? std::min(P16_TILE_ROWS, Q4_TILE_ROWS) : TILE_ROWS);   // occ 1, short tiles -> longest parts -> largest bound
     *bound = eref + efast_bound(q, g);
     return SNPM_OK;

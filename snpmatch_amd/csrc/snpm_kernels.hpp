@@ -200,15 +200,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int BPL>
 struct LoadT;
 template <>
-struct LoadT<1> { typedef uint8_t type; };      // packed panel: one byte = 4 accessions x 2 bits
-template <>
 struct LoadT<4> { typedef uint32_t type; };
 template <>
 struct LoadT<8> { typedef u32x2 type; };
 template <>
 struct LoadT<16> { typedef u32x4 type; };
 
-__device__ __forceinline__ uint32_t dword_of(const uint8_t &v, int) { return v; }
 __device__ __forceinline__ uint32_t dword_of(const uint32_t &v, int) { return v; }
 __device__ __forceinline__ uint32_t dword_of(const u32x2 &v, int k) { return k == 0 ? v.x : v.y; }
 __device__ __forceinline__ uint32_t dword_of(const u32x4 &v, int k)
@@ -252,28 +249,8 @@ __device__ __forceinline__ void fast_row(const uint32_t (&x)[NDW], uint32_t grou
     for (int e = 0; e < NDW * 4; ++e) acc[e] += w[e];
 }
 
-// Packed (2 bits per call) variant of fast_row: x holds one byte = 4 accessions, code 3 = missing.
-//   address of element j = row_base + ((x >> 2j) & 3) * 8: one v_bfe_u32 + one v_lshl_add_u32 per element;
-//   missing counts: bit pairs 11 (or 1x with skip_hets) -> one bit per field -> spread to one byte per
-//   field with a multiply (0x41041 = 1 + 2^6 + 2^12 + 2^18 moves bit 2f to bit 8f; no carries reach a kept bit).
-template <bool SKIP, int U>
-__device__ __forceinline__ void fast_row_packed(uint32_t x, uint32_t row_base, double (&acc)[4], uint32_t (&miss8)[1])
-{
-    double w[4];
-    const uint32_t m = SKIP ? ((x >> 1) & 0x55u) : (x & (x >> 1) & 0x55u);
-    miss8[0] += (m * 0x41041u) & 0x01010101u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t idx = (x >> (2 * j)) & 3u;
-        lds_cdouble *ptr = (lds_cdouble *)(uintptr_t)(row_base + (idx << 3));
-        w[j] = ptr[U * 4];
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] += w[j];
-}
-
 template <int BPL, bool NT>
-__device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[(BPL >= 4 ? BPL / 4 : 1)])
+__device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[BPL / 4])
 {
     typedef typename LoadT<BPL>::type load_t;
     load_t v;
@@ -282,17 +259,11 @@ __device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[(BPL >= 
     else
         v = *reinterpret_cast<const load_t *>(p);
 #pragma unroll
-    for (int k = 0; k < (BPL >= 4 ? BPL / 4 : 1); ++k) x[k] = dword_of(v, k);
+    for (int k = 0; k < BPL / 4; ++k) x[k] = dword_of(v, k);
 }
 
-// one SNP row of one lane: int8 layout -> fast_row (v_perm addresses), packed layout -> fast_row_packed
-#define SCORE_ROW(U, X, GROUP_BASE, ROFF4, ROFF)                                  \
-    do {                                                                          \
-        if constexpr (PACKED)                                                     \
-            fast_row_packed<SKIP, U>((X)[0], (GROUP_BASE) + (ROFF), acc, miss8); \
-        else                                                                      \
-            fast_row<NDW, SKIP, U>((X), (GROUP_BASE), (ROFF4), acc, miss8);       \
-    } while (0)
+// one SNP row of one lane
+#define SCORE_ROW(U, X, GROUP_BASE, ROFF4, ROFF) fast_row<NDW, SKIP, U>((X), (GROUP_BASE), (ROFF4), acc, miss8)
 
 // Fast pass.
 //   grid.x = column blocks (blockDim.x/64 waves x 64 lanes x BPL bytes), grid.y = P parts.
@@ -320,22 +291,20 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
        const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
        const int64_t *__restrict__ part_desc = nullptr)
 {
-    // BPL = bytes per lane and row.  BPL == 1 is the packed panel (2 bits per call): the lane's byte holds 4
-    // accessions, exactly like the 4 bytes of the int8 BPL == 4 layout, so everything downstream is shared.
-    constexpr bool PACKED = (BPL == 1);
-    constexpr int NDW = PACKED ? 1 : BPL / 4;
-    constexpr int EPL = PACKED ? 4 : BPL;   // accessions (= accumulators) per lane
-    // rows per prefetch group: 4 (G*32 B = half a 256-B LUT block) for int8; 8 (a whole block) for the packed
-    // layout, whose 64-B-per-wave row loads need twice as many in flight to cover the HBM latency
-    constexpr int G = PACKED ? 8 : SNPM_FAST_G;     // (8-row groups for int8 spill at the 80-VGPR budget and measured no gain)
+    // BPL = bytes (= accessions = accumulators) per lane and row; packed panels have their own kernels below
+    static_assert(BPL == 4 || BPL == 8 || BPL == 16, "int8 panels: 4, 8 or 16 bytes per lane");
+    constexpr int NDW = BPL / 4;
+    constexpr int EPL = BPL;
+    // rows per prefetch group: 4 (G*32 B = half a 256-B LUT block); 8-row groups spill at the 80-VGPR budget and measured no gain
+    constexpr int G = SNPM_FAST_G;
     __shared__ __attribute__((aligned(256))) double s_lut[2][TILE_ROWS * 4];
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
     const int64_t byte0 = ((int64_t)blockIdx.x * nthr + tid) * BPL;     // byte offset of the lane inside a row
-    const int64_t col0 = PACKED ? byte0 * 4 : byte0;                    // first accession of the lane
-    // a lane works when its bytes lie inside the row (pitch is a multiple of 256 B) AND its accessions inside
-    // the result arrays (ld): on a packed panel 4*pitch can exceed ld, and blocks may carry spare waves
+    const int64_t col0 = byte0;                                          // first accession of the lane
+    // a lane works when its bytes lie inside the row (pitch is a multiple of 256 B) and its accessions inside the result
+    // arrays (ld); blocks may carry spare waves
     const bool lane_on = byte0 < pitch && col0 < ld;
     const int64_t p = SEG ? (int64_t)blockIdx.y + (int64_t)gridDim.y * blockIdx.z : (int64_t)blockIdx.y;
     if (SEG && p >= n) return;             // SEG: n is the number of parts (grid.y * grid.z may exceed it)
@@ -513,8 +482,8 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
 
 // ------------------------------------------------------------------------------------------------
 // Fast pass on a PACKED panel (2 bits per call): 16 accessions per lane, FOUR ROWS PER LOOKUP (k_fast_packed_q4).
-//   The one-byte-per-lane instantiation of k_fast spends ~5.5 VALU operations per comparison and is VALU-bound at a
-//   quarter of the HBM rate.  Here a lane loads a dword per SNP row (16 calls; a wave covers 1024 accessions with 256
+//   (Round 1's one-byte-per-lane instantiation of k_fast spent ~5.5 VALU operations per comparison and was VALU-bound at a
+//   quarter of the HBM rate.)  A lane loads a dword per SNP row (16 calls; a wave covers 1024 accessions with 256
 //   contiguous bytes, the access shape of the int8 kernel), and the block builds, per group of four rows, a 256-entry
 //   table  entry[c0 | c1 << 2 | c2 << 4 | c3 << 6] = ((lut[r][c0] + lut[r+1][c1]) + lut[r+2][c2]) + lut[r+3][c3]
 //   (2 KiB per four rows), so that a lane scores four rows of one accession with ONE 8-byte LDS read and ONE addition.
@@ -543,10 +512,14 @@ static_assert(Q4_TILE_ROWS % (2 * Q4_G) == 0 && Q4_TILE_ROWS <= 127, "two regist
         (L) = __builtin_amdgcn_bitop3_b32(a_, b_, c_, 0x96);                    \
     } while (0)
 
-template <bool SKIP, bool GATHER, bool NT>
+// SEG (batches of samples, windows of a cross: as in k_fast): part p scores the contiguous rows [part_desc[3p],
+// part_desc[3p+1]) of the concatenated matched list -- all inside one segment, never more than EPOCH_TILES tiles of k_fast
+// (8192 rows: one slot, no epochs) -- and writes its partial sums to slot part_desc[3p+2]; n is the number of parts.
+template <bool SKIP, bool GATHER, bool NT, bool SEG = false>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, SNPM_Q4_MIN_WAVES)
 k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
-                 const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
+                 const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
+                 const int64_t *__restrict__ part_desc = nullptr)
 {
     constexpr int G = Q4_G;
     constexpr int TR = Q4_TILE_ROWS;
@@ -560,9 +533,16 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     const int64_t col0 = byte0 * 4;
     const bool lane_on = byte0 < pitch && col0 < ld;
     const bool wave_on = __any(lane_on) != 0;           // wave-uniform
-    const int64_t p = blockIdx.y;
-    const int64_t P = gridDim.y;
-    const int64_t n_tiles_total = (n + TR - 1) / TR;
+    const int64_t p = SEG ? (int64_t)blockIdx.y + (int64_t)gridDim.y * blockIdx.z : (int64_t)blockIdx.y;
+    if (SEG && p >= n) return;             // whole blocks leave (grid.y * grid.z may exceed the number of parts)
+    // tiles of this block: T = T0, T0 + P, ... ; tile T = rows [rbase + T * TR, ...) up to rend
+    const int64_t rbase = SEG ? part_desc[3 * p] : 0;
+    const int64_t rend = SEG ? part_desc[3 * p + 1] : n;
+    const int64_t P = SEG ? 1 : (int64_t)gridDim.y;
+    const int64_t T0 = SEG ? 0 : p;
+    const int64_t slot0 = SEG ? part_desc[3 * p + 2] : p;          // partial slot of epoch 0 (epoch e: slot0 + e * slot_stride)
+    const int64_t slot_stride = SEG ? 1 : (int64_t)gridDim.y;
+    const int64_t n_tiles_total = (rend - rbase + TR - 1) / TR;
 
     double acc[16];
     uint32_t miss16[8];                 // miss16[d]: accession d (low half) and d + 8 (high half)
@@ -627,8 +607,8 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     };
     auto store_partials = [&](int64_t epoch) {
         if (lane_on) {
-            double *os = out_score + (epoch * P + p) * ld + col0;
-            uint32_t *om = out_miss + (epoch * P + p) * ld + col0;
+            double *os = out_score + (slot0 + epoch * slot_stride) * ld + col0;
+            uint32_t *om = out_miss + (slot0 + epoch * slot_stride) * ld + col0;
 #pragma unroll
             for (int i = 0; i < 16; i += 2) *reinterpret_cast<double2 *>(os + i) = make_double2(acc[i], acc[i + 1]);
 #pragma unroll
@@ -730,23 +710,24 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     // LUT rows of the tile that starts at matched row tr: TR * 4 doubles, one per thread (0.0 past the end of the list);
     // blocks with fewer than TR * 4 threads copy the rest synchronously
     auto fetch_l4 = [&](int64_t tr, bool on) -> double {
-        return (on && tid < TR * 4 && tr + (tid >> 2) < n) ? lut[4 * tr + tid] : 0.0;
+        return (on && tid < TR * 4 && tr + (tid >> 2) < rend) ? lut[4 * tr + tid] : 0.0;
     };
     auto store_l4 = [&](int64_t tr, double pre) {
         if (tid < TR * 4) s_l4[tid] = pre;
-        for (int i = tid + nthr; i < TR * 4; i += nthr) s_l4[i] = (tr + (i >> 2) < n) ? lut[4 * tr + i] : 0.0;
+        for (int i = tid + nthr; i < TR * 4; i += nthr) s_l4[i] = (tr + (i >> 2) < rend) ? lut[4 * tr + i] : 0.0;
     };
     int64_t last_epoch = 0;
 
-    if (p < n_tiles_total) {
+    if (T0 < n_tiles_total) {
         // two register sets of G rows (a third one, 16 to 24 row loads in flight per lane, measured no gain)
         uint32_t xa[G], xb[G];
         {
-            const double pre = fetch_l4(p * TR, true);
-            const int rows0 = (int)((n - p * TR < TR) ? (n - p * TR) : TR);
+            const int64_t tr_first = rbase + T0 * TR;
+            const double pre = fetch_l4(tr_first, true);
+            const int rows0 = (int)((rend - tr_first < TR) ? (rend - tr_first) : TR);
 #pragma unroll
-            for (int u = 0; u < G; ++u) xa[u] = (wave_on && u < rows0) ? load(p * TR + u) : 0u;
-            store_l4(p * TR, pre);
+            for (int u = 0; u < G; ++u) xa[u] = (wave_on && u < rows0) ? load(tr_first + u) : 0u;
+            store_l4(tr_first, pre);
         }
         __syncthreads();
         build_tables();
@@ -754,17 +735,17 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
 
         int tiles_in_epoch = 0;
         int64_t epoch = 0;
-        for (int64_t T = p; T < n_tiles_total; T += P) {
-            if (tiles_in_epoch == EPOCH_TILES) {
+        for (int64_t T = T0; T < n_tiles_total; T += P) {
+            if (!SEG && tiles_in_epoch == EPOCH_TILES) {
                 store_partials(epoch);
                 ++epoch;
                 tiles_in_epoch = 0;
             }
             ++tiles_in_epoch;
-            const int64_t tr0 = T * TR;
-            const int rows = (int)((n - tr0 < TR) ? (n - tr0) : TR);
+            const int64_t tr0 = rbase + T * TR;
+            const int rows = (int)((rend - tr0 < TR) ? (rend - tr0) : TR);
             const bool more = (T + P < n_tiles_total);
-            const int64_t ntr0 = more ? (T + P) * TR : tr0;        // my next tile (or a harmless re-read)
+            const int64_t ntr0 = more ? rbase + (T + P) * TR : tr0;        // my next tile (or a harmless re-read)
             const double pre = fetch_l4(ntr0, more);               // waited for at the end of this tile
 
             if (!wave_on) {
@@ -784,7 +765,7 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
                     score_group(xb, g + 1);
                 }
             } else {
-                // the partial last tile of the whole list (nothing follows it): group by group, rows past the end read as 0
+                // a partial tile (the last one of the list or of a part): group by group, rows past the end read as 0
                 for (int g = 0; g * G < rows; ++g) {
 #pragma unroll
                     for (int u = 0; u < G; ++u) xb[u] = (g * G + u < rows) ? load(tr0 + g * G + u) : 0u;

@@ -16,7 +16,7 @@ NB = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 n_match = int(sys.argv[3]) if len(sys.argv) > 3 else 200_000
 n_snp, n_acc, seed = 11_000_000, 1135, 1001
 ctx = engine.Context(0)
-panel = engine.Panel(ctx, n_snp, n_acc)
+panel = engine.Panel(ctx, n_snp, n_acc, packed=os.environ.get("PACKED", "0") == "1")     # PACKED=1: 2-bit packed panel
 panel.fill_synthetic(seed)
 rng = np.random.default_rng(1)
 samples = []
