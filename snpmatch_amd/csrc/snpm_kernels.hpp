@@ -41,9 +41,6 @@
 
 namespace snpm {
 
-#ifndef SNPM_P16_MIN_WAVES
-#define SNPM_P16_MIN_WAVES 4
-#endif
 #ifndef SNPM_Q4_BITIDX
 #define SNPM_Q4_BITIDX 0                // k_fast_packed_q4: 1 = table index with the calls' low bits in bits 0-3 (fewer LDS bank conflicts, 8 more VALU per 64 comparisons)
 #endif
@@ -499,8 +496,8 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
 //   the 16 per-accession counts are kept bit-sliced (planes 1, 2, 4 ... 64) and updated for 8 rows at a time
 //   with carry-save adders (3 operations each), i.e. ~0.4 operations per comparison instead of one.
 //   Geometry, tile-interleaved parts, epochs and the prefetch pipeline are those of k_fast.
-constexpr int P16_TILE_ROWS = 64;       // rows per tile of k_fast_bits (no LDS; the flush period of its bit-sliced counters)
-constexpr int P16_G = 8;                // rows per prefetch group of k_fast_bits
+constexpr int BITS_TILE_ROWS = 128;     // rows per tile of k_fast_bits (no LDS: only the unit in which parts interleave)
+constexpr int BITS_FLUSH_ROWS = 64;     // its bit-sliced counters (7 planes) are flushed into 16-bit counters every 64 rows
 constexpr int Q4_TILE_ROWS = 64;        // 16 four-row tables x 2 KiB = 32 KiB of LDS per block
 constexpr int Q4_G = 8;                 // rows per prefetch group (two tables)
 static_assert(Q4_TILE_ROWS % (2 * Q4_G) == 0 && Q4_TILE_ROWS <= 127, "two register sets per iteration; 7-bit missing counters per tile");
@@ -801,12 +798,12 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
 // Geometry (16 accessions per lane, tile-interleaved parts, epochs, prefetch pipeline) as k_fast_packed_q4;
 // partial scores are written as fp64 counts so that the reduce kernels are shared.  wbits[r] = ref | het << 1 |
 // alt << 2 for query row r, padded to a multiple of 8 entries.
-#define BITS_CSA(H, L, A, B, C)           \
-    do {                                  \
-        const uint32_t u_ = (A) ^ (B);    \
-        const uint32_t h_ = ((A) & (B)) | (u_ & (C)); \
-        (L) = u_ ^ (C);                   \
-        (H) = h_;                         \
+// carry-save adder of three bit vectors: two v_bitop3_b32 (majority 0xE8, parity 0x96)
+#define BITS_CSA(H, L, A, B, C)                                                 \
+    do {                                                                        \
+        const uint32_t a_ = (A), b_ = (B), c_ = (C);                            \
+        (H) = __builtin_amdgcn_bitop3_b32(a_, b_, c_, 0xE8);                    \
+        (L) = __builtin_amdgcn_bitop3_b32(a_, b_, c_, 0x96);                    \
     } while (0)
 
 template <bool SKIP, bool GATHER, bool NT>
@@ -814,8 +811,12 @@ __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, 6)
 k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
             const uint8_t *__restrict__ wbits, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
 {
-    constexpr int G = P16_G;
-    constexpr int TR = P16_TILE_ROWS;
+    // Rows are requested in groups of 4 (two register sets: 4 to 8 row loads in flight per lane) and counted in groups of 8;
+    // 128-row tiles.  Measured with the arithmetic stripped (tools/micro/read_patterns.hip, this panel's 2560-B rows,
+    // one-wave blocks): groups of 8 / 64-row tiles 21.0 ms, groups of 4 / 128-row tiles 19.2 ms per 125 GB; the kernel's own
+    // pattern-only build 22.3 -> 20.5 ms.  (Unpipelined groups of 8 -- request, wait, count -- measured the same as this.)
+    constexpr int H = 4;                    // rows per load group
+    constexpr int TR = BITS_TILE_ROWS;
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
     const int64_t byte0 = ((int64_t)blockIdx.x * nthr + tid) * 4;
@@ -845,13 +846,17 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
         // the row's truth table T[code] = (ref, alt, het, 0) in algebraic normal form over (lo, hi):
         //   hit = D ^ (lo & A) ^ (hi & B) ^ (lo & hi & C),  D = ref, A = ref ^ alt, B = ref ^ het, C = ref ^ alt ^ het
         // (four wave-uniform masks; three 3-input boolean operations per row instead of eight 2-input ones)
-        const uint32_t lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
+        // every step one v_bitop3_b32 (truth-table immediates: (a & b) ^ c = 0x6A, a & b & c = 0x80); the masks carry the
+        // 0x5555... themselves, so x and x >> 1 need no masking of their own
+        const uint32_t M = 0x55555555u, s1 = x >> 1;
         const uint32_t r = wb & 1u, h = SKIP ? 0u : ((wb >> 1) & 1u), a = (wb >> 2) & 1u;
-        const uint32_t md = r ? 0x55555555u : 0u, ma = (r ^ a) ? 0x55555555u : 0u;
-        const uint32_t mb = (r ^ h) ? 0x55555555u : 0u, mc = (r ^ a ^ h) ? 0x55555555u : 0u;
-        const uint32_t both = lo & hi;
-        hit = md ^ (lo & ma) ^ (hi & mb) ^ (both & mc);
-        mis = SKIP ? hi : both;
+        const uint32_t md = r ? M : 0u, ma = (r ^ a) ? M : 0u;
+        const uint32_t mb = (r ^ h) ? M : 0u, mc = (r ^ a ^ h) ? M : 0u;
+        const uint32_t both = __builtin_amdgcn_bitop3_b32(x, s1, M, 0x80);          // lo & hi
+        uint32_t t = __builtin_amdgcn_bitop3_b32(x, ma, md, 0x6A);                  // (lo & ma) ^ md
+        t = __builtin_amdgcn_bitop3_b32(s1, mb, t, 0x6A);                           // ^ (hi & mb)
+        hit = __builtin_amdgcn_bitop3_b32(both, mc, t, 0x6A);                       // ^ (lo & hi & mc)
+        mis = SKIP ? (s1 & M) : both;
     };
     auto ripple = [&](uint32_t c, uint32_t &a1, uint32_t &a2, uint32_t &a4, uint32_t &a8, uint32_t &a16, uint32_t &a32, uint32_t &a64) {
         uint32_t t;
@@ -908,19 +913,18 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
     int64_t last_epoch = 0;
 
     if (p < n_tiles_total) {
-        uint32_t xa[G], xb[G];
-        // the eight weight bytes of a group (one scalar dwordx2) travel with the group's rows, one group ahead: loaded at
-        // the top of the group they were waited for at once, before any row could be classified
+        uint32_t xa[H], xb[H];
+        // the eight weight bytes of a counting group (one scalar dwordx2) travel with its rows, one group ahead
         auto wbits8 = [&](int64_t r) -> uint64_t { return *reinterpret_cast<const uint64_t *>(wbits + r); };
-        uint64_t wa8, wb8;
+        uint64_t w8;
 #pragma unroll
-        for (int u = 0; u < G; ++u) xa[u] = load(p * TR + u);
-        wa8 = wbits8(p * TR);
+        for (int u = 0; u < H; ++u) xa[u] = load(p * TR + u);
+        w8 = wbits8(p * TR);
 
         int tiles_in_epoch = 0;
         int64_t epoch = 0;
         for (int64_t T = p; T < n_tiles_total; T += P) {
-            if (tiles_in_epoch == EPOCH_TILES) {
+            if (tiles_in_epoch == EPOCH_TILES) {              // 8192 rows per epoch: the 16-bit counters hold them
                 store_partials(epoch);
                 ++epoch;
                 tiles_in_epoch = 0;
@@ -930,57 +934,54 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
             const int rows = (int)((n - tr0 < TR) ? (n - tr0) : TR);
             const bool more = (T + P < n_tiles_total);
             const int64_t ntr0 = more ? (T + P) * TR : tr0;
-            const int full_groups = rows / G;
+            const int full8 = rows / 8;
 
-            // 8 rows: classify, then both bit vectors into their bit-sliced counters with carry-save adders
-#define BITS_GROUP(X, W8)                                                                           \
-    do {                                                                                            \
-        _Pragma("unroll") for (int u_ = 0; u_ < G; ++u_) asm volatile("" : "+v"((X)[u_]));         \
-        const uint64_t wb8_ = (W8);                                                                 \
-        uint32_t hb_[8], mb_[8];                                                                    \
-        _Pragma("unroll") for (int u_ = 0; u_ < 8; ++u_)                                            \
-            classify((X)[u_], (uint32_t)(wb8_ >> (8 * u_)) & 0xffu, hb_[u_], mb_[u_]);              \
-        uint32_t t2a_, t2b_, t4a_, t4b_, t8_, c_, d_;                                               \
-        BITS_CSA(t2a_, h1, h1, hb_[0], hb_[1]); BITS_CSA(t2b_, h1, h1, hb_[2], hb_[3]);             \
-        BITS_CSA(t4a_, h2, h2, t2a_, t2b_);                                                         \
-        BITS_CSA(t2a_, h1, h1, hb_[4], hb_[5]); BITS_CSA(t2b_, h1, h1, hb_[6], hb_[7]);             \
-        BITS_CSA(t4b_, h2, h2, t2a_, t2b_);                                                         \
-        BITS_CSA(t8_, h4, h4, t4a_, t4b_);                                                          \
-        c_ = h8 & t8_;  h8 ^= t8_;  d_ = h16 & c_;  h16 ^= c_;  c_ = h32 & d_;  h32 ^= d_;  h64 ^= c_; \
-        BITS_CSA(t2a_, m1, m1, mb_[0], mb_[1]); BITS_CSA(t2b_, m1, m1, mb_[2], mb_[3]);             \
-        BITS_CSA(t4a_, m2, m2, t2a_, t2b_);                                                         \
-        BITS_CSA(t2a_, m1, m1, mb_[4], mb_[5]); BITS_CSA(t2b_, m1, m1, mb_[6], mb_[7]);             \
-        BITS_CSA(t4b_, m2, m2, t2a_, t2b_);                                                         \
-        BITS_CSA(t8_, m4, m4, t4a_, t4b_);                                                          \
-        c_ = m8 & t8_;  m8 ^= t8_;  d_ = m16 & c_;  m16 ^= c_;  c_ = m32 & d_;  m32 ^= d_;  m64 ^= c_; \
-    } while (0)
-
-#ifdef SNPM_FAST_PATTERN_ONLY       // diagnostic build: the loads and the loop structure without the arithmetic
-#undef BITS_GROUP
-#define BITS_GROUP(X, W8)                                                                           \
-    do {                                                                                            \
-        _Pragma("unroll") for (int u_ = 0; u_ < G; ++u_) h1 ^= (X)[u_];                             \
-        m1 ^= (uint32_t)(W8);                                                                       \
-    } while (0)
+            for (int it = 0; it < full8; ++it) {
+                // rows rb .. rb+3 are in xa (requested one step ago), rb+4 .. rb+7 are requested now
+                const int64_t rb = tr0 + (int64_t)it * 8;
+                const int64_t rn = (it + 1 < TR / 8) ? rb + 8 : ntr0;        // the next counting group: in this tile or my next tile
+#pragma unroll
+                for (int u = 0; u < H; ++u) xb[u] = load(rb + H + u);
+                const uint64_t wcur = w8;
+#pragma unroll
+                for (int u = 0; u < H; ++u) asm volatile("" : "+v"(xa[u]));
+#ifndef SNPM_FAST_PATTERN_ONLY
+                uint32_t hb[8], mb[8];
+#pragma unroll
+                for (int u = 0; u < H; ++u) classify(xa[u], (uint32_t)(wcur >> (8 * u)) & 0xffu, hb[u], mb[u]);
+#else       // diagnostic build: the loads and the loop structure without the arithmetic
+                h1 ^= xa[0] ^ xa[1] ^ xa[2] ^ xa[3];
 #endif
-            int g = 0;
-            for (; g + 2 <= full_groups; g += 2) {
-                const int64_t rnext = tr0 + (int64_t)(g + 1) * G;
-                const int64_t rafter = (g + 2 < TR / G) ? rnext + G : ntr0;
 #pragma unroll
-                for (int u = 0; u < G; ++u) xb[u] = load(rnext + u);
-                wb8 = wbits8(rnext);
-                BITS_GROUP(xa, wa8);
+                for (int u = 0; u < H; ++u) xa[u] = load(rn + u);
+                w8 = wbits8(rn);
 #pragma unroll
-                for (int u = 0; u < G; ++u) xa[u] = load(rafter + u);
-                wa8 = wbits8(rafter);
-                BITS_GROUP(xb, wb8);
+                for (int u = 0; u < H; ++u) asm volatile("" : "+v"(xb[u]));
+#ifndef SNPM_FAST_PATTERN_ONLY
+#pragma unroll
+                for (int u = 0; u < H; ++u) classify(xb[u], (uint32_t)(wcur >> (8 * (H + u))) & 0xffu, hb[H + u], mb[H + u]);
+                {   // 8 rows: both bit vectors into their bit-sliced counters with carry-save adders
+                    uint32_t t2a_, t2b_, t4a_, t4b_, t8_, c_, d_;
+                    BITS_CSA(t2a_, h1, h1, hb[0], hb[1]); BITS_CSA(t2b_, h1, h1, hb[2], hb[3]);
+                    BITS_CSA(t4a_, h2, h2, t2a_, t2b_);
+                    BITS_CSA(t2a_, h1, h1, hb[4], hb[5]); BITS_CSA(t2b_, h1, h1, hb[6], hb[7]);
+                    BITS_CSA(t4b_, h2, h2, t2a_, t2b_);
+                    BITS_CSA(t8_, h4, h4, t4a_, t4b_);
+                    c_ = h8 & t8_;  h8 ^= t8_;  d_ = h16 & c_;  h16 ^= c_;  c_ = h32 & d_;  h32 ^= d_;  h64 ^= c_;
+                    BITS_CSA(t2a_, m1, m1, mb[0], mb[1]); BITS_CSA(t2b_, m1, m1, mb[2], mb[3]);
+                    BITS_CSA(t4a_, m2, m2, t2a_, t2b_);
+                    BITS_CSA(t2a_, m1, m1, mb[4], mb[5]); BITS_CSA(t2b_, m1, m1, mb[6], mb[7]);
+                    BITS_CSA(t4b_, m2, m2, t2a_, t2b_);
+                    BITS_CSA(t8_, m4, m4, t4a_, t4b_);
+                    c_ = m8 & t8_;  m8 ^= t8_;  d_ = m16 & c_;  m16 ^= c_;  c_ = m32 & d_;  m32 ^= d_;  m64 ^= c_;
+                }
+#else
+                h1 ^= xb[0] ^ xb[1] ^ xb[2] ^ xb[3];
+                m1 ^= (uint32_t)wcur;
+#endif
+                if (((it + 1) * 8) % BITS_FLUSH_ROWS == 0) flush();
             }
-            if (g < full_groups) {                               // odd group count: only in the last tile of all
-                BITS_GROUP(xa, wa8);
-            }
-#undef BITS_GROUP
-            for (int r = full_groups * G; r < rows; ++r) {      // at most G-1 rows: last tile of all
+            for (int r = full8 * 8; r < rows; ++r) {            // at most 7 rows: last tile of all
                 uint32_t hb, mb;
                 classify(load(tr0 + r), wbits[tr0 + r], hb, mb);
                 ripple(hb, h1, h2, h4, h8, h16, h32, h64);

@@ -144,5 +144,27 @@ int main(int argc, char **argv)
     } while (0)
     ROWS(4, true, 16, 1); ROWS(4, true, 16, 2); ROWS(8, true, 16, 1); ROWS(4, true, 10, 2); ROWS(4, true, 10, 3); ROWS(2, true, 16, 2);
     ROWS_DB(4, true, 8, 3); ROWS_DB(4, true, 8, 2); ROWS_DB(2, true, 8, 3); ROWS_DB(2, true, 8, 4); ROWS_DB(1, true, 8, 3); ROWS_DB(4, true, 4, 4);
+    // the packed panel's rows: 2560 B (10 000 accessions x 2 bits), 64-row tiles, W-wave blocks
+    const long ppitch_dw = 640, pnrows = bytes / 2560 / 128 * 128;
+#define PROWS(U, W, OCC)                                                                                       \
+    do {                                                                                                       \
+        const int colblocks = (int)((ppitch_dw + 64 * W - 1) / (64 * W));                                      \
+        const int parts = cu * OCC / colblocks;                                                                \
+        const double ms = time_ms([&] { hipLaunchKernelGGL((k_rows<U, true>), dim3(colblocks, parts), dim3(64 * W), 0, 0, (const unsigned *)buf, ppitch_dw, pnrows, 128L, out); }); \
+        printf("packed rows (2560 B)  %2d-wave blocks  %2d rows in flight  nt  %2d blocks/CU : %7.3f ms  %6.0f GB/s\n", W, U, OCC, ms, \
+               pnrows * 2560.0 / ms / 1e6);                                                                    \
+    } while (0)
+    PROWS(8, 1, 24); PROWS(16, 1, 24); PROWS(8, 1, 16); PROWS(4, 1, 24); PROWS(8, 2, 12); PROWS(16, 2, 12); PROWS(8, 5, 4); PROWS(8, 5, 5);
+    PROWS(8, 10, 2); PROWS(16, 10, 2); PROWS(4, 10, 3); PROWS(8, 10, 3); PROWS(16, 1, 16); PROWS(16, 1, 32);
+    // k_fast_bits' pipeline: groups of 8 rows, two groups in flight, TR-row tiles, one-wave blocks
+#define PROWS_DB(G, TR, OCC)                                                                                   \
+    do {                                                                                                       \
+        const int colblocks = (int)((ppitch_dw + 63) / 64);                                                    \
+        const int parts = cu * OCC / colblocks;                                                                \
+        const double ms = time_ms([&] { hipLaunchKernelGGL((k_rows_db<G, true>), dim3(colblocks, parts), dim3(64), 0, 0, (const unsigned *)buf, ppitch_dw, pnrows, (long)TR, out); }); \
+        printf("packed rows, pipelined  1-wave blocks  groups of %d  %3d-row tiles  %2d blocks/CU : %7.3f ms  %6.0f GB/s\n", G, TR, OCC, ms, \
+               pnrows * 2560.0 / ms / 1e6);                                                                    \
+    } while (0)
+    PROWS_DB(8, 64, 24); PROWS_DB(8, 128, 24); PROWS_DB(4, 64, 24); PROWS_DB(8, 64, 16); PROWS_DB(4, 128, 24); PROWS_DB(8, 64, 32);
     return 0;
 }
