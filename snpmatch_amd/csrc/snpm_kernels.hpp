@@ -496,7 +496,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
 //   the 16 per-accession counts are kept bit-sliced (planes 1, 2, 4 ... 64) and updated for 8 rows at a time
 //   with carry-save adders (3 operations each), i.e. ~0.4 operations per comparison instead of one.
 //   Geometry, tile-interleaved parts, epochs and the prefetch pipeline are those of k_fast.
-constexpr int BITS_TILE_ROWS = 128;     // rows per tile of k_fast_bits (no LDS: only the unit in which parts interleave)
+constexpr int BITS_TILE_ROWS = 256;     // rows per tile of k_fast_bits (no LDS: only the unit in which parts interleave; 128: +2.4 %, 512: -1.4 %)
 constexpr int BITS_FLUSH_ROWS = 64;     // its bit-sliced counters (7 planes) are flushed into 16-bit counters every 64 rows
 constexpr int Q4_TILE_ROWS = 64;        // 16 four-row tables x 2 KiB = 32 KiB of LDS per block
 constexpr int Q4_G = 8;                 // rows per prefetch group (two tables)
@@ -812,7 +812,7 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
             const uint8_t *__restrict__ wbits, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
 {
     // Rows are requested in groups of 4 (two register sets: 4 to 8 row loads in flight per lane) and counted in groups of 8;
-    // 128-row tiles.  Measured with the arithmetic stripped (tools/micro/read_patterns.hip, this panel's 2560-B rows,
+    // 256-row tiles.  Measured with the arithmetic stripped (tools/micro/read_patterns.hip, this panel's 2560-B rows,
     // one-wave blocks): groups of 8 / 64-row tiles 21.0 ms, groups of 4 / 128-row tiles 19.2 ms per 125 GB; the kernel's own
     // pattern-only build 22.3 -> 20.5 ms.  (Unpipelined groups of 8 -- request, wait, count -- measured the same as this.)
     constexpr int H = 4;                    // rows per load group

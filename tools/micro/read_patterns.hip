@@ -145,7 +145,7 @@ int main(int argc, char **argv)
     ROWS(4, true, 16, 1); ROWS(4, true, 16, 2); ROWS(8, true, 16, 1); ROWS(4, true, 10, 2); ROWS(4, true, 10, 3); ROWS(2, true, 16, 2);
     ROWS_DB(4, true, 8, 3); ROWS_DB(4, true, 8, 2); ROWS_DB(2, true, 8, 3); ROWS_DB(2, true, 8, 4); ROWS_DB(1, true, 8, 3); ROWS_DB(4, true, 4, 4);
     // the packed panel's rows: 2560 B (10 000 accessions x 2 bits), 64-row tiles, W-wave blocks
-    const long ppitch_dw = 640, pnrows = bytes / 2560 / 128 * 128;
+    const long ppitch_dw = 640, pnrows = bytes / 2560 / 1024 * 1024;
 #define PROWS(U, W, OCC)                                                                                       \
     do {                                                                                                       \
         const int colblocks = (int)((ppitch_dw + 64 * W - 1) / (64 * W));                                      \
@@ -166,5 +166,6 @@ int main(int argc, char **argv)
                pnrows * 2560.0 / ms / 1e6);                                                                    \
     } while (0)
     PROWS_DB(8, 64, 24); PROWS_DB(8, 128, 24); PROWS_DB(4, 64, 24); PROWS_DB(8, 64, 16); PROWS_DB(4, 128, 24); PROWS_DB(8, 64, 32);
+    PROWS_DB(4, 256, 24); PROWS_DB(4, 512, 24); PROWS_DB(4, 128, 28); PROWS_DB(4, 128, 16); PROWS_DB(2, 128, 24); PROWS_DB(4, 1024, 24);
     return 0;
 }
