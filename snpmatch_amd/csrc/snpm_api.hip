@@ -573,7 +573,7 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     const bool p16 = p->packed != 0;
     const int bpl = p16 ? 16 : pick_bpl(ctx, p->n_acc);
     const bool bits = p16 && q->hard01 && ctx->bits_path;      // counts instead of weighted sums
-    const int tile_rows = p16 ? (bits ? BITS_TILE_ROWS : Q4_TILE_ROWS) : TILE_ROWS;
+    const int tile_rows = p16 ? (bits ? BITS_TILE_ROWS : Q4_TILE_ROWS * Q4_RUN) : TILE_ROWS;
     // k_fast_bits has no LDS tile and no barrier: one wave per block fills every wave slot of a CU evenly (measured on the
     // packed 10k x 50M panel: 22.4 ms with 1- or 2-wave blocks, 26.9 ms with the 5-wave blocks of the LUT kernels, 30.7 with 3)
     // k_fast_packed_q4: 4-wave blocks (one wave per SIMD; 33.5 ms against 34.5 with 5-wave blocks on 10 000 accessions,

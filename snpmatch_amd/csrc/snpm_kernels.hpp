@@ -500,6 +500,7 @@ constexpr int BITS_TILE_ROWS = 256;     // rows per tile of k_fast_bits (no LDS:
 constexpr int BITS_FLUSH_ROWS = 64;     // its bit-sliced counters (7 planes) are flushed into 16-bit counters every 64 rows
 constexpr int Q4_TILE_ROWS = 64;        // 16 four-row tables x 2 KiB = 32 KiB of LDS per block
 constexpr int Q4_G = 8;                 // rows per prefetch group (two tables)
+constexpr int Q4_RUN = 4;               // tiles a part scores in a row before it jumps ahead (the host's tile = Q4_RUN * Q4_TILE_ROWS rows)
 static_assert(Q4_TILE_ROWS % (2 * Q4_G) == 0 && Q4_TILE_ROWS <= 127, "two register sets per iteration; 7-bit missing counters per tile");
 
 // carry-save adder of three bit vectors: two v_bitop3_b32 (majority 0xE8, parity 0x96)
@@ -540,7 +541,11 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     const int64_t T0 = SEG ? 0 : p;
     const int64_t slot0 = SEG ? part_desc[3 * p + 2] : p;          // partial slot of epoch 0 (epoch e: slot0 + e * slot_stride)
     const int64_t slot_stride = SEG ? 1 : (int64_t)gridDim.y;
+    // parts interleave in RUNS of Q4_RUN tiles (the host's tile = one run: k_fast_bits gained 2-4 % from longer contiguous
+    // pieces per part); my tiles are k = 0, 1, 2, ...: run T0 + (k / RUN) * P, tile k % RUN inside it
+    constexpr int RUN = SEG ? 1 : Q4_RUN;
     const int64_t n_tiles_total = (rend - rbase + TR - 1) / TR;
+    auto tile_of = [&](int64_t k) -> int64_t { return (T0 + (k / RUN) * P) * RUN + (k % RUN); };
 
     double acc[16];
     uint32_t miss16[8];                 // miss16[d]: accession d (low half) and d + 8 (high half)
@@ -716,11 +721,11 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     };
     int64_t last_epoch = 0;
 
-    if (T0 < n_tiles_total) {
+    if (tile_of(0) < n_tiles_total) {
         // two register sets of G rows (a third one, 16 to 24 row loads in flight per lane, measured no gain)
         uint32_t xa[G], xb[G];
         {
-            const int64_t tr_first = rbase + T0 * TR;
+            const int64_t tr_first = rbase + tile_of(0) * TR;
             const double pre = fetch_l4(tr_first, true);
             const int rows0 = (int)((rend - tr_first < TR) ? (rend - tr_first) : TR);
 #pragma unroll
@@ -733,8 +738,8 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
 
         int tiles_in_epoch = 0;
         int64_t epoch = 0;
-        for (int64_t T = T0; T < n_tiles_total; T += P) {
-            if (!SEG && tiles_in_epoch == EPOCH_TILES) {
+        for (int64_t k = 0, T = tile_of(0); T < n_tiles_total; T = tile_of(++k)) {
+            if (!SEG && tiles_in_epoch == EPOCH_TILES * RUN) {
                 store_partials(epoch);
                 ++epoch;
                 tiles_in_epoch = 0;
@@ -742,8 +747,9 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             ++tiles_in_epoch;
             const int64_t tr0 = rbase + T * TR;
             const int rows = (int)((rend - tr0 < TR) ? (rend - tr0) : TR);
-            const bool more = (T + P < n_tiles_total);
-            const int64_t ntr0 = more ? rbase + (T + P) * TR : tr0;        // my next tile (or a harmless re-read)
+            const int64_t Tn = tile_of(k + 1);
+            const bool more = (Tn < n_tiles_total);
+            const int64_t ntr0 = more ? rbase + Tn * TR : tr0;             // my next tile (or a harmless re-read)
             const double pre = fetch_l4(ntr0, more);               // waited for at the end of this tile
 
             if (!wave_on) {
