@@ -143,6 +143,16 @@ int main(int argc, char **argv)
                NT ? "nt" : "  ", OCC, ms, nrows * 10240.0 / ms / 1e6);                                         \
     } while (0)
     ROWS(4, true, 16, 1); ROWS(4, true, 16, 2); ROWS(8, true, 16, 1); ROWS(4, true, 10, 2); ROWS(4, true, 10, 3); ROWS(2, true, 16, 2);
+#define ROWS_DBT(G, W, OCC, TR)                                                                                \
+    do {                                                                                                       \
+        const int colblocks = (int)((pitch_dw + 64 * W - 1) / (64 * W));                                       \
+        const int parts = cu * OCC / colblocks;                                                                \
+        const long nr = nrows / TR * TR;                                                                       \
+        const double ms = time_ms([&] { hipLaunchKernelGGL((k_rows_db<G, true>), dim3(colblocks, parts), dim3(64 * W), 0, 0, (const unsigned *)buf, pitch_dw, nr, (long)TR, out); }); \
+        printf("row tiles, pipelined  %d-wave blocks  groups of %d  %4d-row tiles  %d blocks/CU : %7.3f ms  %6.0f GB/s\n", W, G, TR, OCC, ms, \
+               nr * 10240.0 / ms / 1e6);                                                                       \
+    } while (0)
+    ROWS_DBT(4, 8, 3, 64); ROWS_DBT(4, 8, 3, 128); ROWS_DBT(4, 8, 3, 256); ROWS_DBT(4, 8, 3, 512); ROWS_DBT(4, 8, 3, 1024); ROWS_DBT(4, 5, 4, 512);
     ROWS_DB(4, true, 8, 3); ROWS_DB(4, true, 8, 2); ROWS_DB(2, true, 8, 3); ROWS_DB(2, true, 8, 4); ROWS_DB(1, true, 8, 3); ROWS_DB(4, true, 4, 4);
     // the packed panel's rows: 2560 B (10 000 accessions x 2 bits), 64-row tiles, W-wave blocks
     const long ppitch_dw = 640, pnrows = bytes / 2560 / 1024 * 1024;
