@@ -30,18 +30,20 @@ fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 n_acc = int(os.environ.get("PMC_N_ACC", "10000"))
 n_snp = int(os.environ.get("PMC_N_SNP", "6250000"))
-pitch = (n_acc + 255) // 256 * 256
+packed = os.environ.get("PMC_PACKED", "0") == "1"
+pitch = ((n_acc + 3) // 4 + 255) // 256 * 256 if packed else (n_acc + 255) // 256 * 256
 calib_bytes = n_snp * pitch
 calib_fetch = sum(fetch["k_calib_read"]) / len(fetch["k_calib_read"]) * 1024.0
 factor = calib_bytes / calib_fetch
 kf = sum(fetch["k_fast"]) / len(fetch["k_fast"]) * 1024.0
 kw = sum(write["k_fast"]) / len(write["k_fast"]) * 1024.0
 res = {
-    "n_acc": n_acc, "n_snp": n_snp,
+    "n_acc": n_acc, "n_snp": n_snp, "panel_format": "packed2" if packed else "int8",
+    "sample": "hard calls" if os.environ.get("PMC_HARD", "0") == "1" else "80% PL weights",
     "calibration": {"kernel": "k_calib_read", "known_bytes": calib_bytes, "FETCH_SIZE_bytes_raw": calib_fetch,
                     "correction_factor": factor},
     "k_fast": {"FETCH_SIZE_bytes_raw": kf, "fetch_bytes_corrected": kf * factor, "WRITE_SIZE_bytes": kw,
-               "algorithmic_bytes": n_snp * (n_acc + 24.0)},
+               "algorithmic_bytes": n_snp * ((n_acc / 4.0 if packed else n_acc) + 24.0)},
     "hbm_bytes_per_launch": kf * factor + kw,
 }
 out = {}
