@@ -443,7 +443,9 @@ def main():
         # Beside the headline (the int8 panel BASELINE.json names): the same job on the 2-bit packed panel, which fits one GPU
         # whole (125 GB).  A child process after this one has released its memory; a failure there only drops the extra field.
         whole_job = (args.n_acc == N_ACC_TOTAL and args.n_snp == N_SNP_TOTAL and args.mode == "exact" and not args.hard_calls)
-        if world == 1 and not args.packed and not args.no_alternatives and whole_job:
+        # (not under a profiler: its preloaded tool would follow the child)
+        profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+        if world == 1 and not args.packed and not args.no_alternatives and whole_job and not profiled:
             try:
                 import subprocess
                 child = subprocess.run([sys.executable, os.path.abspath(__file__), "--packed", "--steps", "8", "--warmup", "2",
