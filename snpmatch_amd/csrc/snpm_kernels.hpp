@@ -1611,10 +1611,19 @@ strict4_segments(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         // 2 * SB row loads in flight per wave), and the batch's weights arrive in a few wide scalar loads.
         constexpr int SB = SNPM_STRICT_BATCH;
         auto load_batch = [&](uint32_t (&x)[SB], int64_t rb) {
+            if constexpr (!GATHER) {
+                // consecutive rows: one buffer resource per batch (scalar registers), the row inside the batch in the scalar
+                // offset, the lane's column in the vector offset -- no address arithmetic on the vector unit, which this
+                // kernel saturates (and reads past the batch would return 0 instead of faulting)
+                const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<int8_t *>(db + (row0 + rb) * pitch), 0, (int)(SB * pitch), 0x00020000);
 #pragma unroll
-            for (int u = 0; u < SB; ++u) {
-                const int64_t prow = GATHER ? row_idx[rb + u] : (row0 + rb + u);
-                x[u] = load(db + prow * pitch + coff);
+                for (int u = 0; u < SB; ++u)
+                    x[u] = PACKED ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rows, coff, (int)(u * pitch), 0)
+                                  : (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, coff, (int)(u * pitch), 0);
+            } else {
+#pragma unroll
+                for (int u = 0; u < SB; ++u) x[u] = load(db + row_idx[rb + u] * pitch + coff);
             }
         };
         auto score_batch = [&](const uint32_t (&x)[SB], int64_t rb) {
