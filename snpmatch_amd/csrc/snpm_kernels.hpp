@@ -566,6 +566,21 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         const uint32_t *ptr = reinterpret_cast<const uint32_t *>(rowbase + off);
         return NT ? __builtin_nontemporal_load(ptr) : *ptr;
     };
+    // G consecutive rows starting at matched row r: one buffer resource per group (scalar registers), the row inside the group
+    // in the scalar offset, the lane's bytes in the vector offset -- no per-load vector instruction (the saddr form of
+    // global_load costs a v_mov per load here); gathered rows keep the global loads
+    auto load_group = [&](uint32_t (&x)[G], int64_t r) {
+        if constexpr (!GATHER) {
+            const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<int8_t *>(db + (row0 + r) * pitch), 0, (int)(G * pitch), 0x00020000);
+#pragma unroll
+            for (int u = 0; u < G; ++u)
+                x[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, lane_off, (int)(u * pitch), NT ? 2 : 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < G; ++u) x[u] = load(r + u);
+        }
+    };
     auto missing_bits = [](uint32_t x) -> uint32_t {
         return SKIP ? ((x >> 1) & 0x55555555u) : __builtin_amdgcn_bitop3_b32(x, x >> 1, 0x55555555u, 0x80);
     };
@@ -761,11 +776,9 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
                     // the group after the pair: inside this tile, or the first group of my next tile (a partial last tile
                     // is followed by PREFETCH_PAD_ROWS >= G readable rows)
                     const int64_t rafter = (g + 2 < TR / G) ? rnext + G : ntr0;
-#pragma unroll
-                    for (int u = 0; u < G; ++u) xb[u] = load(rnext + u);
+                    load_group(xb, rnext);
                     score_group(xa, g);
-#pragma unroll
-                    for (int u = 0; u < G; ++u) xa[u] = load(rafter + u);
+                    load_group(xa, rafter);
                     score_group(xb, g + 1);
                 }
             } else {
@@ -821,7 +834,7 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
     // 256-row tiles.  Measured with the arithmetic stripped (tools/micro/read_patterns.hip, this panel's 2560-B rows,
     // one-wave blocks): groups of 8 / 64-row tiles 21.0 ms, groups of 4 / 128-row tiles 19.2 ms per 125 GB; the kernel's own
     // pattern-only build 22.3 -> 20.5 ms.  (Unpipelined groups of 8 -- request, wait, count -- measured the same as this.)
-    constexpr int H = 4;                    // rows per load group
+    constexpr int H = 4;                    // rows per load group (load_rows)
     constexpr int TR = BITS_TILE_ROWS;
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -846,6 +859,19 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
         asm volatile("" : "+v"(off));
         const uint32_t *ptr = reinterpret_cast<const uint32_t *>(rowbase + off);
         return NT ? __builtin_nontemporal_load(ptr) : *ptr;
+    };
+    // H consecutive rows through a buffer resource (see k_fast_packed_q4::load_group)
+    auto load_rows = [&](uint32_t (&x)[4], int64_t r) {
+        if constexpr (!GATHER) {
+            const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<int8_t *>(db + (row0 + r) * pitch), 0, (int)(4 * pitch), 0x00020000);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                x[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, lane_off, (int)(u * pitch), NT ? 2 : 0);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = load(r + u);
+        }
     };
     // (hit bits, missing bits) of one row
     auto classify = [&](uint32_t x, uint32_t wb, uint32_t &hit, uint32_t &mis) {
@@ -946,8 +972,7 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
                 // rows rb .. rb+3 are in xa (requested one step ago), rb+4 .. rb+7 are requested now
                 const int64_t rb = tr0 + (int64_t)it * 8;
                 const int64_t rn = (it + 1 < TR / 8) ? rb + 8 : ntr0;        // the next counting group: in this tile or my next tile
-#pragma unroll
-                for (int u = 0; u < H; ++u) xb[u] = load(rb + H + u);
+                load_rows(xb, rb + H);
                 const uint64_t wcur = w8;
 #pragma unroll
                 for (int u = 0; u < H; ++u) asm volatile("" : "+v"(xa[u]));
@@ -958,8 +983,7 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
 #else       // diagnostic build: the loads and the loop structure without the arithmetic
                 h1 ^= xa[0] ^ xa[1] ^ xa[2] ^ xa[3];
 #endif
-#pragma unroll
-                for (int u = 0; u < H; ++u) xa[u] = load(rn + u);
+                load_rows(xa, rn);
                 w8 = wbits8(rn);
 #pragma unroll
                 for (int u = 0; u < H; ++u) asm volatile("" : "+v"(xb[u]));
