@@ -1,0 +1,16 @@
+#!/bin/bash
+# refresh after the buffer-resource loads (k_strict4, k_fast_packed_q4, k_fast_bits): bench lines + rocprofv3 kernel stats
+set -uo pipefail
+out=gpurun_out/r02b; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --mode strict --n-snp 6250000 > $out/bench_strict_10k_x_6250k.json 2> $out/bench_strict.err; echo "rc=$?"
+timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --mode strict --packed --n-snp 6250000 > $out/bench_strict_packed_10k_x_6250k.json 2> $out/bench_strict_packed.err; echo "rc=$?"
+timeout -k 10 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --packed > $out/bench_packed_full.json 2> $out/bench_packed.err; echo "rc=$?"
+timeout -k 10 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --packed --hard-calls > $out/bench_packed_hardcalls_full.json 2> $out/bench_packed_hc.err; echo "rc=$?"
+for v in strict:"--mode strict --n-snp 6250000" packed:"--packed" packed_hc:"--packed --hard-calls"; do
+  name=${v%%:*}; args=${v#*:}
+  rm -rf $out/prof_$name
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline $args > $out/bench_${name}_under_rocprof.json 2> $out/prof_$name.err; echo "$name rc=$?"
+done
+find $out -name "*.db" -delete 2>/dev/null
+echo done
