@@ -76,7 +76,7 @@ int         snpm_set_stream(snpm_ctx *ctx, void *hip_stream);
 int         snpm_synchronize(snpm_ctx *ctx);
 
 /* ---------------------------------------------------------------- panel (DB genotype matrix in HBM) */
-/* SNP-major int8 [n_snp, pitch], pitch = n_acc rounded up to 256 B, pad bytes = -1. */
+/* SNP-major int8 [n_snp, pitch], pitch = n_acc rounded up to 256 B, pad bytes = -1.  1 <= n_acc <= 2^27 (SNPM_ERR_BADARG). */
 int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out);
 /* Same panel with 2 bits per call (4 accessions per byte: 0 ref, 1 alt, 2 het, 3 missing): 4x less HBM
    capacity and traffic (the 10k x 50M panel is 125 GB and fits one MI355X).  Rows are uploaded as int8

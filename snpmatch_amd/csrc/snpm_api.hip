@@ -1416,7 +1416,8 @@ try {
     if (!ctx) return SNPM_ERR_BADARG;
     CHECK_ARG(ctx, out != nullptr, "out is NULL");
     CHECK_ARG(ctx, n_snp >= 0 && n_acc >= 1, "panel needs n_snp >= 0 and n_acc >= 1");
-    CHECK_ARG(ctx, n_acc <= (int64_t)1 << 30, "n_acc too large");
+    // 2^27 accessions: a group of 8 rows stays below 2^31 bytes (the kernels address row groups through 32-bit buffer offsets)
+    CHECK_ARG(ctx, n_acc <= (int64_t)1 << 27, "n_acc too large (at most 2^27 accessions per panel)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     snpm_panel *p = new snpm_panel();
     p->ctx = ctx;

@@ -1638,7 +1638,8 @@ strict4_segments(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             if constexpr (!GATHER) {
                 // consecutive rows: one buffer resource per batch (scalar registers), the row inside the batch in the scalar
                 // offset, the lane's column in the vector offset -- no address arithmetic on the vector unit, which this
-                // kernel saturates (and reads past the batch would return 0 instead of faulting)
+                // kernel saturates (and reads past the batch would return 0 instead of faulting).  32-bit byte counts: panels
+                // hold at most 2^27 accessions (snpm_panel_create)
                 const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(
                     const_cast<int8_t *>(db + (row0 + rb) * pitch), 0, (int)(SB * pitch), 0x00020000);
 #pragma unroll
