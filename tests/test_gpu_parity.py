@@ -173,6 +173,8 @@ def test_empty_and_ragged(ctx):
         assert np.array_equal(s, np.zeros(5)) and np.array_equal(ni, np.zeros(5, dtype=np.int64))
     with pytest.raises(AssertionError):
         engine.Query(panel, np.array([50], dtype=np.int64), np.ones((1, 3)))       # row outside the panel
+    with pytest.raises(AssertionError, match="n_acc too large"):
+        engine.Panel(ctx, 1, (1 << 27) + 1)                                        # beyond the 32-bit row-group offsets
     with pytest.raises(AssertionError, match="shape == n,3"):
         engine.Query(panel, np.array([1], dtype=np.int64), np.ones((1, 2)))
     # repeated rows are allowed (the reference would gather them twice as well)
