@@ -218,6 +218,10 @@ int snpm_query_run_carry(snpm_query *query, int64_t chunk, int skip_hets, int mo
 int snpm_carry_finish(snpm_carry *carry, double *score, int64_t *ninfo, int32_t *flagged, int64_t cap,
                       int64_t *n_flagged);
 int snpm_carry_patch(snpm_carry *totals, const snpm_carry *cols_pass);
+/* Rigorous bound on |total - reference total| of the slabs scored so far in SNPM_MODE_EXACT (the sum of the slabs'
+   bounds -- reference-order term of every slab, integer-weight slabs included, plus the fast-pass term of the
+   non-integer ones -- and of the slab-order additions); 0 when every slab had integer weights or in other modes. */
+int snpm_carry_error_bound(snpm_carry *carry, double *bound);
 /* device pointers of the totals (float64 [n_acc], int64 [n_acc]): input of snpm_likelihood_device / an all-gather */
 int snpm_carry_device_ptrs(snpm_carry *carry, void **d_score, void **d_ninfo);
 

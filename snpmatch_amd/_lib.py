@@ -38,7 +38,7 @@ SYMBOLS = [
     "snpm_debug_stream_read", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
     "snpm_panel_fill_synthetic_rows", "snpm_sample_synthetic", "snpm_query_create_device", "snpm_query_last_reeval",
     "snpm_query_last_kernel", "snpm_carry_create", "snpm_carry_reset", "snpm_carry_free", "snpm_carry_set_columns", "snpm_carry_bind_outputs", "snpm_panel_segregating_first", "snpm_query_gather_columns", "snpm_query_run_windows_fast", "snpm_score_batch", "snpm_score_batch_coded", "snpm_host_alloc", "snpm_host_free",
-    "snpm_query_run_carry", "snpm_carry_finish", "snpm_carry_patch", "snpm_carry_device_ptrs",
+    "snpm_query_run_carry", "snpm_carry_finish", "snpm_carry_patch", "snpm_carry_device_ptrs", "snpm_carry_error_bound",
 ]
 
 _lib = None
@@ -116,6 +116,7 @@ def load():
     lib.snpm_carry_finish.argtypes = [p, p, p, p, i64, C.POINTER(i64)]
     lib.snpm_carry_patch.argtypes = [p, p]
     lib.snpm_carry_device_ptrs.argtypes = [p, pp, pp]
+    lib.snpm_carry_error_bound.argtypes = [p, C.POINTER(dbl)]
     lib.snpm_query_create.argtypes = [p, p, i64, i64, p, pp]
     lib.snpm_query_free.argtypes = [p]
     lib.snpm_query_bind_outputs.argtypes = [p, p, p]

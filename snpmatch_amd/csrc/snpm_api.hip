@@ -159,6 +159,7 @@ struct snpm_carry {
     int64_t n_rows = 0, n_slabs = 0;
     long double wsum = 0;               // of all slabs (bound of the slab-total additions)
     int mode = -1;                      // mode of the first slab; later slabs must agree
+    bool all_integer = true;            // every slab so far had integer weights only (then any summation order is exact)
     bool finished = false;
     double *own_score = nullptr;        // d_score / d_ninfo point here unless the caller bound its own buffers
     int64_t *own_ninfo = nullptr;
@@ -2387,6 +2388,7 @@ int snpm_carry_reset(snpm_carry *c)
     c->wsum = 0;
     c->mode = -1;
     c->n_cols = -1;
+    c->all_integer = true;
     c->finished = false;
     return SNPM_OK;
 }
@@ -2478,12 +2480,21 @@ try {
         FastGeom g;
         rc = run_fast(q, skip, &g, cert);
         if (rc) return rc;
-        const bool bounded = cert.on && !q->all_integer && q->n > 0;
+        // The job's bound takes the reference-order term of EVERY slab: a slab of integer weights is exact on its own
+        // (run_fast skips its bound), but in a job that also holds non-integer slabs the reference adds this slab's chunk
+        // sums onto a non-integer running total, so its terms pick up gamma(chunks left) like any others.  Only a job
+        // whose slabs are all integer is exact in any order (snpm_carry_finish then flags nothing).
+        const bool bounded = cert.on && q->n > 0;
+        if (bounded && q->all_integer) {
+            rc = ensure_eref(q, chunk, chunks_after);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL(k_carry_add, dim3((unsigned)((p->n_acc + 255) / 256)), dim3(256), 0, ctx->stream, c->d_score,
                            c->d_ninfo, (const double *)q->d_score, (const int64_t *)q->d_ninfo, p->n_acc, c->d_E,
                            bounded ? (const double *)q->cert_eref() : (const double *)nullptr,
-                           bounded ? efast_bound(q, g) : 0.0);
+                           (bounded && !q->all_integer) ? efast_bound(q, g) : 0.0);
         HIPCHK(ctx, hipGetLastError());
+        c->all_integer = c->all_integer && (q->all_integer || q->n == 0);
     }
     c->mode = mode;
     c->n_rows += q->n;
@@ -2492,6 +2503,33 @@ try {
     return SNPM_OK;
 } SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
 
+// integer weights in every slab and totals below 2^53: every partial sum of either order is exact
+static bool carry_is_exact(const snpm_carry *c) { return c->all_integer && c->wsum < 9.0e15L; }
+
+// the slab totals were added in slab order: n_slabs more additions per term
+static double carry_e_extra(const snpm_carry *c)
+{
+    const double u = 1.1102230246251565e-16;
+    const double m = (double)(c->n_slabs + 1);
+    return (double)(c->wsum * (long double)(m * u / (1.0 - m * u))) * 1.0000001;
+}
+
+int snpm_carry_error_bound(snpm_carry *c, double *bound)
+{
+    CHECK_CARRY(c);
+    snpm_ctx *ctx = c->ctx;
+    CHECK_ARG(ctx, bound != nullptr, "bound is NULL");
+    *bound = 0.0;
+    if (c->mode != SNPM_MODE_EXACT || carry_is_exact(c)) return SNPM_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_pinned(ctx, 64);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, c->d_E, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *bound = *(const double *)ctx->h_pinned + carry_e_extra(c);
+    return SNPM_OK;
+}
+
 int snpm_carry_finish(snpm_carry *c, double *score, int64_t *ninfo, int32_t *flagged, int64_t cap, int64_t *n_flagged)
 {
     CHECK_CARRY(c);
@@ -2499,11 +2537,8 @@ int snpm_carry_finish(snpm_carry *c, double *score, int64_t *ninfo, int32_t *fla
     CHECK_ARG(ctx, c->n_cols < 0, "a column-list carry is read with snpm_carry_patch");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int64_t nf = 0;
-    if (c->mode == SNPM_MODE_EXACT) {
-        // the slab totals were added in slab order: n_slabs more additions per term
-        const double u = 1.1102230246251565e-16;
-        const double m = (double)(c->n_slabs + 1);
-        const double e_extra = (double)(c->wsum * (long double)(m * u / (1.0 - m * u))) * 1.0000001;
+    if (c->mode == SNPM_MODE_EXACT && !carry_is_exact(c)) {
+        const double e_extra = carry_e_extra(c);
         HIPCHK(ctx, hipMemsetAsync(c->d_ncols, 0, sizeof(int), ctx->stream));
         hipLaunchKernelGGL(k_carry_flag, dim3((unsigned)((c->n_acc + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const double *)c->d_score, c->n_acc, (const double *)c->d_E, e_extra, ctx->debug_reeval,

@@ -529,6 +529,12 @@ class Carry(object):
         self.n_flagged = nf.value
         return score, ninfo, np.sort(cols[:min(nf.value, 64)])
 
+    def error_bound(self):
+        """bound on |total - reference total| of the slabs scored so far in MODE_EXACT (0 for all-integer jobs)"""
+        b = C.c_double(0)
+        check(self.ctx.lib.snpm_carry_error_bound(self.h, C.byref(b)), self.ctx.h)
+        return b.value
+
     def patch_from(self, cols_carry):
         check(self.ctx.lib.snpm_carry_patch(self.h, cols_carry.h), self.ctx.h)
 

@@ -165,3 +165,115 @@ def test_slab_streamed_job_equals_resident_10000_x_12M():
         assert int(np.argmax(se / ne)) == planted
     finally:
         ctx.close()
+
+
+def synthetic_slab_scorer(ctx, n_acc, slabs, wei_ptr_of, packed=False, acc0=0, buf=None):
+    """SlabScorer over device-regenerated slabs of the synthetic panel SEED: one resident buffer of max(slabs) rows"""
+    starts = np.concatenate([[0], np.cumsum(slabs)]).astype(np.int64)
+    buf = buf or engine.Panel(ctx, max(slabs), n_acc, packed=packed)
+    sc = engine.SlabScorer(buf, slabs, lambda k, p: p.fill_synthetic(SEED, snp0=int(starts[k]), acc0=acc0, row0=0, nrows=slabs[k]),
+                           lambda k: wei_ptr_of(int(starts[k])), device_weights=True)
+    return sc, buf
+
+
+def test_config4_looped_job_12500_x_100M_in_seven_slabs():
+    """configs[4] as SURVEY 8d describes it -- the per-GPU share of 100k x 100M (12 500 accessions x 100M SNPs = 1.25 TB
+    of int8) looped through ONE resident buffer as seven device-regenerated slabs of <= 16M SNPs with a carry over
+    100 000 reference chunks (core/snpmatch.py:218-225 adds every chunk onto ScoreList / NumInfoSites):
+      * all-ones weights: score == ninfo for every accession, ninfo of two quads == the numpy twin over all 100M rows;
+      * PL-weighted planted sample: EXACT counts == STRICT counts for every accession (certificate over the totals,
+        second pass over the slabs for the flagged ones), one quad of the STRICT carry bit for bit == the C oracle
+        over all 100M rows, the planted accession is the top hit;
+      * with 70 forced accessions the certificate flags more than the sparse tier takes: the job is re-run in
+        reference order for every accession (the > 64 branch) and returns the strict bits."""
+    import torch
+    n_snp, n_acc, planted, chunk = 100_000_000, 12_500, 417, 1000
+    slabs = [16_000_000] * 6 + [4_000_000]
+    ctx = reeval_context()              # accessions 0, 1 forced into every second pass
+    try:
+        wei = torch.ones((n_snp, 3), dtype=torch.float64, device="cuda:0")
+        sc, buf = synthetic_slab_scorer(ctx, n_acc, slabs, lambda r0: wei[r0:].data_ptr())
+        s, ni, info = sc.run(engine.MODE_EXACT)
+        assert not info["second_pass"] and info["n_strict_reeval"] == 0          # integer weights: any order is exact
+        assert np.array_equal(s, ni.astype(np.float64)) and ni.min() > 0.94 * n_snp
+        sc.free()
+        quads = {c4: twin_quad(n_snp, 0, c4) for c4 in (416, 12_496)}
+        for c4, cols in quads.items():
+            assert np.array_equal(ni[c4:c4 + 4], n_snp - (cols < 0).sum(axis=0)), c4
+        del quads[12_496]
+        # the bench sample (planted accession 417, 2 % error, 80 % PL weights), generated on the device
+        ctx.sample_synthetic(SEED, 0, n_snp, planted, wei.data_ptr())
+        ctx.synchronize()
+        sc, _ = synthetic_slab_scorer(ctx, n_acc, slabs, lambda r0: wei[r0:].data_ptr(), buf=buf)
+        se, ne, info = sc.run(engine.MODE_EXACT)
+        n_flagged = info["n_strict_reeval"]
+        assert info["second_pass"] and 2 <= n_flagged <= 64, info
+        ss, ns, _ = sc.run(engine.MODE_STRICT)
+        assert np.array_equal(ne, ns) and np.array_equal(ne, ni)
+        assert np.array_equal(se.astype(np.int64), ss.astype(np.int64))
+        assert np.array_equal(bits(se[:2]), bits(ss[:2]))              # the forced accessions carry the reference's bits
+        assert np.max(np.abs(se - ss)) < 1e-2
+        assert int(np.argmax(se / ne)) == planted
+        wei_host = wei.cpu().numpy()
+        ws, wn = c_oracle.genotyper(quads[416], None, wei_host, chunk, False)
+        assert np.array_equal(bits(ss[416:420]), bits(ws)) and np.array_equal(ns[416:420], wn)
+        assert np.array_equal(se[416:420].astype(np.int64), ws.astype(np.int64))
+        del wei_host
+        sc.free()
+        buf.free()
+    finally:
+        ctx.close()
+    # more flagged totals than the sparse tier takes (here: forced) -> second pass in reference order for everyone
+    os.environ["SNPM_DEBUG_REEVAL"] = "70"
+    try:
+        ctx = engine.Context(0)
+    finally:
+        del os.environ["SNPM_DEBUG_REEVAL"]
+    try:
+        sc, buf = synthetic_slab_scorer(ctx, n_acc, slabs, lambda r0: wei[r0:].data_ptr())
+        s70, n70, info = sc.run(engine.MODE_EXACT)
+        assert info["second_pass"] and info["n_strict_reeval"] > 64, info
+        assert np.array_equal(bits(s70), bits(ss)) and np.array_equal(n70, ns)
+        sc.free()
+        buf.free()
+    finally:
+        ctx.close()
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "config5_looped_test_record.json"), "w") as fh:
+            import json
+            json.dump({"shape": "12500 x 100M in slabs %s" % slabs, "flagged_totals_incl_2_forced": int(n_flagged),
+                       "max_abs_exact_minus_strict": float(np.max(np.abs(se - ss)))}, fh)
+
+
+def test_bench_job_int8_slabs_equal_packed_resident_10000_x_50M():
+    """the exact N=1 job of bench.py (10 000 x 50M int8 as slabs of 20.019M + 20.019M + 9.962M rows with a carry) against
+    the same job on ONE resident 2-bit packed panel: every fp64 total bit-identical in reference order, certified
+    counts identical in both (two panel formats, two kernels families, slab carry vs one pass)"""
+    import torch
+    n_snp, n_acc, planted = 50_000_000, 10_000, 417
+    slabs = [20_019_000, 20_019_000, 9_962_000]
+    ctx = reeval_context()
+    try:
+        wei = torch.empty((n_snp, 3), dtype=torch.float64, device="cuda:0")
+        ctx.sample_synthetic(SEED, 0, n_snp, planted, wei.data_ptr())
+        sc, buf = synthetic_slab_scorer(ctx, n_acc, slabs, lambda r0: wei[r0:].data_ptr())
+        ss, ns, _ = sc.run(engine.MODE_STRICT)
+        se, ne, info = sc.run(engine.MODE_EXACT)
+        assert info["second_pass"] and 2 <= info["n_strict_reeval"] <= 64
+        sc.free()
+        buf.free()
+        packed = engine.Panel(ctx, n_snp, n_acc, packed=True)
+        packed.fill_synthetic(SEED)
+        q = engine.Query.from_device(packed, None, wei.data_ptr(), n_snp)
+        ps, pn = q.run(1000, False, engine.MODE_STRICT)
+        pe, pne = q.run(1000, False, engine.MODE_EXACT)
+        assert np.array_equal(bits(ps), bits(ss)) and np.array_equal(pn, ns)
+        assert np.array_equal(pne, ns) and np.array_equal(ne, ns)
+        assert np.array_equal(pe.astype(np.int64), ss.astype(np.int64))
+        assert np.array_equal(se.astype(np.int64), ss.astype(np.int64))
+        assert int(np.argmax(ss / ns)) == planted
+        q.free()
+        packed.free()
+    finally:
+        ctx.close()

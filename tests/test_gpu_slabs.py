@@ -178,3 +178,42 @@ def test_error_bound_on_device_covers_the_host_formula():
         got = q.error_bound(chunk)
         assert eref <= got <= eref * 1.001 + wmax.sum() * 1e-11, (n, chunk, eref, got)
     ctx.close()
+
+
+@pytest.mark.parametrize("order", ["hard_then_pl", "pl_then_hard"])
+def test_mixed_job_hard_call_slab_and_pl_slab(order):
+    """A job with one slab of hard 0/1 calls and one of PL weights: the hard-call slab is exact on its own, but the
+    reference adds its chunk sums onto (or under) a non-integer running total, so its terms belong in the job's bound
+    with the chunks still to come (the bound used to leave them out).  The job's bound must cover the
+    host formula over BOTH slabs; counts equal the oracle's; forced accessions carry the reference's bits."""
+    ctx = make_ctx(SNPM_DEBUG_REEVAL=3)
+    rng = np.random.default_rng(11)
+    n, n_acc, chunk = 20000, 257, 1000
+    db = rand_db(rng, n, n_acc)
+    codes = db[:, 9].copy()
+    codes[codes < 0] = 0
+    hard, pl = synth.sample_weights(rng, codes, frac_pl=0.0), synth.sample_weights(rng, codes, frac_pl=1.0)
+    half = n // 2
+    wei = np.concatenate([hard[:half], pl[half:]] if order == "hard_then_pl" else [pl[:half], hard[half:]])
+    want_s, want_n = c_oracle.genotyper(db, None, wei, chunk, False)
+    sc, panel = slab_scorer(ctx, db, wei, [half, n - half], chunk, False)
+    s, ni, info = sc.run(engine.MODE_EXACT)
+    assert info["second_pass"] and 3 <= info["n_strict_reeval"] <= 64
+    assert np.array_equal(ni, want_n) and np.array_equal(s.astype(np.int64), want_s.astype(np.int64))
+    assert np.array_equal(bits(s[:3]), bits(want_s[:3]))
+    # the bound of the job against the reference-order formula over all 20 chunks (terms of the hard-call slab included)
+    wmax = np.abs(wei).max(axis=1)
+    K, u = n // chunk, 2.0 ** -53
+    eref = sum(wmax[k * chunk:(k + 1) * chunk].sum() * (chunk + 3 + K - k) for k in range(K)) * u
+    bound = sc.carry.error_bound()
+    assert eref <= bound <= eref + wmax.sum() * 20000 * u, (eref, bound)      # + the fast pass's own term (<= 8192 + 64 + groups additions)
+    assert np.max(np.abs(s - want_s)) <= bound
+    sc.free()
+    # a job of hard calls only is exact in any order: nothing flagged (not even the forced accessions), bound 0
+    sc, panel = slab_scorer(ctx, db, hard, [half, n - half], chunk, False)
+    s, ni, info = sc.run(engine.MODE_EXACT)
+    want_s, want_n = c_oracle.genotyper(db, None, hard, chunk, False)
+    assert not info["second_pass"] and sc.carry.error_bound() == 0.0
+    assert np.array_equal(bits(s), bits(want_s)) and np.array_equal(ni, want_n)
+    sc.free()
+    ctx.close()
