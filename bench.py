@@ -51,6 +51,14 @@ def baseline_metric():
         return "accession×SNP comparisons/sec (whole node); achieved HBM GB/s vs peak"
 
 
+def workload_name(n_acc, n_snp):
+    if (n_acc, n_snp) == (N_ACC_TOTAL, N_SNP_TOTAL):
+        return "configs[3]"
+    if (n_acc, n_snp) == (12500, 100_000_000):
+        return "configs[4] per-GPU share (12 500 of 100k accessions x 100M SNPs, looped through one resident slab buffer)"
+    return "configs[3]-shaped"
+
+
 def make_sample(n_snp, seed, planted, err=0.02, frac_pl=0.8, block=2_000_000):
     """host weights [n_snp,3] of the bench sample (numpy twin of the device generator; tools and tests)"""
     from snpmatch_amd import synth
@@ -403,10 +411,10 @@ def main():
             "dtype": "f64",          # weighted match sums accumulate in fp64 (panel elements: int8 / 2-bit codes)
             "data": "synthetic",
             "config": {
-                "workload": "configs[3]: synthetic %d accessions x %d SNPs %s, the whole job, accession-sharded over %d GPU(s); "
+                "workload": "%s: synthetic %d accessions x %d SNPs %s, the whole job, accession-sharded over %d GPU(s); "
                             "per GPU %d accessions x %d SNPs = %.1f GB, scored in %d resident SNP slab(s) of %s rows "
                             "(largest %.1f GB)"
-                            % (n_acc, n_snp, "2-bit packed" if args.packed else "int8", world, n_loc, n_snp,
+                            % (workload_name(n_acc, n_snp), n_acc, n_snp, "2-bit packed" if args.packed else "int8", world, n_loc, n_snp,
                                n_snp * panel.pitch / 1e9, S, "+".join(str(s) for s in slabs), rows_per_slab * panel.pitch / 1e9),
                 "n_acc": n_acc, "n_snp": n_snp, "acc_per_gpu": n_loc, "mode": args.mode, "chunk": chunk,
                 "panel_format": "packed2" if args.packed else "int8", "slabs": slabs,
