@@ -29,8 +29,9 @@
  *     host bookkeeping and make no HIP call.
  *   - calls are blocking from the caller's view unless the name says otherwise; one ctx must not
  *     be used from two threads at once; distinct ctx are independent.  One ctx == one GPU; a
- *     multi-GPU job is one process (one ctx) per GPU with the accession axis sharded by the host
- *     layer (snpmatch_amd.dist) and a final all-gather over RCCL.
+ *     multi-GPU job is a snpm_group (below): one process that drives every GPU, or one process per
+ *     GPU, each member holding an accession range of the DB, with ONE RCCL all-gather of the
+ *     per-accession results inside snpm_group_gather_scores.
  *   - genotype codes: 0 hom-ref, 1 hom-alt, 2 het, negative = missing (stored as -1);
  *     values > 2 are informative but match nothing (stored as 3).
  *   - weights `wei` are float64 [n,3]: column 0 scores db==0, column 1 scores db==2 (het),
@@ -51,6 +52,7 @@ extern "C" {
 #define SNPM_ERR_OOM      -3   /* device or pinned-host allocation failed */
 #define SNPM_ERR_STATE    -4   /* handle used in the wrong state */
 #define SNPM_ERR_DOMAIN   -5   /* likelihood: a score exceeds its informative count (reference asserts y <= n) */
+#define SNPM_ERR_RCCL     -6   /* RCCL could not be loaded, or a communicator / collective call failed */
 
 /* scoring modes of snpm_query_run */
 #define SNPM_MODE_EXACT   0    /* fast streaming pass + strict re-evaluation of every accession whose score could
@@ -63,6 +65,7 @@ typedef struct snpm_ctx   snpm_ctx;
 typedef struct snpm_panel snpm_panel;
 typedef struct snpm_query snpm_query;
 typedef struct snpm_carry snpm_carry;
+typedef struct snpm_group snpm_group;
 
 /* ---------------------------------------------------------------- lifecycle */
 int         snpm_version(void);
@@ -224,6 +227,50 @@ int snpm_carry_patch(snpm_carry *totals, const snpm_carry *cols_pass);
 int snpm_carry_error_bound(snpm_carry *carry, double *bound);
 /* device pointers of the totals (float64 [n_acc], int64 [n_acc]): input of snpm_likelihood_device / an all-gather */
 int snpm_carry_device_ptrs(snpm_carry *carry, void **d_score, void **d_ninfo);
+
+/* ---------------------------------------------------------------- multi-GPU: accession shards + one RCCL all-gather */
+/* Every reduction of matchGTsAccs runs over SNPs (core/snpmatch.py:84-88): accession columns never interact, so
+   member r of a group of R GPUs holds columns [a0_r, a1_r) of every SNP row (snpm_group_shard; boundaries are
+   multiples of 4 accessions), scores them with the entry points above on its own context, and the only exchange is
+   the gather of (score float64, ninfo int64) per accession -- the likelihood step needs the minimum over ALL
+   accessions (core/snpmatch.py:112).  Two ways to form a group:
+     snpm_group_create_local   ONE process drives n GPUs (ncclCommInitAll, no launcher): the group creates the n
+                               contexts (snpm_group_ctx) and destroys them with snpm_group_free;
+     snpm_group_create_rank    one process per GPU: rank 0 calls snpm_group_unique_id, hands the 128 bytes to the
+                               other ranks by any channel (file, environment, socket), every rank then joins with
+                               its own context (ncclCommInitRank).
+   RCCL is bound at the first group call (dlopen: the copy already in the process, else the one beside the HIP
+   runtime in use, else librccl.so.1; SNPMATCH_RCCL_LIB overrides); SNPM_ERR_RCCL when none loads.
+   Errors of group calls: snpm_group_last_error(group) (group == NULL: last failed creation in this thread). */
+#define SNPM_GROUP_ID_BYTES 128
+#define SNPM_GROUP_LOOPBACK 1   /* snpm_group_create_local flag: exchange by device-to-device copies instead of RCCL; a TEST
+                                   transport (it also accepts one device several times: rehearsal on a one-GPU box) */
+int snpm_group_unique_id(void *id_bytes /* [SNPM_GROUP_ID_BYTES] */);
+int snpm_group_create_rank(snpm_ctx *ctx, const void *id_bytes, int world, int rank, snpm_group **out);
+int snpm_group_create_local(const int *device_ids, int n, int flags, snpm_group **out);
+int snpm_group_free(snpm_group *group);
+const char *snpm_group_last_error(const snpm_group *group);
+/* world = ranks of the job, rank0 = global rank of local member 0, n_local = members this process drives */
+int snpm_group_info(const snpm_group *group, int *world, int *rank0, int *n_local);
+int snpm_group_ctx(snpm_group *group, int member, snpm_ctx **ctx);
+/* accession range [a0, a1) of global rank `rank` in a DB of n_acc accessions (equal shards of ceil(n_acc / world)
+   rounded up to 4; the last ranks may be short or empty) */
+int snpm_group_shard(const snpm_group *group, int64_t n_acc, int rank, int64_t *a0, int64_t *a1);
+/* The collective.  d_score[i] / d_ninfo[i] (i < n_local): DEVICE results of local member i's shard, float64 / int64
+   [m, a1_i - a0_i] with row stride in_ld elements (m = 1: genome-wide totals, e.g. the pointers of
+   snpm_query_run_device / snpm_carry_device_ptrs; m = n_win: window rows), produced by work queued on that member's
+   stream.  Per member one pack kernel, ONE ncclAllGather (16 * m * per bytes per rank) and one unpack kernel run on
+   that stream; with lik / lrt the likelihood rows over all accessions follow on member 0 (`truncate` as in
+   snpm_likelihood).  Host outputs [m, n_acc] (any may be NULL; lik and lrt both or neither) come from member 0 and
+   the call waits for them; with every host output NULL nothing waits on the host.  Every rank of the job makes the
+   same call (same m, n_acc). */
+int snpm_group_gather_scores(snpm_group *group, const void *const *d_score, const void *const *d_ninfo, int64_t m,
+                             int64_t n_acc, int64_t in_ld, int truncate, double *score, int64_t *ninfo, double *lik,
+                             double *lrt);
+/* device arrays the last gather left on a local member: float64 / int64 [m, n_acc] (valid until the next gather) */
+int snpm_group_gathered_ptrs(snpm_group *group, int member, void **d_score_all, void **d_ninfo_all);
+/* path of the RCCL library in use, or "loopback" */
+const char *snpm_group_transport(const snpm_group *group);
 
 /* ---------------------------------------------------------------- one-shot forms */
 /* matchGTsAccs on host arrays: db int8 [n, n_acc] (row stride db_pitch), wei float64 [n,3].

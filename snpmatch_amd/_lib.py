@@ -20,6 +20,9 @@ SNPM_ERR_HIP = -2
 SNPM_ERR_OOM = -3
 SNPM_ERR_STATE = -4
 SNPM_ERR_DOMAIN = -5
+SNPM_ERR_RCCL = -6
+GROUP_ID_BYTES = 128
+GROUP_LOOPBACK = 1
 
 MODE_EXACT = 0
 MODE_STRICT = 1
@@ -39,6 +42,9 @@ SYMBOLS = [
     "snpm_panel_fill_synthetic_rows", "snpm_sample_synthetic", "snpm_query_create_device", "snpm_query_last_reeval",
     "snpm_query_last_kernel", "snpm_carry_create", "snpm_carry_reset", "snpm_carry_free", "snpm_carry_set_columns", "snpm_carry_bind_outputs", "snpm_panel_segregating_first", "snpm_query_gather_columns", "snpm_query_run_windows_fast", "snpm_score_batch", "snpm_score_batch_coded", "snpm_host_alloc", "snpm_host_free",
     "snpm_query_run_carry", "snpm_carry_finish", "snpm_carry_patch", "snpm_carry_device_ptrs", "snpm_carry_error_bound",
+    "snpm_group_unique_id", "snpm_group_create_rank", "snpm_group_create_local", "snpm_group_free", "snpm_group_last_error",
+    "snpm_group_info", "snpm_group_ctx", "snpm_group_shard", "snpm_group_gather_scores", "snpm_group_gathered_ptrs",
+    "snpm_group_transport",
 ]
 
 _lib = None
@@ -117,6 +123,19 @@ def load():
     lib.snpm_carry_patch.argtypes = [p, p]
     lib.snpm_carry_device_ptrs.argtypes = [p, pp, pp]
     lib.snpm_carry_error_bound.argtypes = [p, C.POINTER(dbl)]
+    lib.snpm_group_unique_id.argtypes = [p]
+    lib.snpm_group_create_rank.argtypes = [p, p, ci, ci, pp]
+    lib.snpm_group_create_local.argtypes = [C.POINTER(ci), ci, ci, pp]
+    lib.snpm_group_free.argtypes = [p]
+    lib.snpm_group_last_error.argtypes = [p]
+    lib.snpm_group_last_error.restype = C.c_char_p
+    lib.snpm_group_info.argtypes = [p, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
+    lib.snpm_group_ctx.argtypes = [p, ci, pp]
+    lib.snpm_group_shard.argtypes = [p, i64, ci, C.POINTER(i64), C.POINTER(i64)]
+    lib.snpm_group_gather_scores.argtypes = [p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), i64, i64, i64, ci, p, p, p, p]
+    lib.snpm_group_gathered_ptrs.argtypes = [p, ci, pp, pp]
+    lib.snpm_group_transport.argtypes = [p]
+    lib.snpm_group_transport.restype = C.c_char_p
     lib.snpm_query_create.argtypes = [p, p, i64, i64, p, pp]
     lib.snpm_query_free.argtypes = [p]
     lib.snpm_query_bind_outputs.argtypes = [p, p, p]
@@ -154,6 +173,21 @@ def load():
         getattr(lib, name)
     _lib = lib
     return lib
+
+
+def check_group(rc, group_handle=None):
+    """status of a snpm_group_* call -> exception with the group's message"""
+    if rc == SNPM_OK:
+        return
+    msg = load().snpm_group_last_error(group_handle)
+    msg = msg.decode("utf-8", "replace") if msg else ""
+    if rc == SNPM_ERR_BADARG:
+        raise AssertionError(msg)
+    if rc == SNPM_ERR_DOMAIN:
+        raise AssertionError(msg or "provided y is greater than n")
+    if rc == SNPM_ERR_OOM:
+        raise MemoryError(msg)
+    raise SnpmError(rc, msg)
 
 
 def ptr(a):

@@ -149,7 +149,7 @@ class CrossIdentifier(object):
         db_rows, sample_rows, offsets, win_chr = _window_segments(self.genome, self.g.g, self.inputs, self.binLen)
         n_matched = int(offsets[-1])
 
-        query = engine.Query(self.g.panel(), db_rows, self.inputs.wei[sample_rows, ])
+        query = self.g.panel().query(db_rows, self.inputs.wei[sample_rows, ])
         # default: every window in reference order (fp64 window scores with the reference's bits -> byte-identical
         # windowscore.txt).  SNPMATCH_CROSS_FAST=1: the segmented streaming pass with the certificate -- snps_match,
         # snps_info and the totals identical, float scores / likelihoods equal to ~1e-12 relative.
@@ -193,7 +193,7 @@ class CrossIdentifier(object):
         db_rows, sample_rows = self.g.get_positions_idxs(self.inputs.chrs, self.inputs.pos)
         # all pairs in one device call (k_f1_*): per pair np.sum(W[alt, 2]) + np.sum(W[ref, 0]) + np.sum(W[het, 1])
         # with numpy's summation order, so the float scores printed below carry the reference's digits
-        query = engine.Query(self.g.panel(), db_rows, self.inputs.wei[sample_rows, ])
+        query = self.g.panel().query(db_rows, self.inputs.wei[sample_rows, ])
         job = dist.job()
         if job is None:
             extra_s, extra_n = query.f1_pairs(best)

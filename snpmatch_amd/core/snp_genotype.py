@@ -125,30 +125,51 @@ class Genotype(object):
     def panel(self, ctx=None, packed=None):
         """The DB matrix resident in HBM (created on first use; slabs go through pinned staging).
         ``packed`` (default: environment SNPMATCH_PACKED=1) stores 2 bits per call instead of a byte --
-        same results, a quarter of the HBM; DBs with codes other than -1/0/1/2 stay int8."""
+        same results, a quarter of the HBM; DBs with codes other than -1/0/1/2 stay int8.
+        Where the accession columns live:
+          * under ``torch.distributed.run`` (``dist.job()``): this rank's accession shard on this rank's GPU;
+          * several GPUs visible to ONE process (SNPMATCH_GPUS, default all): an ``engine.GroupPanel`` -- a shard per
+            GPU, results joined by one RCCL all-gather inside the library (no launcher);
+          * otherwise: the whole matrix on one GPU."""
         from .. import dist, engine
-        if self._panel is None or self._panel.h is None:
-            ctx = ctx or engine.default_context()
+        if self._panel is None or getattr(self._panel, "h", None) is None:
             if packed is None:
                 packed = os.environ.get("SNPMATCH_PACKED", "0") not in ("", "0")
-            npy = getattr(self.g, "npy_path", None)          # native flat panel: file -> pinned slabs -> HBM
+            n_acc = len(self.accessions)
             job = dist.job()
-            self._shard = job.bounds(len(self.accessions)) if job else None
+            self._shard = job.bounds(n_acc) if job else None
             if self._shard is not None:
                 # accession-sharded job (one process per GPU): this rank holds columns [a0, a1) of every SNP row
                 assert self._shard[1] > self._shard[0], "more ranks than accession quads: this rank's shard is empty"
-                make = lambda pk: engine.Panel.from_host(ctx, self.g.snps, packed=pk, cols=self._shard)  # noqa: E731
+                self._panel = self._member_panel(ctx or engine.default_context(), self._shard[0], self._shard[1], packed)
+                return self._panel
+            group = None
+            if ctx is None:
+                ids = engine.group_devices()
+                if ids is not None:
+                    group = engine.default_group(engine.GroupPanel.usable_members(n_acc, len(ids)))
+            if group is not None:
+                self._panel = engine.GroupPanel.build(group, n_acc, lambda c, a0, a1: self._member_panel(c, a0, a1, packed))
             else:
-                make = (lambda pk: engine.Panel.from_npy(ctx, npy, packed=pk)) if npy else \
-                       (lambda pk: engine.Panel.from_host(ctx, self.g.snps, packed=pk))
-            if packed:
-                try:
-                    self._panel = make(True)
-                    return self._panel
-                except AssertionError:
-                    log.info("DB holds codes a packed panel cannot store; using the int8 panel")
-            self._panel = make(False)
+                self._panel = self._member_panel(ctx or engine.default_context(), 0, n_acc, packed)
         return self._panel
+
+    def _member_panel(self, ctx, a0, a1, packed):
+        """columns [a0, a1) of the DB on one GPU"""
+        from .. import engine
+        whole = (a0 == 0 and a1 == len(self.accessions))
+        npy = getattr(self.g, "npy_path", None)          # native flat panel: file -> pinned slabs -> HBM
+        if whole:
+            make = (lambda pk: engine.Panel.from_npy(ctx, npy, packed=pk)) if npy else \
+                   (lambda pk: engine.Panel.from_host(ctx, self.g.snps, packed=pk))
+        else:
+            make = lambda pk: engine.Panel.from_host(ctx, self.g.snps, packed=pk, cols=(a0, a1))  # noqa: E731
+        if packed:
+            try:
+                return make(True)
+            except AssertionError:
+                log.info("DB holds codes a packed panel cannot store; using the int8 panel")
+        return make(False)
 
     # ------------------------------------------------------------------ position intersection (a5)
     def _region_is_increasing(self, ci, pos):
@@ -237,7 +258,7 @@ class Genotype(object):
         if len(accs_ix) > (len(self.accessions) / 2):
             return None
         panel = self.panel()                       # resident after the genome-wide pass; uploaded now otherwise
-        shard = getattr(self, "_shard", None)
+        shard = getattr(self, "_shard", None)      # (a GroupPanel combines its members' scans itself)
         if shard is not None:
             # accession-sharded: every rank scans the listed accessions it holds; a row segregates when some
             # rank saw two different calls, or two ranks saw different ones

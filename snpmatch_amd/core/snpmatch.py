@@ -172,7 +172,7 @@ class Genotyper(object):
         n_matched = len(db_rows)
         # the reference walks the matched SNPs in chunk_size-row matchGTsAccs calls; here that is one query
         # against the HBM-resident panel whose counts are certified identical to that loop's
-        query = engine.Query(self.g.panel(), db_rows, self.inputs.wei[sample_rows, ])
+        query = self.g.panel().query(db_rows, self.inputs.wei[sample_rows, ])
         scores, ninfo = query.run(self.chunk_size, self._skip_db_hets, engine.MODE_EXACT)
         query.free()
         job = dist.job()
@@ -238,6 +238,10 @@ def genotype_batch(inputs_list, g, out_files, skip_db_hets=False, chunk_size=100
         common.append((db_rows, sample_rows))
         samples.append((db_rows, inputs.wei[sample_rows, ]))
     res = engine.score_batch(g.panel(), samples, chunk_size, skip_db_hets, engine.MODE_EXACT, likelihoods=False)
+    job = dist.job()
+    if job is not None:              # this rank scored its accession shard: B rows gathered like window rows; rank 0 writes
+        res["score"], res["ninfo"] = job.gather_windows(res["score"], res["ninfo"], len(g.g.accessions))
+        out_files = [job.output_prefix(f) for f in out_files]
     results = []
     for b, inputs in enumerate(inputs_list):
         n_matched = len(common[b][0])

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -2939,3 +2940,6 @@ int snpm_profile_read(snpm_ctx *ctx, const char *kernel, int64_t *launches, doub
 }
 
 }  // extern "C"
+
+// ================================================================================================ multi-GPU groups
+#include "snpm_group.hpp"

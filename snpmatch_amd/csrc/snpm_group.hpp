@@ -60,7 +60,7 @@ int rccl_bind(std::string &why)
     dl_iterate_phdr(find_loaded_rccl, &loaded);
     if (!loaded.empty()) tries.push_back(loaded);
     Dl_info di;
-    if (dladdr((void *)&hipMalloc, &di) && di.dli_fname) {          // the HIP runtime this library is bound to
+    if (dladdr((void *)(hipError_t (*)(int))&hipSetDevice, &di) && di.dli_fname) {          // the HIP runtime this library is bound to
         std::string dir(di.dli_fname);
         const size_t slash = dir.rfind('/');
         if (slash != std::string::npos) {
@@ -170,6 +170,11 @@ int group_err(snpm_group *g, int code, const char *fmt, ...)
                              hipGetErrorString(e_));                                                       \
     } while (0)
 
+#define GROUP_GUARD(G)                                                                                     \
+    catch (const std::bad_alloc &) { return group_err((G), SNPM_ERR_OOM, "out of host memory"); }          \
+    catch (const std::exception &e_) { return group_err((G), SNPM_ERR_STATE, "internal error: %s", e_.what()); } \
+    catch (...) { return group_err((G), SNPM_ERR_STATE, "internal error"); }
+
 int64_t group_per(const snpm_group *g, int64_t n_acc)
 {
     const int64_t per = (n_acc + g->world - 1) / g->world;
@@ -192,7 +197,7 @@ try {
     static_assert(sizeof(id) == SNPM_GROUP_ID_BYTES, "ncclUniqueId size");
     memcpy(id_bytes, &id, sizeof(id));
     return SNPM_OK;
-} SNPM_GUARD(nullptr)
+} GROUP_GUARD(nullptr)
 
 // one process per GPU: this process is rank `rank` of `world`, its GPU is the context's
 int snpm_group_create_rank(snpm_ctx *ctx, const void *id_bytes, int world, int rank, snpm_group **out)
@@ -216,7 +221,7 @@ try {
     g->bufs.resize(1);
     *out = g;
     return SNPM_OK;
-} SNPM_GUARD(nullptr)
+} GROUP_GUARD(nullptr)
 
 // one process drives n GPUs (ncclCommInitAll; no launcher): creates the n contexts too (snpm_group_ctx hands them out,
 // snpm_group_free destroys them).  flags: SNPM_GROUP_LOOPBACK = exchange by peer copies instead of RCCL -- a test
@@ -272,7 +277,7 @@ try {
     }
     *out = g;
     return SNPM_OK;
-} SNPM_GUARD(nullptr)
+} GROUP_GUARD(nullptr)
 
 int snpm_group_free(snpm_group *g)
 {
@@ -390,15 +395,15 @@ try {
     snpm_ctx *c0 = g->ctx[0];
     GHIPCHK(g, hipSetDevice(c0->device));
     snpm_group::Bufs &b0 = g->bufs[0];
-    int dom = 0;
     if (lik) {
         int rc;
-        if ((rc = ensure(c0, b0.lik, tot * 8)) || (rc = ensure(c0, b0.lrt, tot * 8))) return group_err(g, rc, "%s", c0->err.c_str());
+        if ((rc = ensure(c0, b0.lik, tot * 8)) || (rc = ensure(c0, b0.lrt, tot * 8)) || (rc = ensure_pinned(c0, 64)))
+            return group_err(g, rc, "%s", c0->err.c_str());
         rc = snpm_likelihood_device(c0, b0.score_all.p, b0.ninfo_all.p, m, n_acc, truncate, NAN, b0.lik.p, b0.lrt.p, nullptr);
         if (rc) return group_err(g, rc, "%s", c0->err.c_str());
         GHIPCHK(g, hipMemcpyAsync(lik, b0.lik.p, tot * 8, hipMemcpyDeviceToHost, c0->stream));
         GHIPCHK(g, hipMemcpyAsync(lrt, b0.lrt.p, tot * 8, hipMemcpyDeviceToHost, c0->stream));
-        GHIPCHK(g, hipMemcpyAsync(&dom, c0->ws_flags.p, sizeof(int), hipMemcpyDeviceToHost, c0->stream));
+        GHIPCHK(g, hipMemcpyAsync(c0->h_pinned, c0->ws_flags.p, sizeof(int), hipMemcpyDeviceToHost, c0->stream));
     }
     if (score) GHIPCHK(g, hipMemcpyAsync(score, b0.score_all.p, tot * 8, hipMemcpyDeviceToHost, c0->stream));
     if (ninfo) GHIPCHK(g, hipMemcpyAsync(ninfo, b0.ninfo_all.p, tot * 8, hipMemcpyDeviceToHost, c0->stream));
@@ -408,10 +413,10 @@ try {
             GHIPCHK(g, hipSetDevice(g->ctx[(size_t)i]->device));
             GHIPCHK(g, hipStreamSynchronize(g->ctx[(size_t)i]->stream));
         }
-        if (dom & 1) return group_err(g, SNPM_ERR_DOMAIN, "provided y is greater than n");
+        if (lik && (*(const int *)c0->h_pinned & 1)) return group_err(g, SNPM_ERR_DOMAIN, "provided y is greater than n");
     }
     return SNPM_OK;
-} SNPM_GUARD(nullptr)
+} GROUP_GUARD(g)
 
 // device arrays of the last gather on a local member: score_all float64 [m, n_acc], ninfo_all int64 [m, n_acc]
 // (valid until the next gather; ordered on that member's stream)

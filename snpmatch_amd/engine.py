@@ -15,11 +15,15 @@ _default_ctx = None
 
 
 class Context(object):
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, _borrowed=None):
         lib = _lib.load()
-        h = C.c_void_p()
-        rc = lib.snpm_init(int(device_id), C.byref(h))
-        check(rc, None)
+        if _borrowed is None:
+            h = C.c_void_p()
+            rc = lib.snpm_init(int(device_id), C.byref(h))
+            check(rc, None)
+        else:                   # a member context of a Group: created and destroyed by the group (snpm_group_create_local)
+            h = _borrowed
+        self._owns = _borrowed is None
         self.lib = lib
         self.h = h
         self.device_id = int(device_id)
@@ -44,7 +48,8 @@ class Context(object):
             for blk in self._pinned:
                 self.lib.snpm_host_free(self.h, blk)
             self._pinned = []
-            self.lib.snpm_destroy(self.h)
+            if self._owns:
+                self.lib.snpm_destroy(self.h)
             self.h = None
             try:
                 atexit.unregister(self._atexit)
@@ -171,6 +176,51 @@ def default_context():
     return _default_ctx
 
 
+_default_group = None
+
+
+def device_count():
+    n = C.c_int(0)
+    check(_lib.load().snpm_device_count(C.byref(n)), None)
+    return n.value
+
+
+def group_devices():
+    """Device ids of the GPUs one process should drive, or None for a single GPU.  SNPMATCH_GPUS = "all" (default when
+    several GPUs are visible and no torch.distributed job is active), a count, or a comma-separated list of device ids
+    (a device named twice needs SNPMATCH_GROUP_LOOPBACK=1: rehearsal of the sharded path on a one-GPU box)."""
+    import os
+    spec = os.environ.get("SNPMATCH_GPUS", "all").strip().lower()
+    if "," in spec:
+        ids = [int(x) for x in spec.split(",") if x.strip() != ""]
+    else:
+        n_vis = device_count()
+        n = n_vis if spec in ("", "all") else max(1, min(int(spec), n_vis))
+        first = int(os.environ.get("SNPMATCH_DEVICE", "0"))
+        ids = [(first + i) % max(n_vis, 1) for i in range(n)]
+    return ids if len(ids) > 1 else None
+
+
+def default_group(n_members=None):
+    """Process-wide ``Group`` over ``group_devices()`` (first ``n_members`` of them), created on first use; None for one GPU."""
+    global _default_group
+    import os
+    ids = group_devices()
+    if ids is None:
+        return None
+    if n_members is not None:
+        ids = ids[:max(1, int(n_members))]
+        if len(ids) < 2:
+            return None
+    if _default_group is not None and _default_group.h and [c.device_id for c in _default_group.contexts] == ids:
+        return _default_group
+    if _default_group is not None:
+        _default_group.free()
+    loopback = os.environ.get("SNPMATCH_GROUP_LOOPBACK", "0") not in ("", "0")
+    _default_group = Group.local(ids, loopback=loopback)
+    return _default_group
+
+
 class Panel(object):
     """int8 [n_snp, n_acc] genotype matrix in HBM (SNP-major, row pitch padded to 256 B)."""
 
@@ -203,6 +253,10 @@ class Panel(object):
                                         dtype=np.int8)
             p.upload_rows(r0, slab)  # returns once `slab` is repacked into the pinned staging buffers and the
         return p                     # copies are enqueued; scoring calls wait for them on the device
+
+    def query(self, row_idx, wei, row0=0):
+        """the matched SNPs of one sample against this panel (``GroupPanel`` / ``StreamedPanel`` offer the same call)"""
+        return Query(self, row_idx, wei, row0=row0)
 
     def upload_rows(self, row0, rows):
         rows = np.ascontiguousarray(rows, dtype=np.int8)
@@ -449,6 +503,8 @@ def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, li
     uint16 codes [n_b, 3] instead, wei = table[codes] (snpm_score_batch_coded: 10 instead of 32 bytes per SNP over PCIe).  ``device`` = (d_row_idx, d_wei, offsets): the concatenated
     inputs already in device memory (raw pointers) instead.  Returns a dict with score / ninfo (and lik / lrt)
     arrays [B, n_acc] and the re-evaluation counters."""
+    if isinstance(panel, GroupPanel):
+        return panel.score_batch(samples, chunk, skip_hets, mode, likelihoods, device, table)
     ctx = panel.ctx
     wdtype = np.float64 if table is None else np.uint16
     if device is None and isinstance(samples, tuple):
@@ -611,3 +667,260 @@ class SlabScorer(object):
             if q is not None:
                 q.free()
         self.carry.free()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# Several GPUs: accession shards + ONE RCCL all-gather of the per-accession results, behind the C ABI
+# (include/snpmatch_hip.h, snpm_group_*).  Reference: accession columns never interact (core/snpmatch.py:84-88); the
+# likelihood step needs the minimum over all accessions (core/snpmatch.py:112).
+class Group(object):
+    """The GPUs of one job.  ``Group.local([0, 1, ...])``: this process drives all of them (ncclCommInitAll, no launcher);
+    ``Group.from_rank(ctx, id_bytes, world, rank)``: one process per GPU (``Group.unique_id()`` on rank 0, handed to the
+    other ranks by the caller).  ``loopback=True`` replaces RCCL by device-to-device copies: a test transport that also
+    takes one device several times."""
+
+    def __init__(self, handle, contexts, owns_contexts):
+        self.lib = _lib.load()
+        self.h = handle
+        self.contexts = contexts
+        self._owns_contexts = owns_contexts
+        w, r0, nl = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check_group(self.lib.snpm_group_info(self.h, C.byref(w), C.byref(r0), C.byref(nl)), self.h)
+        self.world, self.rank0, self.n_local = w.value, r0.value, nl.value
+        ref = weakref.ref(self)
+        self._atexit = lambda: (ref() is not None) and ref().free()
+        atexit.register(self._atexit)
+
+    @staticmethod
+    def unique_id():
+        lib = _lib.load()
+        buf = C.create_string_buffer(_lib.GROUP_ID_BYTES)
+        _lib.check_group(lib.snpm_group_unique_id(buf), None)
+        return buf.raw
+
+    @classmethod
+    def local(cls, device_ids, loopback=False):
+        lib = _lib.load()
+        ids = (C.c_int * len(device_ids))(*[int(d) for d in device_ids])
+        h = C.c_void_p()
+        _lib.check_group(lib.snpm_group_create_local(ids, len(device_ids), _lib.GROUP_LOOPBACK if loopback else 0, C.byref(h)), None)
+        ctxs = []
+        for i, d in enumerate(device_ids):
+            ch = C.c_void_p()
+            _lib.check_group(lib.snpm_group_ctx(h, i, C.byref(ch)), h)
+            ctxs.append(Context(d, _borrowed=ch))
+        return cls(h, ctxs, True)
+
+    @classmethod
+    def from_rank(cls, ctx, id_bytes, world, rank):
+        lib = _lib.load()
+        assert len(id_bytes) == _lib.GROUP_ID_BYTES
+        h = C.c_void_p()
+        _lib.check_group(lib.snpm_group_create_rank(ctx.h, C.c_char_p(bytes(id_bytes)), int(world), int(rank), C.byref(h)), None)
+        return cls(h, [ctx], False)
+
+    @property
+    def transport(self):
+        return (self.lib.snpm_group_transport(self.h) or b"").decode()
+
+    def shard(self, n_acc, rank):
+        a0, a1 = C.c_int64(0), C.c_int64(0)
+        _lib.check_group(self.lib.snpm_group_shard(self.h, int(n_acc), int(rank), C.byref(a0), C.byref(a1)), self.h)
+        return a0.value, a1.value
+
+    def local_shards(self, n_acc):
+        return [self.shard(n_acc, self.rank0 + i) for i in range(self.n_local)]
+
+    def gather(self, d_scores, d_ninfos, n_acc, m=1, in_ld=None, truncate=False, host=True, likelihoods=False):
+        """ONE all-gather of the members' shard results (raw device pointers, one per local member): returns host arrays
+        score / ninfo [n_acc] ([m, n_acc] for m > 1) (+ lik, lrt); ``host=False``: nothing is copied or waited for, the
+        gathered vectors stay on the devices (``gathered_ptrs``)."""
+        n_acc, m = int(n_acc), int(m)
+        if in_ld is None:
+            in_ld = max(a1 - a0 for a0, a1 in self.local_shards(n_acc))
+        ps = (C.c_void_p * self.n_local)(*[C.c_void_p(int(p or 0)) for p in d_scores])
+        pn = (C.c_void_p * self.n_local)(*[C.c_void_p(int(p or 0)) for p in d_ninfos])
+        shape = (n_acc,) if m == 1 else (m, n_acc)
+        out = {}
+        if host:
+            out["score"] = np.empty(shape, dtype=np.float64)
+            out["ninfo"] = np.empty(shape, dtype=np.int64)
+            if likelihoods:
+                out["lik"] = np.empty(shape, dtype=np.float64)
+                out["lrt"] = np.empty(shape, dtype=np.float64)
+        _lib.check_group(self.lib.snpm_group_gather_scores(self.h, ps, pn, m, n_acc, int(in_ld), int(bool(truncate)),
+                                                           ptr(out.get("score")), ptr(out.get("ninfo")), ptr(out.get("lik")),
+                                                           ptr(out.get("lrt"))), self.h)
+        return out
+
+    def gathered_ptrs(self, member=0):
+        ds, dn = C.c_void_p(), C.c_void_p()
+        _lib.check_group(self.lib.snpm_group_gathered_ptrs(self.h, int(member), C.byref(ds), C.byref(dn)), self.h)
+        return ds.value, dn.value
+
+    def free(self):
+        if self.h:
+            for c in self.contexts:
+                if self._owns_contexts:
+                    c.close()           # frees the member's panels / queries / carries; the group destroys the context itself
+            self.lib.snpm_group_free(self.h)
+            self.h = None
+            try:
+                atexit.unregister(self._atexit)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _on_members(fns):
+    """run one callable per group member, each on its own host thread (a context is used by one thread at a time; ctypes
+    releases the GIL, so the members' uploads and scoring calls proceed side by side)"""
+    if len(fns) == 1:
+        return [fns[0]()]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(fns)) as pool:
+        futures = [pool.submit(f) for f in fns]
+        return [f.result() for f in futures]
+
+
+class GroupPanel(object):
+    """A DB whose accession columns are spread over the GPUs of a ``Group`` driven by this process: member i holds
+    columns [a0_i, a1_i) of every SNP row as its own panel (``Panel`` or ``StreamedPanel``).  ``query`` / ``run`` have
+    the signatures of ``Panel`` / ``Query`` and return full-length results."""
+
+    def __init__(self, group, members, n_acc):
+        assert group.rank0 == 0 and group.world == group.n_local == len(members), "GroupPanel: one process drives the whole group"
+        self.group, self.members, self.n_acc = group, members, int(n_acc)
+        self.bounds = group.local_shards(n_acc)
+        assert all(m.n_acc == a1 - a0 for m, (a0, a1) in zip(members, self.bounds))
+        self.n_snp = members[0].n_snp
+        self.packed = members[0].packed
+        self.ctx = members[0].ctx
+
+    @staticmethod
+    def usable_members(n_acc, n_devices):
+        """how many members a DB of n_acc accessions can feed (every member needs at least one accession quad)"""
+        n = max(1, min(int(n_devices), (int(n_acc) + 3) // 4))
+        while n > 1 and (n - 1) * (((n_acc + n - 1) // n + 3) // 4 * 4) >= n_acc:
+            n -= 1                      # the last shard would be empty
+        return n
+
+    @classmethod
+    def build(cls, group, n_acc, make_member):
+        """``make_member(ctx, a0, a1)`` -> the member's panel of columns [a0, a1); members are built side by side"""
+        bounds = group.local_shards(n_acc)
+        assert all(a1 > a0 for a0, a1 in bounds), "more GPUs than accession quads: use GroupPanel.usable_members"
+        members = _on_members([(lambda c=c, b=b: make_member(c, b[0], b[1])) for c, b in zip(group.contexts, bounds)])
+        return cls(group, members, n_acc)
+
+    @classmethod
+    def from_host(cls, group, snps, packed=False):
+        return cls.build(group, snps.shape[1], lambda ctx, a0, a1: Panel.from_host(ctx, snps, packed=packed, cols=(a0, a1)))
+
+    def query(self, row_idx, wei, row0=0):
+        return GroupQuery(self, row_idx, wei, row0)
+
+    def segregating_rows(self, cols):
+        """Genotype.identify_segregating_snps over accessions that live on different GPUs: every member scans the listed
+        accessions it holds (local mask + first informative call per row); a row segregates when some member saw two
+        different calls or two members saw different ones"""
+        cols = np.asarray(cols)
+        parts = _on_members([(lambda m=m, b=b: m.segregating_first(cols[(cols >= b[0]) & (cols < b[1])] - b[0]))
+                             for m, b in zip(self.members, self.bounds)])
+        masks = np.stack([p[0] for p in parts])
+        firsts = np.stack([p[1] for p in parts])
+        seen = firsts != 0xFF
+        lo = np.where(seen, firsts, 255).min(axis=0)
+        hi = np.where(seen, firsts, 0).max(axis=0)
+        return (masks.any(axis=0) | (seen.any(axis=0) & (lo != hi))).astype(np.uint8)
+
+    def score_batch(self, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, likelihoods=True, device=None, table=None):
+        """``score_batch`` with the accession axis spread over the members: every member scores all samples against its
+        columns; the likelihood rows need the minimum over all accessions and are taken on the joined arrays"""
+        assert device is None, "device-resident batch inputs belong to one GPU"
+        parts = _on_members([(lambda m=m: score_batch(m, samples, chunk, skip_hets, mode, False, None, table)) for m in self.members])
+        out = {"score": np.concatenate([p["score"] for p in parts], axis=1),
+               "ninfo": np.concatenate([p["ninfo"] for p in parts], axis=1),
+               "pairs_reeval": sum(p["pairs_reeval"] for p in parts),
+               "strict_fallback": any(p["strict_fallback"] for p in parts)}
+        if likelihoods:
+            out["lik"], out["lrt"] = self.ctx.likelihood(out["score"], out["ninfo"], truncate=True)
+        return out
+
+    def free(self):
+        for m in self.members:
+            m.free()
+
+    @property
+    def h(self):
+        """not None while the members' panels are alive (the test ``Genotype.panel`` uses to decide whether to rebuild)"""
+        return self.members[0].h
+
+
+class GroupQuery(object):
+    """``Query`` against a ``GroupPanel``: the sample's rows and weights are replicated on every member, every member
+    scores its accession shard, one all-gather (RCCL) brings the per-accession results together."""
+
+    def __init__(self, gpanel, row_idx, wei, row0=0):
+        self.panel = gpanel
+        self.parts = _on_members([(lambda m=m: m.query(row_idx, wei, row0=row0)) for m in gpanel.members])
+        self.n = self.parts[0].n
+        self._wei = wei
+
+    def run(self, chunk=1000, skip_hets=False, mode=MODE_EXACT, return_info=False):
+        gp = self.panel
+        ptrs = _on_members([(lambda q=q: q.run_device(chunk, skip_hets, mode)) for q in self.parts])
+        out = gp.group.gather([p[0] for p in ptrs], [p[1] for p in ptrs], gp.n_acc)
+        if return_info:
+            n_re = sum(q.last_reeval() for q in self.parts) if mode == MODE_EXACT else 0
+            return out["score"], out["ninfo"], {"n_strict_reeval": int(n_re), "members": len(self.parts),
+                                                "transport": gp.group.transport}
+        return out["score"], out["ninfo"]
+
+    def run_windows(self, win_off, skip_hets=False, totals=True, fast=False):
+        """per-window rows of every member side by side (host arrays: the window table is built on the host), totals
+        through the all-gather"""
+        res = _on_members([(lambda q=q: q.run_windows(win_off, skip_hets, totals=totals, fast=fast)) for q in self.parts])
+        score = np.concatenate([r[0] for r in res], axis=1)
+        ninfo = np.concatenate([r[1] for r in res], axis=1)
+        tot_s = np.concatenate([r[2] for r in res])
+        tot_n = np.concatenate([r[3] for r in res])
+        infos = [getattr(q, "last_windows_info", None) for q in self.parts]
+        if fast and all(i is not None for i in infos):
+            self.last_windows_info = {"pairs_reeval": sum(i["pairs_reeval"] for i in infos),
+                                      "totals_reeval": sum(i["totals_reeval"] for i in infos),
+                                      "strict_fallback": any(i["strict_fallback"] for i in infos)}
+        return score, ninfo, tot_s, tot_n
+
+    def gather_columns(self, acc_idx):
+        """calls of the accessions ``acc_idx`` (global indices, on whichever member holds them) at the matched rows"""
+        acc_idx = np.asarray(acc_idx)
+        out = np.full((len(acc_idx), self.n), 0xFF, dtype=np.uint8)
+        for q, (a0, a1) in zip(self.parts, self.panel.bounds):
+            mine = np.flatnonzero((acc_idx >= a0) & (acc_idx < a1))
+            if len(mine):
+                out[mine] = q.gather_columns(acc_idx[mine] - a0)
+        return out
+
+    def f1_pairs(self, acc_idx):
+        """the in-silico crosses need the listed columns side by side: they are read where they live and crossed on a
+        small panel of member 0 (core/csmatch.py:115-125)"""
+        acc_idx = np.asarray(acc_idx)
+        codes = self.gather_columns(acc_idx)
+        ctx = self.panel.members[0].ctx
+        small = Panel.from_host(ctx, np.ascontiguousarray(codes.T).view(np.int8))
+        q = Query(small, None, self._wei)
+        try:
+            return q.f1_pairs(np.arange(len(acc_idx)))
+        finally:
+            q.free()
+            small.free()
+
+    def free(self):
+        for q in self.parts:
+            q.free()
