@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--all-ranks-on-device0", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="init the process group and all-gather even at N=1")
+    ap.add_argument("--collective", default="c-abi", choices=["c-abi", "torch"],
+                    help="who runs the all-gather of the per-accession results at N>1: the library itself (snpm_group_*: RCCL "
+                         "communicator inside libsnpmatch_hip.so, one packed all-gather) or torch.distributed")
     args = ap.parse_args()
 
     # Contract: ONE JSON line on stdout.  RCCL prints a version banner to stdout when its first communicator
@@ -212,7 +215,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The collective of the path behind the C ABI (snpm_group_*): rank 0 makes the RCCL id, torch.distributed (already up
+    # for the barriers of the timing contract) carries its 128 bytes to the other ranks, every rank joins with its context.
+    # If any rank cannot form the group, all of them use torch.distributed for the gather instead (reported in `config`).
+    group = None
+    collective = "none"
+    if use_dist:
+        collective = "torch.distributed (%s)" % args.backend
+        if args.collective == "c-abi" and args.backend == "nccl":
+            ok = 1
+            try:
+                box = [engine.Group.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                group = engine.Group.from_rank(ctx, box[0], world, rank)
+                assert group.shard(n_acc, rank) == (shards.a0, shards.a1), "the library and bench.py disagree about the shards"
+            except Exception as e:          # noqa: BLE001
+                sys.stderr.write("rank %d: snpm_group unavailable (%s)\n" % (rank, e))
+                ok = 0
+            t = torch.tensor([ok], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 1:
+                collective = "snpm_group_gather_scores: one ncclAllGather inside libsnpmatch_hip.so (%s)" % group.transport
+            else:
+                if group is not None:
+                    group.free()
+                group = None
+
     def gather_and_likelihood():
+        if group is not None:
+            # pack + ONE ncclAllGather + unpack on the library's stream; the full-length vectors stay on the device
+            group.gather([shards.score_loc.data_ptr()], [shards.ninfo_loc.data_ptr()], n_acc, host=False)
+            src_s, src_n = group.gathered_ptrs(0)
+            ctx.likelihood_device(src_s, src_n, 1, n_acc, lik.data_ptr(), lrt.data_ptr(), truncate=True)
+            return
         src_s, src_n = shards.gather()          # the one collective of the path (no-op at N=1)
         # padded tail entries are (0, 0) -> NaN likelihood, ignored by nanmin
         ctx.likelihood_device(src_s.data_ptr(), src_n.data_ptr(), 1, per * world, lik.data_ptr(), lrt.data_ptr(),
@@ -366,12 +401,14 @@ def main():
             traffic = None
 
     # correctness of what was timed: top hit is the planted accession, counts agree with the CPU path
-    top = int(np.nanargmin(lik.cpu().numpy()))
-    result_ok = (shards.to_global(top) == PLANTED)
+    top = int(np.nanargmin(lik.cpu().numpy()[:n_acc] if group is not None else lik.cpu().numpy()))
+    result_ok = ((top if group is not None else shards.to_global(top)) == PLANTED)
 
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        # rank 0 at every N: the reference's CPU path on a bounded sample of ITS shard, and the counts of the GPU
+        # path on the same rows against it (the other ranks wait at the barrier below)
         load_slab(0)
         nrows = min(100_000, slabs[0])
         db = panel.download_rows(0, nrows)
@@ -420,7 +457,7 @@ def main():
                 "panel_format": "packed2" if args.packed else "int8", "slabs": slabs,
                 "sample": "planted accession %d, 2%% error, %s (generated on the device)"
                           % (PLANTED, "hard 0/1 calls" if args.hard_calls else "80% PL weights"),
-                "parallelism": "acc-shard x%d + all-gather (%s)" % (world, args.backend if world > 1 else "none"),
+                "parallelism": "acc-shard x%d + all-gather (%s)" % (world, collective),
                 "timing": "per slab: regenerate (untimed), K timed scoring steps between barriers; plus K timed "
                           "certificate/gather/likelihood tails%s; ms_per_step = their sum / K"
                           % (" and K timed second-pass steps per slab for the flagged accessions" if second_pass else "")
@@ -431,6 +468,9 @@ def main():
                          "kernel": kname, "launches": launches, "passes": passes, "avg_ms": k_avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes * passes / max(launches, 1), "algorithmic_bytes_per_pass": alg_bytes,
                          "shape": "%d accessions x %d SNPs" % (n_loc, rows_dom),
+                         "kernel_by_shape": [{"shape": "%d x %d" % (n_loc, r), "passes": v[0], "launches": v[1], "avg_ms_per_pass": v[2] / max(v[0], 1),
+                                              "frac": float(r) * row_bytes / (v[2] / max(v[0], 1) * 1e-3) / 1e9 / HBM_PEAK_GBS if v[2] > 0 else None}
+                                             for r, v in sorted(prof.items(), reverse=True)],
                          "all_slabs_frac": (all_bytes / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if all_ms > 0 else None,
                          "end_to_end_frac": float(n_snp) * row_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "read_only_kernel": {"kernel": "k_calib_read", "achieved": ceiling,
@@ -444,7 +484,10 @@ def main():
         }
         if args.packed:      # 0.25 B per comparison: the pass is VALU/LDS-issue-bound, the HBM fraction is informative only
             out["roofline"]["note"] = "packed panel: bound by VALU + LDS issue (DESIGN.md), not by HBM"
+    if group is not None:
+        group.free()
     if use_dist:
+        dist.barrier()                  # rank 0 may have spent ~30 s in the CPU baseline
         dist.destroy_process_group()
     ctx.close()
     if rank == 0:

@@ -97,6 +97,7 @@ def main(argv=None):
     if 'func' not in args:
         parser.print_help()
         return 0
+    job = None
     try:
         from . import dist
         job = dist.init_from_env()       # under torch.distributed.run: accession-sharded over the ranks' GPUs
@@ -110,6 +111,18 @@ def main(argv=None):
         return 0
     except Exception as e:
         logging.exception(e)
+        if job is not None:
+            # a rank that fails must not leave its peers waiting in a collective until the launcher's timeout: tear the
+            # communicator down (abort where the backend has it) so that their pending calls fail at once
+            try:
+                import torch.distributed as td
+                pg = td.distributed_c10d._get_default_group()
+                if hasattr(pg, "abort"):
+                    pg.abort()
+                else:
+                    td.destroy_process_group()
+            except Exception:
+                pass
         return 2
 
 

@@ -29,11 +29,14 @@ class AccessionShards(object):
         self.a0, self.a1 = self.bounds[rank]
         self.n_local = self.a1 - self.a0
         self.device = device
-        # padded tail entries stay (score 0, ninfo 0): NaN likelihood, ignored by nanmin
-        self.score_loc = torch.zeros(self.per, dtype=torch.float64, device=device)
-        self.ninfo_loc = torch.zeros(self.per, dtype=torch.int64, device=device)
+        # padded tail entries stay (score 0, ninfo 0): NaN likelihood, ignored by nanmin.  Both result vectors live in ONE
+        # buffer of 8-byte words [2, per] (row 0: the fp64 scores, row 1: the int64 counts), so that one collective moves them
+        self.pack_loc = torch.zeros((2, self.per), dtype=torch.int64, device=device)
+        self.score_loc = self.pack_loc[0].view(torch.float64)
+        self.ninfo_loc = self.pack_loc[1]
         self.collective = world > 1 or force_collective
         if self.collective:
+            self.pack_all = torch.zeros((world, 2, self.per), dtype=torch.int64, device=device)
             self.score_all = torch.zeros(self.per * world, dtype=torch.float64, device=device)
             self.ninfo_all = torch.zeros(self.per * world, dtype=torch.int64, device=device)
         else:
@@ -50,11 +53,13 @@ class AccessionShards(object):
         self.ninfo_loc[:self.n_local] = t.as_tensor(np.asarray(ninfo, dtype=np.int64), device=self.device)
 
     def gather(self):
-        """the single collective of the path: all-gather of (score, ninfo) along the accession axis"""
+        """the single collective of the path: ONE all-gather of the packed (score, ninfo) words along the accession axis,
+        then two strided device copies into the contiguous full-length vectors"""
         if self.collective:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(self.score_all, self.score_loc, group=self.group)
-            dist.all_gather_into_tensor(self.ninfo_all, self.ninfo_loc, group=self.group)
+            dist.all_gather_into_tensor(self.pack_all.view(-1), self.pack_loc.view(-1), group=self.group)
+            self.score_all.view(self.world, self.per).copy_(self.pack_all[:, 0, :].view(self.torch.float64))
+            self.ninfo_all.view(self.world, self.per).copy_(self.pack_all[:, 1, :])
         return self.score_all, self.ninfo_all
 
     def padded_index(self):
@@ -83,28 +88,27 @@ def sharded_genotyper_scores(score_local_fn, n_acc, world, rank, device="cpu", g
 
 def sharded_window_scores(score_local_fn, n_acc, n_win, world, rank, device="cpu", group=None):
     """Per-window variant (core/csmatch.py:80-95): `score_local_fn(a0, a1) -> (score [n_win, a1 - a0],
-    ninfo [n_win, a1 - a0])` on this rank's shard; one all-gather per result array along the accession axis;
-    returns the full (score [n_win, n_acc], ninfo [n_win, n_acc]) numpy arrays on every rank."""
+    ninfo [n_win, a1 - a0])` on this rank's shard; ONE all-gather of the packed words [2, n_win, per] along the
+    accession axis; returns the full (score [n_win, n_acc], ninfo [n_win, n_acc]) numpy arrays on every rank."""
     import torch
     import torch.distributed as dist
-    sh = AccessionShards(n_acc, world, rank, device, group)
+    sh = AccessionShards(n_acc, world, rank, "cpu", group)          # bounds only
     s, n = score_local_fn(sh.a0, sh.a1)
-    loc_s = torch.zeros((n_win, sh.per), dtype=torch.float64, device=device)
-    loc_n = torch.zeros((n_win, sh.per), dtype=torch.int64, device=device)
-    loc_s[:, :sh.n_local] = torch.as_tensor(np.asarray(s, dtype=np.float64).reshape(n_win, sh.n_local), device=device)
-    loc_n[:, :sh.n_local] = torch.as_tensor(np.asarray(n, dtype=np.int64).reshape(n_win, sh.n_local), device=device)
+    loc = torch.zeros((2, n_win, sh.per), dtype=torch.int64, device=device)
+    loc[0, :, :sh.n_local] = torch.as_tensor(np.ascontiguousarray(np.asarray(s, dtype=np.float64).reshape(n_win, sh.n_local)).view(np.int64),
+                                             device=device)
+    loc[1, :, :sh.n_local] = torch.as_tensor(np.asarray(n, dtype=np.int64).reshape(n_win, sh.n_local), device=device)
     if world > 1:
-        all_s = torch.zeros((world * n_win, sh.per), dtype=torch.float64, device=device)
-        all_n = torch.zeros((world * n_win, sh.per), dtype=torch.int64, device=device)
-        dist.all_gather_into_tensor(all_s, loc_s, group=group)
-        dist.all_gather_into_tensor(all_n, loc_n, group=group)
+        every = torch.zeros((world, 2, n_win, sh.per), dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(every.view(-1), loc.view(-1), group=group)
     else:
-        all_s, all_n = loc_s, loc_n
+        every = loc.reshape(1, 2, n_win, sh.per)
     idx = sh.padded_index()
+    host = every.cpu().numpy()          # [world, 2, n_win, per] -> [n_win, world * per] -> accession order
 
-    def full(t):          # [world * n_win, per] -> [n_win, world * per] -> accession order
-        return t.reshape(world, n_win, sh.per).permute(1, 0, 2).reshape(n_win, world * sh.per).cpu().numpy()[:, idx]
-    return full(all_s), full(all_n)
+    def full(k, dtype):
+        return np.ascontiguousarray(host[:, k].transpose(1, 0, 2).reshape(n_win, world * sh.per)[:, idx]).view(dtype)
+    return full(0, np.float64), full(1, np.int64)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -136,7 +140,10 @@ class Job(object):
         import os
         import tempfile
         if self._tmp is None:
+            import atexit
+            import shutil
             self._tmp = tempfile.mkdtemp(prefix="snpmatch_rank%d_" % self.rank)
+            atexit.register(shutil.rmtree, self._tmp, True)          # the scratch copies of a non-writer rank go with the process
         return os.path.join(self._tmp, os.path.basename(prefix))
 
     def gather_scores(self, score_loc, ninfo_loc, n_acc):

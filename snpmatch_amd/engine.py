@@ -29,14 +29,15 @@ class Context(object):
         self.device_id = int(device_id)
         self._children = weakref.WeakSet()      # panels and queries: freed before the context
         self._pinned = []                       # pinned host blocks handed out by pinned_empty
+        self._pinned_bufs = []                  # ... and the ctypes objects their numpy views hang on
         # every context is closed before the interpreter (and with it the HIP runtime) goes down, also when the
         # script ends with an exception; the weak reference keeps the hook from pinning the object.  The library
         # tolerates the other order too (snpm_destroy orphans live panels / queries, include/snpmatch_hip.h).
         ref = weakref.ref(self)
-        self._atexit = lambda: (ref() is not None) and ref().close()
+        self._atexit = lambda: (ref() is not None) and ref().close(_at_exit=True)
         atexit.register(self._atexit)
 
-    def close(self):
+    def close(self, _at_exit=False):
         if self.h:
             kids = list(self._children)
             for k in kids:
@@ -45,9 +46,17 @@ class Context(object):
             for k in kids:
                 if isinstance(k, (Panel, Carry)):
                     k.free()
+            import sys
+            if not _at_exit and not sys.is_finalizing():
+                # a numpy view of a pinned block that is still referenced would dangle after the free below
+                live = [b for b in self._pinned_bufs if sys.getrefcount(b) > 3]
+                if live:
+                    raise RuntimeError("Context.close(): %d array(s) from pinned_empty() are still referenced; "
+                                       "delete them before closing the context" % len(live))
             for blk in self._pinned:
                 self.lib.snpm_host_free(self.h, blk)
             self._pinned = []
+            self._pinned_bufs = []
             if self._owns:
                 self.lib.snpm_destroy(self.h)
             self.h = None
@@ -58,7 +67,7 @@ class Context(object):
 
     def __del__(self):
         try:
-            self.close()
+            self.close(_at_exit=True)
         except Exception:
             pass
 
@@ -147,13 +156,15 @@ class Context(object):
 
     def pinned_empty(self, shape, dtype):
         """numpy array in pinned host memory (hipHostMalloc): inputs of ``score_batch`` built here skip the staging copy.
-        The memory is released with the context."""
+        The block is released when the context closes: the array (and every view of it) must not be used after
+        ``close()`` -- ``close`` refuses while such arrays are still referenced elsewhere."""
         dtype = np.dtype(dtype)
         n = int(np.prod(shape)) * dtype.itemsize
         h = C.c_void_p()
         check(self.lib.snpm_host_alloc(self.h, n, C.byref(h)), self.h)
-        self._pinned.append(h)
         buf = (C.c_char * max(n, 1)).from_address(h.value)
+        self._pinned.append(h)
+        self._pinned_bufs.append(buf)           # numpy arrays made from it hold references to this ctypes object
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def binom_identity(self, x, n, error_rate=0.0005, pthres=0.05, return_sf=False):
