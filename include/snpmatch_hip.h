@@ -77,6 +77,9 @@ const char *snpm_last_error(const snpm_ctx *ctx);
    NULL restores the library's own stream */
 int         snpm_set_stream(snpm_ctx *ctx, void *hip_stream);
 int         snpm_synchronize(snpm_ctx *ctx);
+/* free / total device memory of the context's GPU in bytes (the host layer plans the residency of a DB with it: int8
+   whole -> 2-bit packed whole -> SNP slabs streamed through two half-buffers) */
+int         snpm_device_mem_info(snpm_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
 
 /* ---------------------------------------------------------------- panel (DB genotype matrix in HBM) */
 /* SNP-major int8 [n_snp, pitch], pitch = n_acc rounded up to 256 B, pad bytes = -1.  1 <= n_acc <= 2^27 (SNPM_ERR_BADARG). */
@@ -98,6 +101,19 @@ int snpm_panel_upload_rows(snpm_panel *panel, int64_t row0, int64_t nrows, const
 /* Same pipeline fed from a file of tightly packed int8 rows (n_acc bytes per row) that starts at byte
    file_offset (the data section of snps.npy in a native flat panel): pread() straight into the pinned slabs. */
 int snpm_panel_load_file(snpm_panel *panel, const char *path, int64_t file_offset, int64_t row0, int64_t nrows);
+/* The general file form: the file holds an int8 matrix with file_pitch bytes per row (>= col0 + n_acc) from byte
+   file_offset on; panel row row0 + i receives columns [col0, col0 + n_acc) of file row row_idx[i] (row_idx != NULL: the
+   matched rows of a sample, the reference's g.g.snps[idx, :], core/snpmatch.py:222) or file_row0 + i.  col0 / file_pitch
+   serve an accession shard of a wider DB.  Contiguous reads of >= 1 GiB use O_DIRECT where the file system takes it
+   (SNPM_ODIRECT=0/1 overrides); packed panels are packed to 2 bits per call by the host threads that fill the slabs
+   (SNPM_HOST_PACK=0: on the device), so a quarter of the bytes cross PCIe. */
+int snpm_panel_load_file_rows(snpm_panel *panel, const char *path, int64_t file_offset, int64_t file_pitch, int64_t col0,
+                              const int64_t *row_idx, int64_t file_row0, int64_t row0, int64_t nrows);
+/* the loader's host-side packer on its own (no ctx, no GPU): int8 calls [nrows, n_acc] (row stride src_pitch) -> 2 bits
+   per call, (n_acc + 3) / 4 bytes per row (row stride dst_pitch; field f of byte b = call 4 b + f: 0 ref, 1 alt, 2 het,
+   3 missing = any negative; fields past n_acc are 3).  *bad (may be NULL) = 1 when a call > 2 was met. */
+int snpm_pack_rows_host(const int8_t *src, int64_t src_pitch, int64_t nrows, int64_t n_acc, uint8_t *dst, int64_t dst_pitch,
+                        int force_scalar, int *bad);
 int snpm_panel_upload_wait(snpm_panel *panel);
 int snpm_panel_download_rows(snpm_panel *panel, int64_t row0, int64_t nrows, int8_t *host, int64_t host_pitch);
 /* Device-side synthetic fill (benchmarks; no PCIe): element (snp, acc) is a pure function of
@@ -158,6 +174,13 @@ int snpm_query_error_bound(snpm_query *query, int64_t chunk, double *bound);
    window: tot_score float64 [n_acc], tot_ninfo int64 [n_acc]. */
 int snpm_query_run_windows(snpm_query *query, const int64_t *win_off, int64_t n_win, int skip_hets,
                            double *score, int64_t *ninfo, double *tot_score, int64_t *tot_ninfo);
+
+/* The same for one SNP slab of a DB scored slab after slab (slabs hold whole windows): the totals continue in `carry`
+   (reference order: the fp64 bits of one pass over all windows; read them with snpm_carry_finish).  The call does NOT
+   wait for the device: score / ninfo [n_win, n_acc] should be pinned host memory (snpm_host_alloc) and are complete when
+   snpm_carry_finish or snpm_synchronize returns -- the caller loads the next slab meanwhile. */
+int snpm_query_run_windows_carry(snpm_query *query, const int64_t *win_off, int64_t n_win, int skip_hets, double *score,
+                                 int64_t *ninfo, snpm_carry *carry);
 
 /* The same window loop at streaming speed (one segmented fast pass over all windows + the certificate per
    (window, accession) and for the totals; uncertain entries are re-scored in reference order): int(score), ninfo and

@@ -31,10 +31,10 @@ MODE_FAST = 2
 # every symbol include/snpmatch_hip.h declares (tests check that the .so exports all of them)
 SYMBOLS = [
     "snpm_version", "snpm_device_count", "snpm_init", "snpm_destroy", "snpm_last_error", "snpm_set_stream",
-    "snpm_synchronize", "snpm_panel_create", "snpm_panel_create_packed", "snpm_panel_is_packed", "snpm_panel_free", "snpm_panel_info", "snpm_panel_upload_rows", "snpm_panel_load_file",
+    "snpm_synchronize", "snpm_device_mem_info", "snpm_panel_create", "snpm_panel_create_packed", "snpm_panel_is_packed", "snpm_panel_free", "snpm_panel_info", "snpm_panel_upload_rows", "snpm_panel_load_file", "snpm_panel_load_file_rows", "snpm_pack_rows_host",
     "snpm_panel_upload_wait", "snpm_panel_download_rows", "snpm_panel_fill_synthetic", "snpm_query_create",
     "snpm_query_free", "snpm_query_bind_outputs", "snpm_query_run", "snpm_query_run_device", "snpm_query_error_bound",
-    "snpm_query_run_windows", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
+    "snpm_query_run_windows", "snpm_query_run_windows_carry", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
     "snpm_binom_identity", "snpm_binom_sf_host", "snpm_intersect_sorted", "snpm_panel_segregating",
     "snpm_query_f1_pairs", "snpm_intersect_sorted_search",
     "snpm_vcf_parse", "snpm_vcf_dims", "snpm_vcf_fill", "snpm_vcf_sample_name", "snpm_vcf_free",
@@ -97,6 +97,7 @@ def load():
     lib.snpm_last_error.restype = C.c_char_p
     lib.snpm_set_stream.argtypes = [p, p]
     lib.snpm_synchronize.argtypes = [p]
+    lib.snpm_device_mem_info.argtypes = [p, C.POINTER(i64), C.POINTER(i64)]
     lib.snpm_panel_create.argtypes = [p, i64, i64, pp]
     lib.snpm_panel_create_packed.argtypes = [p, i64, i64, pp]
     lib.snpm_panel_is_packed.argtypes = [p, C.POINTER(ci)]
@@ -104,6 +105,8 @@ def load():
     lib.snpm_panel_info.argtypes = [p, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), pp]
     lib.snpm_panel_upload_rows.argtypes = [p, i64, i64, p, i64]
     lib.snpm_panel_load_file.argtypes = [p, C.c_char_p, i64, i64, i64]
+    lib.snpm_panel_load_file_rows.argtypes = [p, C.c_char_p, i64, i64, i64, p, i64, i64, i64]
+    lib.snpm_pack_rows_host.argtypes = [p, i64, i64, i64, p, i64, ci, C.POINTER(ci)]
     lib.snpm_panel_upload_wait.argtypes = [p]
     lib.snpm_panel_download_rows.argtypes = [p, i64, i64, p, i64]
     lib.snpm_panel_fill_synthetic.argtypes = [p, C.c_uint64, i64, i64]
@@ -143,6 +146,7 @@ def load():
     lib.snpm_query_run_device.argtypes = [p, i64, ci, ci, pp, pp, p]
     lib.snpm_query_error_bound.argtypes = [p, i64, C.POINTER(dbl)]
     lib.snpm_query_run_windows.argtypes = [p, p, i64, ci, p, p, p, p]
+    lib.snpm_query_run_windows_carry.argtypes = [p, p, i64, ci, p, p, p]
     lib.snpm_query_run_windows_fast.argtypes = [p, p, i64, ci, p, p, p, p, p]
     lib.snpm_score_batch_coded.argtypes = [p, i64, p, p, p, p, i64, i64, ci, ci, p, p, p, p, p]
     lib.snpm_host_alloc.argtypes = [p, i64, pp]

@@ -155,21 +155,40 @@ class Genotype(object):
         return self._panel
 
     def _member_panel(self, ctx, a0, a1, packed):
-        """columns [a0, a1) of the DB on one GPU"""
+        """Columns [a0, a1) of the DB on one GPU, planned by the HBM the GPU has free (SNPM_HBM_BUDGET_GB overrides; 1 GB =
+        1e9 bytes): the int8 matrix whole -> the 2-bit packed matrix whole (same results, a quarter of the bytes; DBs with
+        call codes other than -1/0/1/2 cannot take this step) -> SNP slabs streamed from the file / array through two
+        half-buffers (``engine.StreamedPanel``; the reference reads any size through g.g.snps[idx, :])."""
         from .. import engine
-        whole = (a0 == 0 and a1 == len(self.accessions))
         npy = getattr(self.g, "npy_path", None)          # native flat panel: file -> pinned slabs -> HBM
-        if whole:
-            make = (lambda pk: engine.Panel.from_npy(ctx, npy, packed=pk)) if npy else \
-                   (lambda pk: engine.Panel.from_host(ctx, self.g.snps, packed=pk))
-        else:
-            make = lambda pk: engine.Panel.from_host(ctx, self.g.snps, packed=pk, cols=(a0, a1))  # noqa: E731
-        if packed:
+        store = engine.RowStore(npy=npy) if npy else engine.RowStore(snps=self.g.snps)
+        env = os.environ.get("SNPM_HBM_BUDGET_GB", "")
+        budget = int(float(env) * 1e9) if env else int(0.85 * ctx.mem_info()[0])
+        n_loc = a1 - a0
+
+        def need(pk):
+            width = (n_loc + 3) // 4 if pk else n_loc
+            return (store.n_snp + 32) * ((width + 255) // 256 * 256) + 256
+
+        for pk in ([True] if packed else [False, True]):
+            if need(pk) > budget:
+                continue
             try:
-                return make(True)
+                return engine.Panel.from_store(ctx, store, packed=pk, cols=(a0, a1))
             except AssertionError:
                 log.info("DB holds codes a packed panel cannot store; using the int8 panel")
-        return make(False)
+                if packed and need(False) <= budget:
+                    return engine.Panel.from_store(ctx, store, packed=False, cols=(a0, a1))
+        log.info("DB shard of %.1f GB does not fit the HBM budget of %.1f GB: streaming SNP slabs", need(False) / 1e9, budget / 1e9)
+        if packed:
+            try:
+                sp = engine.StreamedPanel(ctx, store, cols=(a0, a1), packed=True, budget_bytes=budget)
+                sp.store.load(sp.halves[0], sp.cols, (0, min(sp.rows_cap, store.n_snp)), 0)     # probe for codes a packed panel refuses
+                return sp
+            except AssertionError:
+                log.info("DB holds codes a packed panel cannot store; streaming int8 slabs")
+                sp.free()
+        return engine.StreamedPanel(ctx, store, cols=(a0, a1), packed=False, budget_bytes=budget)
 
     # ------------------------------------------------------------------ position intersection (a5)
     def _region_is_increasing(self, ci, pos):

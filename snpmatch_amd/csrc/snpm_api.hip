@@ -69,6 +69,18 @@ struct snpm_ctx {
     int64_t *h_desc = nullptr;          // pinned host image of ws_seg_desc
     size_t h_desc_cap = 0;
     int stage_which = 0;                // next staging slab of stage_bytes
+    // panel loader (snpm_loader.hpp): its own pinned slabs, filled by a persistent pool of host threads
+    static constexpr int kLdStages = 3;
+    void *ld_stage[kLdStages] = {nullptr, nullptr, nullptr};
+    hipEvent_t ld_done[kLdStages] = {nullptr, nullptr, nullptr};
+    bool ld_busy[kLdStages] = {false, false, false};
+    int ld_next = 0;
+    size_t ld_cap = 0;                  // bytes per loader slab (>= one staged row)
+    size_t ld_want = size_t(64) << 20;  // SNPM_STAGE_MB
+    void *pool = nullptr;               // HostPool
+    int host_pack = 1;                  // SNPM_HOST_PACK=0: packed panels cross PCIe as int8 and are packed on the device
+    int odirect = -1;                   // SNPM_ODIRECT: 1 always, 0 never, -1 (default) contiguous reads of >= 1 GiB
+    snpm_panel *last_touched = nullptr; // the panel the compute stream's most recent work reads or writes
     hipEvent_t batch_ev = nullptr;      // "this sub-batch's inputs have arrived" (copy stream -> compute stream)
     // device buffers of freed queries, kept for the next query (hipMalloc / hipFree cost more than a small query's run)
     struct Cached { void *p; size_t cap; };
@@ -87,7 +99,7 @@ struct snpm_ctx {
     int strict4 = 1;           // dense strict scoring with 4 columns per lane (SNPM_STRICT4=0: one column per lane)
     int debug_max_parts = 0;   // SNPM_DEBUG_MAX_PARTS=k: cap the parts of the fast pass (tests of multi-epoch parts)
     int debug_reeval = 0;   // SNPM_DEBUG_REEVAL=k: also re-evaluate accessions 0..k-1 (to time that path)
-    int stage_threads = 8;  // host threads repacking rows into the pinned staging slabs
+    int stage_threads = 8;  // host threads filling the pinned staging slabs (default: the cores of this process, at most 16)
     int nt_loads = 1;      // panel bytes are read once: non-temporal loads (+5-8% measured)
     int64_t f1_slab_bytes = int64_t(2) << 30;   // SNPM_F1_SLAB_BYTES: compacted-weight scratch of the in-silico crosses
     int occ_cap = 0;          // SNPM_OCC_CAP=n: at most n resident blocks per CU in the fast pass (experiments)
@@ -110,6 +122,8 @@ struct snpm_panel {
                                         // class), else 0; lives behind the rows in the same allocation.  k_strict4 reads it.
     hipEvent_t uploaded = nullptr;      // last upload / fill enqueued on copy_stream
     bool upload_pending = false;
+    hipEvent_t used = nullptr;          // recorded on the compute stream when it moved on to another panel: everything that
+    bool used_valid = false;            // reads this panel is complete once it fires (uploads into the panel wait for it)
     // accession-major packed copy (2 bits per call), built on first use by the exactness re-evaluation
     uint8_t *dT = nullptr;
     int64_t pitchT = 0;
@@ -227,6 +241,12 @@ bool hip_alive() { return !g_exiting.load(); }
             return set_err(nullptr, SNPM_ERR_STATE, "query outlived its panel or context");          \
     } while (0)
 
+#define CHECK_CARRY(C)                                                                               \
+    do {                                                                                             \
+        if (!(C)) return set_err(nullptr, SNPM_ERR_BADARG, "carry is NULL");                         \
+        if (!(C)->ctx) return set_err(nullptr, SNPM_ERR_STATE, "carry outlived its context");        \
+    } while (0)
+
 int ensure(snpm_ctx *ctx, Buf &b, size_t bytes)
 {
     if (bytes <= b.cap && b.p) return SNPM_OK;
@@ -315,6 +335,16 @@ struct ProfScope {
 
 int wait_upload(snpm_panel *p)
 {
+    // the compute stream is about to read (or fill) this panel.  If its previous work belonged to ANOTHER panel, mark the end of
+    // that work now: an upload into that panel then waits for this event instead of for everything queued later (stage_rows)
+    snpm_ctx *ctx = p->ctx;
+    if (ctx->last_touched && ctx->last_touched != p) {
+        snpm_panel *o = ctx->last_touched;
+        if (!o->used) HIPCHK(ctx, hipEventCreateWithFlags(&o->used, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(o->used, ctx->stream));
+        o->used_valid = true;
+    }
+    ctx->last_touched = p;
     // make the compute stream wait for any pending staging copies into this panel
     if (p->upload_pending) {
         HIPCHK(p->ctx, hipStreamWaitEvent(p->ctx->stream, p->uploaded, 0));
@@ -1164,93 +1194,9 @@ int upload_seg_off(snpm_ctx *ctx, const std::vector<int64_t> &off)
     return SNPM_OK;
 }
 
-// Staging pipeline shared by snpm_panel_upload_rows (host memory) and snpm_panel_load_file (a file):
-// `fill(dst, first_row, n)` writes n tightly packed rows (n_acc bytes each) into the pinned slab; the slab is
-// copied to a device scratch buffer on the side stream and a device kernel writes the panel rows from it
-// (256-B pitch + canonical codes for int8 panels, 2-bit packing for packed panels).  Two slabs alternate, so
-// filling slab k+1 overlaps the copy and the kernel of slab k.
-template <typename Fill>
-static int stage_rows(snpm_panel *p, int64_t row0, int64_t nrows, Fill fill)
-{
-    snpm_ctx *ctx = p->ctx;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    for (int i = 0; i < 2; ++i) {
-        if (!ctx->stage[i]) {
-            hipError_t e = hipHostMalloc(&ctx->stage[i], snpm_ctx::kStageBytes, hipHostMallocDefault);
-            if (e != hipSuccess) return set_err(ctx, SNPM_ERR_OOM, "hipHostMalloc staging failed: %s", hipGetErrorString(e));
-            HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stage_done[i], hipEventDisableTiming));
-        }
-    }
-    int rc = ensure(ctx, ctx->ws_stage_dev, 2 * snpm_ctx::kStageBytes);
-    if (rc) return rc;
-    rc = ensure(ctx, ctx->ws_flags2, sizeof(int));
-    if (rc) return rc;
-    // rows about to be overwritten may still be read by scoring kernels queued on the compute stream (async
-    // run_device, a caller-provided stream): the copy stream waits for everything queued there so far
-    if (!ctx->compute_mark) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->compute_mark, hipEventDisableTiming));
-    HIPCHK(ctx, hipEventRecord(ctx->compute_mark, ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->compute_mark, 0));
-    if (p->packed) HIPCHK(ctx, hipMemsetAsync(ctx->ws_flags2.p, 0, sizeof(int), ctx->copy_stream));
-    const int64_t spitch = p->n_acc;                                   // staged rows are tight
-    const int64_t slab_rows = std::max<int64_t>(1, (int64_t)(snpm_ctx::kStageBytes / (size_t)spitch));
-    int which = 0;
-    for (int64_t r = 0; r < nrows; r += slab_rows, which ^= 1) {
-        const int64_t nr = std::min(slab_rows, nrows - r);
-        if (ctx->stage_busy[which]) {
-            HIPCHK(ctx, hipEventSynchronize(ctx->stage_done[which]));
-            ctx->stage_busy[which] = false;
-        }
-        int8_t *st = (int8_t *)ctx->stage[which];
-        rc = fill(st, r, nr);
-        if (rc) return rc;
-        int8_t *scratch = (int8_t *)ctx->ws_stage_dev.p + (size_t)which * snpm_ctx::kStageBytes;
-        HIPCHK(ctx, hipMemcpyAsync(scratch, st, (size_t)nr * spitch, hipMemcpyHostToDevice, ctx->copy_stream));
-        if (!p->packed) {
-            const int64_t total = nr * (p->pitch / 4);
-            hipLaunchKernelGGL(k_repitch_canon, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream,
-                               scratch, spitch, nr, p->n_acc, (uint32_t *)(p->d + (row0 + r) * p->pitch), p->pitch, p->d_other);
-        } else {
-            const int64_t total = nr * p->pitch;
-            hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream, scratch,
-                               spitch, nr, p->n_acc, (uint8_t *)p->d + (row0 + r) * p->pitch, p->pitch, (int *)ctx->ws_flags2.p);
-        }
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipEventRecord(ctx->stage_done[which], ctx->copy_stream));
-        ctx->stage_busy[which] = true;
-    }
-    if (p->packed) {
-        int bad = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&bad, ctx->ws_flags2.p, sizeof(int), hipMemcpyDeviceToHost, ctx->copy_stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
-        ctx->stage_busy[0] = ctx->stage_busy[1] = false;
-        if (bad)
-            return set_err(ctx, SNPM_ERR_BADARG, "a packed panel holds only the codes -1 (any negative), 0, 1, 2; "
-                                                 "use the int8 panel for other values");
-    }
-    HIPCHK(ctx, hipEventRecord(p->uploaded, ctx->copy_stream));
-    p->upload_pending = true;
-    p->dT_state = 0;                    // the accession-major copy is stale
-    return SNPM_OK;
-}
-
-// copy n bytes with a few threads (one memcpy stream is ~15 GB/s, well under what PCIe gen5 x16 takes)
-void parallel_copy(snpm_ctx *ctx, int8_t *dst, const int8_t *src, size_t n)
-{
-    const int nthreads = (int)std::min<size_t>((size_t)ctx->stage_threads, std::max<size_t>(1, n >> 20));
-    if (nthreads <= 1) {
-        memcpy(dst, src, n);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const size_t per = (n + nthreads - 1) / nthreads;
-    for (int t = 0; t < nthreads; ++t) {
-        const size_t o = (size_t)t * per;
-        if (o < n) pool.emplace_back([=] { memcpy(dst + o, src + o, std::min(per, n - o)); });
-    }
-    for (auto &th : pool) th.join();
-}
-
 }  // namespace
+
+#include "snpm_loader.hpp"
 
 // ================================================================================================
 extern "C" {
@@ -1309,7 +1255,11 @@ try {
     if (const char *s = getenv("SNPM_DEBUG_REEVAL")) ctx->debug_reeval = atoi(s);
     if (const char *s = getenv("SNPM_STRICT4")) ctx->strict4 = atoi(s);
     if (const char *s = getenv("SNPM_DEBUG_MAX_PARTS")) ctx->debug_max_parts = atoi(s);
+    ctx->stage_threads = default_stage_threads();
     if (const char *s = getenv("SNPM_STAGE_THREADS")) ctx->stage_threads = std::max(1, atoi(s));
+    if (const char *s = getenv("SNPM_STAGE_MB")) ctx->ld_want = (size_t)std::max(1, atoi(s)) << 20;
+    if (const char *s = getenv("SNPM_HOST_PACK")) ctx->host_pack = atoi(s);
+    if (const char *s = getenv("SNPM_ODIRECT")) ctx->odirect = atoi(s);
     *out = ctx;
     return SNPM_OK;
 } SNPM_GUARD(nullptr)
@@ -1337,7 +1287,11 @@ static void orphan_panel(snpm_panel *p, bool use_hip)
         if (p->d) (void)hipFree(p->d);
         if (p->dT) (void)hipFree(p->dT);
         if (p->uploaded) (void)hipEventDestroy(p->uploaded);
+        if (p->used) (void)hipEventDestroy(p->used);
     }
+    if (p->ctx && p->ctx->last_touched == p) p->ctx->last_touched = nullptr;
+    p->used = nullptr;
+    p->used_valid = false;
     p->d = nullptr;
     p->d_other = nullptr;
     p->dT = nullptr;
@@ -1383,12 +1337,17 @@ int snpm_destroy(snpm_ctx *ctx)
             if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
             if (ctx->stage_done[i]) (void)hipEventDestroy(ctx->stage_done[i]);
         }
+        for (int i = 0; i < snpm_ctx::kLdStages; ++i) {
+            if (ctx->ld_stage[i]) (void)hipHostFree(ctx->ld_stage[i]);
+            if (ctx->ld_done[i]) (void)hipEventDestroy(ctx->ld_done[i]);
+        }
         for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
         if (ctx->compute_mark) (void)hipEventDestroy(ctx->compute_mark);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     }
     ctx->qcache.clear();
+    host_pool_destroy(ctx);
     delete ctx;
     return SNPM_OK;
 }
@@ -1401,6 +1360,17 @@ int snpm_set_stream(snpm_ctx *ctx, void *hip_stream)
     HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));   // uploads in flight were only ordered against the old stream
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SNPM_OK;
+}
+
+int snpm_device_mem_info(snpm_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes)
+{
+    if (!ctx) return SNPM_ERR_BADARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    HIPCHK(ctx, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
     return SNPM_OK;
 }
 
@@ -1499,90 +1469,13 @@ int snpm_panel_info(const snpm_panel *p, int64_t *n_snp, int64_t *n_acc, int64_t
     return SNPM_OK;
 }
 
-int snpm_panel_upload_rows(snpm_panel *p, int64_t row0, int64_t nrows, const int8_t *host, int64_t host_pitch)
-try {
-    CHECK_PANEL(p);
-    snpm_ctx *ctx = p->ctx;
-    CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "upload rows outside the panel");
-    CHECK_ARG(ctx, nrows == 0 || host != nullptr, "host pointer is NULL");
-    CHECK_ARG(ctx, host_pitch >= p->n_acc, "host_pitch smaller than n_acc");
-    const int64_t n_acc = p->n_acc;
-    return stage_rows(p, row0, nrows, [&](int8_t *dst, int64_t first, int64_t n) -> int {
-        if (host_pitch == n_acc) {
-            parallel_copy(ctx, dst, host + first * host_pitch, (size_t)n * n_acc);       // contiguous: one big copy
-        } else {
-            const int nthreads = (int)std::min<int64_t>(ctx->stage_threads, std::max<int64_t>(1, n / 1024));
-            auto rows = [&](int64_t k0, int64_t k1) {
-                for (int64_t k = k0; k < k1; ++k) memcpy(dst + k * n_acc, host + (first + k) * host_pitch, (size_t)n_acc);
-            };
-            if (nthreads <= 1) {
-                rows(0, n);
-            } else {
-                std::vector<std::thread> pool;
-                const int64_t per = (n + nthreads - 1) / nthreads;
-                for (int t = 0; t < nthreads; ++t)
-                    if (t * per < n) pool.emplace_back(rows, t * per, std::min<int64_t>(n, (t + 1) * per));
-                for (auto &th : pool) th.join();
-            }
-        }
-        return SNPM_OK;
-    });
-} SNPM_GUARD((p ? p->ctx : nullptr))
-
-// Rows [row0, row0+nrows) straight from a file of tightly packed int8 rows (n_acc bytes per row) starting at
-// byte `file_offset` (e.g. the data section of the .npy inside a native flat panel): pread() into the pinned
-// slabs, no intermediate host copy.
-int snpm_panel_load_file(snpm_panel *p, const char *path, int64_t file_offset, int64_t row0, int64_t nrows)
-try {
-    CHECK_PANEL(p);
-    snpm_ctx *ctx = p->ctx;
-    CHECK_ARG(ctx, path != nullptr && file_offset >= 0, "bad file arguments");
-    CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "load rows outside the panel");
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0) return set_err(ctx, SNPM_ERR_BADARG, "cannot open %s: %s", path, strerror(errno));
-#ifdef POSIX_FADV_SEQUENTIAL
-    (void)posix_fadvise(fd, file_offset, (off_t)(nrows * p->n_acc), POSIX_FADV_SEQUENTIAL);
-#endif
-    const int64_t n_acc = p->n_acc;
-    int rc = stage_rows(p, row0, nrows, [&](int8_t *dst, int64_t first, int64_t n) -> int {
-        // the slab is read by a few threads, each pread()ing its own contiguous piece
-        const size_t want = (size_t)n * n_acc;
-        const off_t base = (off_t)(file_offset + first * n_acc);
-        const int nthreads = (int)std::min<size_t>((size_t)ctx->stage_threads, std::max<size_t>(1, want >> 22));
-        std::vector<int> status((size_t)nthreads, 0);
-        auto piece = [&](int t) {
-            const size_t per = (want + nthreads - 1) / nthreads;
-            size_t o = (size_t)t * per;
-            const size_t end = std::min(want, o + per);
-            while (o < end) {
-                const ssize_t k = pread(fd, dst + o, end - o, base + (off_t)o);
-                if (k < 0 && errno == EINTR) continue;
-                if (k <= 0) { status[(size_t)t] = k < 0 ? errno : -1; return; }
-                o += (size_t)k;
-            }
-        };
-        if (nthreads <= 1) {
-            piece(0);
-        } else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthreads; ++t) pool.emplace_back(piece, t);
-            for (auto &th : pool) th.join();
-        }
-        for (int st : status)
-            if (st != 0)
-                return set_err(ctx, SNPM_ERR_BADARG, "short read from %s (%s)", path, st > 0 ? strerror(st) : "end of file");
-        return SNPM_OK;
-    });
-    close(fd);
-    return rc;
-} SNPM_GUARD((p ? p->ctx : nullptr))
-
 int snpm_panel_upload_wait(snpm_panel *p)
 {
     CHECK_PANEL(p);
     HIPCHK(p->ctx, hipStreamSynchronize(p->ctx->copy_stream));
     p->upload_pending = false;
     p->ctx->stage_busy[0] = p->ctx->stage_busy[1] = false;
+    for (int i = 0; i < snpm_ctx::kLdStages; ++i) p->ctx->ld_busy[i] = false;
     return SNPM_OK;
 }
 
@@ -1953,10 +1846,9 @@ int snpm_query_run(snpm_query *q, int64_t chunk, int skip_hets, int mode, double
     return SNPM_OK;
 }
 
-int snpm_query_run_windows(snpm_query *q, const int64_t *win_off, int64_t n_win, int skip_hets, double *score,
-                           int64_t *ninfo, double *tot_score, int64_t *tot_ninfo)
-try {
-    CHECK_QUERY(q);
+static int run_windows_impl(snpm_query *q, const int64_t *win_off, int64_t n_win, int skip_hets, double *score,
+                            int64_t *ninfo, double *tot_score, int64_t *tot_ninfo, snpm_carry *carry)
+{
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
     CHECK_ARG(ctx, n_win >= 0 && win_off != nullptr, "window offsets missing");
@@ -1979,7 +1871,16 @@ try {
     if (rc) return rc;
     const int thr = 256;
     const size_t na = (size_t)p->n_acc;
-    if (tot_score || tot_ninfo) {
+    if (carry) {
+        // the windows of a DB scored slab after slab: the reference's totals run window after window over the whole genome
+        // (core/csmatch.py:88-90), so the chain of additions continues from the carry, in place
+        ProfScope ps(ctx, PK_SCAN);
+        hipLaunchKernelGGL(k_scan, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
+                           (const double *)ctx->ws_seg_score.p, (const uint32_t *)ctx->ws_seg_miss.p,
+                           win_off[n_win] - win_off[0], n_win, p->ld, p->n_acc, carry->d_score, carry->d_ninfo,
+                           (const double *)carry->d_score, (const int64_t *)carry->d_ninfo, (const int *)nullptr, 0);
+        HIPCHK(ctx, hipGetLastError());
+    } else if (tot_score || tot_ninfo) {
         {
             ProfScope ps(ctx, PK_SCAN);
             hipLaunchKernelGGL(k_scan, dim3((unsigned)((p->n_acc + thr - 1) / thr)), dim3(thr), 0, ctx->stream,
@@ -2013,7 +1914,36 @@ try {
         if (ninfo)
             HIPCHK(ctx, hipMemcpyAsync(ninfo, ctx->ws_tmp_ninfo.p, (size_t)n_win * na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // slab-streamed jobs do not wait here: the next slab is loaded while this one is scored; the per-window rows arrive in the
+    // caller's (pinned) buffers by the time snpm_carry_finish / snpm_synchronize returns
+    if (!carry) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return SNPM_OK;
+}
+
+int snpm_query_run_windows(snpm_query *q, const int64_t *win_off, int64_t n_win, int skip_hets, double *score,
+                           int64_t *ninfo, double *tot_score, int64_t *tot_ninfo)
+try {
+    CHECK_QUERY(q);
+    return run_windows_impl(q, win_off, n_win, skip_hets, score, ninfo, tot_score, tot_ninfo, nullptr);
+} SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
+
+// the same for one SNP slab of a DB that is scored slab after slab: slabs hold whole windows, the totals continue in `carry`
+// (reference order, fp64 bits of one pass over all windows); read them with snpm_carry_finish
+int snpm_query_run_windows_carry(snpm_query *q, const int64_t *win_off, int64_t n_win, int skip_hets, double *score,
+                                 int64_t *ninfo, snpm_carry *c)
+try {
+    CHECK_QUERY(q);
+    CHECK_CARRY(c);
+    snpm_ctx *ctx = q->panel->ctx;
+    CHECK_ARG(ctx, c->ctx == ctx && c->n_acc == q->panel->n_acc, "the carry belongs to another context or panel width");
+    CHECK_ARG(ctx, !c->finished && c->n_cols < 0, "the carry was finished (reset it first) or holds a column list");
+    CHECK_ARG(ctx, c->mode < 0 || c->mode == SNPM_MODE_STRICT, "every slab of a job is scored in the same mode");
+    q->transient_panel = true;
+    int rc = run_windows_impl(q, win_off, n_win, skip_hets, score, ninfo, nullptr, nullptr, c);
+    if (rc) return rc;
+    c->mode = SNPM_MODE_STRICT;
+    c->n_rows += win_off[n_win] - win_off[0];
+    c->n_slabs += 1;
     return SNPM_OK;
 } SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
 
@@ -2369,12 +2299,6 @@ try {
     *out = c;
     return snpm_carry_reset(c);
 } SNPM_GUARD(ctx)
-
-#define CHECK_CARRY(C)                                                                               \
-    do {                                                                                             \
-        if (!(C)) return set_err(nullptr, SNPM_ERR_BADARG, "carry is NULL");                         \
-        if (!(C)->ctx) return set_err(nullptr, SNPM_ERR_STATE, "carry outlived its context");        \
-    } while (0)
 
 int snpm_carry_reset(snpm_carry *c)
 {

@@ -44,7 +44,7 @@ class Context(object):
                 if isinstance(k, Query):
                     k.free()
             for k in kids:
-                if isinstance(k, (Panel, Carry)):
+                if isinstance(k, (Panel, Carry, StreamedPanel)):
                     k.free()
             import sys
             if not _at_exit and not sys.is_finalizing():
@@ -84,6 +84,12 @@ class Context(object):
 
     def synchronize(self):
         check(self.lib.snpm_synchronize(self.h), self.h)
+
+    def mem_info(self):
+        """(free, total) device memory in bytes"""
+        f, t = C.c_int64(0), C.c_int64(0)
+        check(self.lib.snpm_device_mem_info(self.h, C.byref(f), C.byref(t)), self.h)
+        return f.value, t.value
 
     # ---- profiling (HIP events on the stream the kernels run on)
     def profile(self, on=True):
@@ -187,6 +193,56 @@ def default_context():
     return _default_ctx
 
 
+class RowStore(object):
+    """Where the rows of a DB come from on the host side: a flat file of int8 rows (``npy=``: a C-ordered int8 .npy, read
+    natively with pread / O_DIRECT by the library) or an array-like ``snps`` [n_snp, n_acc] (numpy array, memmap, h5py
+    dataset: sliced here, uploaded from host memory).  ``load`` puts rows into a panel through the pinned staging path --
+    the counterpart of the reference's ``g.g.snps[idx, :]`` (core/snpmatch.py:222, pygwas/genotype.py:548-550)."""
+
+    def __init__(self, snps=None, npy=None):
+        assert (snps is None) != (npy is None)
+        self.snps, self.path, self.offset = snps, None, 0
+        if npy is not None:
+            with open(npy, "rb") as fh:
+                major, _ = np.lib.format.read_magic(fh)
+                shape, fortran, dtype = (np.lib.format.read_array_header_1_0(fh) if major == 1
+                                         else np.lib.format.read_array_header_2_0(fh))
+                self.offset = fh.tell()
+            assert len(shape) == 2 and not fortran and np.dtype(dtype) == np.int8, "expected a C-ordered int8 matrix"
+            self.path, self.n_snp, self.n_acc = npy, int(shape[0]), int(shape[1])
+        else:
+            self.n_snp, self.n_acc = int(snps.shape[0]), int(snps.shape[1])
+
+    def load(self, panel, cols, rows, row0, nrows=None, slab_rows=1 << 16):
+        """panel rows [row0, row0 + n) <- DB rows ``rows`` (an increasing int64 list; None: the range [0, nrows), or
+        (first, n) for a range), columns cols = (a0, a1)"""
+        a0, a1 = cols
+        assert a1 - a0 == panel.n_acc
+        if rows is None:
+            rows = (0, self.n_snp if nrows is None else nrows)
+        if not isinstance(rows, tuple):
+            rows = np.ascontiguousarray(rows, dtype=np.int64)
+            if len(rows) and int(rows[-1]) - int(rows[0]) + 1 == len(rows) and (len(rows) < 2 or bool(np.all(np.diff(rows) == 1))):
+                rows = (int(rows[0]), len(rows))            # a contiguous run: the range form (one big read per thread)
+        if self.path is not None:
+            if isinstance(rows, tuple):
+                panel.load_file_rows(self.path, self.offset, self.n_acc, a0, None, rows[0], row0, rows[1])
+            else:
+                panel.load_file_rows(self.path, self.offset, self.n_acc, a0, rows, 0, row0, len(rows))
+            return
+        whole = (a0 == 0 and a1 == self.n_acc)
+        if isinstance(rows, tuple):
+            for r in range(rows[0], rows[0] + rows[1], slab_rows):
+                r1 = min(r + slab_rows, rows[0] + rows[1])
+                blk = self.snps[r:r1] if whole else self.snps[r:r1, a0:a1]
+                panel.upload_rows(row0 + r - rows[0], np.ascontiguousarray(blk, dtype=np.int8))
+        else:
+            for i in range(0, len(rows), slab_rows):
+                idx = rows[i:i + slab_rows]
+                blk = self.snps[idx, :] if whole else self.snps[idx, a0:a1]      # the reference's fancy row read
+                panel.upload_rows(row0 + i, np.ascontiguousarray(blk, dtype=np.int8))
+
+
 _default_group = None
 
 
@@ -256,14 +312,19 @@ class Panel(object):
     def from_host(cls, ctx, snps, slab_rows=1 << 16, packed=False, cols=None):
         """Upload an array-like [n_snp, n_acc] (numpy array, memmap or h5py dataset) slab by slab; ``cols`` = (a0, a1)
         keeps only that accession range (this rank's shard of an accession-sharded job)."""
-        n_snp, n_acc = snps.shape
-        a0, a1 = (0, n_acc) if cols is None else cols
-        p = cls(ctx, n_snp, a1 - a0, packed=packed)
-        for r0 in range(0, n_snp, slab_rows):
-            slab = np.ascontiguousarray(snps[r0:r0 + slab_rows, a0:a1] if cols is not None else snps[r0:r0 + slab_rows],
-                                        dtype=np.int8)
-            p.upload_rows(r0, slab)  # returns once `slab` is repacked into the pinned staging buffers and the
-        return p                     # copies are enqueued; scoring calls wait for them on the device
+        return cls.from_store(ctx, RowStore(snps=snps), packed=packed, cols=cols)
+
+    @classmethod
+    def from_store(cls, ctx, store, packed=False, cols=None):
+        """the whole DB (or its columns ``cols``) resident: every row through the staging path"""
+        a0, a1 = (0, store.n_acc) if cols is None else cols
+        p = cls(ctx, store.n_snp, a1 - a0, packed=packed)
+        try:
+            store.load(p, (a0, a1), None, 0, store.n_snp)
+        except Exception:
+            p.free()
+            raise
+        return p            # returns once the last slab is enqueued; scoring calls wait for the copies on the device
 
     def query(self, row_idx, wei, row0=0):
         """the matched SNPs of one sample against this panel (``GroupPanel`` / ``StreamedPanel`` offer the same call)"""
@@ -279,18 +340,19 @@ class Panel(object):
         nrows = self.n_snp - row0 if nrows is None else nrows
         check(self.ctx.lib.snpm_panel_load_file(self.h, str(path).encode(), int(file_offset), int(row0), int(nrows)), self.ctx.h)
 
+    def load_file_rows(self, path, file_offset, file_pitch, col0=0, row_idx=None, file_row0=0, row0=0, nrows=None):
+        """rows from a file holding an int8 matrix of ``file_pitch`` bytes per row: file rows ``row_idx`` (or file_row0 ..),
+        columns [col0, col0 + n_acc) -> panel rows [row0, row0 + nrows)  (snpm_panel_load_file_rows)"""
+        if row_idx is not None:
+            row_idx = np.ascontiguousarray(row_idx, dtype=np.int64)
+            nrows = len(row_idx) if nrows is None else nrows
+        check(self.ctx.lib.snpm_panel_load_file_rows(self.h, str(path).encode(), int(file_offset), int(file_pitch), int(col0),
+                                                     ptr(row_idx), int(file_row0), int(row0), int(nrows)), self.ctx.h)
+
     @classmethod
-    def from_npy(cls, ctx, path, packed=False):
+    def from_npy(cls, ctx, path, packed=False, cols=None):
         """Panel from an int8 [n_snp, n_acc] .npy file (C order), read natively (no numpy copy)."""
-        with open(path, "rb") as fh:
-            major, minor = np.lib.format.read_magic(fh)
-            shape, fortran, dtype = (np.lib.format.read_array_header_1_0(fh) if major == 1
-                                     else np.lib.format.read_array_header_2_0(fh))
-            offset = fh.tell()
-        assert len(shape) == 2 and not fortran and np.dtype(dtype) == np.int8, "expected a C-ordered int8 matrix"
-        p = cls(ctx, shape[0], shape[1], packed=packed)
-        p.load_file(path, offset)
-        return p
+        return cls.from_store(ctx, RowStore(npy=path), packed=packed, cols=cols)
 
     def upload_wait(self):
         check(self.ctx.lib.snpm_panel_upload_wait(self.h), self.ctx.h)
@@ -935,3 +997,218 @@ class GroupQuery(object):
     def free(self):
         for q in self.parts:
             q.free()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# DBs larger than the HBM budget: the reference streams any size through g.g.snps[idx, :] (core/snpmatch.py:218-225,
+# pygwas/genotype.py:548-550).  Here two half-buffers alternate: while the matched rows of piece k are scored, the host
+# threads read piece k + 1 from the file and the copy stream brings it in.
+class StreamedPanel(object):
+    """Columns ``cols`` of a DB (``RowStore``) that does not fit the HBM budget.  ``query`` has ``Panel.query``'s signature; a
+    run walks the sample's matched rows in pieces that fit one half-buffer.  The pass is bound by the host link (PCIe
+    ~50 GB/s against 5-6 TB/s of HBM), so every piece is scored in the reference's summation order (k_strict4): the fp64
+    totals carry the reference's bits after ONE pass over the file, no certificate and no second pass."""
+
+    def __init__(self, ctx, store, cols=None, packed=False, budget_bytes=None):
+        self.ctx, self.store = ctx, store
+        self.cols = (0, store.n_acc) if cols is None else (int(cols[0]), int(cols[1]))
+        self.n_snp, self.n_acc, self.packed = store.n_snp, self.cols[1] - self.cols[0], bool(packed)
+        acc_per_byte = 4 if packed else 1
+        pitch = ((self.n_acc + acc_per_byte - 1) // acc_per_byte + 255) // 256 * 256
+        if budget_bytes is None:
+            budget_bytes = int(0.85 * ctx.mem_info()[0])
+        self.rows_cap = int(budget_bytes // 2 // pitch) - 32             # the panel keeps 32 prefetch rows of its own
+        assert self.rows_cap >= 1, "HBM budget too small for a single row of this DB"
+        self.rows_cap = min(self.rows_cap, max(self.n_snp, 1))
+        self.halves = [Panel(ctx, self.rows_cap, self.n_acc, packed=packed) for _ in range(2)]
+        ctx._children.add(self)
+        self._pinned = {}
+        self.loads = 0              # pieces loaded so far (tests / timing)
+
+    @property
+    def h(self):
+        return self.halves[0].h if self.halves else None
+
+    def query(self, row_idx, wei, row0=0):
+        return StreamedQuery(self, row_idx, wei, row0)
+
+    def _load(self, which, rows):
+        self.store.load(self.halves[which], self.cols, rows, 0)
+        self.loads += 1
+
+    def _pieces_of_all_rows(self):
+        return [(r, min(r + self.rows_cap, self.n_snp)) for r in range(0, self.n_snp, self.rows_cap)]
+
+    def segregating_first(self, cols):
+        """(mask, first) over ALL DB rows (--refine scans the whole DB, core/snp_genotype.py:188-211): piece by piece"""
+        masks, firsts = [], []
+        for k, (r0, r1) in enumerate(self._pieces_of_all_rows()):
+            self._load(k % 2, (r0, r1 - r0))
+            m, f = self.halves[k % 2].segregating_first(cols)
+            masks.append(m[:r1 - r0])
+            firsts.append(f[:r1 - r0])
+        return np.concatenate(masks), np.concatenate(firsts)
+
+    def segregating_rows(self, cols):
+        out = []
+        for k, (r0, r1) in enumerate(self._pieces_of_all_rows()):
+            self._load(k % 2, (r0, r1 - r0))
+            out.append(self.halves[k % 2].segregating_rows(cols)[:r1 - r0])
+        return np.concatenate(out)
+
+    def pinned(self, key, shape, dtype):
+        """grow-only pinned host arrays for results that arrive while the next piece is loaded"""
+        need = int(np.prod(shape))
+        have = self._pinned.get(key)
+        if have is None or have.size < need:
+            have = self._pinned[key] = self.ctx.pinned_empty((need,), dtype)
+        return have[:need].reshape(shape)
+
+    def free(self):
+        for p in self.halves:
+            p.free()
+        self.halves = []
+        self._pinned = {}
+
+
+class StreamedQuery(object):
+    """``Query`` against a ``StreamedPanel``: same calls, same results (reference order, fp64 bit for bit)."""
+
+    def __init__(self, spanel, row_idx, wei, row0=0):
+        wei = np.asarray(wei)
+        assert wei.ndim == 2 and wei.shape[1] == 3, "SNP weights should be a np.array with  shape == n,3"
+        self.panel, self.wei = spanel, np.ascontiguousarray(wei, dtype=np.float64)
+        self.n = self.wei.shape[0]
+        if row_idx is None:
+            self.rows = np.arange(int(row0), int(row0) + self.n, dtype=np.int64)
+        else:
+            self.rows = np.ascontiguousarray(row_idx, dtype=np.int64)
+            assert self.rows.shape == (self.n,), "please provide same number of positions for both sample and db"
+        assert self.n == 0 or (self.rows.min() >= 0 and self.rows.max() < spanel.n_snp), "row index outside the panel"
+
+    def _walk(self, bounds, score_piece):
+        """load the matched rows [i0, i1) of every piece into alternating half-buffers and hand (half, i0, i1, k) to
+        ``score_piece``, which only ENQUEUES device work: the next piece is read and copied in while it runs"""
+        sp = self.panel
+        if not bounds:
+            return
+        sp._load(0, self.rows[bounds[0][0]:bounds[0][1]])
+        for k, (i0, i1) in enumerate(bounds):
+            score_piece(sp.halves[k % 2], i0, i1, k)
+            if k + 1 < len(bounds):
+                j0, j1 = bounds[k + 1]
+                sp._load((k + 1) % 2, self.rows[j0:j1])
+
+    def _run_carry(self, chunk, skip_hets, mode):
+        sp = self.panel
+        chunk = int(chunk)
+        per = sp.rows_cap // chunk * chunk
+        assert per >= chunk, "HBM budget too small for one %d-row chunk of this DB" % chunk
+        bounds = [(i, min(i + per, self.n)) for i in range(0, self.n, per)]     # pieces of the MATCHED list, cut at chunk boundaries
+        carry = Carry(sp.ctx, sp.n_acc)
+        m = MODE_FAST if mode == MODE_FAST else MODE_STRICT
+        live = []
+
+        def score_piece(half, i0, i1, k):
+            q = Query(half, None, self.wei[i0:i1])
+            after = sum(-(-(b1 - b0) // chunk) for b0, b1 in bounds[k + 1:])
+            q.run_carry(carry, chunk, skip_hets, m, after)
+            live.append(q)
+            if len(live) > 2:                   # the query of piece k - 2 has long finished
+                live.pop(0).free()
+
+        self._walk(bounds, score_piece)
+        carry.finish(want_results=False)            # waits for the last piece
+        for q in live:
+            q.free()
+        return carry, len(bounds)
+
+    def run(self, chunk=1000, skip_hets=False, mode=MODE_EXACT, return_info=False):
+        carry, n_pieces = self._run_carry(chunk, skip_hets, mode)
+        score, ninfo, _ = carry.finish()
+        carry.free()
+        if return_info:
+            return score, ninfo, {"n_strict_reeval": 0, "all_integer_weights": False, "reeval_path": 0, "pieces": n_pieces}
+        return score, ninfo
+
+    def run_device(self, chunk=1000, skip_hets=False, mode=MODE_EXACT):
+        """results left on the device (raw pointers, valid until the next run / free): what a GroupQuery gathers"""
+        if getattr(self, "_carry", None) is not None:
+            self._carry.free()
+        self._carry, _ = self._run_carry(chunk, skip_hets, mode)
+        return self._carry.device_ptrs()
+
+    def last_reeval(self):
+        return 0
+
+    def _window_pieces(self, win_off):
+        sp = self.panel
+        pieces, w0 = [], 0
+        n_win = len(win_off) - 1
+        while w0 < n_win:
+            w1 = w0 + 1
+            assert win_off[w1] - win_off[w0] <= sp.rows_cap, "HBM budget too small for the SNPs of one window"
+            while w1 < n_win and win_off[w1 + 1] - win_off[w0] <= sp.rows_cap:
+                w1 += 1
+            pieces.append((w0, w1))
+            w0 = w1
+        return pieces
+
+    def run_windows(self, win_off, skip_hets=False, totals=True, fast=False):
+        """per-window matchGTsAccs over a streamed DB: pieces hold whole windows, the totals' chain continues in a carry"""
+        sp = self.panel
+        ctx = sp.ctx
+        win_off = np.ascontiguousarray(win_off, dtype=np.int64)
+        n_win = len(win_off) - 1
+        p_score = sp.pinned("w_score", (max(n_win, 1), sp.n_acc), np.float64)
+        p_ninfo = sp.pinned("w_ninfo", (max(n_win, 1), sp.n_acc), np.int64)
+        carry = Carry(ctx, sp.n_acc)
+        pieces = self._window_pieces(win_off)
+        live = []
+
+        def score_piece(half, i0, i1, k):
+            w0, w1 = pieces[k]
+            q = Query(half, None, self.wei[i0:i1])
+            off = np.ascontiguousarray(win_off[w0:w1 + 1] - i0)
+            check(ctx.lib.snpm_query_run_windows_carry(q.h, ptr(off), w1 - w0, int(bool(skip_hets)), ptr(p_score[w0:w1]),
+                                                       ptr(p_ninfo[w0:w1]), carry.h), ctx.h)
+            live.append(q)
+            if len(live) > 2:
+                live.pop(0).free()
+
+        self._walk([(int(win_off[w0]), int(win_off[w1])) for w0, w1 in pieces], score_piece)
+        tot_s, tot_n, _ = carry.finish()            # waits for the device: the pinned rows are complete
+        for q in live:
+            q.free()
+        carry.free()
+        return np.array(p_score[:n_win]), np.array(p_ninfo[:n_win]), tot_s, tot_n
+
+    def gather_columns(self, acc_idx):
+        sp = self.panel
+        per = sp.rows_cap
+        out = []
+
+        def piece(half, i0, i1, k):
+            q = Query(half, None, self.wei[i0:i1])
+            out.append(q.gather_columns(acc_idx))
+            q.free()
+
+        self._walk([(i, min(i + per, self.n)) for i in range(0, self.n, per)], piece)
+        return np.concatenate(out, axis=1) if out else np.zeros((len(acc_idx), 0), dtype=np.uint8)
+
+    def f1_pairs(self, acc_idx):
+        """in-silico crosses: the listed columns at the matched rows are read piece by piece, then crossed on a small panel"""
+        acc_idx = np.asarray(acc_idx)
+        codes = self.gather_columns(acc_idx)
+        small = Panel.from_host(self.panel.ctx, np.ascontiguousarray(codes.T).view(np.int8))
+        q = Query(small, None, self.wei)
+        try:
+            return q.f1_pairs(np.arange(len(acc_idx)))
+        finally:
+            q.free()
+            small.free()
+
+    def free(self):
+        if getattr(self, "_carry", None) is not None:
+            self._carry.free()
+            self._carry = None
