@@ -1092,12 +1092,26 @@ class StreamedQuery(object):
         sp = self.panel
         if not bounds:
             return
+        import os
+        import time
+        trace = [] if os.environ.get("SNPM_STREAM_TRACE") else None
+        t0 = time.perf_counter()
         sp._load(0, self.rows[bounds[0][0]:bounds[0][1]])
+        if trace is not None:
+            trace.append(("load", 0, time.perf_counter() - t0))
         for k, (i0, i1) in enumerate(bounds):
+            t0 = time.perf_counter()
             score_piece(sp.halves[k % 2], i0, i1, k)
+            t1 = time.perf_counter()
             if k + 1 < len(bounds):
                 j0, j1 = bounds[k + 1]
                 sp._load((k + 1) % 2, self.rows[j0:j1])
+            if trace is not None:
+                trace.append(("enqueue", k, t1 - t0))
+                trace.append(("load", k + 1, time.perf_counter() - t1))
+        if trace is not None:
+            import sys
+            sys.stderr.write("stream trace: " + ", ".join("%s[%d] %.3f s" % t for t in trace) + "\n")
 
     def _run_carry(self, chunk, skip_hets, mode):
         sp = self.panel

@@ -76,9 +76,22 @@ def main():
     ctx.close()
     gbytes = host.nbytes / 1e9
 
+    # the wire itself: one pinned 64 MiB block copied to the device over and over (no fill)
+    import torch
+    pin = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+    dev = torch.empty(64 << 20, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        dev.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize()
+    print("\nPCIe ceiling: pinned host -> device, 100 x 64 MiB: %.1f GB/s" % (100 * (64 << 20) / 1e9 / (time.perf_counter() - t0)))
+    del pin, dev
+
     print("\n(a) host memory -> panel, threads filling the pinned slabs")
     for thr in [int(x) for x in args.threads.split(",")]:
-        for label, env, packed in (("int8 panel", {}, False), ("packed panel, packed on the host", {}, True),
+        for label, env, packed in (("int8 panel", {}, False), ("int8 panel, plain memcpy into the slabs", {"SNPM_NO_NT": 1}, False),
+                                   ("packed panel, packed on the host", {}, True),
                                    ("packed panel, packed on the device", {"SNPM_HOST_PACK": 0}, True)):
             c = ctx_with(SNPM_STAGE_THREADS=thr, **env)
             p = engine.Panel(c, n, n_acc, packed=packed)
@@ -147,7 +160,6 @@ def main():
         print("\n(c) streamed DB: %d x %d int8 = %.1f GB in %s (written in %.1f s), HBM budget %.0f GB"
               % (n_big, n_acc, n_big * n_acc / 1e9, path, time.perf_counter() - t0, args.budget_gb))
         try:
-            import torch
             wei = torch.empty((n_big, 3), dtype=torch.float64, device="cuda:0")
             c.sample_synthetic(31337, 0, n_big, 417, wei.data_ptr())
             c.synchronize()
@@ -157,6 +169,10 @@ def main():
             for packed in (False, True):
                 sp = engine.StreamedPanel(c, store, packed=packed, budget_bytes=int(args.budget_gb * 1e9))
                 q = sp.query(None, wei_h)
+                t0 = time.perf_counter()
+                q.run(1000, False, engine.MODE_EXACT)
+                first = time.perf_counter() - t0           # first read of the freshly written file
+                sp.loads = 0
                 c.profile(True)
                 c.profile_reset()
                 t0 = time.perf_counter()
@@ -172,9 +188,9 @@ def main():
                     sp._load(k % 2, (r0, min(per, n_big - r0)))
                 sp.halves[0].upload_wait()
                 loads = time.perf_counter() - t0
-                print("  %-7s %2d pieces of <= %d rows: job %.2f s = %.1f GB/s;  loads alone %.2f s;  scoring kernels alone %.3f s "
-                      "(%d launches);  job / max(load, score) = %.3f, job / (load + score) = %.3f;  top hit %d"
-                      % ("packed" if packed else "int8", pieces, sp.rows_cap, wall, n_big * n_acc / 1e9 / wall, loads, k_ms / 1e3, k_n,
+                print("  %-7s %2d pieces of <= %d rows: job %.2f s = %.1f GB/s (first read of the new file: %.2f s);  loads alone %.2f s;  "
+                      "scoring kernels alone %.3f s (%d launches);  job / max(load, score) = %.3f, job / (load + score) = %.3f;  top hit %d"
+                      % ("packed" if packed else "int8", pieces, sp.rows_cap, wall, n_big * n_acc / 1e9 / wall, first, loads, k_ms / 1e3, k_n,
                          wall / max(loads, k_ms / 1e3), wall / (loads + k_ms / 1e3), int(np.argmax(s / ni))))
                 sp.free()
         finally:
