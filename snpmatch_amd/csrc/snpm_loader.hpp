@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <functional>
 #include <sched.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 
 #if defined(__x86_64__)
@@ -488,11 +489,41 @@ int stage_rows(snpm_panel *p, int64_t row0, int64_t nrows, const RowSource &src)
     return SNPM_OK;
 }
 
-// open a DB file for the loader; O_DIRECT when asked for (or, in auto mode, for large contiguous reads) and the file system takes it
-int open_source(snpm_ctx *ctx, const char *path, bool contiguous, int64_t bytes, RowSource *src)
+// fraction of 64 sample pages of [off, off + bytes) that sit in the page cache (mincore on a read-only mapping; -1: unknown)
+double cached_fraction(int fd, int64_t off, int64_t bytes)
+{
+    const int64_t page = 4096;
+    const int64_t a = off & ~(page - 1);
+    const size_t len = (size_t)(off + bytes - a);
+    void *m = mmap(nullptr, len, PROT_READ, MAP_SHARED, fd, (off_t)a);
+    if (m == MAP_FAILED) return -1.0;
+    int hit = 0, seen = 0;
+    for (int i = 0; i < 64; ++i) {
+        const size_t o = ((len / 64) * (size_t)i) & ~(size_t)(page - 1);
+        unsigned char v = 0;
+        if (o < len && mincore((char *)m + o, 1, &v) == 0) {
+            ++seen;
+            hit += v & 1;
+        }
+    }
+    munmap(m, len);
+    return seen ? (double)hit / seen : -1.0;
+}
+
+// open a DB file for the loader.  O_DIRECT when asked for (SNPM_ODIRECT=1) or, by default, for contiguous reads of >= 1 GiB of
+// a file that is NOT in the page cache (measured on the GPU box's disk, 20 GB: cold 16.3 GB/s direct vs 4.5 GB/s buffered; warm
+// 16.4 GB/s direct vs 28.6 GB/s buffered) and only where the file system takes the flag
+int open_source(snpm_ctx *ctx, const char *path, bool contiguous, int64_t off, int64_t bytes, RowSource *src)
 {
     int fd = -1;
-    const bool want_direct = contiguous && (ctx->odirect == 1 || (ctx->odirect < 0 && bytes >= (int64_t(1) << 30)));
+    bool want_direct = contiguous && (ctx->odirect == 1 || (ctx->odirect < 0 && bytes >= (int64_t(1) << 30)));
+    if (want_direct && ctx->odirect < 0) {
+        const int probe = open(path, O_RDONLY);
+        if (probe >= 0) {
+            if (cached_fraction(probe, off, bytes) >= 0.5) want_direct = false;
+            close(probe);
+        }
+    }
     if (want_direct) {
         fd = open(path, O_RDONLY | O_DIRECT);
         if (fd >= 0) src->direct = true;
@@ -551,7 +582,7 @@ try {
     src.row_idx = row_idx;
     src.file_row0 = row_idx ? 0 : file_row0;
     const bool contiguous = !row_idx && file_pitch == p->n_acc && col0 == 0;
-    int rc = open_source(ctx, path, contiguous, nrows * p->n_acc, &src);
+    int rc = open_source(ctx, path, contiguous, file_offset + file_row0 * file_pitch, nrows * p->n_acc, &src);
     if (rc) return rc;
 #ifdef POSIX_FADV_SEQUENTIAL
     if (contiguous && !src.direct)
