@@ -533,7 +533,7 @@ int ensure_lut(snpm_query *q, int skip)
         ProfScope ps(ctx, PK_LUT);
         const int thr = 256;
         hipLaunchKernelGGL(k_build_lut, dim3((unsigned)((q->n + thr - 1) / thr)), dim3(thr), 0, ctx->stream, q->d_w,
-                           q->d_lut, q->n, skip);
+                           q->d_lut, q->n, skip, (int *)nullptr);
         HIPCHK(ctx, hipGetLastError());
     }
     q->lut_skip = skip;
@@ -1616,6 +1616,7 @@ static int query_finish_setup(snpm_query *q)
     const double *part = (const double *)ctx->h_pinned;
     for (int i = 0; i < grid; ++i) tot += part[i];
     const int flags = *(const int *)((const char *)ctx->h_pinned + (size_t)grid * sizeof(double));
+    if (flags & 4) return set_err(ctx, SNPM_ERR_BADARG, "SNP weights must be finite (a NaN or infinite weight was given)");
     q->wsum = (double)tot * 1.0000001;              // block sums carry ~1e-13 relative rounding: round up
     q->all_integer = !(flags & 1) && tot < 9.0e15L; // every partial sum exactly representable
     q->hard01 = q->all_integer && !(flags & 2);
@@ -2112,7 +2113,7 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
                            p->n_snp, (int *)ctx->ws_flags2.p);
         ProfScope ps(ctx, PK_LUT);
         hipLaunchKernelGGL(k_build_lut, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_w + 3 * r0,
-                           (double *)ctx->ws_blut.p + 4 * r0, n, skip);
+                           (double *)ctx->ws_blut.p + 4 * r0, n, skip, (int *)ctx->ws_flags2.p);
         HIPCHK(ctx, hipGetLastError());
         return SNPM_OK;
     };
@@ -2242,6 +2243,7 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     if (trace)
         fprintf(stderr, "[snpm batch] plan %.3f ms, enqueue %.3f ms (staging %.3f, launches %.3f), finish+likelihood+copy back %.3f ms\n",
                 t_planned - t_begin, t_enqueued - t_planned, t_stage, t_launch, now() - t_enqueued);
+    if (*h_bad & 4) return set_err(ctx, SNPM_ERR_BADARG, "SNP weights must be finite (a NaN or infinite weight was given)");
     if (*h_bad) return set_err(ctx, SNPM_ERR_BADARG, "a row index lies outside the panel (n_snp %lld)", (long long)p->n_snp);
     if (info) { info[0] = n_pairs; info[1] = (strict_all && mode != SNPM_MODE_STRICT) ? 1 : 0; }
     return SNPM_OK;

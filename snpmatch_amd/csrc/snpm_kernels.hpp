@@ -73,11 +73,14 @@ typedef double f64x2_t __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------------
 // LUT build: W [n,3] (ref, het, alt) -> LUT [n,4] = {ref, alt, het (0 if skip_hets), 0}, entry index = db byte & 3
 // (0 -> ref, 1 -> alt, 2 -> het, 3 and 0xFF -> nothing).
-__global__ void k_build_lut(const double *__restrict__ w, double *__restrict__ lut, int64_t n, int skip_hets)
+// bad (may be NULL): bit 2 is raised when a weight is NaN or infinite (batched samples are vetted here; single queries in k_wprops)
+__global__ void k_build_lut(const double *__restrict__ w, double *__restrict__ lut, int64_t n, int skip_hets, int *__restrict__ bad)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double w0 = w[3 * i + 0], w1 = w[3 * i + 1], w2 = w[3 * i + 2];
+    if (bad && !(fabs(w0) <= 1.7976931348623157e308 && fabs(w1) <= 1.7976931348623157e308 && fabs(w2) <= 1.7976931348623157e308))
+        atomicOr(bad, 4);
     double4 e;
     e.x = w0;
     e.y = w2;
@@ -88,8 +91,10 @@ __global__ void k_build_lut(const double *__restrict__ w, double *__restrict__ l
 
 // ------------------------------------------------------------------------------------------------
 // Properties of a sample's weights, computed where the weights live (no host pass over the rows):
-//   k_wprops  block partial sums of wmax_r = max_c |W[r,c]| and two flags: bit 0 = some weight is not an integer
-//             (or not finite), bit 1 = some weight is neither 0 nor 1.
+//   k_wprops  block partial sums of wmax_r = max_c |W[r,c]| and three flags: bit 0 = some weight is not an integer
+//             (or huge), bit 1 = some weight is neither 0 nor 1, bit 2 = some weight is NaN or infinite (refused: the
+//             reference multiplies 0/1 masks by the weights, core/snpmatch.py:85-87, so one such weight turns EVERY
+//             accession's score into NaN and int(NaN) raises in GenotyperOutput, :96).
 //   k_wbits   hard-call samples: one byte of three weight bits per row (ref | het << 1 | alt << 2) for k_fast_bits.
 //   k_eref / k_efinish   the reference-order part of the certificate's error bound (DESIGN.md "Exactness"):
 //             E_ref = u / (1 - m_max u) * sum_k s_k * (len_k + 3 + K - k + chunks_after),  s_k = sum of wmax over
@@ -117,6 +122,7 @@ k_wprops(const double *__restrict__ w, int64_t n, double *__restrict__ partial, 
         if (!(a == floor(a) && b == floor(b) && c == floor(c)) || !(a < 1e300 && b < 1e300 && c < 1e300)) f |= 1;
         const double x = w[3 * r], y = w[3 * r + 1], z = w[3 * r + 2];
         if (!((x == 0.0 || x == 1.0) && (y == 0.0 || y == 1.0) && (z == 0.0 || z == 1.0))) f |= 2;
+        if (!(a <= 1.7976931348623157e308 && b <= 1.7976931348623157e308 && c <= 1.7976931348623157e308)) f |= 4;
     }
     const double tot = block_sum_256(acc, sm);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
