@@ -69,6 +69,8 @@ typedef struct snpm_group snpm_group;
 
 /* ---------------------------------------------------------------- lifecycle */
 int         snpm_version(void);
+/* HIP version of the build (HIP_VERSION: major * 10000000 + minor * 100000 + patch); no GPU needed */
+int         snpm_hip_build_version(void);
 int         snpm_device_count(int *count);
 int         snpm_init(int device_id, snpm_ctx **out);
 int         snpm_destroy(snpm_ctx *ctx);
@@ -376,6 +378,37 @@ int snpm_vcf_dims(const snpm_vcf *vcf, int64_t *n_records, int *chr_width, int *
 int snpm_vcf_fill(const snpm_vcf *vcf, char *chr, int64_t *pos, char *gt, double *pl, int64_t *dp);
 const char *snpm_vcf_sample_name(const snpm_vcf *vcf, int i);
 int snpm_vcf_free(snpm_vcf *vcf);
+
+/* ---------------------------------------------------------------- DB input: the reference's HDF5 files (host only, no GPU) */
+/* A reader for the files the reference keeps its DBs in -- `snps` int8 [num_snps, num_accessions] in lzf chunks of (1000,
+   num_accessions), `positions` with the attributes `chrs` / `chr_regions`, `accessions` (pygwas/genotype.py:310-326), and the
+   accession-major twin in gzip chunks (core/makedb.py:64-81) -- for hosts without h5py / libhdf5.  Scope: files of the default
+   ("earliest") format of HDF5 1.8 / 1.10: superblock 0-3 with version-1 object headers, old-style groups, compact / contiguous /
+   chunked (version-1 B-tree) layouts, filters gzip, shuffle, lzf, integer / float / fixed- and variable-length string data,
+   little-endian.  Anything else returns SNPM_ERR_BADARG with a message in snpm_h5_last_error(file) (file == NULL: of the last
+   failed snpm_h5_open in this thread).  snpm_h5 handles are independent of contexts; reads are thread-safe. */
+typedef struct snpm_h5 snpm_h5;
+int snpm_h5_open(const char *path, snpm_h5 **out);
+int snpm_h5_close(snpm_h5 *file);
+const char *snpm_h5_last_error(const snpm_h5 *file);
+/* member names of a group ("" = root), '\n'-separated; *needed = bytes incl. the terminating NUL */
+int snpm_h5_list(snpm_h5 *file, const char *group, char *buf, int64_t cap, int64_t *needed);
+/* object `path` (attr == NULL) or its attribute `attr`: kind 0 group / 1 data; rank, dims [8], type_class 0 integer / 1 float /
+   3 string (variable-length strings are presented as fixed-length ones of elem_size = the longest), elem_size bytes, chunk [8]
+   (0s: not chunked), number of attributes.  Any output may be NULL. */
+int snpm_h5_info(snpm_h5 *file, const char *path, const char *attr, int *kind, int *rank, int64_t *dims, int *type_class,
+                 int *elem_size, int *is_signed, int64_t *chunk, int *n_attrs);
+int snpm_h5_attr_name(snpm_h5 *file, const char *path, int index, char *buf, int64_t cap);
+/* the whole dataset / attribute in C order; out_bytes = elements * elem_size as snpm_h5_info reports them */
+int snpm_h5_read(snpm_h5 *file, const char *path, const char *attr, void *out, int64_t out_bytes);
+/* rows row_idx[i] (or file_row0 + i when row_idx is NULL), columns [col0, col0 + ncols) of a 1-D / 2-D dataset of fixed-size
+   elements (the reference's g.g.snps[idx, :] / g.g_acc.snps[:, i]) -> out, row stride out_pitch BYTES */
+int snpm_h5_read_rows(snpm_h5 *file, const char *path, const int64_t *row_idx, int64_t file_row0, int64_t nrows, int64_t col0,
+                      int64_t ncols, void *out, int64_t out_pitch);
+/* snpm_panel_load_file_rows for a 2-D int8 dataset of an open HDF5 file: chunks are read and decompressed by the loader's host
+   threads straight into the pinned staging slabs (packed panels: packed there too) */
+int snpm_panel_load_h5(snpm_panel *panel, snpm_h5 *file, const char *dataset, int64_t col0, const int64_t *row_idx,
+                       int64_t file_row0, int64_t row0, int64_t nrows);
 
 #ifdef __cplusplus
 }

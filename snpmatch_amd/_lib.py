@@ -30,7 +30,7 @@ MODE_FAST = 2
 
 # every symbol include/snpmatch_hip.h declares (tests check that the .so exports all of them)
 SYMBOLS = [
-    "snpm_version", "snpm_device_count", "snpm_init", "snpm_destroy", "snpm_last_error", "snpm_set_stream",
+    "snpm_version", "snpm_hip_build_version", "snpm_device_count", "snpm_init", "snpm_destroy", "snpm_last_error", "snpm_set_stream",
     "snpm_synchronize", "snpm_device_mem_info", "snpm_panel_create", "snpm_panel_create_packed", "snpm_panel_is_packed", "snpm_panel_free", "snpm_panel_info", "snpm_panel_upload_rows", "snpm_panel_load_file", "snpm_panel_load_file_rows", "snpm_pack_rows_host",
     "snpm_panel_upload_wait", "snpm_panel_download_rows", "snpm_panel_fill_synthetic", "snpm_query_create",
     "snpm_query_free", "snpm_query_bind_outputs", "snpm_query_run", "snpm_query_run_device", "snpm_query_error_bound",
@@ -45,6 +45,8 @@ SYMBOLS = [
     "snpm_group_unique_id", "snpm_group_create_rank", "snpm_group_create_local", "snpm_group_free", "snpm_group_last_error",
     "snpm_group_info", "snpm_group_ctx", "snpm_group_shard", "snpm_group_gather_scores", "snpm_group_gathered_ptrs",
     "snpm_group_transport",
+    "snpm_h5_open", "snpm_h5_close", "snpm_h5_last_error", "snpm_h5_list", "snpm_h5_info", "snpm_h5_attr_name", "snpm_h5_read",
+    "snpm_h5_read_rows", "snpm_panel_load_h5",
 ]
 
 _lib = None
@@ -57,23 +59,63 @@ class SnpmError(RuntimeError):
         self.msg = msg
 
 
-def _share_hip_runtime_with_torch():
-    """PyTorch wheels bundle their own libamdhip64.so (soname libamdhip64.so.7) and load it by file name.  Imported
-    first, torch's runtime also serves this library (same soname); imported AFTER this library was loaded, torch would
-    bring a second HIP runtime into the process and find no GPU.  Preloading torch's copy (without importing torch)
-    makes the order irrelevant.  SNPMATCH_HIP_RUNTIME=system keeps the system runtime (processes that never use torch)."""
-    if "torch" in sys.modules or os.environ.get("SNPMATCH_HIP_RUNTIME", "") == "system":
-        return
+HIP_RUNTIME = "system"          # which HIP runtime serves the library in this process: "system", "torch (already imported)" or "torch (preloaded)"
+
+
+def _build_hip_major():
+    """major HIP version libsnpmatch_hip.so was built against, read from the file without loading its dependencies"""
+    import re
     try:
-        import importlib.util
-        spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.origin:
-            return
-        path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-        if os.path.exists(path):
-            C.CDLL(path, mode=C.RTLD_GLOBAL)
-    except Exception:
-        pass
+        with open(LIB_PATH, "rb") as fh:
+            m = re.search(rb"libamdhip64\.so\.(\d+)", fh.read())
+        return int(m.group(1)) if m else None
+    except OSError:
+        return None
+
+
+def _torch_hip_major():
+    """major HIP version of the installed PyTorch wheel, from torch/version.py (torch is NOT imported)"""
+    import importlib.util
+    import re
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return None, None
+    base = os.path.dirname(spec.origin)
+    try:
+        m = re.search(r"^hip\b[^=]*=\s*['\"](\d+)\.", open(os.path.join(base, "version.py")).read(), flags=re.M)
+    except OSError:
+        m = None
+    return (int(m.group(1)) if m else None), os.path.join(base, "lib", "libamdhip64.so")
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so and load it by file name.  Imported first, torch's runtime also serves
+    this library; imported AFTER this library was loaded, torch would bring a second HIP runtime into the process and
+    find no GPU.  Preloading torch's copy (without importing torch) makes the order irrelevant -- but it also means the
+    library, built with /opt/rocm's hipcc, runs on the wheel's runtime.  So the preload happens only when that runtime has
+    the MAJOR version the library was linked against (its DT_NEEDED soname libamdhip64.so.N against ``hip`` in
+    torch/version.py); otherwise, and with SNPMATCH_HIP_RUNTIME=system (what the CLI sets when it is not started by
+    torch.distributed.run: it never imports torch), the system runtime is used.  SNPMATCH_HIP_RUNTIME=torch forces the
+    preload.  The choice is kept in ``HIP_RUNTIME`` and logged."""
+    global HIP_RUNTIME
+    import logging
+    log = logging.getLogger(__name__)
+    choice = os.environ.get("SNPMATCH_HIP_RUNTIME", "").lower()
+    if "torch" in sys.modules:
+        HIP_RUNTIME = "torch (already imported)"
+    elif choice != "system":
+        try:
+            major, path = _torch_hip_major()
+            built = _build_hip_major()
+            if path and os.path.exists(path) and (choice == "torch" or (major is not None and major == built)):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+                HIP_RUNTIME = "torch (preloaded)"
+            elif path and os.path.exists(path):
+                log.warning("PyTorch bundles HIP %s, libsnpmatch_hip.so was built for HIP %s: using the system runtime; import "
+                            "torch BEFORE snpmatch_amd if both are needed in one process", major, built)
+        except Exception as e:          # noqa: BLE001
+            log.warning("could not inspect PyTorch's HIP runtime (%s): using the system runtime", e)
+    log.debug("HIP runtime for libsnpmatch_hip.so: %s", HIP_RUNTIME)
 
 
 def load():
@@ -139,6 +181,17 @@ def load():
     lib.snpm_group_gathered_ptrs.argtypes = [p, ci, pp, pp]
     lib.snpm_group_transport.argtypes = [p]
     lib.snpm_group_transport.restype = C.c_char_p
+    lib.snpm_h5_open.argtypes = [C.c_char_p, pp]
+    lib.snpm_h5_close.argtypes = [p]
+    lib.snpm_h5_last_error.argtypes = [p]
+    lib.snpm_h5_last_error.restype = C.c_char_p
+    lib.snpm_h5_list.argtypes = [p, C.c_char_p, p, i64, C.POINTER(i64)]
+    lib.snpm_h5_info.argtypes = [p, C.c_char_p, C.c_char_p, C.POINTER(ci), C.POINTER(ci), C.POINTER(i64), C.POINTER(ci),
+                                 C.POINTER(ci), C.POINTER(ci), C.POINTER(i64), C.POINTER(ci)]
+    lib.snpm_h5_attr_name.argtypes = [p, C.c_char_p, ci, p, i64]
+    lib.snpm_h5_read.argtypes = [p, C.c_char_p, C.c_char_p, p, i64]
+    lib.snpm_h5_read_rows.argtypes = [p, C.c_char_p, p, i64, i64, i64, i64, p, i64]
+    lib.snpm_panel_load_h5.argtypes = [p, p, C.c_char_p, i64, p, i64, i64, i64]
     lib.snpm_query_create.argtypes = [p, p, i64, i64, p, pp]
     lib.snpm_query_free.argtypes = [p]
     lib.snpm_query_bind_outputs.argtypes = [p, p, p]

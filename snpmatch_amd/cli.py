@@ -98,6 +98,10 @@ def main(argv=None):
         parser.print_help()
         return 0
     job = None
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) <= 1:
+        # a plain CLI run never imports torch (several GPUs are driven through the library's own RCCL group): stay on the
+        # HIP runtime the library was built with instead of the copy bundled with a PyTorch wheel
+        os.environ.setdefault("SNPMATCH_HIP_RUNTIME", "system")
     try:
         from . import dist
         job = dist.init_from_env()       # under torch.distributed.run: accession-sharded over the ranks' GPUs

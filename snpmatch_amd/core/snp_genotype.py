@@ -13,7 +13,9 @@ On-disk formats
     (memory-mapped, streamed to the GPU slab by slab) + ``meta.npz`` (accessions, positions, chrs,
     chr_regions).  ``save_native`` / ``Genotype.from_arrays`` create it.
   * ``.npz`` with the same keys plus ``snps`` (small DBs, tests).
-  * the reference's HDF5 layout (pygwas/genotype.py:310-326) when ``h5py`` is importable.
+  * the reference's HDF5 layout (pygwas/genotype.py:310-326: ``snps`` in lzf chunks of (1000, num_accessions), ``positions``
+    with attrs ``chrs`` / ``chr_regions``, ``accessions``), read by the library's own HDF5 reader (``snpmatch_amd.h5``,
+    csrc/snpm_h5.cpp) -- h5py is only a fallback for files in formats that reader refuses.
 """
 import logging
 import os
@@ -75,14 +77,25 @@ def _load_any(path):
     if path.endswith(".npz"):
         d = np.load(path)
         return MemGenotype(d["snps"], d["accessions"], d["positions"], np.asarray(d["chrs"]).astype("U"), d["chr_regions"])
+    # The reference's HDF5 DB (pygwas/genotype.py:310-326, :534-673): read by the library's own reader (csrc/snpm_h5.cpp) -- no
+    # h5py / libhdf5 needed, and the chunks go from the file through the loader's threads into the staging slabs.  Files in a
+    # format that reader does not take (the "latest" HDF5 file format, other filters) go through h5py where it is installed.
+    from .. import h5 as native_h5
     try:
-        import h5py
-    except ImportError:
-        raise ImportError("%s looks like an HDF5 database but h5py is not installed; convert it to the native "
-                          "flat panel format (snpmatch_amd.core.snp_genotype.save_native)" % path)
-    h5 = h5py.File(path, "r")
-    return MemGenotype(h5["snps"], h5["accessions"][:], h5["positions"][:],
-                       h5["positions"].attrs["chrs"].astype("U"), h5["positions"].attrs["chr_regions"])
+        f = native_h5.File(path)
+        g = MemGenotype(f["snps"], f["accessions"][:], f["positions"][:], f["positions"].attrs["chrs"].astype("U"),
+                        f["positions"].attrs["chr_regions"])
+        g.h5_source = (f, "snps")               # lets Genotype.panel() load rows natively (snpm_panel_load_h5)
+        return g
+    except IOError as native_error:
+        try:
+            import h5py
+        except ImportError:
+            raise IOError("%s; h5py is not installed either -- convert the DB where it is (python -m snpmatch_amd makedb-native)"
+                          % native_error)
+        h5 = h5py.File(path, "r")
+        return MemGenotype(h5["snps"], h5["accessions"][:], h5["positions"][:],
+                           h5["positions"].attrs["chrs"].astype("U"), h5["positions"].attrs["chr_regions"])
 
 
 def load_genotype_files(h5file, hdf5_acc_file=None):
@@ -161,7 +174,8 @@ class Genotype(object):
         half-buffers (``engine.StreamedPanel``; the reference reads any size through g.g.snps[idx, :])."""
         from .. import engine
         npy = getattr(self.g, "npy_path", None)          # native flat panel: file -> pinned slabs -> HBM
-        store = engine.RowStore(npy=npy) if npy else engine.RowStore(snps=self.g.snps)
+        h5_source = getattr(self.g, "h5_source", None)   # the reference's HDF5 file: chunks -> loader threads -> pinned slabs -> HBM
+        store = (engine.RowStore(npy=npy) if npy else engine.RowStore(h5=h5_source) if h5_source else engine.RowStore(snps=self.g.snps))
         env = os.environ.get("SNPM_HBM_BUDGET_GB", "")
         budget = int(float(env) * 1e9) if env else int(0.85 * ctx.mem_info()[0])
         n_loc = a1 - a0

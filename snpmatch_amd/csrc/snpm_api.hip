@@ -1203,6 +1203,10 @@ extern "C" {
 
 int snpm_version(void) { return 100; }
 
+// HIP version the library was built against, as hipcc's headers encode it (major * 10000000 + minor * 100000 + patch): the
+// binding compares its major number with the HIP runtime it is about to share with PyTorch
+int snpm_hip_build_version(void) { return HIP_VERSION; }
+
 int snpm_device_count(int *count)
 {
     if (!count) return set_err(nullptr, SNPM_ERR_BADARG, "count is NULL");

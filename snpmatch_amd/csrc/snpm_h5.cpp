@@ -1,0 +1,994 @@
+// snpm_h5.cpp -- a reader for the HDF5 files the reference keeps its DBs in (pygwas/genotype.py:310-326: `snps` int8
+// [num_snps, num_accessions] in lzf-compressed chunks of (1000, num_accessions), `positions` i4 with the attributes
+// `chrs` / `chr_regions`, `accessions`; core/makedb.py:64-81: the accession-major twin with gzip chunks of (num_snps, 1)),
+// so that `-d all_chromosomes_binary.hdf5` works where h5py is not installed and the rows can go straight from the
+// file's chunks into the pinned staging slabs (snpm_loader.hpp).
+//
+// Scope: what h5py / HDF5 1.8-1.10 write with the default ("earliest") format -- superblock version 0 / 1 (2 / 3 are read
+// as far as they point at version-1 object headers), version-1 object headers with continuation blocks, old-style groups
+// (symbol-table B-tree + local heap), data layout message versions 1-3 (compact, contiguous, chunked with a version-1
+// B-tree index), filters gzip (1), shuffle (2), lzf (32000) incl. chunks a filter skipped (filter mask), attributes
+// (message versions 1-3) and datasets of fixed-point / floating-point / fixed-length string / variable-length string
+// (global heap) type, little-endian.  Anything else (version-2 object headers, dense groups / attributes, chunk indexes of
+// the "latest" format, other filters) is refused with a message -- never guessed at.  Every offset read from the file is
+// bounds-checked: a damaged file gives an error, not a fault.  Host only; no GPU, no ctx.
+#include "snpmatch_hip.h"
+#include "snpm_h5.hpp"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_h5_error;
+
+struct H5Err : std::runtime_error {
+    explicit H5Err(const std::string &m) : std::runtime_error(m) {}
+};
+
+[[noreturn]] void fail(const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    throw H5Err(buf);
+}
+
+constexpr uint64_t UNDEF = ~uint64_t(0);
+
+struct Filter {
+    int id = 0;
+    std::vector<uint32_t> cd;
+};
+
+struct TypeInfo {
+    int cls = -1;            // 0 fixed-point, 1 float, 3 string, 9 variable-length
+    int size = 0;            // bytes per element in the file
+    bool is_signed = false;
+    bool vlen_string = false;
+};
+
+struct Chunk {
+    uint64_t addr = UNDEF;
+    uint32_t size = 0, mask = 0;
+};
+
+std::atomic<uint64_t> g_next_uid{1};
+
+struct Object {
+    const uint64_t uid = g_next_uid.fetch_add(1);      // identifies the object in the per-thread chunk caches (addresses get reused)
+    bool is_dataset = false;
+    // groups
+    uint64_t btree = UNDEF, heap = UNDEF;
+    // datasets / attributes
+    TypeInfo type;
+    int rank = 0;
+    uint64_t dims[8] = {0};
+    int layout = -1;         // 0 compact, 1 contiguous, 2 chunked
+    uint64_t data_addr = UNDEF, data_size = 0;
+    std::vector<uint8_t> compact;
+    uint64_t chunk_btree = UNDEF;
+    uint64_t chunk_dims[8] = {0};
+    std::vector<Filter> filters;
+    struct Attr {
+        std::string name;
+        TypeInfo type;
+        int rank = 0;
+        uint64_t dims[8] = {0};
+        std::vector<uint8_t> raw;       // element data as stored in the message
+    };
+    std::vector<Attr> attrs;
+    // chunk index, built on first use
+    bool indexed = false;
+    uint64_t grid[8] = {0};
+    std::vector<Chunk> chunks;          // row-major over the chunk grid
+    uint64_t n_elems() const
+    {
+        uint64_t n = 1;
+        for (int i = 0; i < rank; ++i) n *= dims[i];
+        return n;
+    }
+};
+
+}  // namespace
+
+struct snpm_h5 {
+    int fd = -1;
+    uint64_t file_size = 0, base = 0;
+    int so = 8, sl = 8;      // size of offsets / lengths
+    uint64_t root_header = UNDEF, root_btree = UNDEF, root_heap = UNDEF;
+    std::string path, err;
+    std::mutex mu;
+    std::map<std::string, std::unique_ptr<Object>> objects;
+
+    void read(uint64_t off, void *dst, size_t n) const
+    {
+        if (off == UNDEF || off + base > file_size || n > file_size - (off + base)) fail("read of %zu bytes at %llu lies outside the file", n, (unsigned long long)off);
+        size_t o = 0;
+        while (o < n) {
+            const ssize_t k = pread(fd, (char *)dst + o, n - o, (off_t)(off + base + o));
+            if (k < 0 && errno == EINTR) continue;
+            if (k <= 0) fail("cannot read %zu bytes at %llu: %s", n, (unsigned long long)off, k < 0 ? strerror(errno) : "end of file");
+            o += (size_t)k;
+        }
+    }
+    std::vector<uint8_t> bytes(uint64_t off, size_t n) const
+    {
+        if (n > (size_t(1) << 31)) fail("unreasonable block size %zu", n);
+        std::vector<uint8_t> v(n);
+        read(off, v.data(), n);
+        return v;
+    }
+};
+
+namespace {
+
+struct Cursor {
+    const uint8_t *p, *end;
+    Cursor(const uint8_t *b, size_t n) : p(b), end(b + n) {}
+    void need(size_t n) const
+    {
+        if ((size_t)(end - p) < n) fail("truncated structure");
+    }
+    uint64_t u(int n)
+    {
+        need((size_t)n);
+        uint64_t v = 0;
+        for (int i = 0; i < n; ++i) v |= (uint64_t)p[i] << (8 * i);
+        p += n;
+        return v;
+    }
+    void skip(size_t n)
+    {
+        need(n);
+        p += n;
+    }
+    size_t left() const { return (size_t)(end - p); }
+};
+
+void parse_datatype(Cursor &c, TypeInfo &t)
+{
+    const uint64_t w = c.u(4);
+    const int cls = (int)(w & 0x0f), ver = (int)((w >> 4) & 0x0f);
+    const uint32_t bits = (uint32_t)(w >> 8);
+    t.cls = cls;
+    t.size = (int)c.u(4);
+    if (ver < 1 || ver > 3) fail("datatype message version %d not supported", ver);
+    switch (cls) {
+    case 0:
+        if (bits & 1) fail("big-endian integers are not supported");
+        t.is_signed = (bits & 8) != 0;
+        c.skip(4);
+        break;
+    case 1:
+        if (bits & 1) fail("big-endian floats are not supported");
+        c.skip(12);
+        break;
+    case 3:
+        break;
+    case 9: {
+        const int kind = (int)(bits & 0x0f);
+        TypeInfo base;
+        parse_datatype(c, base);
+        if (kind != 1) fail("variable-length sequences are not supported (only strings)");
+        t.vlen_string = true;
+        break;
+    }
+    default:
+        fail("datatype class %d not supported", cls);
+    }
+}
+
+void parse_dataspace(Cursor &c, int &rank, uint64_t *dims, int sl)
+{
+    const int ver = (int)c.u(1);
+    rank = (int)c.u(1);
+    const int flags = (int)c.u(1);
+    if (ver == 1) c.skip(5);
+    else if (ver == 2) c.skip(1);
+    else fail("dataspace message version %d not supported", ver);
+    if (rank > 8) fail("rank %d not supported", rank);
+    for (int i = 0; i < rank; ++i) dims[i] = c.u(sl);
+    if (flags & 1) c.skip((size_t)rank * sl);
+}
+
+void parse_filters(Cursor &c, std::vector<Filter> &out)
+{
+    const int ver = (int)c.u(1);
+    const int n = (int)c.u(1);
+    if (ver == 1) c.skip(6);
+    else if (ver != 2) fail("filter pipeline message version %d not supported", ver);
+    for (int i = 0; i < n; ++i) {
+        Filter f;
+        f.id = (int)c.u(2);
+        size_t name_len = 0;
+        if (ver == 1 || f.id >= 256) name_len = (size_t)c.u(2);
+        c.u(2);                                             // flags (bit 0: optional)
+        const int ncd = (int)c.u(2);
+        if (ver == 1) c.skip((name_len + 7) & ~size_t(7));
+        else c.skip(name_len);
+        for (int k = 0; k < ncd; ++k) f.cd.push_back((uint32_t)c.u(4));
+        if (ver == 1 && (ncd & 1)) c.skip(4);
+        if (f.id != 1 && f.id != 2 && f.id != 32000)
+            fail("filter %d is not supported (gzip, shuffle and lzf are)", f.id);
+        out.push_back(f);
+    }
+}
+
+void parse_layout(Cursor &c, Object &o, const snpm_h5 &f)
+{
+    const int ver = (int)c.u(1);
+    if (ver == 3) {
+        o.layout = (int)c.u(1);
+        if (o.layout == 0) {
+            const size_t n = (size_t)c.u(2);
+            c.need(n);
+            o.compact.assign(c.p, c.p + n);
+            c.skip(n);
+        } else if (o.layout == 1) {
+            o.data_addr = c.u(f.so);
+            o.data_size = c.u(f.sl);
+        } else if (o.layout == 2) {
+            const int nd = (int)c.u(1);
+            if (nd < 2 || nd > 9) fail("chunk dimensionality %d not supported", nd);
+            o.chunk_btree = c.u(f.so);
+            for (int i = 0; i < nd - 1; ++i) o.chunk_dims[i] = c.u(4);
+            c.u(4);                                         // element size
+        } else {
+            fail("data layout class %d not supported", o.layout);
+        }
+    } else if (ver == 1 || ver == 2) {
+        const int nd = (int)c.u(1);
+        o.layout = (int)c.u(1);
+        c.skip(5);
+        if (o.layout != 0) {
+            const uint64_t a = c.u(f.so);
+            if (o.layout == 1) o.data_addr = a;
+            else o.chunk_btree = a;
+        }
+        uint64_t d[9] = {0};
+        if (nd > 9) fail("layout dimensionality %d not supported", nd);
+        for (int i = 0; i < nd; ++i) d[i] = c.u(4);
+        if (o.layout == 2)
+            for (int i = 0; i < nd - 1 && i < 8; ++i) o.chunk_dims[i] = d[i];
+        if (o.layout == 0) {
+            const size_t n = (size_t)c.u(4);
+            c.need(n);
+            o.compact.assign(c.p, c.p + n);
+        }
+    } else {
+        fail("data layout message version %d (the \"latest\" file format) is not supported", ver);
+    }
+}
+
+void parse_attribute(Cursor &c, Object &o, const snpm_h5 &f)
+{
+    const int ver = (int)c.u(1);
+    if (ver < 1 || ver > 3) fail("attribute message version %d not supported", ver);
+    const int flags = (int)c.u(1);
+    if (ver >= 2 && (flags & 3)) fail("shared datatypes / dataspaces in attributes are not supported");
+    const size_t name_sz = (size_t)c.u(2), dt_sz = (size_t)c.u(2), ds_sz = (size_t)c.u(2);
+    if (ver == 3) c.skip(1);
+    auto pad = [&](size_t n) { return ver == 1 ? ((n + 7) & ~size_t(7)) : n; };
+    Object::Attr a;
+    c.need(pad(name_sz));
+    a.name.assign((const char *)c.p, strnlen((const char *)c.p, name_sz));
+    c.skip(pad(name_sz));
+    {
+        c.need(pad(dt_sz));
+        Cursor d(c.p, dt_sz);
+        parse_datatype(d, a.type);
+        c.skip(pad(dt_sz));
+    }
+    {
+        c.need(pad(ds_sz));
+        Cursor d(c.p, ds_sz);
+        parse_dataspace(d, a.rank, a.dims, f.sl);
+        c.skip(pad(ds_sz));
+    }
+    uint64_t n = 1;
+    for (int i = 0; i < a.rank; ++i) n *= a.dims[i];
+    const uint64_t bytes = n * (uint64_t)a.type.size;
+    if (bytes > c.left()) fail("attribute %s: data runs past its message", a.name.c_str());
+    a.raw.assign(c.p, c.p + bytes);
+    o.attrs.push_back(std::move(a));
+}
+
+void parse_messages(const snpm_h5 &f, const std::vector<uint8_t> &block, int &msgs_left, Object &o, std::vector<std::pair<uint64_t, uint64_t>> &cont)
+{
+    Cursor c(block.data(), block.size());
+    while (msgs_left > 0 && c.left() >= 8) {
+        const int type = (int)c.u(2);
+        const size_t size = (size_t)c.u(2);
+        const int flags = (int)c.u(1);
+        c.skip(3);
+        c.need(size);
+        Cursor m(c.p, size);
+        c.skip(size);
+        --msgs_left;
+        if ((flags & 2) && (type == 1 || type == 3 || type == 8 || type == 0x0b || type == 0x0c))
+            fail("shared object header messages are not supported");
+        switch (type) {
+        case 0x0001:
+            parse_dataspace(m, o.rank, o.dims, f.sl);
+            o.is_dataset = true;
+            break;
+        case 0x0003:
+            parse_datatype(m, o.type);
+            break;
+        case 0x0008:
+            parse_layout(m, o, f);
+            break;
+        case 0x000b:
+            parse_filters(m, o.filters);
+            break;
+        case 0x000c:
+            parse_attribute(m, o, f);
+            break;
+        case 0x0010: {
+            const uint64_t a = m.u(f.so), l = m.u(f.sl);
+            cont.push_back({a, l});
+            break;
+        }
+        case 0x0011:
+            o.btree = m.u(f.so);
+            o.heap = m.u(f.so);
+            break;
+        case 0x0002:        // link info: new-style group
+        case 0x0006:        // link
+            fail("new-style groups (the \"latest\" file format) are not supported");
+        case 0x0015:        // attribute info (dense attribute storage)
+            fail("dense attribute storage is not supported");
+        default:
+            break;          // nil, fill value, modification time, comment, ...: not needed
+        }
+    }
+}
+
+std::unique_ptr<Object> read_object(const snpm_h5 &f, uint64_t addr)
+{
+    uint8_t head[16];
+    f.read(addr, head, 16);
+    if (head[0] != 1) {
+        if (memcmp(head, "OHDR", 4) == 0) fail("version-2 object headers (the \"latest\" file format) are not supported");
+        fail("object header version %d not supported", head[0]);
+    }
+    Cursor c(head, 16);
+    c.skip(2);
+    int msgs = (int)c.u(2);
+    c.skip(4);
+    const uint64_t hsize = c.u(4);
+    std::unique_ptr<Object> o(new Object());
+    std::vector<std::pair<uint64_t, uint64_t>> cont;
+    cont.push_back({addr + 16, hsize});
+    for (size_t i = 0; i < cont.size() && msgs > 0; ++i) {
+        if (i > 4096) fail("object header continuation chain too long");
+        const std::vector<uint8_t> block = f.bytes(cont[i].first, (size_t)cont[i].second);
+        parse_messages(f, block, msgs, *o, cont);
+    }
+    return o;
+}
+
+// names and object header addresses of an old-style group
+void list_group(const snpm_h5 &f, uint64_t btree, uint64_t heap, std::vector<std::pair<std::string, uint64_t>> &out)
+{
+    uint8_t hh[8 + 3 * 8];
+    f.read(heap, hh, (size_t)(8 + 2 * f.sl + f.so));
+    if (memcmp(hh, "HEAP", 4) != 0) fail("local heap signature missing");
+    Cursor hc(hh + 8, (size_t)(2 * f.sl + f.so));
+    const uint64_t seg_size = hc.u(f.sl);
+    hc.u(f.sl);
+    const uint64_t seg_addr = hc.u(f.so);
+    const std::vector<uint8_t> names = f.bytes(seg_addr, (size_t)seg_size);
+    std::vector<std::pair<uint64_t, int>> stack;        // (node address, depth)
+    stack.push_back({btree, 0});
+    while (!stack.empty()) {
+        const uint64_t node = stack.back().first;
+        const int depth = stack.back().second;
+        stack.pop_back();
+        if (depth > 64) fail("group B-tree too deep");
+        uint8_t nh[8];
+        f.read(node, nh, 8);
+        if (memcmp(nh, "TREE", 4) == 0) {
+            if (nh[4] != 0) fail("group B-tree node of type %d", nh[4]);
+            const int level = nh[5], used = nh[6] | (nh[7] << 8);
+            const size_t body = (size_t)(2 * f.so + (size_t)used * (f.sl + f.so) + f.sl);
+            const std::vector<uint8_t> b = f.bytes(node + 8, body);
+            Cursor c(b.data(), b.size());
+            c.skip((size_t)(2 * f.so));
+            std::vector<uint64_t> kids;
+            for (int i = 0; i < used; ++i) {
+                c.u(f.sl);
+                kids.push_back(c.u(f.so));
+            }
+            (void)level;
+            for (auto it = kids.rbegin(); it != kids.rend(); ++it) stack.push_back({*it, depth + 1});
+        } else if (memcmp(nh, "SNOD", 4) == 0) {
+            const int n = nh[6] | (nh[7] << 8);
+            const size_t esz = (size_t)(2 * f.so + 8 + 16);
+            const std::vector<uint8_t> b = f.bytes(node + 8, (size_t)n * esz);
+            for (int i = 0; i < n; ++i) {
+                Cursor c(b.data() + (size_t)i * esz, esz);
+                const uint64_t name_off = c.u(f.so), hdr = c.u(f.so);
+                if (name_off >= names.size()) fail("symbol name outside the local heap");
+                const char *s = (const char *)names.data() + name_off;
+                out.push_back({std::string(s, strnlen(s, names.size() - name_off)), hdr});
+            }
+        } else {
+            fail("unexpected node in a group B-tree");
+        }
+    }
+}
+
+// resolve "a/b/c" from the root; cached.  f.mu must be held.
+Object *lookup(snpm_h5 &f, const std::string &path_in)
+{
+    std::string path;
+    for (size_t i = 0; i < path_in.size(); ++i)
+        if (!(path_in[i] == '/' && (path.empty() || path.back() == '/'))) path.push_back(path_in[i]);
+    while (!path.empty() && path.back() == '/') path.pop_back();
+    auto it = f.objects.find(path);
+    if (it != f.objects.end()) return it->second.get();
+    std::unique_ptr<Object> cur(new Object());
+    cur->btree = f.root_btree;
+    cur->heap = f.root_heap;
+    if (f.root_btree == UNDEF) {
+        cur = read_object(f, f.root_header);
+    }
+    size_t pos = 0;
+    while (pos < path.size()) {
+        size_t slash = path.find('/', pos);
+        if (slash == std::string::npos) slash = path.size();
+        const std::string name = path.substr(pos, slash - pos);
+        pos = slash + 1;
+        if (cur->is_dataset || cur->btree == UNDEF) fail("%s: not a group on the way to %s", name.c_str(), path.c_str());
+        std::vector<std::pair<std::string, uint64_t>> kids;
+        list_group(f, cur->btree, cur->heap, kids);
+        uint64_t hdr = UNDEF;
+        for (auto &k : kids)
+            if (k.first == name) hdr = k.second;
+        if (hdr == UNDEF) fail("no object named %s in the file", path.c_str());
+        cur = read_object(f, hdr);
+    }
+    Object *raw = cur.get();
+    f.objects[path] = std::move(cur);
+    return raw;
+}
+
+// ---- chunk index (version-1 B-tree, node type 1) ---------------------------------------------------------------------------
+void index_chunks(const snpm_h5 &f, Object &o)
+{
+    if (o.indexed) return;
+    uint64_t total = 1;
+    for (int i = 0; i < o.rank; ++i) {
+        if (o.chunk_dims[i] == 0) fail("chunk dimension of size 0");
+        o.grid[i] = (o.dims[i] + o.chunk_dims[i] - 1) / o.chunk_dims[i];
+        total *= std::max<uint64_t>(o.grid[i], 1);
+    }
+    if (total > (uint64_t(1) << 28)) fail("too many chunks (%llu)", (unsigned long long)total);
+    o.chunks.assign((size_t)total, Chunk());
+    if (o.chunk_btree != UNDEF) {
+        std::vector<std::pair<uint64_t, int>> stack;
+        stack.push_back({o.chunk_btree, 0});
+        const size_t key_sz = 8 + 8 * (size_t)(o.rank + 1);
+        while (!stack.empty()) {
+            const uint64_t node = stack.back().first;
+            const int depth = stack.back().second;
+            stack.pop_back();
+            if (depth > 64) fail("chunk B-tree too deep");
+            uint8_t nh[8];
+            f.read(node, nh, 8);
+            if (memcmp(nh, "TREE", 4) != 0 || nh[4] != 1) fail("chunk B-tree node signature missing");
+            const int level = nh[5], used = nh[6] | (nh[7] << 8);
+            const std::vector<uint8_t> b = f.bytes(node + 8, (size_t)(2 * f.so) + (size_t)used * (key_sz + f.so) + key_sz);
+            Cursor c(b.data(), b.size());
+            c.skip((size_t)(2 * f.so));
+            for (int i = 0; i < used; ++i) {
+                Chunk ch;
+                ch.size = (uint32_t)c.u(4);
+                ch.mask = (uint32_t)c.u(4);
+                uint64_t idx = 0;
+                bool inside = true;
+                for (int d = 0; d < o.rank; ++d) {
+                    const uint64_t off = c.u(8);
+                    if (off % o.chunk_dims[d] != 0 || off / o.chunk_dims[d] >= o.grid[d]) inside = false;
+                    idx = idx * o.grid[d] + (inside ? off / o.chunk_dims[d] : 0);
+                }
+                c.u(8);                                     // offset in the element-size dimension (0)
+                ch.addr = c.u(f.so);
+                if (level > 0) stack.push_back({ch.addr, depth + 1});
+                else if (inside) o.chunks[(size_t)idx] = ch;
+            }
+        }
+    }
+    o.indexed = true;
+}
+
+// ---- filters ---------------------------------------------------------------------------------------------------------------
+// liblzf decompression (the format h5py's LZF filter writes); false on malformed input
+bool lzf_decompress(const uint8_t *ip, size_t in_len, uint8_t *op, size_t out_len, size_t *produced)
+{
+    const uint8_t *const in_end = ip + in_len;
+    uint8_t *const out0 = op, *const out_end = op + out_len;
+    while (ip < in_end) {
+        unsigned ctrl = *ip++;
+        if (ctrl < 32) {
+            ++ctrl;
+            if ((size_t)(out_end - op) < ctrl || (size_t)(in_end - ip) < ctrl) return false;
+            memcpy(op, ip, ctrl);
+            op += ctrl;
+            ip += ctrl;
+        } else {
+            unsigned len = ctrl >> 5;
+            if (ip >= in_end) return false;
+            if (len == 7) {
+                len += *ip++;
+                if (ip >= in_end) return false;
+            }
+            const size_t back = ((size_t)(ctrl & 0x1f) << 8) + *ip++ + 1;
+            len += 2;
+            if (back > (size_t)(op - out0) || (size_t)(out_end - op) < len) return false;
+            const uint8_t *ref = op - back;
+            for (unsigned i = 0; i < len; ++i) op[i] = ref[i];      // may overlap: byte by byte
+            op += len;
+        }
+    }
+    *produced = (size_t)(op - out0);
+    return true;
+}
+
+struct ChunkBuf {
+    uint64_t owner = 0;
+    size_t index = ~size_t(0);
+    std::vector<uint8_t> data, tmp;
+};
+thread_local ChunkBuf t_chunk;
+
+// decompressed bytes of chunk `index` of dataset o (thread-local cache of one chunk)
+const uint8_t *load_chunk(const snpm_h5 &f, const Object &o, size_t index, size_t chunk_bytes)
+{
+    ChunkBuf &cb = t_chunk;
+    if (cb.owner == o.uid && cb.index == index && cb.data.size() == chunk_bytes) return cb.data.data();
+    cb.owner = 0;
+    const Chunk &ch = o.chunks[index];
+    cb.data.resize(chunk_bytes);
+    if (ch.addr == UNDEF) {                                 // never written: the fill value (0)
+        memset(cb.data.data(), 0, chunk_bytes);
+    } else {
+        cb.tmp.resize(ch.size);
+        f.read(ch.addr, cb.tmp.data(), ch.size);
+        std::vector<uint8_t> *cur = &cb.tmp, *other = &cb.data;
+        size_t cur_len = ch.size;
+        for (int k = (int)o.filters.size() - 1; k >= 0; --k) {             // reading: the pipeline in reverse
+            if (ch.mask & (1u << k)) continue;                             // this filter was skipped when the chunk was written
+            const Filter &fl = o.filters[(size_t)k];
+            if (fl.id == 32000) {
+                other->resize(chunk_bytes);
+                size_t got = 0;
+                if (!lzf_decompress(cur->data(), cur_len, other->data(), chunk_bytes, &got)) fail("corrupt lzf chunk");
+                cur_len = got;
+            } else if (fl.id == 1) {
+                other->resize(chunk_bytes);
+                uLongf got = (uLongf)chunk_bytes;
+                if (uncompress(other->data(), &got, cur->data(), (uLong)cur_len) != Z_OK) fail("corrupt gzip chunk");
+                cur_len = (size_t)got;
+            } else {                                        // shuffle: byte planes back to elements
+                const size_t es = fl.cd.empty() ? (size_t)o.type.size : (size_t)fl.cd[0];
+                other->resize(cur_len);
+                if (es > 1 && cur_len >= es) {
+                    const size_t n = cur_len / es;
+                    for (size_t b = 0; b < es; ++b)
+                        for (size_t i = 0; i < n; ++i) (*other)[i * es + b] = (*cur)[b * n + i];
+                    memcpy(other->data() + n * es, cur->data() + n * es, cur_len - n * es);
+                } else {
+                    memcpy(other->data(), cur->data(), cur_len);
+                }
+            }
+            std::swap(cur, other);
+        }
+        if (cur_len != chunk_bytes) fail("chunk of %zu bytes where %zu were expected", cur_len, chunk_bytes);
+        if (cur != &cb.data) cb.data.swap(cb.tmp);
+    }
+    cb.owner = o.uid;
+    cb.index = index;
+    return cb.data.data();
+}
+
+// rows [r0, r0 + nr) x columns [c0, c0 + nc) of a dataset viewed as 2-D (rank 1: one column) -> out (row stride out_pitch bytes)
+void read_block_2d(const snpm_h5 &f, Object &o, uint64_t r0, uint64_t nr, uint64_t c0, uint64_t nc, uint8_t *out, size_t out_pitch)
+{
+    const size_t es = (size_t)o.type.size;
+    const uint64_t n_rows = o.rank >= 1 ? o.dims[0] : 1, n_cols = o.rank == 2 ? o.dims[1] : 1;
+    if (r0 + nr > n_rows || c0 + nc > n_cols) fail("block outside the dataset");
+    if (nr == 0 || nc == 0) return;
+    if (o.layout == 0 || o.layout == 1) {
+        for (uint64_t r = 0; r < nr; ++r) {
+            const uint64_t off = ((r0 + r) * n_cols + c0) * es;
+            if (o.layout == 0) {
+                if (off + nc * es > o.compact.size()) fail("compact data too short");
+                memcpy(out + r * out_pitch, o.compact.data() + off, (size_t)(nc * es));
+            } else if (o.data_addr == UNDEF) {
+                memset(out + r * out_pitch, 0, (size_t)(nc * es));
+            } else if (nc == n_cols && out_pitch == nc * es) {
+                f.read(o.data_addr + off, out + r * out_pitch, (size_t)((nr - r) * nc * es));      // one read for the rest
+                break;
+            } else {
+                f.read(o.data_addr + off, out + r * out_pitch, (size_t)(nc * es));
+            }
+        }
+        return;
+    }
+    const uint64_t ch_r = o.chunk_dims[0], ch_c = o.rank == 2 ? o.chunk_dims[1] : 1, gc = o.rank == 2 ? o.grid[1] : 1;
+    const size_t chunk_bytes = (size_t)(ch_r * ch_c * es);
+    for (uint64_t ci = r0 / ch_r; ci <= (r0 + nr - 1) / ch_r; ++ci) {
+        for (uint64_t cj = c0 / ch_c; cj <= (c0 + nc - 1) / ch_c; ++cj) {
+            const uint8_t *src = load_chunk(f, o, (size_t)(ci * gc + cj), chunk_bytes);
+            const uint64_t ra = std::max(r0, ci * ch_r), rb = std::min(r0 + nr, (ci + 1) * ch_r);
+            const uint64_t ca = std::max(c0, cj * ch_c), cb2 = std::min(c0 + nc, (cj + 1) * ch_c);
+            for (uint64_t r = ra; r < rb; ++r)
+                memcpy(out + (r - r0) * out_pitch + (ca - c0) * es, src + ((r - ci * ch_r) * ch_c + (ca - cj * ch_c)) * es,
+                       (size_t)((cb2 - ca) * es));
+        }
+    }
+}
+
+std::string vlen_string(const snpm_h5 &f, const uint8_t *elem)
+{
+    Cursor c(elem, (size_t)(4 + f.so + 4));
+    const uint64_t len = c.u(4), coll = c.u(f.so), idx = c.u(4);
+    if (len == 0 || coll == 0 || coll == UNDEF) return std::string();
+    uint8_t head[16];
+    f.read(coll, head, (size_t)(8 + f.sl));
+    if (memcmp(head, "GCOL", 4) != 0) fail("global heap collection signature missing");
+    Cursor hc(head + 8, (size_t)f.sl);
+    const uint64_t csize = hc.u(f.sl);
+    const std::vector<uint8_t> blk = f.bytes(coll, (size_t)csize);
+    size_t p = (size_t)(8 + f.sl);
+    while (p + 8 + (size_t)f.sl <= blk.size()) {
+        Cursor oc(blk.data() + p, blk.size() - p);
+        const uint64_t oi = oc.u(2);
+        oc.skip(6);
+        const uint64_t osz = oc.u(f.sl);
+        const size_t data = p + 8 + (size_t)f.sl;
+        if (oi == 0) break;
+        if (oi == idx) {
+            if (data + osz > blk.size() || len > osz) fail("global heap object runs past its collection");
+            return std::string((const char *)blk.data() + data, (size_t)len);
+        }
+        p = data + (((size_t)osz + 7) & ~size_t(7));
+    }
+    fail("global heap object %llu not found", (unsigned long long)idx);
+}
+
+int set_h5_err(snpm_h5 *f, int code, const std::string &msg)
+{
+    g_h5_error = msg;
+    if (f) f->err = msg;
+    return code;
+}
+
+#define H5_TRY(F) try {
+#define H5_CATCH(F)                                                                                   \
+    }                                                                                                 \
+    catch (const H5Err &e) { return set_h5_err((F), SNPM_ERR_BADARG, std::string((F) ? (F)->path : std::string("hdf5")) + ": " + e.what()); } \
+    catch (const std::bad_alloc &) { return set_h5_err((F), SNPM_ERR_OOM, "out of host memory"); }    \
+    catch (const std::exception &e) { return set_h5_err((F), SNPM_ERR_STATE, std::string("internal error: ") + e.what()); }
+
+struct Target {              // a dataset, or one of its attributes presented like a small contiguous dataset
+    Object *obj = nullptr;
+    const Object::Attr *attr = nullptr;
+    const TypeInfo &type() const { return attr ? attr->type : obj->type; }
+    int rank() const { return attr ? attr->rank : obj->rank; }
+    const uint64_t *dims() const { return attr ? attr->dims : obj->dims; }
+};
+
+Target find_target(snpm_h5 &f, const char *path, const char *attr)
+{
+    Target t;
+    t.obj = lookup(f, path ? path : "");
+    if (attr) {
+        for (auto &a : t.obj->attrs)
+            if (a.name == attr) t.attr = &a;
+        if (!t.attr) fail("%s has no attribute %s", path, attr);
+    }
+    return t;
+}
+
+// longest string of a variable-length string object (the element size the caller sees)
+size_t vlen_width(snpm_h5 &f, const Target &t, std::vector<std::string> *out)
+{
+    uint64_t n = 1;
+    for (int i = 0; i < t.rank(); ++i) n *= t.dims()[i];
+    const size_t es = (size_t)(4 + f.so + 4);
+    std::vector<uint8_t> raw;
+    if (t.attr) {
+        raw = t.attr->raw;
+    } else {
+        raw.resize((size_t)n * es);
+        if (t.obj->layout == 2) index_chunks(f, *t.obj);
+        if (t.obj->rank > 2) fail("variable-length strings of rank %d", t.obj->rank);
+        read_block_2d(f, *t.obj, 0, t.obj->rank >= 1 ? t.obj->dims[0] : 1, 0, t.obj->rank == 2 ? t.obj->dims[1] : 1, raw.data(),
+                      (size_t)((t.obj->rank == 2 ? t.obj->dims[1] : 1) * es));
+    }
+    size_t width = 1;
+    for (uint64_t i = 0; i < n; ++i) {
+        std::string s = vlen_string(f, raw.data() + (size_t)i * es);
+        width = std::max(width, s.size());
+        if (out) out->push_back(std::move(s));
+    }
+    return width;
+}
+
+}  // namespace
+
+// ---- internal entry point for the loader (snpm_loader.hpp): thread-safe once the dataset is indexed ---------------------------
+int snpm_h5_rows_raw(snpm_h5 *f, const void *dataset, const int64_t *row_idx, int64_t file_row0, int64_t nrows, int64_t col0,
+                     int64_t ncols, int8_t *out, int64_t out_pitch)
+{
+    H5_TRY(f)
+    Object &o = *(Object *)dataset;
+    if (row_idx) {
+        for (int64_t i = 0; i < nrows;) {                   // runs of consecutive rows share a read
+            int64_t j = i + 1;
+            while (j < nrows && row_idx[j] == row_idx[j - 1] + 1) ++j;
+            if (row_idx[i] < 0) fail("negative row index");
+            read_block_2d(*f, o, (uint64_t)row_idx[i], (uint64_t)(j - i), (uint64_t)col0, (uint64_t)ncols, (uint8_t *)out + i * out_pitch,
+                          (size_t)out_pitch);
+            i = j;
+        }
+    } else {
+        read_block_2d(*f, o, (uint64_t)file_row0, (uint64_t)nrows, (uint64_t)col0, (uint64_t)ncols, (uint8_t *)out, (size_t)out_pitch);
+    }
+    return SNPM_OK;
+    }                                                       // worker threads report through their own thread-local message
+    catch (const H5Err &e) { return set_h5_err(nullptr, SNPM_ERR_BADARG, f->path + ": " + e.what()); }
+    catch (const std::bad_alloc &) { return set_h5_err(nullptr, SNPM_ERR_OOM, "out of host memory"); }
+    catch (const std::exception &e) { return set_h5_err(nullptr, SNPM_ERR_STATE, std::string("internal error: ") + e.what()); }
+}
+
+const void *snpm_h5_int8_matrix(snpm_h5 *f, const char *path, int64_t *n_rows, int64_t *n_cols, int64_t *chunk_rows)
+{
+    try {
+        std::lock_guard<std::mutex> lk(f->mu);
+        Object *o = lookup(*f, path);
+        if (!o->is_dataset || o->rank != 2 || o->type.cls != 0 || o->type.size != 1) fail("%s is not a 2-D int8 dataset", path);
+        if (o->layout == 2) index_chunks(*f, *o);
+        *n_rows = (int64_t)o->dims[0];
+        *n_cols = (int64_t)o->dims[1];
+        *chunk_rows = o->layout == 2 ? (int64_t)o->chunk_dims[0] : 0;
+        return o;
+    } catch (const std::exception &e) {
+        set_h5_err(f, SNPM_ERR_BADARG, f->path + ": " + e.what());
+        return nullptr;
+    }
+}
+
+const char *snpm_h5_thread_error() { return g_h5_error.c_str(); }
+
+// ---- C ABI --------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *snpm_h5_last_error(const snpm_h5 *f) { return f ? f->err.c_str() : g_h5_error.c_str(); }
+
+int snpm_h5_open(const char *path, snpm_h5 **out)
+{
+    if (!path || !out) return set_h5_err(nullptr, SNPM_ERR_BADARG, "path / out is NULL");
+    *out = nullptr;
+    std::unique_ptr<snpm_h5> f(new snpm_h5());
+    f->path = path;
+    f->fd = open(path, O_RDONLY);
+    if (f->fd < 0) return set_h5_err(nullptr, SNPM_ERR_BADARG, std::string("cannot open ") + path + ": " + strerror(errno));
+    snpm_h5 *fp = f.get();
+    int rc = [&]() -> int {
+        H5_TRY(fp)
+        struct stat st;
+        if (fstat(fp->fd, &st) != 0) fail("fstat failed");
+        fp->file_size = (uint64_t)st.st_size;
+        uint64_t sb = UNDEF;
+        for (uint64_t off = 0; off + 8 <= fp->file_size; off = off ? off * 2 : 512) {      // 0, 512, 1024, ...
+            uint8_t sig[8];
+            fp->read(off, sig, 8);
+            if (memcmp(sig, "\x89HDF\r\n\x1a\n", 8) == 0) {
+                sb = off;
+                break;
+            }
+            if (off > (uint64_t(1) << 24)) break;
+        }
+        if (sb == UNDEF) fail("not an HDF5 file (signature missing)");
+        uint8_t b[128];
+        const size_t have = (size_t)std::min<uint64_t>(sizeof(b), fp->file_size - sb);
+        fp->read(sb, b, have);
+        Cursor c(b, have);
+        c.skip(8);
+        const int ver = (int)c.u(1);
+        if (ver == 0 || ver == 1) {
+            c.skip(4);
+            fp->so = (int)c.u(1);
+            fp->sl = (int)c.u(1);
+            c.skip(1 + 2 + 2 + 4);
+            if (ver == 1) c.skip(4);
+            if ((fp->so != 8 && fp->so != 4) || (fp->sl != 8 && fp->sl != 4)) fail("offsets / lengths of %d / %d bytes", fp->so, fp->sl);
+            fp->base = c.u(fp->so);
+            c.u(fp->so);
+            c.u(fp->so);
+            c.u(fp->so);
+            c.u(fp->so);                                    // root entry: link name offset
+            fp->root_header = c.u(fp->so);
+            const uint64_t cache = c.u(4);
+            c.skip(4);
+            if (cache == 1) {
+                fp->root_btree = c.u(fp->so);
+                fp->root_heap = c.u(fp->so);
+            }
+        } else if (ver == 2 || ver == 3) {
+            fp->so = (int)c.u(1);
+            fp->sl = (int)c.u(1);
+            c.skip(1);
+            fp->base = c.u(fp->so);
+            c.u(fp->so);
+            c.u(fp->so);
+            fp->root_header = c.u(fp->so);
+        } else {
+            fail("superblock version %d not supported", ver);
+        }
+        fp->base += 0;                                      // addresses are relative to the base address (normally 0 = the superblock)
+        std::lock_guard<std::mutex> lk(fp->mu);
+        (void)lookup(*fp, "");                              // the root group parses
+        return SNPM_OK;
+        H5_CATCH(fp)
+    }();
+    if (rc) {
+        close(f->fd);
+        return rc;
+    }
+    *out = f.release();
+    return SNPM_OK;
+}
+
+int snpm_h5_close(snpm_h5 *f)
+{
+    if (!f) return SNPM_OK;
+    if (f->fd >= 0) close(f->fd);
+    delete f;
+    return SNPM_OK;
+}
+
+// names of the members of a group, '\n'-separated (needed = bytes incl. the terminating NUL)
+int snpm_h5_list(snpm_h5 *f, const char *group, char *buf, int64_t cap, int64_t *needed)
+{
+    if (!f) return set_h5_err(nullptr, SNPM_ERR_BADARG, "file is NULL");
+    H5_TRY(f)
+    std::lock_guard<std::mutex> lk(f->mu);
+    Object *g = lookup(*f, group ? group : "");
+    if (g->is_dataset || g->btree == UNDEF) fail("%s is not a group", group);
+    std::vector<std::pair<std::string, uint64_t>> kids;
+    list_group(*f, g->btree, g->heap, kids);
+    std::string all;
+    for (auto &k : kids) all += k.first + "\n";
+    if (needed) *needed = (int64_t)all.size() + 1;
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>(all.size(), (size_t)cap - 1);
+        memcpy(buf, all.data(), n);
+        buf[n] = 0;
+    }
+    return SNPM_OK;
+    H5_CATCH(f)
+}
+
+// kind: 0 group, 1 dataset (attr == NULL) or the attribute `attr` of that object.  type_class: 0 integer, 1 float, 3 string
+// (variable-length strings are presented as fixed-length ones of elem_size = the longest).  chunk: chunk shape, 0s when not chunked.
+int snpm_h5_info(snpm_h5 *f, const char *path, const char *attr, int *kind, int *rank, int64_t *dims, int *type_class,
+                 int *elem_size, int *is_signed, int64_t *chunk, int *n_attrs)
+{
+    if (!f) return set_h5_err(nullptr, SNPM_ERR_BADARG, "file is NULL");
+    H5_TRY(f)
+    std::lock_guard<std::mutex> lk(f->mu);
+    const Target t = find_target(*f, path, attr);
+    const bool data = attr || t.obj->is_dataset;
+    if (kind) *kind = data ? 1 : 0;
+    if (n_attrs) *n_attrs = (int)t.obj->attrs.size();
+    if (rank) *rank = data ? t.rank() : 0;
+    for (int i = 0; i < 8; ++i) {
+        if (dims) dims[i] = (data && i < t.rank()) ? (int64_t)t.dims()[i] : 0;
+        if (chunk) chunk[i] = (!attr && data && t.obj->layout == 2 && i < t.rank()) ? (int64_t)t.obj->chunk_dims[i] : 0;
+    }
+    if (data) {
+        const TypeInfo &ty = t.type();
+        if (type_class) *type_class = ty.cls == 9 ? 3 : ty.cls;
+        if (is_signed) *is_signed = ty.is_signed ? 1 : 0;
+        if (elem_size) *elem_size = ty.vlen_string ? (int)vlen_width(*f, t, nullptr) : ty.size;
+    }
+    return SNPM_OK;
+    H5_CATCH(f)
+}
+
+int snpm_h5_attr_name(snpm_h5 *f, const char *path, int i, char *buf, int64_t cap)
+{
+    if (!f || !buf || cap < 1) return set_h5_err(f, SNPM_ERR_BADARG, "bad arguments");
+    H5_TRY(f)
+    std::lock_guard<std::mutex> lk(f->mu);
+    Object *o = lookup(*f, path ? path : "");
+    if (i < 0 || i >= (int)o->attrs.size()) fail("attribute index %d out of range", i);
+    snprintf(buf, (size_t)cap, "%s", o->attrs[(size_t)i].name.c_str());
+    return SNPM_OK;
+    H5_CATCH(f)
+}
+
+// the whole dataset / attribute, C order, into `out` (out_bytes must be elements * elem_size as snpm_h5_info reports them)
+int snpm_h5_read(snpm_h5 *f, const char *path, const char *attr, void *out, int64_t out_bytes)
+{
+    if (!f || !out) return set_h5_err(f, SNPM_ERR_BADARG, "bad arguments");
+    H5_TRY(f)
+    std::lock_guard<std::mutex> lk(f->mu);
+    const Target t = find_target(*f, path, attr);
+    if (!attr && !t.obj->is_dataset) fail("%s is a group", path);
+    uint64_t n = 1;
+    for (int i = 0; i < t.rank(); ++i) n *= t.dims()[i];
+    const TypeInfo &ty = t.type();
+    if (ty.vlen_string) {
+        std::vector<std::string> strs;
+        const size_t w = vlen_width(*f, t, &strs);
+        if ((uint64_t)out_bytes != n * w) fail("output buffer of %lld bytes, %llu needed", (long long)out_bytes, (unsigned long long)(n * w));
+        memset(out, 0, (size_t)out_bytes);
+        for (uint64_t i = 0; i < n; ++i) memcpy((char *)out + i * w, strs[(size_t)i].data(), strs[(size_t)i].size());
+        return SNPM_OK;
+    }
+    if ((uint64_t)out_bytes != n * (uint64_t)ty.size) fail("output buffer of %lld bytes, %llu needed", (long long)out_bytes, (unsigned long long)(n * ty.size));
+    if (t.attr) {
+        memcpy(out, t.attr->raw.data(), (size_t)out_bytes);
+        return SNPM_OK;
+    }
+    Object &o = *t.obj;
+    if (o.layout == 2) index_chunks(*f, o);
+    if (o.rank <= 2) {
+        const uint64_t cols = o.rank == 2 ? o.dims[1] : 1;
+        read_block_2d(*f, o, 0, o.rank >= 1 ? o.dims[0] : 1, 0, cols, (uint8_t *)out, (size_t)(cols * ty.size));
+    } else {
+        if (o.layout == 2) fail("chunked datasets of rank %d are not supported", o.rank);
+        if (o.layout == 0) memcpy(out, o.compact.data(), std::min<size_t>(o.compact.size(), (size_t)out_bytes));
+        else f->read(o.data_addr, out, (size_t)out_bytes);
+    }
+    return SNPM_OK;
+    H5_CATCH(f)
+}
+
+// rows row_idx[0..nrows) (or file_row0 + i when row_idx is NULL), columns [col0, col0 + ncols) of a 1-D / 2-D dataset of
+// fixed-size elements -> out (row stride out_pitch BYTES)
+int snpm_h5_read_rows(snpm_h5 *f, const char *path, const int64_t *row_idx, int64_t file_row0, int64_t nrows, int64_t col0,
+                      int64_t ncols, void *out, int64_t out_pitch)
+{
+    if (!f || (!out && nrows > 0)) return set_h5_err(f, SNPM_ERR_BADARG, "bad arguments");
+    const void *ds = nullptr;
+    {
+        H5_TRY(f)
+        std::lock_guard<std::mutex> lk(f->mu);
+        Object *o = lookup(*f, path ? path : "");
+        if (!o->is_dataset || o->rank < 1 || o->rank > 2 || o->type.vlen_string) fail("%s: not a 1-D / 2-D dataset of fixed-size elements", path);
+        if (nrows < 0 || col0 < 0 || ncols < 0 || out_pitch < ncols * o->type.size) fail("bad block arguments");
+        if (o->layout == 2) index_chunks(*f, *o);
+        ds = o;
+        H5_CATCH(f)
+    }
+    const int rc = snpm_h5_rows_raw(f, ds, row_idx, file_row0, nrows, col0, ncols, (int8_t *)out, out_pitch);
+    if (rc) f->err = g_h5_error;
+    return rc;
+}
+
+}  // extern "C"

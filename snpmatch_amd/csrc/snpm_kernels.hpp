@@ -507,6 +507,14 @@ constexpr int BITS_FLUSH_ROWS = 64;     // its bit-sliced counters (7 planes) ar
 constexpr int Q4_TILE_ROWS = 64;        // 16 four-row tables x 2 KiB = 32 KiB of LDS per block
 constexpr int Q4_G = 8;                 // rows per prefetch group (two tables)
 constexpr int Q4_RUN = 4;               // tiles a part scores in a row before it jumps ahead (the host's tile = Q4_RUN * Q4_TILE_ROWS rows)
+// Epoch sizes are coupled across three places: the 16-bit missing-call counters of the packed kernels (flushed once per
+// epoch), and the host's fast-pass error bound (efast_bound, snpm_api.hip), which counts at most EPOCH_TILES * TILE_ROWS
+// additions per term inside a part.  k_fast_packed_q4 adds pre-summed quads of rows (a quarter of its rows + 3 table additions
+// per term); k_fast_bits only runs on all-integer weights (bound 0), but its counters still have to hold an epoch.
+static_assert(EPOCH_TILES * BITS_TILE_ROWS <= 65535, "k_fast_bits: an epoch overflows the 16-bit counters");
+static_assert(EPOCH_TILES * Q4_RUN * Q4_TILE_ROWS <= 65535, "k_fast_packed_q4: an epoch overflows the 16-bit counters");
+static_assert(EPOCH_TILES * Q4_RUN * Q4_TILE_ROWS / 4 + 3 <= EPOCH_TILES * TILE_ROWS,
+              "k_fast_packed_q4: more additions per term and epoch than efast_bound assumes");
 static_assert(Q4_TILE_ROWS % (2 * Q4_G) == 0 && Q4_TILE_ROWS <= 127, "two register sets per iteration; 7-bit missing counters per tile");
 
 // carry-save adder of three bit vectors: two v_bitop3_b32 (majority 0xE8, parity 0x96)
@@ -962,7 +970,7 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
         int tiles_in_epoch = 0;
         int64_t epoch = 0;
         for (int64_t T = p; T < n_tiles_total; T += P) {
-            if (tiles_in_epoch == EPOCH_TILES) {              // 8192 rows per epoch: the 16-bit counters hold them
+            if (tiles_in_epoch == EPOCH_TILES) {              // EPOCH_TILES * BITS_TILE_ROWS = 16384 rows per epoch: the 16-bit counters hold them (static_assert below the tile constants)
                 store_partials(epoch);
                 ++epoch;
                 tiles_in_epoch = 0;

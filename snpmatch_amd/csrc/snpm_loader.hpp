@@ -23,6 +23,8 @@
 #include <immintrin.h>
 #endif
 
+#include "snpm_h5.hpp"
+
 namespace {
 
 // ---------------------------------------------------------------------------------------------- host thread pool
@@ -256,6 +258,10 @@ struct RowSource {
     int64_t file_offset = 0, file_pitch = 0, col0 = 0, file_row0 = 0;
     const int64_t *row_idx = nullptr;
     const char *path = "";
+    // or a 2-D int8 dataset of an open HDF5 file (the reference's DB format): chunks are decompressed by the filling threads
+    snpm_h5 *h5 = nullptr;
+    const void *h5_dataset = nullptr;
+    int64_t h5_chunk_rows = 0;
 };
 
 struct ThreadScratch {
@@ -318,15 +324,45 @@ int fill_rows(snpm_ctx *ctx, const RowSource &src, int64_t n_acc, bool pack, int
 {
     static const pack_row_fn pack_row = pick_pack_row();
     const int64_t out_pitch = pack ? (n_acc + 3) / 4 : n_acc;
-    const int64_t run = std::max<int64_t>(1, (int64_t)((size_t(1) << 20) / (size_t)n_acc));      // ~1 MiB of source per task
-    const int tasks = (int)std::min<int64_t>(1 << 20, (n + run - 1) / run);
+    int64_t run = std::max<int64_t>(1, (int64_t)((size_t(1) << 20) / (size_t)n_acc));      // ~1 MiB of source per task
+    int64_t lead = 0;                   // rows of the first task (HDF5: up to the next chunk boundary, so that a chunk is decompressed once)
+    if (src.h5 && !src.row_idx && src.h5_chunk_rows > 0) {
+        run = src.h5_chunk_rows;
+        lead = (run - (src.file_row0 + first) % run) % run;
+    } else if (src.h5) {
+        run = 256;                      // a row list: runs of the list, each thread keeps its last chunk
+    }
+    const int tasks = (int)std::min<int64_t>(1 << 20, (lead > 0 ? 1 : 0) + (std::max<int64_t>(n - lead, 0) + run - 1) / run);
     std::atomic<int> bad_any{0}, err_any{0};
+    std::mutex msg_mu;
+    std::string h5_msg;
     const bool contiguous_file = src.fd >= 0 && !src.row_idx && src.file_pitch == n_acc && src.col0 == 0;
     host_pool(ctx)->run(tasks, [&](int t) {
-        const int64_t k0 = (int64_t)t * run, k1 = std::min<int64_t>(n, k0 + run);
+        int64_t k0, k1;
+        if (lead > 0) {
+            k0 = t == 0 ? 0 : lead + (int64_t)(t - 1) * run;
+            k1 = t == 0 ? std::min(lead, n) : std::min<int64_t>(n, k0 + run);
+        } else {
+            k0 = (int64_t)t * run;
+            k1 = std::min<int64_t>(n, k0 + run);
+        }
         if (k0 >= k1 || err_any.load(std::memory_order_relaxed)) return;
         int b = 0;
-        if (src.host) {
+        if (src.h5) {
+            const size_t len = (size_t)(k1 - k0) * n_acc;
+            int8_t *to = pack ? t_scratch.get(len + 64) : dst + k0 * n_acc;
+            int rc = to ? snpm_h5_rows_raw(src.h5, src.h5_dataset, src.row_idx ? src.row_idx + first + k0 : nullptr,
+                                           src.file_row0 + first + k0, k1 - k0, src.col0, n_acc, to, n_acc)
+                        : SNPM_ERR_OOM;
+            if (rc) {
+                std::lock_guard<std::mutex> lk(msg_mu);
+                if (h5_msg.empty()) h5_msg = snpm_h5_thread_error();
+                err_any.store(EIO);
+                return;
+            }
+            if (pack)
+                for (int64_t k = k0; k < k1; ++k) b |= pack_row(to + (k - k0) * n_acc, n_acc, (uint8_t *)dst + k * out_pitch);
+        } else if (src.host) {
             if (!pack && src.host_pitch == n_acc) {
                 copy_to_slab(dst + k0 * n_acc, src.host + (first + k0) * n_acc, (size_t)(k1 - k0) * n_acc);
             } else {
@@ -373,6 +409,7 @@ int fill_rows(snpm_ctx *ctx, const RowSource &src, int64_t n_acc, bool pack, int
     });
     if (bad_any.load()) *bad |= 1;
     const int e = err_any.load();
+    if (e && src.h5) return set_err(ctx, SNPM_ERR_BADARG, "%s", h5_msg.c_str());
     if (e) return set_err(ctx, SNPM_ERR_BADARG, "short read from %s (%s)", src.path, e > 0 ? strerror(e) : "end of file");
     return SNPM_OK;
 }
@@ -591,6 +628,35 @@ try {
     rc = stage_rows(p, row0, nrows, src);
     close(src.fd);
     return rc;
+} SNPM_GUARD((p ? p->ctx : nullptr))
+
+int snpm_panel_load_h5(snpm_panel *p, snpm_h5 *file, const char *dataset, int64_t col0, const int64_t *row_idx, int64_t file_row0,
+                       int64_t row0, int64_t nrows)
+try {
+    CHECK_PANEL(p);
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, file != nullptr && dataset != nullptr, "HDF5 file / dataset name is NULL");
+    CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "load rows outside the panel");
+    int64_t n_rows = 0, n_cols = 0, chunk_rows = 0;
+    const void *ds = snpm_h5_int8_matrix(file, dataset, &n_rows, &n_cols, &chunk_rows);
+    if (!ds) return set_err(ctx, SNPM_ERR_BADARG, "%s", snpm_h5_last_error(file));
+    CHECK_ARG(ctx, col0 >= 0 && col0 + p->n_acc <= n_cols, "columns outside the HDF5 dataset");
+    if (row_idx) {
+        for (int64_t i = 0; i < nrows; ++i)
+            if (row_idx[i] < 0 || row_idx[i] >= n_rows)
+                return set_err(ctx, SNPM_ERR_BADARG, "row %lld at %lld lies outside the HDF5 dataset (%lld rows)", (long long)row_idx[i],
+                               (long long)i, (long long)n_rows);
+    } else {
+        CHECK_ARG(ctx, file_row0 >= 0 && file_row0 + nrows <= n_rows, "rows outside the HDF5 dataset");
+    }
+    RowSource src;
+    src.h5 = file;
+    src.h5_dataset = ds;
+    src.h5_chunk_rows = chunk_rows;
+    src.col0 = col0;
+    src.row_idx = row_idx;
+    src.file_row0 = row_idx ? 0 : file_row0;
+    return stage_rows(p, row0, nrows, src);
 } SNPM_GUARD((p ? p->ctx : nullptr))
 
 // the host packer on its own (no ctx, no GPU): nrows rows of n_acc int8 calls (row stride src_pitch) -> rows of (n_acc + 3) / 4

@@ -199,10 +199,14 @@ class RowStore(object):
     dataset: sliced here, uploaded from host memory).  ``load`` puts rows into a panel through the pinned staging path --
     the counterpart of the reference's ``g.g.snps[idx, :]`` (core/snpmatch.py:222, pygwas/genotype.py:548-550)."""
 
-    def __init__(self, snps=None, npy=None):
-        assert (snps is None) != (npy is None)
-        self.snps, self.path, self.offset = snps, None, 0
-        if npy is not None:
+    def __init__(self, snps=None, npy=None, h5=None):
+        assert (snps is not None) + (npy is not None) + (h5 is not None) == 1
+        self.snps, self.path, self.offset, self.h5 = snps, None, 0, h5
+        if h5 is not None:                  # (snpmatch_amd.h5.File, dataset name): the reference's HDF5 DB, read natively
+            ds = h5[0][h5[1]]
+            assert ds.ndim == 2 and ds.dtype == np.int8, "expected a 2-D int8 dataset"
+            self.n_snp, self.n_acc = int(ds.shape[0]), int(ds.shape[1])
+        elif npy is not None:
             with open(npy, "rb") as fh:
                 major, _ = np.lib.format.read_magic(fh)
                 shape, fortran, dtype = (np.lib.format.read_array_header_1_0(fh) if major == 1
@@ -224,6 +228,12 @@ class RowStore(object):
             rows = np.ascontiguousarray(rows, dtype=np.int64)
             if len(rows) and int(rows[-1]) - int(rows[0]) + 1 == len(rows) and (len(rows) < 2 or bool(np.all(np.diff(rows) == 1))):
                 rows = (int(rows[0]), len(rows))            # a contiguous run: the range form (one big read per thread)
+        if self.h5 is not None:
+            if isinstance(rows, tuple):
+                panel.load_h5(self.h5[0], self.h5[1], a0, None, rows[0], row0, rows[1])
+            else:
+                panel.load_h5(self.h5[0], self.h5[1], a0, rows, 0, row0, len(rows))
+            return
         if self.path is not None:
             if isinstance(rows, tuple):
                 panel.load_file_rows(self.path, self.offset, self.n_acc, a0, None, rows[0], row0, rows[1])
@@ -348,6 +358,15 @@ class Panel(object):
             nrows = len(row_idx) if nrows is None else nrows
         check(self.ctx.lib.snpm_panel_load_file_rows(self.h, str(path).encode(), int(file_offset), int(file_pitch), int(col0),
                                                      ptr(row_idx), int(file_row0), int(row0), int(nrows)), self.ctx.h)
+
+    def load_h5(self, h5_file, dataset, col0=0, row_idx=None, file_row0=0, row0=0, nrows=None):
+        """rows of a 2-D int8 dataset of an open ``snpmatch_amd.h5.File`` (the reference's DB format): the loader's threads read
+        and decompress the chunks straight into the staging slabs (snpm_panel_load_h5)"""
+        if row_idx is not None:
+            row_idx = np.ascontiguousarray(row_idx, dtype=np.int64)
+            nrows = len(row_idx) if nrows is None else nrows
+        check(self.ctx.lib.snpm_panel_load_h5(self.h, h5_file.h, dataset.encode(), int(col0), ptr(row_idx), int(file_row0), int(row0),
+                                              int(nrows)), self.ctx.h)
 
     @classmethod
     def from_npy(cls, ctx, path, packed=False, cols=None):

@@ -250,3 +250,51 @@ def test_residency_plan_prefers_whole_panels(tmp_path, monkeypatch):
     assert plan(int8_bytes - 1, odd) == ("StreamedPanel", False)
     monkeypatch.setenv("SNPMATCH_PACKED", "1")
     assert plan(packed_bytes - 1) == ("StreamedPanel", True)
+
+
+def test_reference_hdf5_db_through_the_native_reader(golden_dir, tmp_path, monkeypatch):
+    """`-d toy_db.hdf5`: the reference's own DB format (lzf chunks of (1000, n_acc), written by real h5py) read by the
+    library -- chunks decompressed by the loader's threads into the staging slabs -- resident, packed, as an accession
+    shard, streamed through a budget, and through the CLI: the reference's files"""
+    import subprocess
+    import sys
+    monkeypatch.setenv("SNPMATCH_GPUS", "1")
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    path = os.path.join(golden_dir, "h5", "toy_db.hdf5")
+    gold = json.load(open(os.path.join(golden_dir, "g2_inbred.json")))["inbred_skip0"]
+    ctx = make_ctx(SNPM_STAGE_MB=1)
+    from snpmatch_amd import h5
+    f = h5.File(path)
+    store = engine.RowStore(h5=(f, "snps"))
+    for packed in (False, True):
+        p = engine.Panel.from_store(ctx, store, packed=packed)
+        assert np.array_equal(p.download_rows(0, 10000), toy["snps"])
+        p.free()
+        p = engine.Panel.from_store(ctx, store, packed=packed, cols=(12, 40))
+        assert np.array_equal(p.download_rows(0, 10000), toy["snps"][:, 12:40])
+        rows = np.array([9999, 3, 1000, 999, 1001, 5000], dtype=np.int64)
+        store.load(p, (12, 40), rows, 100)
+        assert np.array_equal(p.download_rows(100, 6), toy["snps"][rows, 12:40])
+        store.load(p, (12, 40), (2500, 1300), 0)                                   # starts and ends inside chunks
+        assert np.array_equal(p.download_rows(0, 1300), toy["snps"][2500:3800, 12:40])
+        p.free()
+    ctx.close()
+    for budget_rows in (None, 1000):
+        if budget_rows:
+            monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(budget_for(budget_rows, 50) / 1e9))
+        g = snp_genotype.Genotype(path, None)
+        out = str(tmp_path / ("h5_%s" % budget_rows))
+        snpmatch.Genotyper(make_inputs(toy), g, out, run_genotyper=True)
+        assert type(g.panel()).__name__ == ("StreamedPanel" if budget_rows else "Panel")
+        cmp_scores_table(open(out + ".scores.txt").read(), gold["scores.txt"])
+        assert open(out + ".matches.json").read() == gold["matches.json"]
+    monkeypatch.delenv("SNPM_HBM_BUDGET_GB")
+    sample = str(tmp_path / "sample.npz")
+    np.savez(sample, chr=toy["s_chrs"], pos=toy["s_pos"], gt=toy["s_gt"], wei=toy["s_wei"], dp=toy["s_dp"])
+    out = str(tmp_path / "cli_h5")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "snpmatch_amd", "inbred", "-i", sample, "-d", path, "-o", out],
+                       env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    cmp_scores_table(open(out + ".scores.txt").read(), gold["scores.txt"])
+    assert open(out + ".matches.json").read() == gold["matches.json"]

@@ -49,3 +49,38 @@ def test_host_sources_under_asan_and_ubsan(tmp_path, golden_dir):
     assert "rc=0 records=1" in out["no_newline_at_end"]
     for declined in ("crlf", "bad_pos", "bad_dp", "bad_pl", "huge_gt", "huge_chrom", "long_number"):
         assert "rc=-4" in out[declined], out[declined]
+
+
+def test_hdf5_reader_under_asan_and_ubsan(tmp_path, golden_dir):
+    """csrc/snpm_h5.cpp parses untrusted files: the three fixtures written by real h5py, then 120 randomly damaged copies of
+    them (bytes overwritten, files cut short), under AddressSanitizer + UBSan.  Damage may produce errors, never a fault."""
+    import numpy as np
+    exe = str(tmp_path / "h5_asan_driver")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+                           os.path.join(ROOT, "tests", "h5_asan_driver.cpp"), os.path.join(CSRC, "snpm_h5.cpp"), "-lz", "-o", exe])
+    h5dir = os.path.join(golden_dir, "h5")
+    good = [os.path.join(h5dir, n) for n in ("toy_db.hdf5", "toy_db.acc.hdf5", "stress.hdf5")]
+    rng = np.random.default_rng(11)
+    bad = []
+    for k in range(120):
+        raw = bytearray(open(good[k % 3], "rb").read())
+        if k % 4 == 3:
+            raw = raw[:int(rng.integers(16, len(raw)))]
+        else:
+            for _ in range(int(rng.integers(1, 40))):
+                # most of the damage goes where the metadata lives (the first 8 KB), the rest anywhere
+                hi = 8192 if rng.random() < 0.7 else len(raw)
+                raw[int(rng.integers(8, min(hi, len(raw))))] = int(rng.integers(0, 256))
+        p = str(tmp_path / ("damaged_%03d.hdf5" % k))
+        open(p, "wb").write(bytes(raw))
+        bad.append(p)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:allocator_may_return_null=1", UBSAN_OPTIONS="print_stacktrace=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe] + good + bad, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    lines = r.stdout.strip().split("\n")
+    assert lines[-1] == "done" and len(lines) == 124
+    assert lines[0].startswith("toy_db.hdf5 rc=0 objects=4") and lines[1].startswith("toy_db.acc.hdf5 rc=0 objects=4")
+    assert lines[2].startswith("stress.hdf5 rc=0 objects=10")
