@@ -44,6 +44,9 @@ namespace snpm {
 #ifndef SNPM_Q4_BITIDX
 #define SNPM_Q4_BITIDX 0                // k_fast_packed_q4: 1 = table index with the calls' low bits in bits 0-3 (fewer LDS bank conflicts, 8 more VALU per 64 comparisons)
 #endif
+#ifndef SNPM_Q4_SWZ
+#define SNPM_Q4_SWZ 1                   // k_fast_packed_q4: table index bit 1 ^= low bit of the fourth row's call, bit 3 ^= high bits of rows 3, 4 (level 2): the
+#endif                                  // frequent entries (all calls ref / alt) land in 16 distinct LDS bank pairs instead of 8; 0 = the plain field index
 #ifndef SNPM_Q4_MIN_WAVES
 #define SNPM_Q4_MIN_WAVES 4
 #endif
@@ -614,6 +617,15 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             dst[8] = pre3 + l3a.y;          // c3 = 1: bit 3
             dst[128] = pre3 + l3b.x;        // c3 = 2: bit 7
             dst[136] = pre3 + l3b.y;        // c3 = 3
+#elif SNPM_Q4_SWZ
+            // swizzled positions (see score_quad): entry (c0, c1, c2, c3) lives at index  e ^ ((c3 & 1) << 1) ^ (((c2 ^ c3) >> 1) << 3)  + 64 c3
+            double *tb = s_tab + 256 * (i >> 6);
+            const int h2 = (SNPM_Q4_SWZ >= 2) ? ((e >> 5) & 1) << 3 : 0;      // c2's high bit -> bit 3
+            const int h3 = (SNPM_Q4_SWZ >= 2) ? 8 : 0;                        // c3's high bit -> bit 3
+            tb[(e ^ h2)] = pre3 + l3a.x;                       // c3 = 0
+            tb[(e ^ h2 ^ 2) + 64] = pre3 + l3a.y;              // c3 = 1
+            tb[(e ^ h2 ^ h3) + 128] = pre3 + l3b.x;            // c3 = 2
+            tb[(e ^ h2 ^ h3 ^ 2) + 192] = pre3 + l3b.y;        // c3 = 3
 #else
             double *dst = s_tab + 256 * (i >> 6) + e;
             dst[0] = pre3 + l3a.x;
@@ -689,6 +701,18 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         const uint32_t e01 = bfi(M3, l01, l23 << 2), o01 = bfi(M3, l01 >> 2, l23);      // nibbles [lo0 lo1 lo2 lo3]
         const uint32_t e23 = bfi(M3, h01, h23 << 2), o23 = bfi(M3, h01 >> 2, h23);      // nibbles [hi0 hi1 hi2 hi3]
 #else
+#if SNPM_Q4_SWZ
+        // The LDS bank pair of an entry is its index mod 32 = c0 | c1 << 2 | (c2 & 1) << 4: the sixteen entries whose calls are
+        // all ref / alt (3 of 4 lookups on real panels) share EIGHT bank pairs, entries that differ in the fourth row's call
+        // always collide -- 63 % of the LDS-array cycles were bank-conflict cycles (profiles/r02b_sq_fast_packed_q4.txt).
+        // Swizzle: index bit 1 (row 1's high bit, rarely set) ^= the low bit of row 4's call: two VALU operations per 16
+        // lookups here, the table is built at the swizzled positions.  Level 2 also folds the high bits of rows 3 and 4 into
+        // bit 3 (row 2's high bit), so that entries with a het / missing call in those rows leave the frequent banks.
+        x0 = __builtin_amdgcn_bitop3_b32(x0, x3 << 1, 0xAAAAAAAAu, 0x78);             // x0 ^ ((x3 << 1) & 0xAAAA...)
+#if SNPM_Q4_SWZ >= 2
+        x1 = __builtin_amdgcn_bitop3_b32(x1, x2 ^ x3, 0xAAAAAAAAu, 0x78);             // x1 ^ ((x2 ^ x3) & 0xAAAA...)
+#endif
+#endif
         const uint32_t e01 = bfi(M3, x0, x1 << 2), o01 = bfi(M3, x0 >> 2, x1);
         const uint32_t e23 = bfi(M3, x2, x3 << 2), o23 = bfi(M3, x2 >> 2, x3);
 #endif
