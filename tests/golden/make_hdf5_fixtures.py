@@ -86,6 +86,13 @@ def main():
         g = f.create_group("grp")
         g.create_dataset("inner", data=np.arange(12, dtype="f8").reshape(3, 4))
     np.savez_compressed(os.path.join(OUT, "stress_expected.npz"), snps=snps, noise=noise, wide=wide, pos=pos)
+    # a file in the "latest" HDF5 file format (version-2 object headers, new chunk indexes): the native reader must refuse it
+    with h5py.File(os.path.join(OUT, "latest_format.hdf5"), "w", libver="latest") as f:
+        f.create_dataset("snps", data=snps[:2000], compression="lzf", chunks=(1000, a))
+        f.create_dataset("accessions", data=np.array(["a%d" % i for i in range(a)], dtype="S"))
+        f.create_dataset("positions", data=pos[:2000])
+        f["positions"].attrs["chrs"] = np.array(["1"], dtype="S")
+        f["positions"].attrs["chr_regions"] = [(0, 2000)]
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

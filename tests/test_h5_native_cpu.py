@@ -135,3 +135,40 @@ def test_genotype_opens_the_reference_hdf5_and_makedb_native_converts_it(toy, tm
     g2 = snp_genotype.Genotype(out, None)
     assert np.array_equal(np.asarray(g2.g.snps), toy["snps"]) and g2.accessions.tolist() == g.accessions.tolist()
     assert np.array_equal(g2.g.positions, toy["positions"]) and np.array_equal(g2.g.chr_regions, toy["regions"])
+
+
+def test_latest_format_is_refused_and_h5py_is_the_fallback(monkeypatch):
+    """a file written with libver='latest' (version-2 object headers) is outside the native reader's scope: it says so, and
+    Genotype falls back to h5py where that is importable -- here a stand-in module that serves the expected arrays, so that the
+    fallback branch of core/snp_genotype._load_any runs (the test image has no h5py for the interpreter the tests use)"""
+    import sys
+    import types
+    from snpmatch_amd.core import snp_genotype
+    path = os.path.join(H5DIR, "latest_format.hdf5")
+    with pytest.raises(IOError, match="latest|version-2|not supported"):
+        h5.File(path)
+    monkeypatch.setitem(sys.modules, "h5py", None)                  # import h5py -> ImportError
+    with pytest.raises(IOError, match="h5py is not installed"):
+        snp_genotype.Genotype(path, None)
+    want = np.load(os.path.join(H5DIR, "stress_expected.npz"))
+
+    class FakeDataset(object):
+        def __init__(self, arr, attrs=None):
+            self.arr, self.attrs, self.shape = arr, attrs or {}, arr.shape
+
+        def __getitem__(self, key):
+            return self.arr[key]
+
+    class FakeFile(dict):
+        def __init__(self, name, mode="r"):
+            assert name == path and mode == "r"
+            dict.__init__(self, snps=FakeDataset(want["snps"][:2000]), accessions=FakeDataset(np.array(["a%d" % i for i in range(8)], dtype="S")),
+                          positions=FakeDataset(want["pos"][:2000], {"chrs": np.array(["1"], dtype="S"), "chr_regions": np.array([[0, 2000]])}))
+
+    fake = types.ModuleType("h5py")
+    fake.File = FakeFile
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    g = snp_genotype.Genotype(path, None)
+    assert g.accessions.tolist() == ["a%d" % i for i in range(8)] and g.g.num_snps == 2000 and g.chrs.tolist() == ["1"]
+    assert np.array_equal(g.g.snps[np.array([1, 1999]), :], want["snps"][[1, 1999]])
+    assert not hasattr(g.g, "h5_source")
