@@ -182,3 +182,38 @@ def test_product_path_over_a_group_matches_reference_files(golden_dir, tmp_path,
     for o in outs:
         cmp_scores_table(open(o + ".scores.txt").read(), gold["scores.txt"])
         assert open(o + ".matches.json").read() == gold["matches.json"]
+
+
+def test_group_of_streamed_members_matches_reference_files(golden_dir, tmp_path, monkeypatch):
+    """two GPUs' worth of members, each too small for its accession shard: every member streams its columns of the `.snpm` file in
+    slabs (column range of a wider file, two half-buffers), the group gathers the carries' totals -- the reference's files"""
+    from snpmatch_amd.core import snp_genotype
+    monkeypatch.setenv("SNPMATCH_GPUS", "0,0")
+    monkeypatch.setenv("SNPMATCH_GROUP_LOOPBACK", "1")
+    monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(2 * (1000 + 32) * 256 / 1e9))
+    try:
+        toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+        gold = json.load(open(os.path.join(golden_dir, "g2_inbred.json")))["inbred_skip0"]
+        db = str(tmp_path / "toy.snpm")
+        snp_genotype.save_native(db, toy["snps"], toy["accs"], toy["positions"], toy["chrs"], toy["regions"])
+        g = snp_genotype.Genotype(db, None)
+        out = str(tmp_path / "inbred")
+        snpmatch.Genotyper(make_inputs(toy), g, out, run_genotyper=True)
+        p = g.panel()
+        assert isinstance(p, engine.GroupPanel) and [type(m).__name__ for m in p.members] == ["StreamedPanel"] * 2
+        assert [m.n_acc for m in p.members] == [28, 22] and all(m.loads == 3 for m in p.members)
+        cmp_scores_table(open(out + ".scores.txt").read(), gold["scores.txt"])
+        assert open(out + ".matches.json").read() == gold["matches.json"]
+        toy = np.load(os.path.join(golden_dir, "toy_db_cross.npz"))
+        gold = json.load(open(os.path.join(golden_dir, "g5_cross.json")))["cross_skip0"]
+        out = str(tmp_path / "cross")
+        g = make_g(toy)
+        csmatch.CrossIdentifier(make_inputs(toy), g, "athaliana_tair10", 300000, out, run_identifier=True)
+        assert [type(m).__name__ for m in g.panel().members] == ["StreamedPanel"] * 2
+        cmp_window_table(open(out + ".windowscore.txt").read(), gold[".windowscore.txt"])
+        cmp_scores_table(open(out + ".scores.txt").read(), gold[".scores.txt"])
+        assert open(out + ".scores.txt.matches.json").read() == gold[".scores.txt.matches.json"]
+    finally:
+        if engine._default_group is not None:
+            engine._default_group.free()
+            engine._default_group = None
