@@ -418,6 +418,14 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     if (bpl == 4 && tile_rows == TILE_ROWS && occ_blocks_hint > 0 && !ctx->full_occupancy && (g.wpb == 4 || g.wpb == 5) &&
         n * pitch_bytes >= (int64_t(32) << 30))
         occ = std::min(occ, std::max(3, 18 / g.wpb));
+    // Full 8-wave blocks (n_acc within 8 waves of a multiple of 2048): TWO resident blocks per CU instead of the three that fit
+    // -- 16 row loads in flight per SIMD instead of 24 -- measured better or equal on every shape of that kind from 20 GB up
+    // (round 3, profiles/r03b_ab_occ_cap*.txt: 10 000 x 20M 0.791 -> 0.808 of HBM peak, 8192 x 24M 0.767 -> 0.787, 16 384 x 12M
+    // 0.758 -> 0.779, 6144 x 30M 0.822 -> 0.833, 20 480 x 9M 0.805 -> 0.821, 4096 x 40M 0.796 -> 0.804, 2048 x 50M equal), while
+    // 5- and 7-wave blocks lose 10-25 % with it (1252 / 2500 / 5000 / 12 500 accessions) and keep their own cap above.
+    if (bpl == 4 && tile_rows == TILE_ROWS && occ_blocks_hint > 0 && !ctx->full_occupancy && g.wpb == 8 &&
+        n * pitch_bytes >= (int64_t(4) << 30))
+        occ = std::min(occ, 2);
     if (ctx->occ_cap > 0) occ = std::min(occ, ctx->occ_cap);
     int64_t resident = (int64_t)ctx->n_cu * occ * std::max(1, ctx->parts_mult);
     int64_t n_parts = std::max<int64_t>(1, resident / g.n_colblocks);
