@@ -2,7 +2,7 @@
 # Round-3 evidence, final pass: smoke, the default bench line, the same job under rocprofv3 (pooled stats + per-slab summary),
 # the packed variants, strict mode, bench.py's N>1 path with the library's communicator, PMC traffic of the dominant shapes.
 set -uo pipefail
-out=gpurun_out/r03b; mkdir -p $out
+out=gpurun_out/${SNPM_MEASURE_TAG:-r03b}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 echo "== smoke"; timeout -k 10 300 python __graft_entry__.py smoke > $out/smoke.log 2>&1; echo "rc=$?"
 echo "== default bench"
