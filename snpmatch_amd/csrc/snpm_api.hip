@@ -79,6 +79,7 @@ struct snpm_ctx {
     size_t ld_want = size_t(64) << 20;  // SNPM_STAGE_MB
     void *pool = nullptr;               // HostPool
     int host_pack = 1;                  // SNPM_HOST_PACK=0: packed panels cross PCIe as int8 and are packed on the device
+    int ld_avx2 = 1, ld_nt = 1;         // SNPM_NO_AVX2 / SNPM_NO_NT: scalar packer, plain memcpy into the slabs (the AVX2 forms need the CPU to have it)
     int odirect = -1;                   // SNPM_ODIRECT: 1 always, 0 never, -1 (default) contiguous reads of >= 1 GiB
     snpm_panel *last_touched = nullptr; // the panel the compute stream's most recent work reads or writes
     hipEvent_t batch_ev = nullptr;      // "this sub-batch's inputs have arrived" (copy stream -> compute stream)
@@ -1272,6 +1273,8 @@ try {
     if (const char *s = getenv("SNPM_STAGE_MB")) ctx->ld_want = (size_t)std::max(1, atoi(s)) << 20;
     if (const char *s = getenv("SNPM_HOST_PACK")) ctx->host_pack = atoi(s);
     if (const char *s = getenv("SNPM_ODIRECT")) ctx->odirect = atoi(s);
+    if (getenv("SNPM_NO_AVX2")) ctx->ld_avx2 = 0;
+    ctx->ld_nt = (cpu_has_avx2() && ctx->ld_avx2 && !getenv("SNPM_NO_NT")) ? 1 : 0;
     *out = ctx;
     return SNPM_OK;
 } SNPM_GUARD(nullptr)

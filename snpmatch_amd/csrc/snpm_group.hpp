@@ -135,6 +135,8 @@ struct snpm_group {
     struct Bufs { Buf send, recv, score_all, ninfo_all, lik, lrt; };
     std::vector<Bufs> bufs;
     std::vector<hipEvent_t> ev;               // loopback: "member i has packed its send buffer"
+    std::vector<hipEvent_t> ev_done;          // loopback: "member i has copied every member's send buffer" (the buffers may be rewritten)
+    bool gathered_once = false;
     std::string err;
 };
 
@@ -264,8 +266,10 @@ try {
     }
     if (!rc && loopback) {
         g->ev.assign((size_t)n, nullptr);
+        g->ev_done.assign((size_t)n, nullptr);
         for (int i = 0; i < n && !rc; ++i) {
-            if (hipSetDevice(device_ids[i]) != hipSuccess || hipEventCreateWithFlags(&g->ev[(size_t)i], hipEventDisableTiming) != hipSuccess)
+            if (hipSetDevice(device_ids[i]) != hipSuccess || hipEventCreateWithFlags(&g->ev[(size_t)i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&g->ev_done[(size_t)i], hipEventDisableTiming) != hipSuccess)
                 rc = group_err(nullptr, SNPM_ERR_HIP, "hipEventCreate failed");
         }
     }
@@ -293,6 +297,7 @@ int snpm_group_free(snpm_group *g)
             for (Buf *b : bufs)
                 if (b->p) (void)hipFree(b->p);
             if (i < g->ev.size() && g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+            if (i < g->ev_done.size() && g->ev_done[i]) (void)hipEventDestroy(g->ev_done[i]);
         }
         if (g->owns_ctx) (void)snpm_destroy(c);
     }
@@ -359,6 +364,8 @@ try {
         if ((rc = ensure(c, b.send, words * 8)) || (rc = ensure(c, b.recv, words * 8 * (size_t)g->world)) ||
             (rc = ensure(c, b.score_all, tot * 8)) || (rc = ensure(c, b.ninfo_all, tot * 8)))
             return group_err(g, rc, "member %d: %s", i, c->err.c_str());
+        if (g->transport == 1 && g->gathered_once)          // the previous gather's copies out of this send buffer are done (every member's)
+            for (int j = 0; j < nl; ++j) GHIPCHK(g, hipStreamWaitEvent(c->stream, g->ev_done[(size_t)j], 0));
         hipLaunchKernelGGL(k_group_pack, dim3((unsigned)((m * per + 255) / 256)), dim3(256), 0, c->stream, (const double *)d_score[i],
                            (const int64_t *)d_ninfo[i], m, n_loc, in_ld, per, (uint64_t *)b.send.p);
         GHIPCHK(g, hipGetLastError());
@@ -382,7 +389,9 @@ try {
                 GHIPCHK(g, hipMemcpyAsync((uint64_t *)g->bufs[(size_t)i].recv.p + (size_t)j * words, g->bufs[(size_t)j].send.p, words * 8,
                                           hipMemcpyDeviceToDevice, c->stream));
             }
+            GHIPCHK(g, hipEventRecord(g->ev_done[(size_t)i], c->stream));
         }
+        g->gathered_once = true;
     }
     for (int i = 0; i < nl; ++i) {
         snpm_ctx *c = g->ctx[(size_t)i];

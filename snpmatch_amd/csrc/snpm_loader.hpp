@@ -156,16 +156,25 @@ __attribute__((target("avx2"))) void copy_nt_avx2(int8_t *dst, const int8_t *src
 }
 #endif
 
-void copy_to_slab(int8_t *dst, const int8_t *src, size_t n)
+void copy_to_slab(bool nt, int8_t *dst, const int8_t *src, size_t n)
 {
 #if defined(__x86_64__)
-    static const bool avx2 = !getenv("SNPM_NO_AVX2") && !getenv("SNPM_NO_NT") && __builtin_cpu_supports("avx2");
-    if (avx2 && n >= 4096) {
+    if (nt && n >= 4096) {
         copy_nt_avx2(dst, src, n);
         return;
     }
 #endif
+    (void)nt;
     memcpy(dst, src, n);
+}
+
+bool cpu_has_avx2()
+{
+#if defined(__x86_64__)
+    return __builtin_cpu_supports("avx2") != 0;
+#else
+    return false;
+#endif
 }
 
 // copy n bytes with the pool (one memcpy stream is ~10-15 GB/s, well under what PCIe gen5 x16 takes)
@@ -180,7 +189,7 @@ void parallel_copy(snpm_ctx *ctx, int8_t *dst, const int8_t *src, size_t n)
     const size_t per = ((n + tasks - 1) / tasks + 63) & ~size_t(63);
     host_pool(ctx)->run(tasks, [=](int t) {
         const size_t o = (size_t)t * per;
-        if (o < n) copy_to_slab(dst + o, src + o, std::min(per, n - o));
+        if (o < n) copy_to_slab(ctx->ld_nt != 0, dst + o, src + o, std::min(per, n - o));
     });
 }
 
@@ -238,11 +247,12 @@ __attribute__((target("avx2"))) int pack_row_avx2(const int8_t *src, int64_t n, 
 
 typedef int (*pack_row_fn)(const int8_t *, int64_t, uint8_t *);
 
-pack_row_fn pick_pack_row()
+pack_row_fn pick_pack_row(bool avx2 = true)
 {
 #if defined(__x86_64__)
-    if (!getenv("SNPM_NO_AVX2") && __builtin_cpu_supports("avx2")) return pack_row_avx2;
+    if (avx2 && cpu_has_avx2()) return pack_row_avx2;
 #endif
+    (void)avx2;
     return pack_row_scalar;
 }
 
@@ -322,7 +332,8 @@ int pread_direct(int fd, int8_t *buf, size_t len, off_t off, const int8_t **data
 // `first`.  Work is cut into runs of rows handed to the pool.  Returns SNPM_OK or an error; *bad |= 1 on a call > 2 (pack).
 int fill_rows(snpm_ctx *ctx, const RowSource &src, int64_t n_acc, bool pack, int8_t *dst, int64_t first, int64_t n, int *bad)
 {
-    static const pack_row_fn pack_row = pick_pack_row();
+    const pack_row_fn pack_row = pick_pack_row(ctx->ld_avx2 != 0);
+    const bool nt = ctx->ld_nt != 0;
     const int64_t out_pitch = pack ? (n_acc + 3) / 4 : n_acc;
     int64_t run = std::max<int64_t>(1, (int64_t)((size_t(1) << 20) / (size_t)n_acc));      // ~1 MiB of source per task
     int64_t lead = 0;                   // rows of the first task (HDF5: up to the next chunk boundary, so that a chunk is decompressed once)
@@ -364,12 +375,12 @@ int fill_rows(snpm_ctx *ctx, const RowSource &src, int64_t n_acc, bool pack, int
                 for (int64_t k = k0; k < k1; ++k) b |= pack_row(to + (k - k0) * n_acc, n_acc, (uint8_t *)dst + k * out_pitch);
         } else if (src.host) {
             if (!pack && src.host_pitch == n_acc) {
-                copy_to_slab(dst + k0 * n_acc, src.host + (first + k0) * n_acc, (size_t)(k1 - k0) * n_acc);
+                copy_to_slab(nt, dst + k0 * n_acc, src.host + (first + k0) * n_acc, (size_t)(k1 - k0) * n_acc);
             } else {
                 for (int64_t k = k0; k < k1; ++k) {
                     const int8_t *row = src.host + (first + k) * src.host_pitch;
                     if (pack) b |= pack_row(row, n_acc, (uint8_t *)dst + k * out_pitch);
-                    else copy_to_slab(dst + k * n_acc, row, (size_t)n_acc);
+                    else copy_to_slab(nt, dst + k * n_acc, row, (size_t)n_acc);
                 }
             }
         } else if (contiguous_file) {
@@ -387,7 +398,7 @@ int fill_rows(snpm_ctx *ctx, const RowSource &src, int64_t n_acc, bool pack, int
                 } else if (pack) {
                     for (int64_t k = k0; k < k1; ++k) b |= pack_row(data + (k - k0) * n_acc, n_acc, (uint8_t *)dst + k * out_pitch);
                 } else {
-                    copy_to_slab(dst + k0 * n_acc, data, len);
+                    copy_to_slab(nt, dst + k0 * n_acc, data, len);
                 }
             }
         } else {
