@@ -110,6 +110,7 @@ struct snpm_ctx {
     // queries), so that a panel / query handle freed AFTER its context is a harmless host-side delete
     std::vector<snpm_panel *> panels;
     std::vector<snpm_carry *> carries;
+    std::vector<snpm_group *> groups;   // groups this context joined as a rank (snpm_group_create_rank): told when the context goes away
 };
 
 struct snpm_panel {
@@ -221,6 +222,8 @@ std::atomic<bool> g_exiting{false};
 void mark_exiting() { g_exiting.store(true); }
 
 bool hip_alive() { return !g_exiting.load(); }
+
+void group_forget_ctx(snpm_group *g, snpm_ctx *ctx, bool use_hip);      // snpm_group.hpp
 
 // an entry point that allocates host memory (std::vector, std::string, new) ends with SNPM_GUARD(ctx): no C++
 // exception crosses the C ABI (ctypes would call std::terminate)
@@ -1322,6 +1325,9 @@ int snpm_destroy(snpm_ctx *ctx)
         (void)hipSetDevice(ctx->device);
         (void)hipDeviceSynchronize();
     }
+    // a group this context joined as a rank loses its member now (communicator and buffers released); its handle stays valid
+    for (snpm_group *g : ctx->groups) group_forget_ctx(g, ctx, use_hip);
+    ctx->groups.clear();
     // panels and queries created from this context may be freed later (or never): they become orphans now
     for (snpm_panel *p : ctx->panels) orphan_panel(p, use_hip);
     ctx->panels.clear();

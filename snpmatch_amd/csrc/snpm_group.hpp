@@ -177,6 +177,44 @@ int group_err(snpm_group *g, int code, const char *fmt, ...)
     catch (const std::exception &e_) { return group_err((G), SNPM_ERR_STATE, "internal error: %s", e_.what()); } \
     catch (...) { return group_err((G), SNPM_ERR_STATE, "internal error"); }
 
+void group_release_member(snpm_group *g, size_t i, bool use_hip)
+{
+    snpm_ctx *c = g->ctx[i];
+    if (!c) return;
+    if (use_hip) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (i < g->comm.size() && g->comm[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comm[i]);
+        Buf *bufs[] = {&g->bufs[i].send, &g->bufs[i].recv, &g->bufs[i].score_all, &g->bufs[i].ninfo_all, &g->bufs[i].lik, &g->bufs[i].lrt};
+        for (Buf *b : bufs) {
+            if (b->p) (void)hipFree(b->p);
+            b->p = nullptr;
+            b->cap = 0;
+        }
+        if (i < g->ev.size() && g->ev[i]) (void)hipEventDestroy(g->ev[i]);
+        if (i < g->ev_done.size() && g->ev_done[i]) (void)hipEventDestroy(g->ev_done[i]);
+    }
+    if (i < g->comm.size()) g->comm[i] = nullptr;
+    if (i < g->ev.size()) g->ev[i] = nullptr;
+    if (i < g->ev_done.size()) g->ev_done[i] = nullptr;
+}
+
+// the context of a rank-style group is being destroyed before the group: release what lives on it, keep the handle valid
+void group_forget_ctx(snpm_group *g, snpm_ctx *ctx, bool use_hip)
+{
+    for (size_t i = 0; i < g->ctx.size(); ++i)
+        if (g->ctx[i] == ctx) {
+            group_release_member(g, i, use_hip);
+            g->ctx[i] = nullptr;
+        }
+}
+
+#define CHECK_GROUP_ALIVE(G)                                                                               \
+    do {                                                                                                   \
+        for (snpm_ctx *c_ : (G)->ctx)                                                                      \
+            if (!c_) return group_err((G), SNPM_ERR_STATE, "the group outlived a context it was made of (snpm_destroy was called)"); \
+    } while (0)
+
 int64_t group_per(const snpm_group *g, int64_t n_acc)
 {
     const int64_t per = (n_acc + g->world - 1) / g->world;
@@ -221,6 +259,7 @@ try {
     g->ctx.push_back(ctx);
     g->comm.push_back(comm);
     g->bufs.resize(1);
+    ctx->groups.push_back(g);
     *out = g;
     return SNPM_OK;
 } GROUP_GUARD(nullptr)
@@ -289,17 +328,10 @@ int snpm_group_free(snpm_group *g)
     const bool use_hip = hip_alive();
     for (size_t i = 0; i < g->ctx.size(); ++i) {
         snpm_ctx *c = g->ctx[i];
-        if (use_hip) {
-            (void)hipSetDevice(c->device);
-            (void)hipStreamSynchronize(c->stream);
-            if (i < g->comm.size() && g->comm[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comm[i]);
-            Buf *bufs[] = {&g->bufs[i].send, &g->bufs[i].recv, &g->bufs[i].score_all, &g->bufs[i].ninfo_all, &g->bufs[i].lik, &g->bufs[i].lrt};
-            for (Buf *b : bufs)
-                if (b->p) (void)hipFree(b->p);
-            if (i < g->ev.size() && g->ev[i]) (void)hipEventDestroy(g->ev[i]);
-            if (i < g->ev_done.size() && g->ev_done[i]) (void)hipEventDestroy(g->ev_done[i]);
-        }
+        if (!c) continue;                   // the context went first and took the member with it
+        group_release_member(g, i, use_hip);
         if (g->owns_ctx) (void)snpm_destroy(c);
+        else c->groups.erase(std::remove(c->groups.begin(), c->groups.end(), g), c->groups.end());
     }
     delete g;
     return SNPM_OK;
@@ -318,6 +350,7 @@ int snpm_group_ctx(snpm_group *g, int member, snpm_ctx **ctx)
 {
     if (!g || !ctx) return group_err(g, SNPM_ERR_BADARG, "group / ctx is NULL");
     if (member < 0 || member >= (int)g->ctx.size()) return group_err(g, SNPM_ERR_BADARG, "member %d outside the group's local members", member);
+    CHECK_GROUP_ALIVE(g);
     *ctx = g->ctx[(size_t)member];
     return SNPM_OK;
 }
@@ -347,6 +380,7 @@ try {
     if (!g) return group_err(nullptr, SNPM_ERR_BADARG, "group is NULL");
     if (!d_score || !d_ninfo || m < 1 || n_acc < 1) return group_err(g, SNPM_ERR_BADARG, "gather needs device pointers, m >= 1, n_acc >= 1");
     if ((lik == nullptr) != (lrt == nullptr)) return group_err(g, SNPM_ERR_BADARG, "lik and lrt: both or neither");
+    CHECK_GROUP_ALIVE(g);
     const int nl = (int)g->ctx.size();
     const int64_t per = group_per(g, n_acc);
     const size_t words = (size_t)(2 * m * per);

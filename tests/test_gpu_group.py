@@ -217,3 +217,25 @@ def test_group_of_streamed_members_matches_reference_files(golden_dir, tmp_path,
         if engine._default_group is not None:
             engine._default_group.free()
             engine._default_group = None
+
+
+def test_group_handle_survives_its_context():
+    """snpm_destroy on the context of a rank-style group releases the member (communicator, buffers); the group handle then
+    refuses work with SNPM_ERR_STATE and can still be freed -- the lifetime rule of panels / queries (include/snpmatch_hip.h)"""
+    ctx = engine.Context(0)
+    group = engine.Group.from_rank(ctx, engine.Group.unique_id(), 1, 0)
+    ctx.close()
+    with pytest.raises(_lib.SnpmError, match="outlived"):
+        group.gather([0], [0], 8)
+    group.free()
+    # and the other order with live work in between
+    ctx = engine.Context(0)
+    group = engine.Group.from_rank(ctx, engine.Group.unique_id(), 1, 0)
+    db, wei = make_case(3, 5000, 64)
+    q = engine.Query(engine.Panel.from_host(ctx, db), None, wei)
+    d_s, d_n = q.run_device(1000, False, engine.MODE_STRICT)
+    out = group.gather([d_s], [d_n], 64)
+    want_s, want_n = c_oracle.genotyper(db, None, wei, 1000, False)
+    assert np.array_equal(bits(out["score"]), bits(want_s)) and np.array_equal(out["ninfo"], want_n)
+    group.free()
+    ctx.close()
