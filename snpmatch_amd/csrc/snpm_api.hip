@@ -2815,6 +2815,8 @@ int snpm_debug_stream_read(snpm_panel *p, int64_t *bytes_read)
     HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = ensure(ctx, ctx->ws_flags, sizeof(int));
     if (rc) return rc;
+    rc = wait_upload(p);
+    if (rc) return rc;
     const int64_t n_dwords = p->n_snp * p->pitch / 4;
     const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_dwords + 1023) / 1024, (int64_t)ctx->n_cu * 8));
     hipLaunchKernelGGL(k_calib_read, dim3(blocks), dim3(256), 0, ctx->stream, (const uint32_t *)p->d, n_dwords,
