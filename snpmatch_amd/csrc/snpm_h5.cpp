@@ -527,7 +527,37 @@ bool lzf_decompress(const uint8_t *ip, size_t in_len, uint8_t *op, size_t out_le
 {
     const uint8_t *const in_end = ip + in_len;
     uint8_t *const out0 = op, *const out_end = op + out_len;
-    while (ip < in_end) {
+    // Fast zone: a token consumes at most 33 input bytes and produces at most 264 output bytes, and the copies below may write 8
+    // (literals: 32) bytes more than the token needs -- while both cursors are far enough from the ends no per-copy check is
+    // needed.  The DBs' chunks decode into millions of 3-8-byte tokens: fixed-size copies instead of length-dependent ones.
+    if (in_len >= 64 && out_len >= 512) {
+        const uint8_t *const in_safe = in_end - 40;
+        uint8_t *const out_safe = out_end - 304;
+        while (ip < in_safe && op < out_safe) {
+            unsigned ctrl = *ip++;
+            if (ctrl < 32) {
+                memcpy(op, ip, 16);
+                if (ctrl >= 16) memcpy(op + 16, ip + 16, 16);
+                op += ctrl + 1;
+                ip += ctrl + 1;
+            } else {
+                unsigned len = ctrl >> 5;
+                if (len == 7) len += *ip++;
+                const size_t back = ((size_t)(ctrl & 0x1f) << 8) + *ip++ + 1;
+                len += 2;
+                if (back > (size_t)(op - out0)) return false;
+                const uint8_t *ref = op - back;
+                if (back >= 8) {
+                    memcpy(op, ref, 8);
+                    for (unsigned i = 8; i < len; i += 8) memcpy(op + i, ref + i, 8);
+                } else {
+                    for (unsigned i = 0; i < len; ++i) op[i] = ref[i];      // overlapping (run-length style)
+                }
+                op += len;
+            }
+        }
+    }
+    while (ip < in_end) {                                   // the ends of the buffers: every access checked
         unsigned ctrl = *ip++;
         if (ctrl < 32) {
             ++ctrl;
@@ -546,7 +576,7 @@ bool lzf_decompress(const uint8_t *ip, size_t in_len, uint8_t *op, size_t out_le
             len += 2;
             if (back > (size_t)(op - out0) || (size_t)(out_end - op) < len) return false;
             const uint8_t *ref = op - back;
-            for (unsigned i = 0; i < len; ++i) op[i] = ref[i];      // may overlap: byte by byte
+            for (unsigned i = 0; i < len; ++i) op[i] = ref[i];
             op += len;
         }
     }
