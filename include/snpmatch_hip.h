@@ -111,6 +111,11 @@ int snpm_panel_load_file(snpm_panel *panel, const char *path, int64_t file_offse
    (SNPM_HOST_PACK=0: on the device), so a quarter of the bytes cross PCIe. */
 int snpm_panel_load_file_rows(snpm_panel *panel, const char *path, int64_t file_offset, int64_t file_pitch, int64_t col0,
                               const int64_t *row_idx, int64_t file_row0, int64_t row0, int64_t nrows);
+/* The same from a PACKED flat file (2 bits per call, 4 accessions per byte as in a packed panel; file_pitch = BYTES per file
+   row): accessions [acc0, acc0 + n_acc) (acc0 a multiple of 4) of file row row_idx[i] or file_row0 + i.  Either panel kind
+   takes it (an int8 panel is unpacked on the device); a quarter of the bytes leave the disk and cross PCIe. */
+int snpm_panel_load_file_rows_packed(snpm_panel *panel, const char *path, int64_t file_offset, int64_t file_pitch, int64_t acc0,
+                                     const int64_t *row_idx, int64_t file_row0, int64_t row0, int64_t nrows);
 /* the loader's host-side packer on its own (no ctx, no GPU): int8 calls [nrows, n_acc] (row stride src_pitch) -> 2 bits
    per call, (n_acc + 3) / 4 bytes per row (row stride dst_pitch; field f of byte b = call 4 b + f: 0 ref, 1 alt, 2 het,
    3 missing = any negative; fields past n_acc are 3).  *bad (may be NULL) = 1 when a call > 2 was met. */

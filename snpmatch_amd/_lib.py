@@ -31,7 +31,7 @@ MODE_FAST = 2
 # every symbol include/snpmatch_hip.h declares (tests check that the .so exports all of them)
 SYMBOLS = [
     "snpm_version", "snpm_hip_build_version", "snpm_device_count", "snpm_init", "snpm_destroy", "snpm_last_error", "snpm_set_stream",
-    "snpm_synchronize", "snpm_device_mem_info", "snpm_panel_create", "snpm_panel_create_packed", "snpm_panel_is_packed", "snpm_panel_free", "snpm_panel_info", "snpm_panel_upload_rows", "snpm_panel_load_file", "snpm_panel_load_file_rows", "snpm_pack_rows_host",
+    "snpm_synchronize", "snpm_device_mem_info", "snpm_panel_create", "snpm_panel_create_packed", "snpm_panel_is_packed", "snpm_panel_free", "snpm_panel_info", "snpm_panel_upload_rows", "snpm_panel_load_file", "snpm_panel_load_file_rows", "snpm_panel_load_file_rows_packed", "snpm_pack_rows_host",
     "snpm_panel_upload_wait", "snpm_panel_download_rows", "snpm_panel_fill_synthetic", "snpm_query_create",
     "snpm_query_free", "snpm_query_bind_outputs", "snpm_query_run", "snpm_query_run_device", "snpm_query_error_bound",
     "snpm_query_run_windows", "snpm_query_run_windows_carry", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
@@ -148,6 +148,7 @@ def load():
     lib.snpm_panel_upload_rows.argtypes = [p, i64, i64, p, i64]
     lib.snpm_panel_load_file.argtypes = [p, C.c_char_p, i64, i64, i64]
     lib.snpm_panel_load_file_rows.argtypes = [p, C.c_char_p, i64, i64, i64, p, i64, i64, i64]
+    lib.snpm_panel_load_file_rows_packed.argtypes = [p, C.c_char_p, i64, i64, i64, p, i64, i64, i64]
     lib.snpm_pack_rows_host.argtypes = [p, i64, i64, i64, p, i64, ci, C.POINTER(ci)]
     lib.snpm_panel_upload_wait.argtypes = [p]
     lib.snpm_panel_download_rows.argtypes = [p, i64, i64, p, i64]
@@ -310,6 +311,19 @@ def vcf_parse(path, sample_index=0):
         lib.snpm_vcf_free(h)
     return {"chr": chrom, "pos": pos, "gt": gt, "pl": pl, "dp": dp, "names": names,
             "has_gt": bool(flags.value & 1), "has_pl": bool(flags.value & 2), "has_dp": bool(flags.value & 4)}
+
+
+def pack_rows_host(snps):
+    """int8 calls [n, n_acc] -> uint8 [n, (n_acc + 3) // 4], 2 bits per call (the loader's host packer); AssertionError when a
+    call code other than -1 (any negative), 0, 1, 2 is met"""
+    snps = np.ascontiguousarray(snps, dtype=np.int8)
+    n, n_acc = snps.shape
+    out = np.empty((n, (n_acc + 3) // 4), dtype=np.uint8)
+    bad = C.c_int(0)
+    rc = load().snpm_pack_rows_host(ptr(snps), n_acc, n, n_acc, ptr(out), out.shape[1], 0, C.byref(bad))
+    assert rc == SNPM_OK
+    assert not bad.value, "a packed panel holds only the codes -1 (any negative), 0, 1, 2; use the int8 format for other values"
+    return out
 
 
 def binom_sf_host(k, n, p):

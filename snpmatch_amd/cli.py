@@ -51,7 +51,7 @@ def makedb_native(args):
     """<db>.npz (snps, accessions, positions, chrs, chr_regions) or HDF5 -> <out>.snpm flat panel"""
     from .core import snp_genotype
     g = snp_genotype._load_any(args['inFile'])
-    snp_genotype.save_native(args['outFile'], g.snps, g.accessions, g.positions, g.chrs, g.chr_regions)
+    snp_genotype.save_native(args['outFile'], g.snps, g.accessions, g.positions, g.chrs, g.chr_regions, packed=args.get('packed', False))
 
 
 def get_options(description, version_message):
@@ -85,6 +85,8 @@ def get_options(description, version_message):
     mk = sub.add_parser('makedb-native', help="Convert a DB (.npz / HDF5) to the native flat panel format")
     mk.add_argument("-i", "--input", dest="inFile")
     mk.add_argument("-o", "--output", dest="outFile")
+    mk.add_argument("--packed", action="store_true", dest="packed", default=False,
+                    help="store 2 bits per call (a quarter of the disk and of the bytes a load moves; DBs with the codes -1/0/1/2 only)")
     mk.add_argument("-v", "--verbose", action="store_true", dest="logDebug", default=False)
     mk.set_defaults(func=makedb_native)
     return p

@@ -9,9 +9,10 @@ adds ``g.panel(ctx)``: the int8 matrix resident in HBM (uploaded once through th
 path of libsnpmatch_hip), which is what ``Genotyper`` / ``CrossIdentifier`` score against.
 
 On-disk formats
-  * native flat panel ``<name>.snpm/``: ``snps.i8`` = raw int8 [num_snps, num_accessions] C-order
-    (memory-mapped, streamed to the GPU slab by slab) + ``meta.npz`` (accessions, positions, chrs,
-    chr_regions).  ``save_native`` / ``Genotype.from_arrays`` create it.
+  * native flat panel ``<name>.snpm/``: ``snps.npy`` = int8 [num_snps, num_accessions] C-order (read natively by the
+    library's loader threads, streamed to the GPU slab by slab) or ``snps.p2.npy`` = the same matrix with 2 bits per call
+    (``save_native(..., packed=True)`` / ``makedb-native --packed``: a quarter of the disk and of the bytes a load moves),
+    + ``meta.npz`` (accessions, positions, chrs, chr_regions).
   * ``.npz`` with the same keys plus ``snps`` (small DBs, tests).
   * the reference's HDF5 layout (pygwas/genotype.py:310-326: ``snps`` in lzf chunks of (1000, num_accessions), ``positions``
     with attrs ``chrs`` / ``chr_regions``, ``accessions``), read by the library's own HDF5 reader (``snpmatch_amd.h5``,
@@ -53,13 +54,62 @@ class MemGenotype(object):
         return self.snps.shape[0]
 
 
-def save_native(path, snps, accessions, positions, chrs, chr_regions):
-    """Write the native flat panel directory ``path`` (conventionally ``*.snpm``)."""
+class PackedRows(object):
+    """Host view of the 2-bit matrix of a packed flat panel (``snps.p2.npy``: uint8 [n_snp, ceil(n_acc / 4)], field f of byte b =
+    accession 4 b + f, 0 ref / 1 alt / 2 het / 3 missing): behaves like the int8 matrix for the reads the host side makes
+    (``snps[idx, :]``, ``snps[:, i]``, slices), unpacking what is asked for."""
+
+    def __init__(self, packed, n_acc):
+        self.packed, self.shape, self.dtype, self.ndim = packed, (int(packed.shape[0]), int(n_acc)), np.dtype(np.int8), 2
+
+    def __len__(self):
+        return self.shape[0]
+
+    @staticmethod
+    def unpack(block, n_acc, a0=0):
+        """uint8 rows holding accessions a0 .. (a0 % 4 == 0) -> int8 [n, n_acc]"""
+        block = np.ascontiguousarray(block)
+        fields = (block[:, :, None] >> np.array([0, 2, 4, 6], dtype=np.uint8)) & 3
+        out = fields.reshape(block.shape[0], -1)[:, :n_acc].astype(np.int8)
+        out[out == 3] = -1
+        return out
+
+    def __getitem__(self, key):
+        if not isinstance(key, tuple):
+            key = (key, slice(None))
+        rows, cols = key
+        one_row = isinstance(rows, (int, np.integer))
+        block = self.packed[[rows], :] if one_row else self.packed[rows, :]
+        if isinstance(cols, (int, np.integer)):
+            c = int(cols) + (self.shape[1] if cols < 0 else 0)
+            v = ((np.asarray(block[:, c // 4]) >> (2 * (c % 4))) & 3).astype(np.int8)
+            v[v == 3] = -1
+            return v[0] if one_row else v
+        full = self.unpack(block, self.shape[1])[:, cols]
+        return full[0] if one_row else full
+
+    def __array__(self, dtype=None, copy=None):
+        a = self[:, :]
+        return a.astype(dtype) if dtype is not None else a
+
+
+def save_native(path, snps, accessions, positions, chrs, chr_regions, packed=False):
+    """Write the native flat panel directory ``path`` (conventionally ``*.snpm``): ``snps.npy`` (int8 [n_snp, n_acc]) or, with
+    ``packed``, ``snps.p2.npy`` (2 bits per call: a quarter of the disk and of the bytes a load moves; only for DBs whose codes
+    are -1 / 0 / 1 / 2) plus ``meta.npz``."""
     os.makedirs(path, exist_ok=True)
-    snps = np.asarray(snps)
-    mm = np.lib.format.open_memmap(os.path.join(path, "snps.npy"), mode="w+", dtype=np.int8, shape=snps.shape)
-    for r0 in range(0, snps.shape[0], 1 << 16):
-        mm[r0:r0 + (1 << 16)] = snps[r0:r0 + (1 << 16)]
+    n_snp, n_acc = snps.shape
+    for stale in ("snps.npy", "snps.p2.npy"):
+        if os.path.exists(os.path.join(path, stale)):
+            os.remove(os.path.join(path, stale))
+    if packed:
+        mm = np.lib.format.open_memmap(os.path.join(path, "snps.p2.npy"), mode="w+", dtype=np.uint8, shape=(n_snp, (n_acc + 3) // 4))
+        for r0 in range(0, n_snp, 1 << 16):
+            mm[r0:r0 + (1 << 16)] = _lib.pack_rows_host(np.asarray(snps[r0:r0 + (1 << 16)]))
+    else:
+        mm = np.lib.format.open_memmap(os.path.join(path, "snps.npy"), mode="w+", dtype=np.int8, shape=(n_snp, n_acc))
+        for r0 in range(0, n_snp, 1 << 16):
+            mm[r0:r0 + (1 << 16)] = snps[r0:r0 + (1 << 16)]
     mm.flush()
     del mm
     np.savez(os.path.join(path, "meta.npz"), accessions=np.asarray(accessions).astype("S"),
@@ -70,6 +120,12 @@ def save_native(path, snps, accessions, positions, chrs, chr_regions):
 def _load_any(path):
     if os.path.isdir(path):
         meta = np.load(os.path.join(path, "meta.npz"))
+        p2 = os.path.join(path, "snps.p2.npy")
+        if os.path.exists(p2):                           # packed flat panel: 2 bits per call on disk
+            snps = PackedRows(np.load(p2, mmap_mode="r"), len(meta["accessions"]))
+            g = MemGenotype(snps, meta["accessions"], meta["positions"], meta["chrs"].astype("U"), meta["chr_regions"])
+            g.npy_packed_path = p2
+            return g
         snps = np.load(os.path.join(path, "snps.npy"), mmap_mode="r")
         g = MemGenotype(snps, meta["accessions"], meta["positions"], meta["chrs"].astype("U"), meta["chr_regions"])
         g.npy_path = os.path.join(path, "snps.npy")      # lets Genotype.panel() stream the file natively
@@ -175,7 +231,9 @@ class Genotype(object):
         from .. import engine
         npy = getattr(self.g, "npy_path", None)          # native flat panel: file -> pinned slabs -> HBM
         h5_source = getattr(self.g, "h5_source", None)   # the reference's HDF5 file: chunks -> loader threads -> pinned slabs -> HBM
-        store = (engine.RowStore(npy=npy) if npy else engine.RowStore(h5=h5_source) if h5_source else engine.RowStore(snps=self.g.snps))
+        p2 = getattr(self.g, "npy_packed_path", None)    # packed flat panel: the file's 2-bit rows travel as they are
+        store = (engine.RowStore(npy=npy) if npy else engine.RowStore(npy_packed=(p2, len(self.accessions))) if p2
+                 else engine.RowStore(h5=h5_source) if h5_source else engine.RowStore(snps=self.g.snps))
         env = os.environ.get("SNPM_HBM_BUDGET_GB", "")
         budget = int(float(env) * 1e9) if env else int(0.85 * ctx.mem_info()[0])
         n_loc = a1 - a0

@@ -268,6 +268,8 @@ struct RowSource {
     int64_t file_offset = 0, file_pitch = 0, col0 = 0, file_row0 = 0;
     const int64_t *row_idx = nullptr;
     const char *path = "";
+    bool prepacked = false;             // the file's rows are already 2 bits per call (a packed .snpm): col0 / file_pitch in BYTES of
+                                        // packed row, the panel's first accession is a multiple of 4
     // or a 2-D int8 dataset of an open HDF5 file (the reference's DB format): chunks are decompressed by the filling threads
     snpm_h5 *h5 = nullptr;
     const void *h5_dataset = nullptr;
@@ -334,6 +336,41 @@ int fill_rows(snpm_ctx *ctx, const RowSource &src, int64_t n_acc, bool pack, int
 {
     const pack_row_fn pack_row = pick_pack_row(ctx->ld_avx2 != 0);
     const bool nt = ctx->ld_nt != 0;
+    if (src.prepacked) {
+        // rows of a packed file travel as they are: (n_acc + 3) / 4 bytes per row; the unused fields of the last byte (accessions of
+        // a neighbouring shard, or padding) become "missing"
+        const int64_t pk = (n_acc + 3) / 4;
+        const uint8_t tail = (n_acc & 3) ? (uint8_t)(0xFFu << (2 * (n_acc & 3))) : 0;
+        const int64_t run_p = std::max<int64_t>(1, (int64_t)((size_t(1) << 20) / (size_t)pk));
+        const int tasks_p = (int)std::min<int64_t>(1 << 20, (n + run_p - 1) / run_p);
+        std::atomic<int> err_p{0};
+        const bool contiguous = !src.row_idx && src.file_pitch == pk && src.col0 == 0;
+        host_pool(ctx)->run(tasks_p, [&](int t) {
+            const int64_t k0 = (int64_t)t * run_p, k1 = std::min<int64_t>(n, k0 + run_p);
+            if (k0 >= k1 || err_p.load(std::memory_order_relaxed)) return;
+            if (contiguous) {
+                const off_t off = (off_t)(src.file_offset + (src.file_row0 + first + k0) * pk);
+                const size_t len = (size_t)(k1 - k0) * pk;
+                int8_t *buf = t_scratch.get(len + 8192);
+                const int8_t *data = buf;
+                int e = buf ? 0 : ENOMEM;
+                if (!e) e = src.direct ? pread_direct(src.fd, buf, len, off, &data) : pread_full(src.fd, buf, len, off);
+                if (e) { err_p.store(e); return; }
+                copy_to_slab(nt, dst + k0 * pk, data, len);
+            } else {
+                for (int64_t k = k0; k < k1; ++k) {
+                    const int64_t r = src.row_idx ? src.row_idx[first + k] : src.file_row0 + first + k;
+                    const int e = pread_full(src.fd, dst + k * pk, (size_t)pk, (off_t)(src.file_offset + r * src.file_pitch + src.col0));
+                    if (e) { err_p.store(e); return; }
+                }
+            }
+            if (tail)
+                for (int64_t k = k0; k < k1; ++k) ((uint8_t *)dst)[k * pk + pk - 1] |= tail;
+        });
+        const int e = err_p.load();
+        if (e) return set_err(ctx, SNPM_ERR_BADARG, "short read from %s (%s)", src.path, e > 0 ? strerror(e) : "end of file");
+        return SNPM_OK;
+    }
     const int64_t out_pitch = pack ? (n_acc + 3) / 4 : n_acc;
     int64_t run = std::max<int64_t>(1, (int64_t)((size_t(1) << 20) / (size_t)n_acc));      // ~1 MiB of source per task
     int64_t lead = 0;                   // rows of the first task (HDF5: up to the next chunk boundary, so that a chunk is decompressed once)
@@ -443,6 +480,26 @@ __global__ void k_repitch_packed(const uint8_t *__restrict__ src, int64_t src_pi
     dst[i] = out;
 }
 
+// packed staged rows (tight, src_pitch bytes) -> int8 panel rows (256-B pitch): one thread per destination dword = one source byte;
+// bytes past the row's accessions are 0xFF
+__global__ void k_unpack_repitch(const uint8_t *__restrict__ src, int64_t src_pitch, int64_t nrows, int64_t n_acc,
+                                 uint32_t *__restrict__ dst, int64_t dst_pitch)
+{
+    const int64_t dwords_per_row = dst_pitch / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrows * dwords_per_row) return;
+    const int64_t r = i / dwords_per_row, d = i - r * dwords_per_row;
+    const uint32_t b = d < src_pitch ? src[r * src_pitch + d] : 0xffu;
+    uint32_t out = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t v = (b >> (2 * j)) & 3u;
+        const uint32_t c = (d * 4 + j < n_acc && v != 3u) ? v : 0xffu;
+        out |= c << (8 * j);
+    }
+    dst[i] = out;
+}
+
 int ensure_loader(snpm_ctx *ctx, size_t min_slab)
 {
     const size_t want = std::max(ctx->ld_want, min_slab);
@@ -470,8 +527,9 @@ int stage_rows(snpm_panel *p, int64_t row0, int64_t nrows, const RowSource &src)
     snpm_ctx *ctx = p->ctx;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const int64_t n_acc = p->n_acc;
-    const bool host_pack = p->packed && ctx->host_pack;
-    const int64_t spitch = host_pack ? (n_acc + 3) / 4 : n_acc;                      // staged rows are tight
+    // staged rows are tight: n_acc bytes, or (n_acc + 3) / 4 when they are packed on the host (packed panels) or come from a packed file
+    const bool host_pack = src.prepacked || (p->packed && ctx->host_pack);
+    const int64_t spitch = host_pack ? (n_acc + 3) / 4 : n_acc;
     int rc = ensure_loader(ctx, (size_t)spitch);
     if (rc) return rc;
     rc = ensure(ctx, ctx->ws_flags2, sizeof(int));
@@ -503,7 +561,11 @@ int stage_rows(snpm_panel *p, int64_t row0, int64_t nrows, const RowSource &src)
         if (bad) break;
         int8_t *scratch = (int8_t *)ctx->ws_stage_dev.p + (size_t)which * ctx->ld_cap;
         HIPCHK(ctx, hipMemcpyAsync(scratch, st, (size_t)nr * spitch, hipMemcpyHostToDevice, ctx->copy_stream));
-        if (!p->packed) {
+        if (!p->packed && host_pack) {              // a packed file into an int8 panel: unpacked on the device
+            const int64_t total = nr * (p->pitch / 4);
+            hipLaunchKernelGGL(k_unpack_repitch, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream,
+                               (const uint8_t *)scratch, spitch, nr, n_acc, (uint32_t *)(p->d + (row0 + r) * p->pitch), p->pitch);
+        } else if (!p->packed) {
             const int64_t total = nr * (p->pitch / 4);
             hipLaunchKernelGGL(k_repitch_canon, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream,
                                scratch, spitch, nr, n_acc, (uint32_t *)(p->d + (row0 + r) * p->pitch), p->pitch, p->d_other);
@@ -682,6 +744,44 @@ int snpm_pack_rows_host(const int8_t *src, int64_t src_pitch, int64_t nrows, int
     if (bad) *bad = b ? 1 : 0;
     return SNPM_OK;
 }
+
+// The same from a PACKED flat file (a .snpm written with 2 bits per call: 4 accessions per byte, field f of byte b = accession
+// 4 b + f; file_pitch BYTES per row): panel row row0 + i receives accessions [acc0, acc0 + n_acc) (acc0 a multiple of 4) of file
+// row row_idx[i] or file_row0 + i.  A quarter of the bytes leave the disk and cross PCIe, whatever the panel's format.
+int snpm_panel_load_file_rows_packed(snpm_panel *p, const char *path, int64_t file_offset, int64_t file_pitch, int64_t acc0,
+                                     const int64_t *row_idx, int64_t file_row0, int64_t row0, int64_t nrows)
+try {
+    CHECK_PANEL(p);
+    snpm_ctx *ctx = p->ctx;
+    CHECK_ARG(ctx, path != nullptr && file_offset >= 0, "bad file arguments");
+    CHECK_ARG(ctx, row0 >= 0 && nrows >= 0 && row0 + nrows <= p->n_snp, "load rows outside the panel");
+    CHECK_ARG(ctx, acc0 >= 0 && (acc0 & 3) == 0, "the first accession of a shard of a packed file must be a multiple of 4");
+    const int64_t pk = (p->n_acc + 3) / 4, col0 = acc0 / 4;
+    CHECK_ARG(ctx, file_pitch >= col0 + pk, "file_pitch smaller than the bytes of the requested accessions");
+    CHECK_ARG(ctx, row_idx != nullptr || file_row0 >= 0, "negative file row");
+    struct stat st;
+    if (stat(path, &st) != 0) return set_err(ctx, SNPM_ERR_BADARG, "cannot open %s: %s", path, strerror(errno));
+    if (row_idx) {
+        for (int64_t i = 0; i < nrows; ++i)
+            if (row_idx[i] < 0 || file_offset + row_idx[i] * file_pitch + col0 + pk > (int64_t)st.st_size)
+                return set_err(ctx, SNPM_ERR_BADARG, "file row %lld at %lld lies outside %s", (long long)row_idx[i], (long long)i, path);
+    } else if (nrows > 0 && file_offset + (file_row0 + nrows - 1) * file_pitch + col0 + pk > (int64_t)st.st_size) {
+        return set_err(ctx, SNPM_ERR_BADARG, "short read from %s (end of file)", path);
+    }
+    RowSource src;
+    src.prepacked = true;
+    src.file_offset = file_offset;
+    src.file_pitch = file_pitch;
+    src.col0 = col0;
+    src.row_idx = row_idx;
+    src.file_row0 = row_idx ? 0 : file_row0;
+    const bool contiguous = !row_idx && file_pitch == pk && col0 == 0;
+    int rc = open_source(ctx, path, contiguous, file_offset + file_row0 * file_pitch, nrows * pk, &src);
+    if (rc) return rc;
+    rc = stage_rows(p, row0, nrows, src);
+    close(src.fd);
+    return rc;
+} SNPM_GUARD((p ? p->ctx : nullptr))
 
 // the contiguous form: tightly packed rows of exactly n_acc bytes starting at file_offset (the data section of snps.npy)
 int snpm_panel_load_file(snpm_panel *p, const char *path, int64_t file_offset, int64_t row0, int64_t nrows)

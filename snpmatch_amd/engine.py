@@ -199,10 +199,20 @@ class RowStore(object):
     dataset: sliced here, uploaded from host memory).  ``load`` puts rows into a panel through the pinned staging path --
     the counterpart of the reference's ``g.g.snps[idx, :]`` (core/snpmatch.py:222, pygwas/genotype.py:548-550)."""
 
-    def __init__(self, snps=None, npy=None, h5=None):
-        assert (snps is not None) + (npy is not None) + (h5 is not None) == 1
-        self.snps, self.path, self.offset, self.h5 = snps, None, 0, h5
-        if h5 is not None:                  # (snpmatch_amd.h5.File, dataset name): the reference's HDF5 DB, read natively
+    def __init__(self, snps=None, npy=None, h5=None, npy_packed=None):
+        assert (snps is not None) + (npy is not None) + (h5 is not None) + (npy_packed is not None) == 1
+        self.snps, self.path, self.offset, self.h5, self.packed_file = snps, None, 0, h5, False
+        if npy_packed is not None:          # (path of a uint8 .npy [n_snp, ceil(n_acc / 4)] with 2 bits per call, n_acc): a packed .snpm
+            npy, n_acc_true = npy_packed
+            with open(npy, "rb") as fh:
+                major, _ = np.lib.format.read_magic(fh)
+                shape, fortran, dtype = (np.lib.format.read_array_header_1_0(fh) if major == 1
+                                         else np.lib.format.read_array_header_2_0(fh))
+                self.offset = fh.tell()
+            assert len(shape) == 2 and not fortran and np.dtype(dtype) == np.uint8 and shape[1] == (int(n_acc_true) + 3) // 4, \
+                "expected a C-ordered uint8 matrix of 2-bit calls"
+            self.path, self.n_snp, self.n_acc, self.packed_file, self.file_pitch = npy, int(shape[0]), int(n_acc_true), True, int(shape[1])
+        elif h5 is not None:                  # (snpmatch_amd.h5.File, dataset name): the reference's HDF5 DB, read natively
             ds = h5[0][h5[1]]
             assert ds.ndim == 2 and ds.dtype == np.int8, "expected a 2-D int8 dataset"
             self.n_snp, self.n_acc = int(ds.shape[0]), int(ds.shape[1])
@@ -233,6 +243,13 @@ class RowStore(object):
                 panel.load_h5(self.h5[0], self.h5[1], a0, None, rows[0], row0, rows[1])
             else:
                 panel.load_h5(self.h5[0], self.h5[1], a0, rows, 0, row0, len(rows))
+            return
+        if self.packed_file:
+            assert a0 % 4 == 0, "accession shards of a packed DB start at multiples of 4"
+            if isinstance(rows, tuple):
+                panel.load_file_rows_packed(self.path, self.offset, self.file_pitch, a0, None, rows[0], row0, rows[1])
+            else:
+                panel.load_file_rows_packed(self.path, self.offset, self.file_pitch, a0, rows, 0, row0, len(rows))
             return
         if self.path is not None:
             if isinstance(rows, tuple):
@@ -358,6 +375,14 @@ class Panel(object):
             nrows = len(row_idx) if nrows is None else nrows
         check(self.ctx.lib.snpm_panel_load_file_rows(self.h, str(path).encode(), int(file_offset), int(file_pitch), int(col0),
                                                      ptr(row_idx), int(file_row0), int(row0), int(nrows)), self.ctx.h)
+
+    def load_file_rows_packed(self, path, file_offset, file_pitch, acc0=0, row_idx=None, file_row0=0, row0=0, nrows=None):
+        """rows from a PACKED flat file (2 bits per call, ``file_pitch`` bytes per row): accessions [acc0, acc0 + n_acc), acc0 % 4 == 0"""
+        if row_idx is not None:
+            row_idx = np.ascontiguousarray(row_idx, dtype=np.int64)
+            nrows = len(row_idx) if nrows is None else nrows
+        check(self.ctx.lib.snpm_panel_load_file_rows_packed(self.h, str(path).encode(), int(file_offset), int(file_pitch), int(acc0),
+                                                            ptr(row_idx), int(file_row0), int(row0), int(nrows)), self.ctx.h)
 
     def load_h5(self, h5_file, dataset, col0=0, row_idx=None, file_row0=0, row0=0, nrows=None):
         """rows of a 2-D int8 dataset of an open ``snpmatch_amd.h5.File`` (the reference's DB format): the loader's threads read

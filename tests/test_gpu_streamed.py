@@ -298,3 +298,49 @@ def test_reference_hdf5_db_through_the_native_reader(golden_dir, tmp_path, monke
     assert r.returncode == 0, r.stderr
     cmp_scores_table(open(out + ".scores.txt").read(), gold["scores.txt"])
     assert open(out + ".matches.json").read() == gold["matches.json"]
+
+
+def test_packed_flat_panel_file_feeds_both_panel_kinds(case, golden_dir, tmp_path, monkeypatch):
+    """a .snpm written with 2 bits per call: its rows travel as they are (snpm_panel_load_file_rows_packed) into packed panels
+    (re-pitch) and into int8 panels (unpacked on the device) -- whole, as accession shards starting at multiples of 4, as row
+    lists, streamed through a budget -- and Genotyper writes the reference's files from it"""
+    db, wei, _ = case
+    n, n_acc = db.shape
+    monkeypatch.setenv("SNPMATCH_GPUS", "1")
+    out = str(tmp_path / "packed.snpm")
+    meta = (np.array(["a%d" % i for i in range(n_acc - 1)]), np.arange(1, n + 1), np.array(["1"]), np.array([[0, n]]))
+    snp_genotype.save_native(out, db[:, :n_acc - 1], *meta, packed=True)          # 299 accessions: a partial last byte
+    store = engine.RowStore(npy_packed=(os.path.join(out, "snps.p2.npy"), n_acc - 1))
+    rows = np.sort(np.random.default_rng(8).choice(n, size=5000, replace=False)).astype(np.int64)
+    for env in ({}, {"SNPM_ODIRECT": 1, "SNPM_STAGE_MB": 1}):
+        ctx = make_ctx(**env)
+        for packed in (False, True):
+            p = engine.Panel.from_store(ctx, store, packed=packed)
+            assert np.array_equal(p.download_rows(0, n), db[:, :n_acc - 1])
+            p.free()
+            p = engine.Panel(ctx, 6000, 103, packed=packed)                        # accessions 196 .. 298: a shard that ends in the partial byte
+            store.load(p, (196, 299), rows, 3)
+            assert np.array_equal(p.download_rows(3, 5000), db[rows, 196:299])
+            store.load(p, (196, 299), (21_000, 6000), 0)
+            assert np.array_equal(p.download_rows(0, 6000), db[21_000:27_000, 196:299])
+            p.free()
+            p = engine.Panel(ctx, 100, 50, packed=packed)                          # a shard in the middle: the neighbours' calls in its last byte are masked
+            store.load(p, (100, 150), (0, 100), 0)
+            assert np.array_equal(p.download_rows(0, 100), db[:100, 100:150])
+            with pytest.raises(AssertionError):
+                store.load(p, (101, 151), (0, 100), 0)
+            p.free()
+        ctx.close()
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    gold = json.load(open(os.path.join(golden_dir, "g2_inbred.json")))["inbred_skip0"]
+    path = str(tmp_path / "toy_packed.snpm")
+    snp_genotype.save_native(path, toy["snps"], toy["accs"], toy["positions"], toy["chrs"], toy["regions"], packed=True)
+    for budget_rows in (None, 1000):
+        if budget_rows:
+            monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(budget_for(budget_rows, 50) / 1e9))
+        g = snp_genotype.Genotype(path, None)
+        o = str(tmp_path / ("packedfile_%s" % budget_rows))
+        snpmatch.Genotyper(make_inputs(toy), g, o, run_genotyper=True)
+        assert type(g.panel()).__name__ == ("StreamedPanel" if budget_rows else "Panel")
+        cmp_scores_table(open(o + ".scores.txt").read(), gold["scores.txt"])
+        assert open(o + ".matches.json").read() == gold["matches.json"]

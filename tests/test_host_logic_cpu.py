@@ -220,3 +220,29 @@ def test_binom_sf_algorithm_matches_scipy(golden_dir):
     k = np.floor(rng.random(500) * (n + 2)) - 1
     for p in (0.0005, 0.02, 0.3, 0.9):
         np.testing.assert_allclose(_lib.binom_sf_host(k, n, p), stats.binom.sf(k, n, p), rtol=1e-9, atol=1e-280)
+
+
+def test_packed_flat_panel_on_disk_reads_like_the_int8_matrix(tmp_path, golden_dir):
+    """save_native(packed=True) / makedb-native --packed: 2 bits per call on disk; the host view answers the reads the reference
+    makes on its DB (g.g.snps[idx, :], g.g_acc.snps[:, i], slices) with the int8 values; odd call codes are refused"""
+    import os
+    from snpmatch_amd import cli
+    from snpmatch_amd.core import snp_genotype
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    want = toy["snps"][:, :47]                                  # 47 accessions: the last byte of a row holds one unused field
+    out = str(tmp_path / "p.snpm")
+    snp_genotype.save_native(out, want, toy["accs"][:47], toy["positions"], toy["chrs"], toy["regions"], packed=True)
+    assert os.path.getsize(os.path.join(out, "snps.p2.npy")) < want.size // 3 and not os.path.exists(os.path.join(out, "snps.npy"))
+    g = snp_genotype.Genotype(out, None)
+    s = g.g.snps
+    assert s.shape == (10000, 47) and s.dtype == np.int8 and len(s) == 10000
+    idx = np.array([5, 9999, 0, 123])
+    assert np.array_equal(s[idx, :], want[idx]) and np.array_equal(s[:, 46], want[:, 46]) and np.array_equal(s[100:200], want[100:200])
+    assert np.array_equal(np.asarray(s), want) and np.array_equal(s[7, :], want[7]) and np.array_equal(s[10:20, 3:9], want[10:20, 3:9])
+    assert np.array_equal(g.g_acc.snps[:, 3], want[:, 3]) and g.accessions.tolist() == [str(a) for a in toy["accs"][:47]]
+    odd = want.copy()
+    odd[3, 3] = 7
+    with pytest.raises(AssertionError):
+        snp_genotype.save_native(str(tmp_path / "odd.snpm"), odd, toy["accs"][:47], toy["positions"], toy["chrs"], toy["regions"], packed=True)
+    assert cli.main(["makedb-native", "--packed", "-i", os.path.join(golden_dir, "h5", "toy_db.hdf5"), "-o", str(tmp_path / "q.snpm")]) == 0
+    assert np.array_equal(np.asarray(snp_genotype.Genotype(str(tmp_path / "q.snpm"), None).g.snps), toy["snps"])
