@@ -121,14 +121,45 @@ def main():
             p.free()
             c.close()
 
+    def packed_file_rates(path_p2, title, cold):
+        print("\n(b') %s" % title)
+        store = engine.RowStore(npy_packed=(path_p2, n_acc))
+        for label, env, packed in (("packed panel, buffered", {"SNPM_ODIRECT": 0}, True), ("packed panel, O_DIRECT", {"SNPM_ODIRECT": 1}, True),
+                                   ("int8 panel (unpacked on the device), buffered", {"SNPM_ODIRECT": 0}, False)):
+            c = ctx_with(SNPM_STAGE_THREADS=16, **env)
+            p = engine.Panel(c, n, n_acc, packed=packed)
+
+            def go():
+                if cold:
+                    drop_cache(path_p2)
+                store.load(p, (0, n_acc), None, 0, n)
+            dt = timed_load(go, p, reps=2)
+            print("  %-46s %6.1f GB/s int8-equivalent  (%.3f s)" % (label, gbytes / dt, dt))
+            if not packed:
+                assert np.array_equal(p.download_rows(n - 1000, 1000), host[n - 1000:])
+            p.free()
+            c.close()
+
+    from snpmatch_amd import _lib
     shm = os.path.join(args.shm_dir, "snpm_time_loader.npy")
     t0 = time.perf_counter()
     np.save(shm, host)
     print("\nwrote %s in %.2f s" % (shm, time.perf_counter() - t0))
+    shm_p2 = os.path.join(args.shm_dir, "snpm_time_loader.p2.npy")
     try:
         file_rates(shm, "flat file in %s (memory-backed), 16 threads" % args.shm_dir, cold=False)
+        mm = np.lib.format.open_memmap(shm_p2, mode="w+", dtype=np.uint8, shape=(n, (n_acc + 3) // 4))
+        t0 = time.perf_counter()
+        for r0 in range(0, n, 1 << 18):
+            mm[r0:r0 + (1 << 18)] = _lib.pack_rows_host(host[r0:r0 + (1 << 18)])
+        mm.flush()
+        del mm
+        print("\npacked the DB on one host thread in %.2f s (%.1f GB/s of int8)" % (time.perf_counter() - t0, gbytes / (time.perf_counter() - t0)))
+        packed_file_rates(shm_p2, "PACKED flat file (2 bits per call) in %s, 16 threads" % args.shm_dir, cold=False)
     finally:
         os.remove(shm)
+        if os.path.exists(shm_p2):
+            os.remove(shm_p2)
     disk = os.path.join(args.disk_dir, "snpm_time_loader.npy")
     try:
         t0 = time.perf_counter()
@@ -137,6 +168,19 @@ def main():
         print("\nwrote %s in %.2f s" % (disk, time.perf_counter() - t0))
         file_rates(disk, "flat file on disk (%s), cache dropped before every read, 16 threads" % args.disk_dir, cold=True)
         file_rates(disk, "the same file, warm (page cache)", cold=False)
+        os.remove(disk)
+        disk_p2 = os.path.join(args.disk_dir, "snpm_time_loader.p2.npy")
+        try:
+            mm = np.lib.format.open_memmap(disk_p2, mode="w+", dtype=np.uint8, shape=(n, (n_acc + 3) // 4))
+            for r0 in range(0, n, 1 << 18):
+                mm[r0:r0 + (1 << 18)] = _lib.pack_rows_host(host[r0:r0 + (1 << 18)])
+            mm.flush()
+            del mm
+            os.sync()
+            packed_file_rates(disk_p2, "PACKED flat file on disk (%s), cache dropped before every read" % args.disk_dir, cold=True)
+        finally:
+            if os.path.exists(disk_p2):
+                os.remove(disk_p2)
     finally:
         if os.path.exists(disk):
             os.remove(disk)
