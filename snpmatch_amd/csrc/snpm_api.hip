@@ -106,6 +106,7 @@ struct snpm_ctx {
     int occ_cap = 0;          // SNPM_OCC_CAP=n: at most n resident blocks per CU in the fast pass (experiments)
     int full_occupancy = 0;   // SNPM_FULL_OCCUPANCY=1: as many resident blocks as the occupancy API allows
     int bits_path = 1;     // SNPM_BITS=0: hard-call samples on packed panels go through k_fast_packed_q4 like any other
+    int64_t long_scan_rows = 2000000;   // SNPM_LONG_SCAN_ROWS: queries of at least this many rows walk LONG_TILE_ROWS-row tiles (int8 fast pass); -1: never
     // live panels of this context: snpm_destroy releases their device memory and orphans them (and their
     // queries), so that a panel / query handle freed AFTER its context is a harmless host-side delete
     std::vector<snpm_panel *> panels;
@@ -360,6 +361,7 @@ int wait_upload(snpm_panel *p)
 // ---- launch geometry of the fast pass ---------------------------------------------------------
 struct FastGeom {
     int bpl, wpb;
+    int tile_rows = TILE_ROWS;
     int64_t n_wc, n_colblocks, n_parts, part_rows;
     int64_t n_epochs, n_slots, n_groups;      // partial slots = n_epochs * n_parts, reduced in groups
 };
@@ -388,6 +390,7 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
 {
     FastGeom g;
     g.bpl = bpl;
+    g.tile_rows = tile_rows;
     const int64_t span = (int64_t)WAVE * bpl;
     g.n_wc = std::max<int64_t>(1, (n_acc + span - 1) / span);
     if (ctx->force_wpb >= 1 && ctx->force_wpb <= MAX_WAVES_PER_BLOCK) {
@@ -419,7 +422,7 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     // 5000 x 12.5M), while 6- to 8-wave blocks and short scans (1135 x 11M, 14 GB) are 1-3 % better at full
     // occupancy.  The part count stays a multiple of the CU count either way (uneven counts cost 5-10 %).
     const int64_t pitch_bytes = ((n_acc + 255) / 256) * 256;
-    if (bpl == 4 && tile_rows == TILE_ROWS && occ_blocks_hint > 0 && !ctx->full_occupancy && (g.wpb == 4 || g.wpb == 5) &&
+    if (bpl == 4 && occ_blocks_hint > 0 && !ctx->full_occupancy && (g.wpb == 4 || g.wpb == 5) &&
         n * pitch_bytes >= (int64_t(32) << 30))
         occ = std::min(occ, std::max(3, 18 / g.wpb));
     // Full 8-wave blocks (n_acc within 8 waves of a multiple of 2048): TWO resident blocks per CU instead of the three that fit
@@ -427,7 +430,7 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     // (round 3, profiles/r03b_ab_occ_cap*.txt: 10 000 x 20M 0.791 -> 0.808 of HBM peak, 8192 x 24M 0.767 -> 0.787, 16 384 x 12M
     // 0.758 -> 0.779, 6144 x 30M 0.822 -> 0.833, 20 480 x 9M 0.805 -> 0.821, 4096 x 40M 0.796 -> 0.804, 2048 x 50M equal), while
     // 5- and 7-wave blocks lose 10-25 % with it (1252 / 2500 / 5000 / 12 500 accessions) and keep their own cap above.
-    if (bpl == 4 && tile_rows == TILE_ROWS && occ_blocks_hint > 0 && !ctx->full_occupancy && g.wpb == 8 &&
+    if (bpl == 4 && occ_blocks_hint > 0 && !ctx->full_occupancy && g.wpb == 8 &&
         n * pitch_bytes >= (int64_t(4) << 30))
         occ = std::min(occ, 2);
     if (ctx->occ_cap > 0) occ = std::min(occ, ctx->occ_cap);
@@ -454,8 +457,13 @@ int launch_fast_t(snpm_query *q, const FastGeom &g)
     dim3 grid((unsigned)g.n_colblocks, (unsigned)g.n_parts);
     dim3 block(WAVE * g.wpb);
     ProfScope ps(ctx, PK_FAST);
-    hipLaunchKernelGGL((k_fast<BPL, SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0,
-                       q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
+    if (BPL == 4 && g.tile_rows == LONG_TILE_ROWS)          // long scans: tiles of LONG_TILE_ROWS rows (fast_tile_rows)
+        hipLaunchKernelGGL((k_fast<BPL, SKIP, GATHER, NT, false, (BPL == 4 ? LONG_TILE_ROWS : TILE_ROWS)>), grid, block, 0, ctx->stream, p->d,
+                           p->pitch, q->d_row_idx, q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p,
+                           p->ld, (const int64_t *)nullptr);
+    else
+        hipLaunchKernelGGL((k_fast<BPL, SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0,
+                           q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }
@@ -594,7 +602,7 @@ double efast_bound(const snpm_query *q, const FastGeom &g)
 {
     const double u = 1.1102230246251565e-16;
     // a term passes through <= EPOCH_TILES*TILE_ROWS adds inside k_fast, REDUCE_GROUP in its group, n_groups after
-    const double m = (double)(std::min<int64_t>(g.part_rows, (int64_t)EPOCH_TILES * TILE_ROWS) + REDUCE_GROUP + g.n_groups + 2);
+    const double m = (double)(std::min<int64_t>(g.part_rows, (int64_t)EPOCH_TILES * std::max(g.tile_rows, TILE_ROWS)) + REDUCE_GROUP + g.n_groups + 2);
     return (q->wsum * (m * u / (1.0 - m * u))) * 1.0000001;
 }
 
@@ -603,6 +611,16 @@ struct Certify {            // what the last reduce step of a fast pass should c
     bool flag = true;       // false: only the bound is prepared (slab-streamed jobs certify their totals at the end)
     int64_t chunk = 1000, chunks_after = 0;
 };
+
+// rows per LUT tile of the fast pass for this query: packed panels have their own tile sizes; the int8 kernel walks longer tiles
+// on long scans (LONG_TILE_ROWS, snpm_kernels.hpp), where the part count is bounded by the resident blocks, not by the tiles
+int fast_tile_rows(const snpm_query *q, bool bits)
+{
+    const snpm_panel *p = q->panel;
+    if (p->packed) return bits ? BITS_TILE_ROWS : Q4_TILE_ROWS * Q4_RUN;
+    const bool long_tiles = q->n >= p->ctx->long_scan_rows && pick_bpl(p->ctx, p->n_acc) == 4;
+    return long_tiles ? LONG_TILE_ROWS : TILE_ROWS;
+}
 
 // fast pass + ordered reduce -> q->d_score / q->d_ninfo (+ the list of accessions the certificate cannot vouch
 // for, left on the device); returns the geometry used
@@ -617,7 +635,7 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     const bool p16 = p->packed != 0;
     const int bpl = p16 ? 16 : pick_bpl(ctx, p->n_acc);
     const bool bits = p16 && q->hard01 && ctx->bits_path;      // counts instead of weighted sums
-    const int tile_rows = p16 ? (bits ? BITS_TILE_ROWS : Q4_TILE_ROWS * Q4_RUN) : TILE_ROWS;
+    const int tile_rows = fast_tile_rows(q, bits);
     // k_fast_bits has no LDS tile and no barrier: one wave per block fills every wave slot of a CU evenly (measured on the
     // packed 10k x 50M panel: 22.4 ms with 1- or 2-wave blocks, 26.9 ms with the 5-wave blocks of the LUT kernels, 30.7 with 3)
     // k_fast_packed_q4: 4-wave blocks (one wave per SIMD; 33.5 ms against 34.5 with 5-wave blocks on 10 000 accessions,
@@ -1263,6 +1281,7 @@ try {
     if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
     if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
     if (const char *s = getenv("SNPM_BITS")) ctx->bits_path = atoi(s);
+    if (const char *s = getenv("SNPM_LONG_SCAN_ROWS")) ctx->long_scan_rows = atoll(s) < 0 ? INT64_MAX : atoll(s);
     if (const char *s = getenv("SNPM_FULL_OCCUPANCY")) ctx->full_occupancy = atoi(s);
     if (const char *s = getenv("SNPM_OCC_CAP")) ctx->occ_cap = atoi(s);
     if (const char *s = getenv("SNPM_F1_SLAB_BYTES")) ctx->f1_slab_bytes = std::max<int64_t>(1, atoll(s));
@@ -1769,7 +1788,8 @@ try {
     const double eref = *(const double *)ctx->h_pinned;
     const bool p16 = q->panel->packed != 0;
     const int bpl = p16 ? 16 : pick_bpl(ctx, q->panel->n_acc);
-    FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl, p16 ? std::min(BITS_TILE_ROWS, Q4_TILE_ROWS) : TILE_ROWS);   // occ 1, short tiles -> longest parts -> largest bound
+    // occ 1 -> the fewest, longest parts -> the largest bound; the tile size the run uses (the bound counts epochs of its tiles)
+    FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl, p16 ? std::min(BITS_TILE_ROWS, Q4_TILE_ROWS) : fast_tile_rows(q, false));
     *bound = eref + efast_bound(q, g);
     return SNPM_OK;
 } SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))

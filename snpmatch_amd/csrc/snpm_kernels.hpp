@@ -64,6 +64,14 @@ namespace snpm {
 #endif
 constexpr int WAVE = 64;
 constexpr int TILE_ROWS = 128;          // rows per LDS LUT tile (4 KiB); also the SWAR counter flush period (<= 255)
+#ifndef SNPM_LONG_TILE_ROWS
+#define SNPM_LONG_TILE_ROWS 248
+#endif
+// Long scans of the int8 fast pass (>= 2M rows) walk tiles of 248 rows: half as many barriers / LUT-tile loads per row
+// (round 3, profiles/r03c_ab_tile_rows.txt: 10 000 x 20M 0.819 -> 0.828 of HBM peak, 12 500 x 16M 0.779 -> 0.796, 8192 x 24M
+// 0.805 -> 0.811, 1252 / 2500 x 50M unchanged); short queries, batches and windows keep 128 (more tiles = more parts to spread).
+constexpr int LONG_TILE_ROWS = SNPM_LONG_TILE_ROWS;
+static_assert(LONG_TILE_ROWS % 8 == 0 && LONG_TILE_ROWS <= 255 && TILE_ROWS <= 255, "two prefetch groups per iteration; byte counters of missing calls are flushed once per tile");
 constexpr int LUT_ROW_BYTES = 32;       // 4 x fp64
 constexpr int MAX_WAVES_PER_BLOCK = 8;
 constexpr int EPOCH_TILES = 64;         // k_fast writes its partial sums out (and restarts them) every 64 of its tiles
@@ -292,7 +300,7 @@ __device__ __forceinline__ void load_row(const int8_t *p, uint32_t (&x)[BPL / 4]
 // [part_desc[3p], part_desc[3p+1]) of the (concatenated) matched list -- never more than EPOCH_TILES tiles, all inside
 // one segment -- and writes its partial sums to slot part_desc[3p+2]; k_reduce_seg adds the slots of a segment in
 // order.  Without SEG the arguments part_desc is unused and the code is the tile-interleaved pass described above.
-template <int BPL, bool SKIP, bool GATHER, bool NT, bool SEG = false>
+template <int BPL, bool SKIP, bool GATHER, bool NT, bool SEG = false, int TR = TILE_ROWS>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (BPL <= 4 ? SNPM_FAST_MIN_WAVES : 1))
 k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
        const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
@@ -304,7 +312,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     constexpr int EPL = BPL;
     // rows per prefetch group: 4 (G*32 B = half a 256-B LUT block); 8-row groups spill at the 80-VGPR budget and measured no gain
     constexpr int G = SNPM_FAST_G;
-    __shared__ __attribute__((aligned(256))) double s_lut[2][TILE_ROWS * 4];
+    __shared__ __attribute__((aligned(256))) double s_lut[2][TR * 4];
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -315,14 +323,14 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     const bool lane_on = byte0 < pitch && col0 < ld;
     const int64_t p = SEG ? (int64_t)blockIdx.y + (int64_t)gridDim.y * blockIdx.z : (int64_t)blockIdx.y;
     if (SEG && p >= n) return;             // SEG: n is the number of parts (grid.y * grid.z may exceed it)
-    // tiles of this block: T = T0, T0 + TS, ... < n_tiles_total; tile T = rows [rbase + T * TILE_ROWS, ...) up to rend
+    // tiles of this block: T = T0, T0 + TS, ... < n_tiles_total; tile T = rows [rbase + T * TR, ...) up to rend
     const int64_t rbase = SEG ? part_desc[3 * p] : 0;
     const int64_t rend = SEG ? part_desc[3 * p + 1] : n;
     const int64_t P = SEG ? 1 : (int64_t)gridDim.y;               // tile stride
     const int64_t T0 = SEG ? 0 : p;
     const int64_t slot0 = SEG ? part_desc[3 * p + 2] : p;         // partial slot of epoch 0 (epoch e: slot0 + e * slot_stride)
     const int64_t slot_stride = SEG ? 1 : (int64_t)gridDim.y;
-    const int64_t n_tiles_total = (rend - rbase + TILE_ROWS - 1) / TILE_ROWS;
+    const int64_t n_tiles_total = (rend - rbase + TR - 1) / TR;
 
     double acc[EPL];
     uint32_t miss16[NDW * 2];               // packed 2 x u16 per register, flushed from packed u8 every tile
@@ -375,15 +383,15 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     if (T0 < n_tiles_total) {
         // first LUT tile -> LDS; first group in flight
         {
-            const int64_t tr0 = rbase + T0 * TILE_ROWS;
-            const int rows2 = 2 * (int)((rend - tr0 < TILE_ROWS) ? (rend - tr0) : TILE_ROWS);
+            const int64_t tr0 = rbase + T0 * TR;
+            const int rows2 = 2 * (int)((rend - tr0 < TR) ? (rend - tr0) : TR);
             const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * tr0);
             double2 *dst = reinterpret_cast<double2 *>(&s_lut[0][0]);
             for (int i = tid; i < rows2; i += nthr) dst[i] = src[i];
         }
         uint32_t xa[G][NDW], xb[G][NDW];
 #pragma unroll
-        for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rbase + T0 * TILE_ROWS + u), xa[u]);
+        for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rbase + T0 * TR + u), xa[u]);
         __syncthreads();
 
         int buf = 0;
@@ -396,15 +404,15 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
                 tiles_in_epoch = 0;
             }
             ++tiles_in_epoch;
-            const int64_t tr0 = rbase + T * TILE_ROWS;
-            const int rows = (int)((rend - tr0 < TILE_ROWS) ? (rend - tr0) : TILE_ROWS);
+            const int64_t tr0 = rbase + T * TR;
+            const int rows = (int)((rend - tr0 < TR) ? (rend - tr0) : TR);
             const bool more = (T + P < n_tiles_total);
-            const int64_t ntr0 = more ? rbase + (T + P) * TILE_ROWS : tr0;      // my next tile (or a harmless re-read)
+            const int64_t ntr0 = more ? rbase + (T + P) * TR : tr0;      // my next tile (or a harmless re-read)
             // stage the next LUT tile (256 double2) in ONE register pair per thread when the block has
             // >= 256 threads; narrower blocks copy it synchronously at the end of the tile instead
             double2 pre0 = make_double2(0.0, 0.0);
-            const bool staged = more && nthr >= TILE_ROWS * 2;
-            const int nrows2 = more ? 2 * (int)((rend - ntr0 < TILE_ROWS) ? (rend - ntr0) : TILE_ROWS) : 0;
+            const bool staged = more && nthr >= TR * 2;
+            const int nrows2 = more ? 2 * (int)((rend - ntr0 < TR) ? (rend - ntr0) : TR) : 0;
 #if !defined(SNPM_FAST_PATTERN_ONLY) || SNPM_FAST_PATTERN_ONLY != 2
             if (staged && tid < nrows2) pre0 = reinterpret_cast<const double2 *>(lut + 4 * ntr0)[tid];
 #endif
@@ -438,7 +446,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
             for (; g + 2 <= full_groups; g += 2) {
                 const int64_t rnext = tr0 + (int64_t)(g + 1) * G;
                 // the group after the pair: inside this tile, or the first group of my next tile
-                const int64_t rafter = (g + 2 < TILE_ROWS / G) ? rnext + G : ntr0;
+                const int64_t rafter = (g + 2 < TR / G) ? rnext + G : ntr0;
                 // ---- group g (data in xa); request group g+1 into xb
 #pragma unroll
                 for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rnext + u), xb[u]);
@@ -459,7 +467,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
                 const uint32_t roff4 = (uint32_t)(r & 7) * 0x20202020u;        // (r & 7) * 32 in every byte
                 SCORE_ROW(0, x, group_base, roff4, (uint32_t)(r & 7) * 32u);
             }
-            // flush packed u8 counters (<= TILE_ROWS <= 255 per byte) into packed u16 pairs
+            // flush packed u8 counters (<= TR <= 255 per byte) into packed u16 pairs
 #pragma unroll
             for (int k = 0; k < NDW; ++k) {
                 miss16[2 * k + 0] += miss8[k] & 0x00ff00ffu;          // bytes 0 and 2
@@ -470,7 +478,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
             if (more) {
                 double2 *dst = reinterpret_cast<double2 *>(&s_lut[buf ^ 1][0]);
                 if (staged) {
-                    if (tid < TILE_ROWS * 2) dst[tid] = pre0;
+                    if (tid < TR * 2) dst[tid] = pre0;
                 } else {
                     const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * ntr0);
                     for (int i = tid; i < nrows2; i += nthr) dst[i] = src[i];

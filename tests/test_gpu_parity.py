@@ -577,11 +577,26 @@ def test_packed_large_panel_equals_int8(ctx):
 
 
 def test_fuzz_random_configurations(ctx):
+    _fuzz_random_configurations(ctx, 300, 20260101)
+
+
+def test_fuzz_random_configurations_on_long_tiles():
+    """the same differential check when every int8 query walks 248-row LUT tiles (what scans of >= 2M rows use)"""
+    os.environ["SNPM_LONG_SCAN_ROWS"] = "1"
+    try:
+        c = engine.Context(0)
+    finally:
+        del os.environ["SNPM_LONG_SCAN_ROWS"]
+    _fuzz_random_configurations(c, 120, 20261004)
+    c.close()
+
+
+def _fuzz_random_configurations(ctx, n_cases, seed):
     """300 seeded random configurations (shape, chunk, skip_hets, dense / gathered / repeated rows, int8 / packed,
     weight mix incl. zero rows and weights > 1 capped by ninfo) against the C oracle:
     strict mode = fp64 bits, default mode = counts + certified bound, windows = fp64 bits."""
-    rng = np.random.default_rng(20260101)
-    for case in range(300):
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
         n_snp = int(rng.integers(1, 7000))
         n_acc = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 700, 1135, 2049]))
         packed = bool(rng.integers(0, 2))
@@ -623,17 +638,22 @@ def test_fuzz_random_configurations(ctx):
         panel.free()
 
 
-def test_fuzz_long_parts_multi_epoch():
+@pytest.mark.parametrize("long_tiles", [False, True])
+def test_fuzz_long_parts_multi_epoch(long_tiles):
     """Same differential check with the fast pass forced into few, long parts (several accumulation epochs
-    per part, partial last tiles, odd tile counts), int8 and packed."""
+    per part, partial last tiles, odd tile counts), int8 and packed; ``long_tiles``: every int8 query walks the 248-row tiles
+    that long scans (>= 2M rows) use (SNPM_LONG_SCAN_ROWS=1)."""
     os.environ["SNPM_DEBUG_MAX_PARTS"] = "3"
+    if long_tiles:
+        os.environ["SNPM_LONG_SCAN_ROWS"] = "1"
     try:
         c = engine.Context(0)
     finally:
         del os.environ["SNPM_DEBUG_MAX_PARTS"]
+        os.environ.pop("SNPM_LONG_SCAN_ROWS", None)
     rng = np.random.default_rng(77)
     for case in range(30):
-        n_snp = int(rng.choice([8191, 8192, 8193, 24576, 24577, 30001, 49153, 70000]))
+        n_snp = int(rng.choice([8191, 8192, 8193, 24576, 24577, 30001, 49153, 70000, 15872, 15873, 47617]))
         n_acc = int(rng.choice([3, 64, 257, 1135, 4200]))      # 4200: blocks of >= 256 threads (register-staged LUT tiles)
         packed = bool(rng.integers(0, 2))
         skip = bool(rng.integers(0, 2))
