@@ -106,7 +106,7 @@ struct snpm_ctx {
     int occ_cap = 0;          // SNPM_OCC_CAP=n: at most n resident blocks per CU in the fast pass (experiments)
     int full_occupancy = 0;   // SNPM_FULL_OCCUPANCY=1: as many resident blocks as the occupancy API allows
     int bits_path = 1;     // SNPM_BITS=0: hard-call samples on packed panels go through k_fast_packed_q4 like any other
-    int64_t pitch_align = 64;           // SNPM_PITCH_ALIGN: bytes a panel row is padded to (a multiple of 64)
+    int64_t pitch_align = 256;          // SNPM_PITCH_ALIGN: bytes a panel row is padded to (a multiple of 64; experiments)
     int64_t long_scan_rows = 2000000;   // SNPM_LONG_SCAN_ROWS: queries of at least this many rows walk LONG_TILE_ROWS-row tiles (int8 fast pass); -1: never
     // live panels of this context: snpm_destroy releases their device memory and orphans them (and their
     // queries), so that a panel / query handle freed AFTER its context is a harmless host-side delete
@@ -118,7 +118,7 @@ struct snpm_ctx {
 struct snpm_panel {
     snpm_ctx *ctx = nullptr;
     int64_t n_snp = 0, n_acc = 0;
-    int64_t pitch = 0;                  // bytes per SNP row (int8: >= n_acc; packed: >= n_acc / 4), multiple of 64 (ctx->pitch_align)
+    int64_t pitch = 0;                  // bytes per SNP row (int8: >= n_acc; packed: >= n_acc / 4), multiple of ctx->pitch_align (256)
     int64_t ld = 0;                     // accessions per row rounded up to 256: leading dimension of result arrays
     int packed = 0;                     // 0 = int8 (one byte per call), 1 = 2 bits per call (4 accessions per byte)
     int8_t *d = nullptr;
@@ -1439,9 +1439,10 @@ try {
     p->n_acc = n_acc;
     p->packed = packed ? 1 : 0;
     p->ld = ((n_acc + 255) / 256) * 256;
-    // Row pitch: whole 64-B sectors (round 2 padded rows to 256 B, the width of a wave's read: 10 000 accessions -> 10 240 B,
-    // 2.4 % of every pass read for nothing; lanes past the pitch are masked and re-read byte 0, so 10 048 B per row now move).
-    // SNPM_PITCH_ALIGN=256 restores the old layout (experiments).
+    // Row pitch: padded to 256 B, the width of a wave's read (10 000 accessions -> 10 240 B: 2.4 % of every pass is padding).
+    // Round 3 tried whole 64-B sectors instead (SNPM_PITCH_ALIGN=64: lanes past the pitch are masked, 10 048 B per row move; all
+    // tests pass): 1135 x 11M +3 %, 2500 x 50M +1 %, but 10 000 x 20M 0.816 -> 0.784 and 5000 x 40M 0.787 -> 0.740 of HBM peak
+    // (profiles/r03e_ab_pitch.txt) -- a wave's 256-B read that straddles two 256-B units costs more than the padding saves.
     const int64_t align = ctx->pitch_align;
     p->pitch = packed ? (((n_acc + 3) / 4 + align - 1) / align) * align : ((n_acc + align - 1) / align) * align;
     // PREFETCH_PAD_ROWS extra rows: the fast pass prefetches (and never scores) a few rows past a part

@@ -503,7 +503,7 @@ def test_packed_panel_modes_vs_oracle(ctx, n_snp, n_acc, n_match, chunk, skip):
         db[:, 2] = -1
         db[::5, 3] = -7                    # any negative value is "missing"
     panel = engine.Panel.from_host(ctx, db, packed=True)
-    assert panel.packed and panel.pitch == ((n_acc + 3) // 4 + 63) // 64 * 64          # rows are padded to whole 64-B sectors
+    assert panel.packed and panel.pitch == ((n_acc + 3) // 4 + 255) // 256 * 256
     back = panel.download_rows(0, n_snp)
     assert np.array_equal(back, np.where(db < 0, -1, db))
     if n_match is None:

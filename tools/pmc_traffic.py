@@ -31,7 +31,7 @@ write = per_kernel(sys.argv[2], "WRITE_SIZE")
 n_acc = int(os.environ.get("PMC_N_ACC", "10000"))
 n_snp = int(os.environ.get("PMC_N_SNP", "6250000"))
 packed = os.environ.get("PMC_PACKED", "0") == "1"
-align = int(os.environ.get("SNPM_PITCH_ALIGN", "64"))           # rows are padded to whole 64-B sectors since round 3 (256 before)
+align = int(os.environ.get("SNPM_PITCH_ALIGN", "256"))          # bytes a panel row is padded to
 pitch = ((n_acc + 3) // 4 + align - 1) // align * align if packed else (n_acc + align - 1) // align * align
 calib_bytes = n_snp * pitch
 calib_fetch = sum(fetch["k_calib_read"]) / len(fetch["k_calib_read"]) * 1024.0
