@@ -213,7 +213,10 @@ class Genotype(object):
                 self._panel = self._member_panel(ctx or engine.default_context(), self._shard[0], self._shard[1], packed)
                 return self._panel
             group = None
-            if ctx is None:
+            # several GPUs from one process: when asked for (SNPMATCH_GPUS), or by default for DBs of at least 1 GiB -- below
+            # that one GPU loads and scores the DB faster than a communicator is set up
+            big = int(self.g.snps.shape[0]) * n_acc >= (1 << 30)
+            if ctx is None and (big or os.environ.get("SNPMATCH_GPUS", "") != ""):
                 ids = engine.group_devices()
                 if ids is not None:
                     group = engine.default_group(engine.GroupPanel.usable_members(n_acc, len(ids)))
