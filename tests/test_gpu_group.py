@@ -68,7 +68,6 @@ def test_rccl_group_of_one_equals_plain_run():
         d_s, d_n = q.run_device(1000, False, engine.MODE_EXACT)
         assert group.gather([d_s], [d_n], 1135, host=False) == {}
         gs, gn = group.gathered_ptrs(0)
-        l2, _ = np.empty(1135), np.empty(1135)
         import torch
         t_l = torch.empty(1135, dtype=torch.float64, device="cuda:0")
         t_r = torch.empty(1135, dtype=torch.float64, device="cuda:0")
