@@ -603,7 +603,11 @@ double efast_bound(const snpm_query *q, const FastGeom &g)
 {
     const double u = 1.1102230246251565e-16;
     // a term passes through <= EPOCH_TILES*TILE_ROWS adds inside k_fast, REDUCE_GROUP in its group, n_groups after
-    const double m = (double)(std::min<int64_t>(g.part_rows, (int64_t)EPOCH_TILES * std::max(g.tile_rows, TILE_ROWS)) + REDUCE_GROUP + g.n_groups + 2);
+    // (int8 kernel: an accumulator takes one addition per row of its epoch = EPOCH_TILES tiles of g.tile_rows rows; the packed
+    // kernels add pre-summed quads of rows or run on integer weights only: the static_asserts beside Q4_RUN keep them below
+    // EPOCH_TILES * TILE_ROWS additions per epoch)
+    const int64_t epoch_adds = (int64_t)EPOCH_TILES * (g.bpl == 4 ? std::max(g.tile_rows, TILE_ROWS) : TILE_ROWS);
+    const double m = (double)(std::min<int64_t>(g.part_rows, epoch_adds) + REDUCE_GROUP + g.n_groups + 2);
     return (q->wsum * (m * u / (1.0 - m * u))) * 1.0000001;
 }
 

@@ -238,3 +238,27 @@ def test_group_handle_survives_its_context():
     assert np.array_equal(bits(out["score"]), bits(want_s)) and np.array_equal(out["ninfo"], want_n)
     group.free()
     ctx.close()
+
+
+def test_back_to_back_gathers_do_not_race():
+    """60 gathers in a row without host synchronisation in between (results left on the devices), alternating two different
+    shard results: every member's gathered vector is the one of ITS gather -- over the loopback transport (send buffers are
+    rewritten while other members may still be copying the previous ones) and over an RCCL group of one rank"""
+    import torch
+    n_acc = 1135
+    for n_members, loopback in ((3, True), (1, False)):
+        group = engine.Group.local([0] * n_members, loopback=loopback)
+        bounds = group.local_shards(n_acc)
+        vals = []
+        for v in range(2):
+            vals.append([(torch.full((b[1] - b[0],), float(100 * v + i), dtype=torch.float64, device="cuda:0"),
+                          torch.full((b[1] - b[0],), 7 * v + i, dtype=torch.int64, device="cuda:0")) for i, b in enumerate(bounds)])
+        torch.cuda.synchronize()
+        for it in range(60):
+            v = it % 2
+            group.gather([t[0].data_ptr() for t in vals[v]], [t[1].data_ptr() for t in vals[v]], n_acc, host=False)
+        out = group.gather([t[0].data_ptr() for t in vals[1]], [t[1].data_ptr() for t in vals[1]], n_acc)
+        want_s = np.concatenate([np.full(b[1] - b[0], 100.0 + i) for i, b in enumerate(bounds)])
+        want_n = np.concatenate([np.full(b[1] - b[0], 7 + i) for i, b in enumerate(bounds)])
+        assert np.array_equal(out["score"], want_s) and np.array_equal(out["ninfo"], want_n)
+        group.free()
