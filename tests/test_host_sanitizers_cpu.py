@@ -84,3 +84,22 @@ def test_hdf5_reader_under_asan_and_ubsan(tmp_path, golden_dir):
     assert lines[-1] == "done" and len(lines) == 124
     assert lines[0].startswith("toy_db.hdf5 rc=0 objects=4") and lines[1].startswith("toy_db.acc.hdf5 rc=0 objects=4")
     assert lines[2].startswith("stress.hdf5 rc=0 objects=10")
+
+
+def test_loader_building_blocks_under_tsan_and_asan(tmp_path):
+    """csrc/snpm_hostpool.hpp (thread pool, 2-bit packer, non-temporal copies, exact / O_DIRECT reads) under ThreadSanitizer and
+    under AddressSanitizer + UBSan: SURVEY 5 "race detection" for the threaded part of the loader"""
+    src = os.path.join(ROOT, "tests", "loader_tsan_driver.cpp")
+    for name, flags in (("tsan", ["-fsanitize=thread"]), ("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=all"])):
+        exe = str(tmp_path / ("loader_driver_" + name))
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-pthread"] + flags +
+                              ["-I", CSRC, src, "-o", exe])
+        work = tmp_path / name
+        work.mkdir()
+        env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1", ASAN_OPTIONS="detect_leaks=1",
+                   UBSAN_OPTIONS="print_stacktrace=1")
+        env.pop("LD_PRELOAD", None)
+        r = subprocess.run([exe, str(work)], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, (name, r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+        assert "ThreadSanitizer" not in r.stderr and "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+        assert "fails=0" in r.stdout and r.stdout.strip().endswith("done")
