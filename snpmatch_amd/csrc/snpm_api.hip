@@ -478,7 +478,16 @@ int launch_fast_b(snpm_query *q, const FastGeom &g, bool skip, bool gather)
 }
 
 // block shape of k_fast_packed_q4 (a wave covers 1024 accessions): see run_fast
-static int q4_waves_per_block(int64_t n_acc) { return (n_acc + 1023) / 1024 == 5 ? 5 : 4; }
+// waves per block of k_fast_packed_q4 (a wave covers 1024 accessions): 4, except one 5-wave block for panels of exactly five waves
+// and full 8-wave blocks when the width is a multiple of eight waves (round 3, profiles/r03g_ab_q4_wpb.txt: 8192 x 50M 21.1 ->
+// 19.9 ms = 0.65 of HBM peak on packed bytes; a block builds its tables once for eight waves instead of four).  Widths in between
+// keep 4-wave blocks: their last block carries idle waves (10 000 accessions: 2 of 12), which is what holds that shape at 0.55.
+static int q4_waves_per_block(int64_t n_acc)
+{
+    const int64_t n_wc = (n_acc + 1023) / 1024;
+    if (n_wc == 5) return 5;
+    return (n_wc % 8 == 0) ? 8 : 4;
+}
 
 // packed panels, 16 accessions per lane (k_fast_packed_q4)
 template <bool SKIP, bool GATHER, bool NT>
