@@ -478,18 +478,28 @@ int launch_fast_b(snpm_query *q, const FastGeom &g, bool skip, bool gather)
 }
 
 // block shape of k_fast_packed_q4 (a wave covers 1024 accessions): see run_fast
-// waves per block of k_fast_packed_q4 (a wave covers 1024 accessions): 4, except one 5-wave block for panels of exactly five waves
-// and full 8-wave blocks when the width is a multiple of eight waves (round 3, profiles/r03g_ab_q4_wpb.txt: 8192 x 50M 21.1 ->
-// 19.9 ms = 0.65 of HBM peak on packed bytes; a block builds its tables once for eight waves instead of four).  Widths in between
-// keep 4-wave blocks: their last block carries idle waves (10 000 accessions: 2 of 12), which is what holds that shape at 0.55.
+// Waves per block of k_fast_packed_q4 (a wave covers 1024 accessions; a block builds its four-row tables once for all its waves, and
+// the waves of the last block that lie past the panel only help with that).  Round 3 sweep (profiles/r03g_ab_q4_wpb*.txt): panels of up
+// to eight waves run as ONE block of exactly that many waves (6144 accessions 0.476 -> 0.556 of HBM peak on packed bytes, 7000
+// 0.53 -> 0.588, 8192 0.61 -> 0.65); wider panels take the block size among 4, 7 and 8 waves that launches the fewest waves (ties: the
+// larger block): 13 312 -> 7-wave blocks 0.519 -> 0.576, 14 336 -> 7 (0.546 -> 0.598), 15 360 / 16 384 / 24 576 -> 8 (0.577 -> 0.616,
+// 0.60 -> 0.63), 9216 / 10 000 / 11 264 / 12 288 stay on 4-wave blocks (5- and 6-wave blocks lose 10-30 % there).
 static int q4_waves_per_block(int64_t n_acc)
 {
     const int64_t n_wc = (n_acc + 1023) / 1024;
-    if (n_wc == 5) return 5;
-    return (n_wc % 8 == 0) ? 8 : 4;
+    if (n_wc <= 8) return (int)n_wc;
+    int best = 4;
+    int64_t best_waves = (n_wc + 3) / 4 * 4;
+    for (int w : {7, 8}) {
+        const int64_t waves = (n_wc + w - 1) / w * w;
+        if (waves <= best_waves) {
+            best = w;
+            best_waves = waves;
+        }
+    }
+    return best;
 }
 
-// packed panels, 16 accessions per lane (k_fast_packed_q4)
 template <bool SKIP, bool GATHER, bool NT>
 int launch_p16_t(snpm_query *q, const FastGeom &g, int *occ_out, int threads)
 {
