@@ -94,6 +94,7 @@ struct snpm_ctx {
     // tunables (environment)
     int force_bpl = 0;
     int force_wpb = 0;
+    int q4_tile_rows = 0;               // SNPM_Q4_TILE_ROWS: rows per LDS tile of k_fast_packed_q4 (0: by block size)
     int parts_mult = 1;
     int use_acc_major = 1;  // keep an accession-major packed copy (+25 % memory) for contiguous re-evaluation reads
     int64_t acc_major_min_rows = 1000000;   // ... once a query is long enough for the strided path to hurt
@@ -500,31 +501,45 @@ static int q4_waves_per_block(int64_t n_acc)
     return best;
 }
 
-template <bool SKIP, bool GATHER, bool NT>
+// rows per LDS tile of k_fast_packed_q4 by block size (see the kernel): blocks of fewer than four waves take smaller tiles so that
+// LDS does not bound the resident waves of a CU (SNPM_Q4_TILE_ROWS = 16 / 32 / 64 forces one size)
+static int q4_tile_rows(const snpm_ctx *ctx, int wpb)
+{
+    if (ctx->q4_tile_rows == 16 || ctx->q4_tile_rows == 32 || ctx->q4_tile_rows == 64) return ctx->q4_tile_rows;
+    return wpb >= 4 ? 64 : (wpb >= 2 ? 32 : 16);
+}
+
+template <bool SKIP, bool GATHER, bool NT, int TR>
 int launch_p16_t(snpm_query *q, const FastGeom &g, int *occ_out, int threads)
 {
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
     if (occ_out) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_packed_q4<SKIP, GATHER, NT>, threads, 0) != hipSuccess) nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_fast_packed_q4<SKIP, GATHER, NT, false, TR>, threads, 0) != hipSuccess) nb = 0;
         *occ_out = nb;
         return SNPM_OK;
     }
     dim3 grid((unsigned)g.n_colblocks, (unsigned)g.n_parts);
     dim3 block(WAVE * g.wpb);
     ProfScope ps(ctx, PK_FAST);
-    hipLaunchKernelGGL((k_fast_packed_q4<SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx,
-                       q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
+    hipLaunchKernelGGL((k_fast_packed_q4<SKIP, GATHER, NT, false, TR>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx,
+                       q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, p->n_acc);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }
 
 int launch_p16(snpm_query *q, const FastGeom &g, bool skip, bool gather, bool nt, int *occ_out, int threads)
 {
-#define P16_CASE(S, G, N) if (skip == S && gather == G && nt == N) return launch_p16_t<S, G, N>(q, g, occ_out, threads)
-    P16_CASE(false, false, false); P16_CASE(false, false, true); P16_CASE(false, true, false); P16_CASE(false, true, true);
-    P16_CASE(true, false, false);  P16_CASE(true, false, true);  P16_CASE(true, true, false);  P16_CASE(true, true, true);
+    const int tr = q4_tile_rows(q->panel->ctx, threads / WAVE);
+#define P16_CASE(S, G, N)                                                                           \
+    if (skip == S && gather == G && nt == N) {                                                      \
+        if (tr == 16) return launch_p16_t<S, G, N, 16>(q, g, occ_out, threads);                     \
+        if (tr == 32) return launch_p16_t<S, G, N, 32>(q, g, occ_out, threads);                     \
+        return launch_p16_t<S, G, N, 64>(q, g, occ_out, threads);                                   \
+    }
+    P16_CASE(false, false, false) P16_CASE(false, false, true) P16_CASE(false, true, false) P16_CASE(false, true, true)
+    P16_CASE(true, false, false)  P16_CASE(true, false, true)  P16_CASE(true, true, false)  P16_CASE(true, true, true)
 #undef P16_CASE
     return SNPM_ERR_STATE;
 }
@@ -948,14 +963,22 @@ static int launch_q4_seg(snpm_ctx *ctx, const SegJob &j, dim3 grid, dim3 block, 
     snpm_panel *p = j.p;
     const bool gather = j.d_row_idx != nullptr;
     ProfScope ps(ctx, PK_FAST);
+    const int tr = q4_tile_rows(ctx, (int)(block.x / WAVE));
+#define LAUNCH_SEG_TR(S, G, TR)                                                                                   \
+    hipLaunchKernelGGL((k_fast_packed_q4<S, G, NT, true, TR>), grid, block, 0, ctx->stream, p->d, p->pitch, j.d_row_idx, j.row0, \
+                       n_parts, j.d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, p->n_acc, d_desc)
 #define LAUNCH_SEG(S, G)                                                                                          \
-    hipLaunchKernelGGL((k_fast_packed_q4<S, G, NT, true>), grid, block, 0, ctx->stream, p->d, p->pitch, j.d_row_idx, j.row0, \
-                       n_parts, j.d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, d_desc)
+    do {                                                                                                          \
+        if (tr == 16) LAUNCH_SEG_TR(S, G, 16);                                                                    \
+        else if (tr == 32) LAUNCH_SEG_TR(S, G, 32);                                                               \
+        else LAUNCH_SEG_TR(S, G, 64);                                                                             \
+    } while (0)
     if (j.skip) {
         if (gather) LAUNCH_SEG(true, true); else LAUNCH_SEG(true, false);
     } else {
         if (gather) LAUNCH_SEG(false, true); else LAUNCH_SEG(false, false);
     }
+#undef LAUNCH_SEG_TR
 #undef LAUNCH_SEG
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
@@ -1303,6 +1326,7 @@ try {
     if (const char *s = getenv("SNPM_FORCE_BPL")) ctx->force_bpl = atoi(s);
     if (const char *s = getenv("SNPM_PARTS_MULT")) ctx->parts_mult = std::max(1, atoi(s));
     if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
+    if (const char *s = getenv("SNPM_Q4_TILE_ROWS")) ctx->q4_tile_rows = atoi(s);
     if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
     if (const char *s = getenv("SNPM_BITS")) ctx->bits_path = atoi(s);
     if (const char *s = getenv("SNPM_PITCH_ALIGN")) ctx->pitch_align = std::max<int64_t>(64, (atoll(s) + 63) / 64 * 64);

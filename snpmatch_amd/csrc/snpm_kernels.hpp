@@ -37,6 +37,7 @@
 //   k_patch, k_calib_read: small helpers.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace snpm {
@@ -47,6 +48,12 @@ namespace snpm {
 #ifndef SNPM_Q4_SWZ
 #define SNPM_Q4_SWZ 1                   // k_fast_packed_q4: table index bit 1 ^= low bit of the fourth row's call, bit 3 ^= high bits of rows 3, 4 (level 2): the
 #endif                                  // frequent entries (all calls ref / alt) land in 16 distinct LDS bank pairs instead of 8; 0 = the plain field index
+#ifndef SNPM_Q4_PHASES
+#define SNPM_Q4_PHASES 1                // k_fast_packed_q4: a last wave with <= 32 lanes inside the panel splits its lanes over row groups (see the kernel)
+#endif
+#ifndef SNPM_Q4_PROTO_QUAD
+#define SNPM_Q4_PROTO_QUAD 0            // 1: timing experiment only (results are wrong): k_fast_packed_q4 without its 4 x 16 transpose
+#endif
 #ifndef SNPM_Q4_MIN_WAVES
 #define SNPM_Q4_MIN_WAVES 4
 #endif
@@ -524,7 +531,7 @@ constexpr int Q4_RUN = 4;               // tiles a part scores in a row before i
 // per term); k_fast_bits only runs on all-integer weights (bound 0), but its counters still have to hold an epoch.
 static_assert(EPOCH_TILES * BITS_TILE_ROWS <= 65535, "k_fast_bits: an epoch overflows the 16-bit counters");
 static_assert(EPOCH_TILES * Q4_RUN * Q4_TILE_ROWS <= 65535, "k_fast_packed_q4: an epoch overflows the 16-bit counters");
-static_assert(EPOCH_TILES * Q4_RUN * Q4_TILE_ROWS / 4 + 3 <= EPOCH_TILES * TILE_ROWS,
+static_assert(EPOCH_TILES * Q4_RUN * Q4_TILE_ROWS / 4 + 3 + 8 <= EPOCH_TILES * TILE_ROWS,          // + the phase additions of a phased wave
               "k_fast_packed_q4: more additions per term and epoch than efast_bound assumes");
 static_assert(Q4_TILE_ROWS % (2 * Q4_G) == 0 && Q4_TILE_ROWS <= 127, "two register sets per iteration; 7-bit missing counters per tile");
 
@@ -539,23 +546,47 @@ static_assert(Q4_TILE_ROWS % (2 * Q4_G) == 0 && Q4_TILE_ROWS <= 127, "two regist
 // SEG (batches of samples, windows of a cross: as in k_fast): part p scores the contiguous rows [part_desc[3p],
 // part_desc[3p+1]) of the concatenated matched list -- all inside one segment, never more than EPOCH_TILES tiles of k_fast
 // (8192 rows: one slot, no epochs) -- and writes its partial sums to slot part_desc[3p+2]; n is the number of parts.
-template <bool SKIP, bool GATHER, bool NT, bool SEG = false>
+// TR_: rows per tile = TR_ / 4 tables of 2 KiB in LDS.  64 for blocks of four waves and more; narrow panels run blocks of one
+// to three waves, and with 34 KiB each only four of those fit a CU (1135 accessions: 8 resident waves, 512 and fewer: 4 -- one
+// per SIMD): their tiles have 16 (one wave) or 32 rows (two, three), so that LDS stops bounding the resident waves.
+template <bool SKIP, bool GATHER, bool NT, bool SEG = false, int TR_ = Q4_TILE_ROWS>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, SNPM_Q4_MIN_WAVES)
 k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
                  const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
-                 const int64_t *__restrict__ part_desc = nullptr)
+                 int64_t n_acc, const int64_t *__restrict__ part_desc = nullptr)
 {
     constexpr int G = Q4_G;
-    constexpr int TR = Q4_TILE_ROWS;
+    constexpr int TR = TR_;
     constexpr int NQ = TR / 4;
+    constexpr int NG = TR / G;
+    static_assert(TR % (2 * G) == 0 && TR <= Q4_TILE_ROWS && Q4_TILE_ROWS % TR == 0, "two register sets per iteration; whole tiles per run");
     __shared__ __attribute__((aligned(256))) double s_tab[NQ * 256];
     __shared__ __attribute__((aligned(16))) double s_l4[TR * 4];       // the tile's 4-entry LUT rows (table build only)
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
-    const int64_t byte0 = ((int64_t)blockIdx.x * nthr + tid) * 4;      // 4 bytes = 16 accessions per lane and row
+    // PHASED waves (narrow panels and the ragged end of any panel): a wave whose first dword lies t <= 32 dwords before the
+    // end of the row would run its whole instruction stream for t lanes -- on the 1135 accessions of the 1001 Genomes panel
+    // (71 dwords) the second wave scored 7 lanes at the price of 64.  Such a wave instead gives lane l the dword l % t of
+    // the row groups (8 rows) ph_j + ph * i of every tile, ph_j = l / t < ph = min(8, 64 / t): it walks a tile in
+    // ceil(8 / ph) steps instead of 8, looks its four-row tables up at a per-lane offset, and adds its ph phases together
+    // (lanes of phase 0, in phase order) before it writes partial sums.  Every term passes through FEWER additions than
+    // in an ordinary wave (its phase's share of the quads + ph - 1 <= 7 phase additions).
+    const int lane = tid & (WAVE - 1);
+    const int64_t dw_first = (int64_t)blockIdx.x * nthr + __builtin_amdgcn_readfirstlane(tid - lane);   // first dword of my wave (scalar)
+    const int64_t dw_end = (pitch / 4 < (n_acc + 15) / 16) ? pitch / 4 : (n_acc + 15) / 16;   // dwords of a row that hold accessions
+    int ph_t = 0, ph = 1;                               // wave-uniform
+    if (SNPM_Q4_PHASES && dw_first < dw_end && dw_end - dw_first <= WAVE / 2) {
+        ph_t = (int)(dw_end - dw_first);
+        ph = (WAVE / ph_t < NG) ? WAVE / ph_t : NG;
+    }
+    const bool phased = ph > 1;
+    const int ph_j = phased ? lane / ph_t : 0;           // my phase
+    const int n_it = (NG + ph - 1) / ph;                // steps per tile of a phased wave
+    const int64_t my_dw = phased ? dw_first + (lane - ph_j * ph_t) : (int64_t)blockIdx.x * nthr + tid;
+    const int64_t byte0 = my_dw * 4;                    // 4 bytes = 16 accessions per lane and row
     const int64_t col0 = byte0 * 4;
-    const bool lane_on = byte0 < pitch && col0 < ld;
+    const bool lane_on = phased ? (ph_j < ph) : (byte0 < pitch && col0 < ld);
     const bool wave_on = __any(lane_on) != 0;           // wave-uniform
     const int64_t p = SEG ? (int64_t)blockIdx.y + (int64_t)gridDim.y * blockIdx.z : (int64_t)blockIdx.y;
     if (SEG && p >= n) return;             // whole blocks leave (grid.y * grid.z may exceed the number of parts)
@@ -568,7 +599,7 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     const int64_t slot_stride = SEG ? 1 : (int64_t)gridDim.y;
     // parts interleave in RUNS of Q4_RUN tiles (the host's tile = one run: k_fast_bits gained 2-4 % from longer contiguous
     // pieces per part); my tiles are k = 0, 1, 2, ...: run T0 + (k / RUN) * P, tile k % RUN inside it
-    constexpr int RUN = SEG ? 1 : Q4_RUN;
+    constexpr int RUN = SEG ? 1 : Q4_RUN * (Q4_TILE_ROWS / TR);
     const int64_t n_tiles_total = (rend - rbase + TR - 1) / TR;
     auto tile_of = [&](int64_t k) -> int64_t { return (T0 + (k / RUN) * P) * RUN + (k % RUN); };
 
@@ -580,7 +611,8 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
 #pragma unroll
     for (int i = 0; i < 8; ++i) miss16[i] = 0;
 
-    const uint32_t lane_off = lane_on ? (uint32_t)byte0 : 0u;
+    // phased lanes: + the first row of my phase's group (32 bits hold it: 56 rows of at most 2^25 bytes)
+    const uint32_t lane_off = lane_on ? (uint32_t)byte0 + (uint32_t)(ph_j * G) * (uint32_t)pitch : 0u;
     uint32_t three = 3u;                                   // shift count of the table index (SDWA takes no literal)
     asm volatile("" : "+v"(three));
     auto load = [&](int64_t rr) -> uint32_t {
@@ -658,7 +690,22 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         p1 = p2 = p4 = p8 = p16 = p32 = p64 = 0;
     };
     auto store_partials = [&](int64_t epoch) {
-        if (lane_on) {
+        if (phased) {                           // wave-uniform: every lane takes part in the shuffles
+            for (int sft = 1; sft < ph; ++sft) {
+                const int src = lane + sft * ph_t;          // phase 0 receives phase sft (src < 64 there)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const double v = __shfl(acc[i], src);
+                    if (ph_j == 0) acc[i] += v;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t v = (uint32_t)__shfl((int)miss16[i], src);
+                    if (ph_j == 0) miss16[i] += v;
+                }
+            }
+        }
+        if (lane_on && ph_j == 0) {
             double *os = out_score + (slot0 + epoch * slot_stride) * ld + col0;
             uint32_t *om = out_miss + (slot0 + epoch * slot_stride) * ld + col0;
 #pragma unroll
@@ -688,7 +735,7 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     //   w[0] byte m = accession 4m, w[1] byte m = accession 4m+1, w[2]: 4m+2, w[3]: 4m+3
     // (an index with the calls' low bits in bits 0-3 -- ref and alt entries of all four rows in distinct LDS banks -- costs
     // the same 24 operations and measured 8 % SLOWER: the pass is bound by instruction issue, not by the LDS array)
-    auto score_quad = [&](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, const double *tab) {
+    auto score_quad = [&](uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, const double *tab, uint32_t lane_tab = 0u) {
         // the pass is bound by VALU issue: every step below is pinned to the one instruction it needs (the compiler expands
         // the merges into and / and / or and the byte extractions into shift + and: 6.2 instead of 4.2 VALU per lookup)
         const uint32_t M3 = 0x33333333u, MF = 0x0F0F0F0Fu;
@@ -709,7 +756,7 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         const uint32_t e01 = bfi(M3, l01, l23 << 2), o01 = bfi(M3, l01 >> 2, l23);      // nibbles [lo0 lo1 lo2 lo3]
         const uint32_t e23 = bfi(M3, h01, h23 << 2), o23 = bfi(M3, h01 >> 2, h23);      // nibbles [hi0 hi1 hi2 hi3]
 #else
-#if SNPM_Q4_SWZ
+#if SNPM_Q4_SWZ && !SNPM_Q4_PROTO_QUAD
         // The LDS bank pair of an entry is its index mod 32 = c0 | c1 << 2 | (c2 & 1) << 4: the sixteen entries whose calls are
         // all ref / alt (3 of 4 lookups on real panels) share EIGHT bank pairs, entries that differ in the fourth row's call
         // always collide -- 63 % of the LDS-array cycles were bank-conflict cycles (profiles/r02b_sq_fast_packed_q4.txt).
@@ -725,10 +772,23 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         const uint32_t e23 = bfi(M3, x2, x3 << 2), o23 = bfi(M3, x2 >> 2, x3);
 #endif
         uint32_t w[4];
+#if SNPM_Q4_PROTO_QUAD
+        // TIMING EXPERIMENT ONLY (wrong results): the four dwords taken as ready-made index bytes, i.e. what the lookup would
+        // cost on a panel stored four rows per byte (tools/ab_q4_proto_quad.sh)
+        (void)e01; (void)o01; (void)e23; (void)o23; (void)MF;
+        w[0] = x0; w[1] = x1; w[2] = x2; w[3] = x3;
+#if SNPM_Q4_SWZ
+        // the bank swizzle of the shipped kernel on ready-made index bytes (a real four-rows-per-byte panel would store
+        // the swizzled bytes: these 8 operations per 16 lookups would not exist)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = __builtin_amdgcn_bitop3_b32(w[j], w[j] >> 5, 0x02020202u, 0x78);
+#endif
+#else
         w[0] = bfi(MF, e01, e23 << 4);
         w[1] = bfi(MF, o01, o23 << 4);
         w[2] = bfi(MF, e01 >> 4, e23);
         w[3] = bfi(MF, o01 >> 4, o23);
+#endif
         const char *tabc = reinterpret_cast<const char *>(tab);
 #define Q4_IDX(D, W, SEL)                                                                                             \
     asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL              \
@@ -743,7 +803,7 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             }
             double t[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) t[c] = *reinterpret_cast<const double *>(tabc + a8[c]);
+            for (int c = 0; c < 8; ++c) t[c] = *reinterpret_cast<const double *>(tabc + (a8[c] + lane_tab));
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[8 * h + c] += t[c];
         }
@@ -780,17 +840,44 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         if (tid < TR * 4) s_l4[tid] = pre;
         for (int i = tid + nthr; i < TR * 4; i += nthr) s_l4[i] = (tr + (i >> 2) < rend) ? lut[4 * tr + i] : 0.0;
     };
+    // phased waves: the G rows of my phase's group in step `it` of the tile that starts at matched row tr (`rows` of it exist)
+    auto ph_load = [&](uint32_t (&x)[G], int64_t tr, int rows, int it) {
+        const int grp = it * ph + ph_j;
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const bool on = lane_on && grp * G + u < rows;              // grp < NG follows (rows <= TR)
+            if constexpr (GATHER) {
+                x[u] = 0u;
+                if (on) {
+                    const uint32_t *ptr = reinterpret_cast<const uint32_t *>(db + row_idx[tr + grp * G + u] * pitch + byte0);
+                    x[u] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
+                }
+            } else {
+                x[u] = on ? load(tr + (int64_t)it * ph * G + u) : 0u;   // lane_off carries my phase's rows
+            }
+        }
+    };
     int64_t last_epoch = 0;
 
-    if (tile_of(0) < n_tiles_total) {
+    // The walk over my tiles, in two exclusive copies: ordinary waves and phased waves (PH).  One loop with both kinds of
+    // scoring inside kept the scalars and row registers of both alive at once (72 scalar and 47 vector registers spilled, and
+    // every reload waits for ALL loads in flight: the kernel ran at a quarter of its speed); the barriers of the two copies
+    // pair up because every wave of a block walks the same tiles.
+    auto walk = [&](auto ph_tag) {
+        constexpr bool PH = decltype(ph_tag)::value;
+        if (!(tile_of(0) < n_tiles_total)) return;
         // two register sets of G rows (a third one, 16 to 24 row loads in flight per lane, measured no gain)
         uint32_t xa[G], xb[G];
         {
             const int64_t tr_first = rbase + tile_of(0) * TR;
             const double pre = fetch_l4(tr_first, true);
             const int rows0 = (int)((rend - tr_first < TR) ? (rend - tr_first) : TR);
+            if constexpr (PH) {
+                ph_load(xa, tr_first, rows0, 0);
+            } else {
 #pragma unroll
-            for (int u = 0; u < G; ++u) xa[u] = (wave_on && u < rows0) ? load(tr_first + u) : 0u;
+                for (int u = 0; u < G; ++u) xa[u] = (wave_on && u < rows0) ? load(tr_first + u) : 0u;
+            }
             store_l4(tr_first, pre);
         }
         __syncthreads();
@@ -813,7 +900,25 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             const int64_t ntr0 = more ? rbase + Tn * TR : tr0;             // my next tile (or a harmless re-read)
             const double pre = fetch_l4(ntr0, more);               // waited for at the end of this tile
 
-            if (!wave_on) {
+            if constexpr (PH) {
+                // xa holds step 0 of this tile; the step after the current one (or step 0 of my next tile) is requested first
+                const int nrows = more ? (int)((rend - ntr0 < TR) ? (rend - ntr0) : TR) : 0;
+                for (int it = 0; it < n_it; ++it) {
+                    if (it + 1 < n_it) ph_load(xb, tr0, rows, it + 1);
+                    else ph_load(xb, ntr0, nrows, 0);
+#pragma unroll
+                    for (int u = 0; u < G; ++u) asm volatile("" : "+v"(xa[u]));
+                    const int grp = it * ph + ph_j;
+                    if (lane_on && grp * G < rows) {          // rows of the group past the end read as 0 against table rows of 0.0
+                        const uint32_t lane_tab = (uint32_t)grp * (2u * 256u * (uint32_t)sizeof(double));
+                        score_quad(xa[0], xa[1], xa[2], xa[3], s_tab, lane_tab);
+                        score_quad(xa[4], xa[5], xa[6], xa[7], s_tab + 256, lane_tab);
+                        count_group(xa);
+                    }
+#pragma unroll
+                    for (int u = 0; u < G; ++u) xa[u] = xb[u];
+                }
+            } else if (!wave_on) {
                 // a wave whose lanes all lie past the last accession only helps to build the tables
             } else if (rows == TR) {
 #pragma unroll
@@ -846,7 +951,9 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             __syncthreads();
         }
         last_epoch = epoch;
-    }
+    };
+    if (phased) walk(std::true_type{});
+    else walk(std::false_type{});
     store_partials(last_epoch);
 }
 #undef Q4_CSA

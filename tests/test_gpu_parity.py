@@ -525,6 +525,58 @@ def test_packed_panel_modes_vs_oracle(ctx, n_snp, n_acc, n_match, chunk, skip):
     assert np.array_equal(ni, want_n) and np.max(np.abs(s - want_s)) <= bound
 
 
+@pytest.mark.parametrize("max_parts", [0, 2])
+def test_packed_phased_waves(max_parts):
+    """k_fast_packed_q4 gives the lanes of a last wave that covers <= 32 dwords of the row to row groups (phases): every
+    phase count (2, 3, 4, 5, 6, 8) and the widths just outside the rule, dense and gathered rows, partial last tiles and
+    groups, one long multi-epoch part per column block (SNPM_DEBUG_MAX_PARTS) as well as many short ones, a batch of samples
+    (the segmented launch) -- informative counts exact, scores inside the certified bound, integer parts equal."""
+    if max_parts:
+        os.environ["SNPM_DEBUG_MAX_PARTS"] = str(max_parts)
+    try:
+        c = engine.Context(0)
+    finally:
+        os.environ.pop("SNPM_DEBUG_MAX_PARTS", None)
+    rng = np.random.default_rng(4711 + max_parts)
+    # accessions -> dwords in the last wave -> phases: 512 -> 32 -> 2, 300 -> 19 -> 3, 250 -> 16 -> 4, 170 -> 11 -> 5,
+    # 1184 -> 10 -> 6, 1135 -> 7 -> 8, 16 -> 1 -> 8, 1530 -> 32 -> 2, 2400 -> 22 -> 2; 513 / 1025 + 528: 33 dwords, not phased
+    for n_acc in (512, 300, 250, 170, 1184, 1135, 16, 1530, 2400, 513, 1553):
+        n_snp = int(rng.choice([1, 5, 63, 64, 71, 1000, 16389, 40003] if not max_parts else [16389, 40003, 70001]))
+        db = rand_db(rng, n_snp, n_acc)
+        db[:, n_acc - 1] = -1                       # the last accession: no informative site
+        panel = engine.Panel.from_host(c, db, packed=True)
+        for gathered in (False, True):
+            rows = None
+            n = n_snp
+            if gathered:
+                n = max(1, n_snp - int(rng.integers(0, 50)))
+                rows = np.sort(rng.choice(n_snp, size=n, replace=False)).astype(np.int64)
+            wei = rand_wei(rng, n)
+            skip = bool(rng.integers(0, 2))
+            want_s, want_n = c_oracle.genotyper(db, rows, wei, 1000, skip)
+            q = engine.Query(panel, rows, wei)
+            for mode in (engine.MODE_FAST, engine.MODE_EXACT):
+                s, ni = q.run(1000, skip, mode)
+                tag = "%d x %d gathered=%s skip=%s mode=%d" % (n_snp, n_acc, gathered, skip, mode)
+                assert np.array_equal(ni, want_n), tag
+                assert np.max(np.abs(s - want_s)) <= q.error_bound(1000), tag
+            assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int)), tag
+            q.free()
+        if n_snp >= 1000 and not max_parts:
+            samples = []
+            for b in range(5):
+                nb = int(rng.integers(1, n_snp))
+                r = np.sort(rng.choice(n_snp, size=nb, replace=False)).astype(np.int64)
+                samples.append((r, rand_wei(rng, nb)))
+            got = engine.score_batch(panel, samples, 1000, False, engine.MODE_EXACT, likelihoods=False)
+            for b, (r, w) in enumerate(samples):
+                want_s, want_n = c_oracle.genotyper(db, r, w, 1000, False)
+                assert np.array_equal(got["ninfo"][b], want_n), (n_acc, b)
+                assert np.array_equal(np.array(got["score"][b], dtype=np.int64), np.array(want_s, dtype=np.int64)), (n_acc, b)
+        panel.free()
+    c.close()
+
+
 def test_packed_panel_misc(ctx, golden_dir):
     # codes > 2 cannot be stored
     with pytest.raises(AssertionError, match="packed panel"):
