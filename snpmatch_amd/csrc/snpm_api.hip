@@ -559,7 +559,7 @@ int launch_bits_t(snpm_query *q, const FastGeom &g, int *occ_out, int threads)
     ProfScope ps(ctx, PK_FAST);
     hipLaunchKernelGGL((k_fast_bits<SKIP, GATHER, NT>), dim3((unsigned)g.n_colblocks, (unsigned)g.n_parts), dim3(WAVE * g.wpb), 0,
                        ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, q->n, (const uint8_t *)q->d_wbits,
-                       (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
+                       (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, p->n_acc);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }

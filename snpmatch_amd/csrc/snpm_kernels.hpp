@@ -572,8 +572,13 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     // ceil(8 / ph) steps instead of 8, looks its four-row tables up at a per-lane offset, and adds its ph phases together
     // (lanes of phase 0, in phase order) before it writes partial sums.  Every term passes through FEWER additions than
     // in an ordinary wave (its phase's share of the quads + ph - 1 <= 7 phase additions).
-    const int lane = tid & (WAVE - 1);
-    const int64_t dw_first = (int64_t)blockIdx.x * nthr + __builtin_amdgcn_readfirstlane(tid - lane);   // first dword of my wave (scalar)
+    // Values that are needed once per tile or once per epoch (lane, phase, column, LDS / LUT addresses of the tile refill) are
+    // recomputed from a thread index the compiler cannot hoist (tid_now): kept alive across the scoring loop they were
+    // spilled, and a reload in the wrong place waits for every row load in flight -- or worse: this compiler placed spill
+    // stores in front of the s_or that ends a divergent region (the SEG / dense / 32-row-tile build lost ph_j and col0 of the
+    // lanes that had been inactive there and wrote garbage counts; tests/test_gpu_batch.py::test_dense_windows_on_narrow_packed_panels).
+    auto tid_now = [&]() -> int { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; };
+    const int64_t dw_first = (int64_t)blockIdx.x * nthr + __builtin_amdgcn_readfirstlane(tid & ~(WAVE - 1));   // first dword of my wave (scalar)
     const int64_t dw_end = (pitch / 4 < (n_acc + 15) / 16) ? pitch / 4 : (n_acc + 15) / 16;   // dwords of a row that hold accessions
     int ph_t = 0, ph = 1;                               // wave-uniform
     if (SNPM_Q4_PHASES && dw_first < dw_end && dw_end - dw_first <= WAVE / 2) {
@@ -581,27 +586,37 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         ph = (WAVE / ph_t < NG) ? WAVE / ph_t : NG;
     }
     const bool phased = ph > 1;
-    const int ph_j = phased ? lane / ph_t : 0;           // my phase
     const int n_it = (NG + ph - 1) / ph;                // steps per tile of a phased wave
-    const int64_t my_dw = phased ? dw_first + (lane - ph_j * ph_t) : (int64_t)blockIdx.x * nthr + tid;
-    const int64_t byte0 = my_dw * 4;                    // 4 bytes = 16 accessions per lane and row
-    const int64_t col0 = byte0 * 4;
-    const bool lane_on = phased ? (ph_j < ph) : (byte0 < pitch && col0 < ld);
+    // (my phase, my dword, am I inside the panel) -- cheap enough to derive again wherever they are needed
+    auto my_phase = [&]() -> int { return phased ? (tid_now() & (WAVE - 1)) / ph_t : 0; };
+    auto my_dword = [&](int phj) -> int64_t {
+        const int t = tid_now();
+        return phased ? dw_first + ((t & (WAVE - 1)) - phj * ph_t) : (int64_t)blockIdx.x * nthr + t;
+    };
+    auto lane_inside = [&](int phj, int64_t dw) -> bool { return phased ? (phj < ph) : (dw * 4 < pitch && dw * 16 < ld); };
+    bool lane_on;
+    uint32_t lane_off;                                  // byte offset of my dword in a row (+ the first row of my phase's group: 32 bits hold 56 rows of <= 2^25 bytes)
+    {
+        const int phj = my_phase();
+        const int64_t dw = my_dword(phj);
+        lane_on = lane_inside(phj, dw);
+        lane_off = lane_on ? (uint32_t)(dw * 4) + (uint32_t)(phj * G) * (uint32_t)pitch : 0u;
+    }
     const bool wave_on = __any(lane_on) != 0;           // wave-uniform
     const int64_t p = SEG ? (int64_t)blockIdx.y + (int64_t)gridDim.y * blockIdx.z : (int64_t)blockIdx.y;
     if (SEG && p >= n) return;             // whole blocks leave (grid.y * grid.z may exceed the number of parts)
     // tiles of this block: T = T0, T0 + P, ... ; tile T = rows [rbase + T * TR, ...) up to rend
     const int64_t rbase = SEG ? part_desc[3 * p] : 0;
     const int64_t rend = SEG ? part_desc[3 * p + 1] : n;
-    const int64_t P = SEG ? 1 : (int64_t)gridDim.y;
-    const int64_t T0 = SEG ? 0 : p;
+    const int P = SEG ? 1 : (int)gridDim.y;            // tile indices are 32-bit (a scalar 64-bit compare costs a vector register pair)
+    const int T0 = SEG ? 0 : (int)p;
     const int64_t slot0 = SEG ? part_desc[3 * p + 2] : p;          // partial slot of epoch 0 (epoch e: slot0 + e * slot_stride)
     const int64_t slot_stride = SEG ? 1 : (int64_t)gridDim.y;
     // parts interleave in RUNS of Q4_RUN tiles (the host's tile = one run: k_fast_bits gained 2-4 % from longer contiguous
     // pieces per part); my tiles are k = 0, 1, 2, ...: run T0 + (k / RUN) * P, tile k % RUN inside it
     constexpr int RUN = SEG ? 1 : Q4_RUN * (Q4_TILE_ROWS / TR);
-    const int64_t n_tiles_total = (rend - rbase + TR - 1) / TR;
-    auto tile_of = [&](int64_t k) -> int64_t { return (T0 + (k / RUN) * P) * RUN + (k % RUN); };
+    const int n_tiles_total = (int)((rend - rbase + TR - 1) / TR);
+    auto tile_of = [&](int k) -> int { return (T0 + (k / RUN) * P) * RUN + (k % RUN); };
 
     double acc[16];
     uint32_t miss16[8];                 // miss16[d]: accession d (low half) and d + 8 (high half)
@@ -611,8 +626,6 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
 #pragma unroll
     for (int i = 0; i < 8; ++i) miss16[i] = 0;
 
-    // phased lanes: + the first row of my phase's group (32 bits hold it: 56 rows of at most 2^25 bytes)
-    const uint32_t lane_off = lane_on ? (uint32_t)byte0 + (uint32_t)(ph_j * G) * (uint32_t)pitch : 0u;
     uint32_t three = 3u;                                   // shift count of the table index (SDWA takes no literal)
     asm volatile("" : "+v"(three));
     auto load = [&](int64_t rr) -> uint32_t {
@@ -644,7 +657,7 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     // tables of one tile from its LUT rows in s_l4
     auto build_tables = [&]() {
         // one thread per (table, c0, c1, c2): the three-row prefix once, then the four entries that differ in c3
-        for (int i = tid; i < NQ * 64; i += nthr) {
+        for (int i = tid_now(); i < NQ * 64; i += nthr) {
             const double *L = s_l4 + 16 * (i >> 6);
             const int e = i & 63;
             const double pre3 = (L[e & 3] + L[4 + ((e >> 2) & 3)]) + L[8 + (e >> 4)];
@@ -690,7 +703,9 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         p1 = p2 = p4 = p8 = p16 = p32 = p64 = 0;
     };
     auto store_partials = [&](int64_t epoch) {
+        const int ph_j = my_phase();
         if (phased) {                           // wave-uniform: every lane takes part in the shuffles
+            const int lane = tid_now() & (WAVE - 1);
             for (int sft = 1; sft < ph; ++sft) {
                 const int src = lane + sft * ph_t;          // phase 0 receives phase sft (src < 64 there)
 #pragma unroll
@@ -706,6 +721,7 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             }
         }
         if (lane_on && ph_j == 0) {
+            const int64_t col0 = my_dword(ph_j) * 16;
             double *os = out_score + (slot0 + epoch * slot_stride) * ld + col0;
             uint32_t *om = out_miss + (slot0 + epoch * slot_stride) * ld + col0;
 #pragma unroll
@@ -834,14 +850,16 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     // LUT rows of the tile that starts at matched row tr: TR * 4 doubles, one per thread (0.0 past the end of the list);
     // blocks with fewer than TR * 4 threads copy the rest synchronously
     auto fetch_l4 = [&](int64_t tr, bool on) -> double {
-        return (on && tid < TR * 4 && tr + (tid >> 2) < rend) ? lut[4 * tr + tid] : 0.0;
+        const int t = tid_now();
+        return (on && t < TR * 4 && tr + (t >> 2) < rend) ? (lut + 4 * tr)[t] : 0.0;
     };
     auto store_l4 = [&](int64_t tr, double pre) {
-        if (tid < TR * 4) s_l4[tid] = pre;
-        for (int i = tid + nthr; i < TR * 4; i += nthr) s_l4[i] = (tr + (i >> 2) < rend) ? lut[4 * tr + i] : 0.0;
+        const int t = tid_now();
+        if (t < TR * 4) s_l4[t] = pre;
+        for (int i = t + nthr; i < TR * 4; i += nthr) s_l4[i] = (tr + (i >> 2) < rend) ? (lut + 4 * tr)[i] : 0.0;
     };
     // phased waves: the G rows of my phase's group in step `it` of the tile that starts at matched row tr (`rows` of it exist)
-    auto ph_load = [&](uint32_t (&x)[G], int64_t tr, int rows, int it) {
+    auto ph_load = [&](uint32_t (&x)[G], int64_t tr, int rows, int it, int ph_j) {
         const int grp = it * ph + ph_j;
 #pragma unroll
         for (int u = 0; u < G; ++u) {
@@ -849,7 +867,7 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             if constexpr (GATHER) {
                 x[u] = 0u;
                 if (on) {
-                    const uint32_t *ptr = reinterpret_cast<const uint32_t *>(db + row_idx[tr + grp * G + u] * pitch + byte0);
+                    const uint32_t *ptr = reinterpret_cast<const uint32_t *>(db + row_idx[tr + grp * G + u] * pitch + my_dword(ph_j) * 4);
                     x[u] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
                 }
             } else {
@@ -866,14 +884,15 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     auto walk = [&](auto ph_tag) {
         constexpr bool PH = decltype(ph_tag)::value;
         if (!(tile_of(0) < n_tiles_total)) return;
+        const int ph_j = PH ? my_phase() : 0;
         // two register sets of G rows (a third one, 16 to 24 row loads in flight per lane, measured no gain)
         uint32_t xa[G], xb[G];
         {
-            const int64_t tr_first = rbase + tile_of(0) * TR;
+            const int64_t tr_first = rbase + (int64_t)tile_of(0) * TR;
             const double pre = fetch_l4(tr_first, true);
             const int rows0 = (int)((rend - tr_first < TR) ? (rend - tr_first) : TR);
             if constexpr (PH) {
-                ph_load(xa, tr_first, rows0, 0);
+                ph_load(xa, tr_first, rows0, 0, ph_j);
             } else {
 #pragma unroll
                 for (int u = 0; u < G; ++u) xa[u] = (wave_on && u < rows0) ? load(tr_first + u) : 0u;
@@ -886,26 +905,26 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
 
         int tiles_in_epoch = 0;
         int64_t epoch = 0;
-        for (int64_t k = 0, T = tile_of(0); T < n_tiles_total; T = tile_of(++k)) {
+        for (int k = 0, T = tile_of(0); T < n_tiles_total; T = tile_of(++k)) {
             if (!SEG && tiles_in_epoch == EPOCH_TILES * RUN) {
                 store_partials(epoch);
                 ++epoch;
                 tiles_in_epoch = 0;
             }
             ++tiles_in_epoch;
-            const int64_t tr0 = rbase + T * TR;
+            const int64_t tr0 = rbase + (int64_t)T * TR;
             const int rows = (int)((rend - tr0 < TR) ? (rend - tr0) : TR);
-            const int64_t Tn = tile_of(k + 1);
+            const int Tn = tile_of(k + 1);
             const bool more = (Tn < n_tiles_total);
-            const int64_t ntr0 = more ? rbase + Tn * TR : tr0;             // my next tile (or a harmless re-read)
+            const int64_t ntr0 = more ? rbase + (int64_t)Tn * TR : tr0;             // my next tile (or a harmless re-read)
             const double pre = fetch_l4(ntr0, more);               // waited for at the end of this tile
 
             if constexpr (PH) {
                 // xa holds step 0 of this tile; the step after the current one (or step 0 of my next tile) is requested first
                 const int nrows = more ? (int)((rend - ntr0 < TR) ? (rend - ntr0) : TR) : 0;
                 for (int it = 0; it < n_it; ++it) {
-                    if (it + 1 < n_it) ph_load(xb, tr0, rows, it + 1);
-                    else ph_load(xb, ntr0, nrows, 0);
+                    if (it + 1 < n_it) ph_load(xb, tr0, rows, it + 1, ph_j);
+                    else ph_load(xb, ntr0, nrows, 0, ph_j);
 #pragma unroll
                     for (int u = 0; u < G; ++u) asm volatile("" : "+v"(xa[u]));
                     const int grp = it * ph + ph_j;
@@ -981,7 +1000,8 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
 template <bool SKIP, bool GATHER, bool NT>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, 6)
 k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
-            const uint8_t *__restrict__ wbits, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
+            const uint8_t *__restrict__ wbits, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
+            int64_t n_acc)
 {
     // Rows are requested in groups of 4 (two register sets: 4 to 8 row loads in flight per lane) and counted in groups of 8;
     // 256-row tiles.  Measured with the arithmetic stripped (tools/micro/read_patterns.hip, this panel's 2560-B rows,
@@ -991,9 +1011,25 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
     constexpr int TR = BITS_TILE_ROWS;
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
-    const int64_t byte0 = ((int64_t)blockIdx.x * nthr + tid) * 4;
+    // PHASED waves, as in k_fast_packed_q4: a wave that starts t <= 32 dwords before the end of the row (the second wave of the
+    // 1135-accession panel holds 7) gives lane l the dword l % t of the 8-row groups ph_j + ph * i of every tile, ph_j = l / t <
+    // ph = min(8, 64 / t), classifies its rows with per-lane weight masks and adds its phases together before it writes its
+    // counts (1024 and 1040 accessions x 40M rows took 1.7 and 3.3 ms: the nearly empty wave cost as much as the full one).
+    constexpr int PH_MAX = 8;
+    const int lane = tid & (WAVE - 1);
+    const int64_t dw_first = (int64_t)blockIdx.x * nthr + __builtin_amdgcn_readfirstlane(tid - lane);   // first dword of my wave (scalar)
+    const int64_t dw_end = (pitch / 4 < (n_acc + 15) / 16) ? pitch / 4 : (n_acc + 15) / 16;   // dwords of a row that hold accessions
+    int ph_t = 0, ph = 1;                               // wave-uniform
+    if (SNPM_Q4_PHASES && dw_first < dw_end && dw_end - dw_first <= WAVE / 2) {
+        ph_t = (int)(dw_end - dw_first);
+        ph = (WAVE / ph_t < PH_MAX) ? WAVE / ph_t : PH_MAX;
+    }
+    const bool phased = ph > 1;
+    const int ph_j = phased ? lane / ph_t : 0;           // my phase
+    const int64_t my_dw = phased ? dw_first + (lane - ph_j * ph_t) : (int64_t)blockIdx.x * nthr + tid;
+    const int64_t byte0 = my_dw * 4;
     const int64_t col0 = byte0 * 4;
-    const bool lane_on = byte0 < pitch && col0 < ld;
+    const bool lane_on = phased ? (ph_j < ph) : (byte0 < pitch && col0 < ld);
     const int64_t p = blockIdx.y;
     const int64_t P = gridDim.y;
     const int64_t n_tiles_total = (n + TR - 1) / TR;
@@ -1004,7 +1040,8 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
 #pragma unroll
     for (int i = 0; i < 8; ++i) hit16[i] = miss16[i] = 0;
 
-    const uint32_t lane_off = lane_on ? (uint32_t)byte0 : 0u;
+    // phased lanes: + the first row of my phase's group
+    const uint32_t lane_off = lane_on ? (uint32_t)byte0 + (uint32_t)(ph_j * 8) * (uint32_t)pitch : 0u;
     auto load = [&](int64_t rr) -> uint32_t {
         const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
         const int8_t *rowbase = db + prow * pitch;
@@ -1068,7 +1105,17 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
         m1 = m2 = m4 = m8 = m16 = m32 = m64 = 0;
     };
     auto store_partials = [&](int64_t epoch) {
-        if (lane_on) {
+        if (phased) {                           // wave-uniform: every lane takes part in the shuffles
+            for (int sft = 1; sft < ph; ++sft) {
+                const int src = lane + sft * ph_t;          // phase 0 receives phase sft (src < 64 there)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t vh = (uint32_t)__shfl((int)hit16[i], src), vm = (uint32_t)__shfl((int)miss16[i], src);
+                    if (ph_j == 0) { hit16[i] += vh; miss16[i] += vm; }
+                }
+            }
+        }
+        if (lane_on && ph_j == 0) {
             double *os = out_score + (epoch * P + p) * ld + col0;
             uint32_t *om = out_miss + (epoch * P + p) * ld + col0;
 #pragma unroll
@@ -1097,7 +1144,7 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
     };
     int64_t last_epoch = 0;
 
-    if (p < n_tiles_total) {
+    if (!phased && p < n_tiles_total) {
         uint32_t xa[H], xb[H];
         // the eight weight bytes of a counting group (one scalar dwordx2) travel with its rows, one group ahead
         auto wbits8 = [&](int64_t r) -> uint64_t { return *reinterpret_cast<const uint64_t *>(wbits + r); };
@@ -1169,6 +1216,68 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
                 classify(load(tr0 + r), wbits[tr0 + r], hb, mb);
                 ripple(hb, h1, h2, h4, h8, h16, h32, h64);
                 ripple(mb, m1, m2, m4, m8, m16, m32, m64);
+            }
+            flush();
+        }
+        last_epoch = epoch;
+    }
+    // the same walk for a phased wave: per step the 8 rows of my phase's group (no second register set: one-wave blocks, the
+    // other resident waves cover the wait), weight bytes and masks per lane
+    if (phased && p < n_tiles_total) {
+        constexpr int NGT = TR / 8;                     // counting groups per tile
+        const int n_it = (NGT + ph - 1) / ph;
+        int tiles_in_epoch = 0;
+        int64_t epoch = 0;
+        for (int64_t T = p; T < n_tiles_total; T += P) {
+            if (tiles_in_epoch == EPOCH_TILES) {
+                store_partials(epoch);
+                ++epoch;
+                tiles_in_epoch = 0;
+            }
+            ++tiles_in_epoch;
+            const int64_t tr0 = T * TR;
+            const int rows = (int)((n - tr0 < TR) ? (n - tr0) : TR);
+            for (int it = 0; it < n_it && it * ph * 8 < rows; ++it) {
+                const int grp = it * ph + ph_j;
+                uint32_t x[8];
+                uint64_t w8 = 0;
+                if (lane_on && grp * 8 < rows) w8 = *reinterpret_cast<const uint64_t *>(wbits + tr0 + grp * 8);   // padded to 8 entries
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const bool on = lane_on && grp * 8 + u < rows;
+                    if constexpr (GATHER) {
+                        x[u] = 0u;
+                        if (on) {
+                            const uint32_t *ptr = reinterpret_cast<const uint32_t *>(db + row_idx[tr0 + grp * 8 + u] * pitch + byte0);
+                            x[u] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
+                        }
+                    } else {
+                        x[u] = on ? load(tr0 + (int64_t)it * ph * 8 + u) : 0u;      // lane_off carries my phase's rows
+                    }
+                }
+                uint32_t hb[8], mb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    // rows past the end: x = 0 and weight byte 0 (a partial last group reads the padding of wbits, which is 0)
+                    const bool on = grp * 8 + u < rows;
+                    classify(x[u], on ? (uint32_t)(w8 >> (8 * u)) & 0xffu : 0u, hb[u], mb[u]);
+                }
+                {
+                    uint32_t t2a_, t2b_, t4a_, t4b_, t8_, c_, d_;
+                    BITS_CSA(t2a_, h1, h1, hb[0], hb[1]); BITS_CSA(t2b_, h1, h1, hb[2], hb[3]);
+                    BITS_CSA(t4a_, h2, h2, t2a_, t2b_);
+                    BITS_CSA(t2a_, h1, h1, hb[4], hb[5]); BITS_CSA(t2b_, h1, h1, hb[6], hb[7]);
+                    BITS_CSA(t4b_, h2, h2, t2a_, t2b_);
+                    BITS_CSA(t8_, h4, h4, t4a_, t4b_);
+                    c_ = h8 & t8_;  h8 ^= t8_;  d_ = h16 & c_;  h16 ^= c_;  c_ = h32 & d_;  h32 ^= d_;  h64 ^= c_;
+                    BITS_CSA(t2a_, m1, m1, mb[0], mb[1]); BITS_CSA(t2b_, m1, m1, mb[2], mb[3]);
+                    BITS_CSA(t4a_, m2, m2, t2a_, t2b_);
+                    BITS_CSA(t2a_, m1, m1, mb[4], mb[5]); BITS_CSA(t2b_, m1, m1, mb[6], mb[7]);
+                    BITS_CSA(t4b_, m2, m2, t2a_, t2b_);
+                    BITS_CSA(t8_, m4, m4, t4a_, t4b_);
+                    c_ = m8 & t8_;  m8 ^= t8_;  d_ = m16 & c_;  m16 ^= c_;  c_ = m32 & d_;  m32 ^= d_;  m64 ^= c_;
+                }
+                if (((it + 1) * 8) % BITS_FLUSH_ROWS == 0) flush();
             }
             flush();
         }

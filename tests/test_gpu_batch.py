@@ -92,6 +92,38 @@ def test_batch_equals_single_runs_and_oracle(packed, skip):
     ctx.close()
 
 
+@pytest.mark.parametrize("n_acc", [257, 1135, 1300, 2048, 2400, 3072])
+def test_dense_windows_on_narrow_packed_panels(n_acc):
+    """The segmented pass on packed panels whose blocks have one to three waves (16- / 32-row tiles, a phased last wave), DENSE
+    rows: certified fast windows against the reference-order windows -- informative counts, integer parts and totals.  (A
+    build of exactly this variant once lost per-lane values to a spill placed inside a divergent region: every column of
+    the full waves came back with garbage counts.)"""
+    ctx = make_ctx()
+    rng = np.random.default_rng(n_acc)
+    for n_snp in (32, 64, 257, 1000, 9000):
+        db = rand_db(rng, n_snp, n_acc)
+        panel = engine.Panel.from_host(ctx, db, packed=True)
+        codes = rng.choice(np.array([0, 1, 2], dtype=np.int8), size=n_snp, p=[0.6, 0.35, 0.05])
+        wei = synth.sample_weights(rng, codes, 0.8)
+        q = engine.Query(panel, None, wei)
+        for off in ([0, n_snp], [0, 1, n_snp], [0, n_snp // 3, 2 * n_snp // 3, n_snp],
+                    np.concatenate([[0], np.sort(rng.integers(0, n_snp + 1, size=6)), [n_snp]]).tolist()):
+            off = np.array(off, dtype=np.int64)
+            ws, wn, ts, tn = q.run_windows(off, False)
+            fs, fn, fts, ftn = q.run_windows(off, False, fast=True)
+            assert np.array_equal(fn, wn) and np.array_equal(ftn, tn), (n_snp, off.tolist())
+            assert np.array_equal(np.array(fs, dtype=np.int64), np.array(ws, dtype=np.int64)), (n_snp, off.tolist())
+            assert np.array_equal(np.array(fts, dtype=np.int64), np.array(ts, dtype=np.int64)), (n_snp, off.tolist())
+            for w in range(len(off) - 1):                         # and the oracle, window by window
+                if off[w + 1] == off[w]:
+                    continue
+                want_s, want_n = c_oracle.genotyper(db[off[w]:off[w + 1]], None, wei[off[w]:off[w + 1]], 1 << 30, False)
+                assert np.array_equal(wn[w], want_n) and np.array_equal(bits(ws[w]), bits(want_s)), (n_snp, w)
+        q.free()
+        panel.free()
+    ctx.close()
+
+
 def test_batch_device_inputs_forced_pairs_and_fallback():
     import torch
     ctx = make_ctx(SNPM_DEBUG_REEVAL=3)          # accessions 0..2 of every sample go through the pair re-evaluation

@@ -527,7 +527,7 @@ def test_packed_panel_modes_vs_oracle(ctx, n_snp, n_acc, n_match, chunk, skip):
 
 @pytest.mark.parametrize("max_parts", [0, 2])
 def test_packed_phased_waves(max_parts):
-    """k_fast_packed_q4 gives the lanes of a last wave that covers <= 32 dwords of the row to row groups (phases): every
+    """k_fast_packed_q4 and k_fast_bits give the lanes of a last wave that covers <= 32 dwords of the row to row groups (phases): every
     phase count (2, 3, 4, 5, 6, 8) and the widths just outside the rule, dense and gathered rows, partial last tiles and
     groups, one long multi-epoch part per column block (SNPM_DEBUG_MAX_PARTS) as well as many short ones, a batch of samples
     (the segmented launch) -- informative counts exact, scores inside the certified bound, integer parts equal."""
@@ -545,19 +545,19 @@ def test_packed_phased_waves(max_parts):
         db = rand_db(rng, n_snp, n_acc)
         db[:, n_acc - 1] = -1                       # the last accession: no informative site
         panel = engine.Panel.from_host(c, db, packed=True)
-        for gathered in (False, True):
+        for gathered, frac_pl in ((False, 0.8), (True, 0.8), (False, 0.0), (True, 0.0)):     # 0.0: hard calls (k_fast_bits)
             rows = None
             n = n_snp
             if gathered:
                 n = max(1, n_snp - int(rng.integers(0, 50)))
                 rows = np.sort(rng.choice(n_snp, size=n, replace=False)).astype(np.int64)
-            wei = rand_wei(rng, n)
+            wei = rand_wei(rng, n, frac_pl)
             skip = bool(rng.integers(0, 2))
             want_s, want_n = c_oracle.genotyper(db, rows, wei, 1000, skip)
             q = engine.Query(panel, rows, wei)
             for mode in (engine.MODE_FAST, engine.MODE_EXACT):
                 s, ni = q.run(1000, skip, mode)
-                tag = "%d x %d gathered=%s skip=%s mode=%d" % (n_snp, n_acc, gathered, skip, mode)
+                tag = "%d x %d gathered=%s pl=%s skip=%s mode=%d" % (n_snp, n_acc, gathered, frac_pl, skip, mode)
                 assert np.array_equal(ni, want_n), tag
                 assert np.max(np.abs(s - want_s)) <= q.error_bound(1000), tag
             assert np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int)), tag
