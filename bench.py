@@ -29,6 +29,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -127,6 +128,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--all-ranks-on-device0", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="init the process group and all-gather even at N=1")
+    ap.add_argument("--group-timeout", type=float, default=120.0,
+                    help="seconds the ranks may take to join the library's RCCL group before all of them fall back to torch.distributed")
     ap.add_argument("--collective", default="c-abi", choices=["c-abi", "torch"],
                     help="who runs the all-gather of the per-accession results at N>1: the library itself (snpm_group_*: RCCL "
                          "communicator inside libsnpmatch_hip.so, one packed all-gather) or torch.distributed")
@@ -220,6 +223,7 @@ def main():
     # If any rank cannot form the group, all of them use torch.distributed for the gather instead (reported in `config`).
     group = None
     collective = "none"
+    stuck_threads = []
     if use_dist:
         collective = "torch.distributed (%s)" % args.backend
         if args.collective == "c-abi" and args.backend == "nccl":
@@ -227,7 +231,26 @@ def main():
             try:
                 box = [engine.Group.unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
-                group = engine.Group.from_rank(ctx, box[0], world, rank)
+                # ncclCommInitRank is collective: a rank that cannot reach its peers would wait for ever.  The driver's
+                # scaling run must end either way, so the join runs beside a watchdog; on a timeout every rank falls back
+                # to torch.distributed (the MIN below) and the process leaves through os._exit at the end.
+                made = {}
+
+                def join_group():
+                    try:
+                        made["group"] = engine.Group.from_rank(ctx, box[0], world, rank)
+                    except Exception as exc:          # noqa: BLE001
+                        made["error"] = exc
+
+                th = threading.Thread(target=join_group, daemon=True)
+                th.start()
+                th.join(args.group_timeout)
+                if th.is_alive():
+                    stuck_threads.append(th)
+                    raise TimeoutError("snpm_group_create_rank did not return within %.0f s" % args.group_timeout)
+                if "error" in made:
+                    raise made["error"]
+                group = made["group"]
                 assert group.shard(n_acc, rank) == (shards.a0, shards.a1), "the library and bench.py disagree about the shards"
             except Exception as e:          # noqa: BLE001
                 sys.stderr.write("rank %d: snpm_group unavailable (%s)\n" % (rank, e))
@@ -489,7 +512,8 @@ def main():
     if use_dist:
         dist.barrier()                  # rank 0 may have spent ~30 s in the CPU baseline
         dist.destroy_process_group()
-    ctx.close()
+    if not stuck_threads:               # a thread still inside ncclCommInitRank holds the context
+        ctx.close()
     if rank == 0:
         # Beside the headline (the int8 panel BASELINE.json names): the same job on the 2-bit packed panel, which fits one GPU
         # whole (125 GB).  A child process after this one has released its memory; a failure there only drops the extra field.
@@ -513,6 +537,8 @@ def main():
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
+    if stuck_threads:
+        os._exit(0)
 
 
 if __name__ == "__main__":
