@@ -135,7 +135,8 @@ def _load_any(path):
         return MemGenotype(d["snps"], d["accessions"], d["positions"], np.asarray(d["chrs"]).astype("U"), d["chr_regions"])
     # The reference's HDF5 DB (pygwas/genotype.py:310-326, :534-673): read by the library's own reader (csrc/snpm_h5.cpp) -- no
     # h5py / libhdf5 needed, and the chunks go from the file through the loader's threads into the staging slabs.  Files in a
-    # format that reader does not take (the "latest" HDF5 file format, other filters) go through h5py where it is installed.
+    # form that reader does not take (unlimited dimensions or more than 8 group members in the "latest" HDF5 file format, other
+    # filters) go through h5py where it is installed.
     from .. import h5 as native_h5
     try:
         f = native_h5.File(path)

@@ -4,14 +4,21 @@
 // so that `-d all_chromosomes_binary.hdf5` works where h5py is not installed and the rows can go straight from the
 // file's chunks into the pinned staging slabs (snpm_loader.hpp).
 //
-// Scope: what h5py / HDF5 1.8-1.10 write with the default ("earliest") format -- superblock version 0 / 1 (2 / 3 are read
-// as far as they point at version-1 object headers), version-1 object headers with continuation blocks, old-style groups
-// (symbol-table B-tree + local heap), data layout message versions 1-3 (compact, contiguous, chunked with a version-1
-// B-tree index), filters gzip (1), shuffle (2), lzf (32000) incl. chunks a filter skipped (filter mask), attributes
-// (message versions 1-3) and datasets of fixed-point / floating-point / fixed-length string / variable-length string
-// (global heap) type, little-endian.  Anything else (version-2 object headers, dense groups / attributes, chunk indexes of
-// the "latest" format, other filters) is refused with a message -- never guessed at.  Every offset read from the file is
-// bounds-checked: a damaged file gives an error, not a fault.  Host only; no GPU, no ctx.
+// Scope: what h5py / HDF5 1.8-1.10 write, in both generations of the file format.
+//   "earliest" (the default, what the reference's writers produce): superblock version 0 / 1, version-1 object headers with
+//   continuation blocks, old-style groups (symbol-table B-tree + local heap), data layout message versions 1-3 (compact,
+//   contiguous, chunked with a version-1 B-tree index);
+//   "latest" (libver='latest'): superblock version 2 / 3, version-2 object headers (OHDR / OCHK chunks, optional times and
+//   creation order), new-style groups with COMPACT link storage (link messages in the header: up to 8 members), data layout
+//   message version 4 with the chunk indexes single-chunk, implicit and fixed array (paged beyond 1024 entries, filtered or
+//   not) -- i.e. every dataset of fixed shape;
+//   in both: filters gzip (1), shuffle (2), lzf (32000) incl. chunks a filter skipped (filter mask), attributes (message
+//   versions 1-3, compact storage) and datasets of fixed-point / floating-point / fixed-length string / variable-length
+//   string (global heap) type, little-endian.
+// Refused BY NAME, never guessed at: datasets with unlimited dimensions in the latest format (extensible-array / version-2
+// B-tree chunk indexes), groups and attributes in dense storage (fractal heaps), shared messages, other filters, virtual
+// datasets.  Every offset read from the file is bounds-checked: a damaged file gives an error, not a fault (ASan / UBSan over
+// 180 damaged copies, tests/test_host_sanitizers_cpu.py).  Host only; no GPU, no ctx.
 #include "snpmatch_hip.h"
 #include "snpm_h5.hpp"
 
@@ -75,8 +82,11 @@ std::atomic<uint64_t> g_next_uid{1};
 struct Object {
     const uint64_t uid = g_next_uid.fetch_add(1);      // identifies the object in the per-thread chunk caches (addresses get reused)
     bool is_dataset = false;
-    // groups
+    // groups: old style (symbol table: B-tree + local heap) or new style (link messages in the object header)
     uint64_t btree = UNDEF, heap = UNDEF;
+    bool new_group = false;
+    std::vector<std::pair<std::string, uint64_t>> links;     // hard links of a new-style group with compact link storage
+    bool is_group() const { return !is_dataset && (btree != UNDEF || new_group); }
     // datasets / attributes
     TypeInfo type;
     int rank = 0;
@@ -86,6 +96,13 @@ struct Object {
     std::vector<uint8_t> compact;
     uint64_t chunk_btree = UNDEF;
     uint64_t chunk_dims[8] = {0};
+    // version-4 layout messages (the "latest" file format) name their chunk index: 0 = version-1 B-tree (older layouts),
+    // 1 single chunk, 2 implicit (chunks one after the other), 3 fixed array
+    int chunk_index = 0;
+    uint64_t chunk_index_addr = UNDEF;
+    bool single_filtered = false;
+    uint64_t single_size = 0;
+    uint32_t single_mask = 0;
     std::vector<Filter> filters;
     struct Attr {
         std::string name;
@@ -273,8 +290,52 @@ void parse_layout(Cursor &c, Object &o, const snpm_h5 &f)
             c.need(n);
             o.compact.assign(c.p, c.p + n);
         }
+    } else if (ver == 4) {
+        o.layout = (int)c.u(1);
+        if (o.layout == 0) {
+            const size_t n = (size_t)c.u(2);
+            c.need(n);
+            o.compact.assign(c.p, c.p + n);
+            c.skip(n);
+        } else if (o.layout == 1) {
+            o.data_addr = c.u(f.so);
+            o.data_size = c.u(f.sl);
+        } else if (o.layout == 2) {
+            const int flags = (int)c.u(1);
+            const int nd = (int)c.u(1);
+            const int enc = (int)c.u(1);
+            if (nd < 2 || nd > 9 || enc < 1 || enc > 8) fail("chunk dimensionality %d (%d-byte sizes) not supported", nd, enc);
+            for (int i = 0; i < nd; ++i) {
+                const uint64_t d = c.u(enc);
+                if (i < nd - 1) o.chunk_dims[i] = d;        // the last one is the element size
+            }
+            o.chunk_index = (int)c.u(1);
+            switch (o.chunk_index) {
+            case 1:                                         // single chunk
+                if (flags & 2) {
+                    o.single_filtered = true;
+                    o.single_size = c.u(f.sl);
+                    o.single_mask = (uint32_t)c.u(4);
+                }
+                break;
+            case 2:                                         // implicit: no index, unfiltered chunks one after the other
+                break;
+            case 3:                                         // fixed array
+                c.u(1);                                     // page bits (repeated in the array's header)
+                break;
+            case 4:
+                fail("chunk index: extensible array (a dataset with an unlimited dimension in the \"latest\" file format) is not supported");
+            case 5:
+                fail("chunk index: version-2 B-tree (several unlimited dimensions in the \"latest\" file format) is not supported");
+            default:
+                fail("chunk index type %d not supported", o.chunk_index);
+            }
+            o.chunk_index_addr = c.u(f.so);
+        } else {
+            fail("data layout class %d not supported", o.layout);
+        }
     } else {
-        fail("data layout message version %d (the \"latest\" file format) is not supported", ver);
+        fail("data layout message version %d not supported", ver);
     }
 }
 
@@ -311,6 +372,75 @@ void parse_attribute(Cursor &c, Object &o, const snpm_h5 &f)
     o.attrs.push_back(std::move(a));
 }
 
+// one object header message (both header versions frame the same bodies)
+void handle_message(const snpm_h5 &f, int type, int flags, Cursor &m, Object &o, std::vector<std::pair<uint64_t, uint64_t>> &cont)
+{
+    if ((flags & 2) && (type == 1 || type == 3 || type == 8 || type == 0x0b || type == 0x0c))
+        fail("shared object header messages are not supported");
+    switch (type) {
+    case 0x0001:
+        parse_dataspace(m, o.rank, o.dims, f.sl);
+        o.is_dataset = true;
+        break;
+    case 0x0003:
+        parse_datatype(m, o.type);
+        break;
+    case 0x0008:
+        parse_layout(m, o, f);
+        break;
+    case 0x000b:
+        parse_filters(m, o.filters);
+        break;
+    case 0x000c:
+        parse_attribute(m, o, f);
+        break;
+    case 0x0010: {
+        const uint64_t a = m.u(f.so), l = m.u(f.sl);
+        cont.push_back({a, l});
+        break;
+    }
+    case 0x0011:
+        o.btree = m.u(f.so);
+        o.heap = m.u(f.so);
+        break;
+    case 0x0002: {      // link info: a new-style group; its links are messages of this header (compact) or live in a fractal heap (dense)
+        const int ver = (int)m.u(1);
+        if (ver != 0) fail("link info message version %d not supported", ver);
+        const int lf = (int)m.u(1);
+        if (lf & 1) m.skip(8);
+        const uint64_t fheap = m.u(f.so);
+        if (fheap != UNDEF) fail("groups with dense link storage (more than 8 members in the \"latest\" file format) are not supported");
+        o.new_group = true;
+        break;
+    }
+    case 0x0006: {      // link
+        const int ver = (int)m.u(1);
+        if (ver != 1) fail("link message version %d not supported", ver);
+        const int lf = (int)m.u(1);
+        const int ltype = (lf & 8) ? (int)m.u(1) : 0;
+        if (lf & 4) m.skip(8);
+        if (lf & 0x10) m.skip(1);
+        const size_t nlen = (size_t)m.u(1 << (lf & 3));
+        m.need(nlen);
+        const std::string name((const char *)m.p, nlen);
+        m.skip(nlen);
+        if (ltype == 0) o.links.push_back({name, m.u(f.so)});       // soft / external links are not followed
+        o.new_group = true;
+        break;
+    }
+    case 0x0015: {      // attribute info: dense attribute storage lives in a fractal heap
+        const int ver = (int)m.u(1);
+        if (ver != 0) fail("attribute info message version %d not supported", ver);
+        const int af = (int)m.u(1);
+        if (af & 1) m.skip(2);
+        if (m.u(f.so) != UNDEF) fail("dense attribute storage is not supported");
+        break;
+    }
+    default:
+        break;          // nil, fill value, group info, modification time, comment, ...: not needed
+    }
+}
+
 void parse_messages(const snpm_h5 &f, const std::vector<uint8_t> &block, int &msgs_left, Object &o, std::vector<std::pair<uint64_t, uint64_t>> &cont)
 {
     Cursor c(block.data(), block.size());
@@ -323,42 +453,24 @@ void parse_messages(const snpm_h5 &f, const std::vector<uint8_t> &block, int &ms
         Cursor m(c.p, size);
         c.skip(size);
         --msgs_left;
-        if ((flags & 2) && (type == 1 || type == 3 || type == 8 || type == 0x0b || type == 0x0c))
-            fail("shared object header messages are not supported");
-        switch (type) {
-        case 0x0001:
-            parse_dataspace(m, o.rank, o.dims, f.sl);
-            o.is_dataset = true;
-            break;
-        case 0x0003:
-            parse_datatype(m, o.type);
-            break;
-        case 0x0008:
-            parse_layout(m, o, f);
-            break;
-        case 0x000b:
-            parse_filters(m, o.filters);
-            break;
-        case 0x000c:
-            parse_attribute(m, o, f);
-            break;
-        case 0x0010: {
-            const uint64_t a = m.u(f.so), l = m.u(f.sl);
-            cont.push_back({a, l});
-            break;
-        }
-        case 0x0011:
-            o.btree = m.u(f.so);
-            o.heap = m.u(f.so);
-            break;
-        case 0x0002:        // link info: new-style group
-        case 0x0006:        // link
-            fail("new-style groups (the \"latest\" file format) are not supported");
-        case 0x0015:        // attribute info (dense attribute storage)
-            fail("dense attribute storage is not supported");
-        default:
-            break;          // nil, fill value, modification time, comment, ...: not needed
-        }
+        handle_message(f, type, flags, m, o, cont);
+    }
+}
+
+// messages of a version-2 header chunk (`block` without its signature and its checksum)
+void parse_messages_v2(const snpm_h5 &f, const uint8_t *p, size_t n, int hdr_flags, Object &o, std::vector<std::pair<uint64_t, uint64_t>> &cont)
+{
+    Cursor c(p, n);
+    const size_t head = 4 + ((hdr_flags & 4) ? 2u : 0u);
+    while (c.left() >= head) {
+        const int type = (int)c.u(1);
+        const size_t size = (size_t)c.u(2);
+        const int flags = (int)c.u(1);
+        if (hdr_flags & 4) c.skip(2);                       // creation order
+        if (size > c.left()) break;                         // the gap in front of the checksum
+        Cursor m(c.p, size);
+        c.skip(size);
+        handle_message(f, type, flags, m, o, cont);
     }
 }
 
@@ -366,10 +478,35 @@ std::unique_ptr<Object> read_object(const snpm_h5 &f, uint64_t addr)
 {
     uint8_t head[16];
     f.read(addr, head, 16);
-    if (head[0] != 1) {
-        if (memcmp(head, "OHDR", 4) == 0) fail("version-2 object headers (the \"latest\" file format) are not supported");
-        fail("object header version %d not supported", head[0]);
+    if (memcmp(head, "OHDR", 4) == 0) {
+        // version 2 (the "latest" file format): signature, version, flags, [times], [attribute phase change], size of chunk 0,
+        // messages, checksum; continuation chunks carry the signature OCHK
+        const size_t pre_max = (size_t)std::min<uint64_t>(40, f.file_size - (addr + f.base));
+        const std::vector<uint8_t> pre = f.bytes(addr, pre_max);
+        Cursor c(pre.data(), pre.size());
+        c.skip(4);
+        if (c.u(1) != 2) fail("object header version not supported");
+        const int hf = (int)c.u(1);
+        if (hf & 0x20) c.skip(16);
+        if (hf & 0x10) c.skip(4);
+        const uint64_t size0 = c.u(1 << (hf & 3));
+        const uint64_t body = addr + (uint64_t)(c.p - pre.data());
+        std::unique_ptr<Object> o(new Object());
+        std::vector<std::pair<uint64_t, uint64_t>> cont;
+        {
+            const std::vector<uint8_t> block = f.bytes(body, (size_t)size0);
+            parse_messages_v2(f, block.data(), block.size(), hf, *o, cont);
+        }
+        for (size_t i = 0; i < cont.size(); ++i) {
+            if (i > 4096) fail("object header continuation chain too long");
+            if (cont[i].second < 8) fail("object header continuation chunk too short");
+            const std::vector<uint8_t> block = f.bytes(cont[i].first, (size_t)cont[i].second);
+            if (memcmp(block.data(), "OCHK", 4) != 0) fail("object header continuation signature missing");
+            parse_messages_v2(f, block.data() + 4, block.size() - 8, hf, *o, cont);
+        }
+        return o;
     }
+    if (head[0] != 1) fail("object header version %d not supported", head[0]);
     Cursor c(head, 16);
     c.skip(2);
     int msgs = (int)c.u(2);
@@ -437,6 +574,13 @@ void list_group(const snpm_h5 &f, uint64_t btree, uint64_t heap, std::vector<std
     }
 }
 
+// members of a group of either style
+void group_members(const snpm_h5 &f, const Object &g, std::vector<std::pair<std::string, uint64_t>> &out)
+{
+    if (g.new_group) out = g.links;
+    else list_group(f, g.btree, g.heap, out);
+}
+
 // resolve "a/b/c" from the root; cached.  f.mu must be held.
 Object *lookup(snpm_h5 &f, const std::string &path_in)
 {
@@ -458,9 +602,9 @@ Object *lookup(snpm_h5 &f, const std::string &path_in)
         if (slash == std::string::npos) slash = path.size();
         const std::string name = path.substr(pos, slash - pos);
         pos = slash + 1;
-        if (cur->is_dataset || cur->btree == UNDEF) fail("%s: not a group on the way to %s", name.c_str(), path.c_str());
+        if (!cur->is_group()) fail("%s: not a group on the way to %s", name.c_str(), path.c_str());
         std::vector<std::pair<std::string, uint64_t>> kids;
-        list_group(f, cur->btree, cur->heap, kids);
+        group_members(f, *cur, kids);
         uint64_t hdr = UNDEF;
         for (auto &k : kids)
             if (k.first == name) hdr = k.second;
@@ -484,7 +628,75 @@ void index_chunks(const snpm_h5 &f, Object &o)
     }
     if (total > (uint64_t(1) << 28)) fail("too many chunks (%llu)", (unsigned long long)total);
     o.chunks.assign((size_t)total, Chunk());
-    if (o.chunk_btree != UNDEF) {
+    uint64_t chunk_bytes = (uint64_t)o.type.size;
+    for (int i = 0; i < o.rank; ++i) chunk_bytes *= o.chunk_dims[i];
+    if (chunk_bytes > 0xffffffffull) fail("chunks of %llu bytes", (unsigned long long)chunk_bytes);
+    if (o.chunk_index == 1) {                                // single chunk
+        if (total != 1) fail("a single-chunk index on a grid of %llu chunks", (unsigned long long)total);
+        if (o.chunk_index_addr != UNDEF) {
+            o.chunks[0].addr = o.chunk_index_addr;
+            o.chunks[0].size = (uint32_t)(o.single_filtered ? o.single_size : chunk_bytes);
+            o.chunks[0].mask = o.single_filtered ? o.single_mask : 0;
+        }
+    } else if (o.chunk_index == 2) {                         // implicit: unfiltered chunks one after the other
+        if (!o.filters.empty()) fail("an implicit chunk index on a filtered dataset");
+        if (o.chunk_index_addr != UNDEF)
+            for (uint64_t i = 0; i < total; ++i) {
+                o.chunks[(size_t)i].addr = o.chunk_index_addr + i * chunk_bytes;
+                o.chunks[(size_t)i].size = (uint32_t)chunk_bytes;
+            }
+    } else if (o.chunk_index == 3) {                         // fixed array: header FAHD -> data block FADB (paged beyond 2^page_bits entries)
+        if (o.chunk_index_addr != UNDEF) {
+            const std::vector<uint8_t> hb = f.bytes(o.chunk_index_addr, (size_t)(4 + 4 + f.sl + f.so + 4));
+            if (memcmp(hb.data(), "FAHD", 4) != 0) fail("fixed-array header signature missing");
+            Cursor h(hb.data() + 4, hb.size() - 4);
+            if (h.u(1) != 0) fail("fixed-array header version not supported");
+            const int client = (int)h.u(1);
+            const size_t esz = (size_t)h.u(1);
+            const int page_bits = (int)h.u(1);
+            const uint64_t nelmts = h.u(f.sl);
+            const uint64_t dblk = h.u(f.so);
+            const size_t want = (size_t)f.so + (client == 1 ? 4u + 1u : 0u);
+            if (client > 1 || esz < want || esz > (size_t)f.so + 8 + 4 || page_bits < 1 || page_bits > 30)
+                fail("fixed-array header: client %d, %zu-byte entries, %d page bits", client, esz, page_bits);
+            if (nelmts != total) fail("fixed array of %llu entries for %llu chunks", (unsigned long long)nelmts, (unsigned long long)total);
+            auto decode = [&](const uint8_t *e, Chunk &ch) {
+                Cursor c(e, esz);
+                ch.addr = c.u(f.so);
+                if (client == 1) {
+                    ch.size = (uint32_t)c.u((int)(esz - (size_t)f.so - 4));
+                    ch.mask = (uint32_t)c.u(4);
+                } else {
+                    ch.size = (uint32_t)chunk_bytes;
+                    ch.mask = 0;
+                }
+                if (ch.addr == UNDEF) ch = Chunk();
+            };
+            if (dblk != UNDEF) {
+                const size_t pre = (size_t)(4 + 2 + f.so);
+                const std::vector<uint8_t> db = f.bytes(dblk, pre);
+                if (memcmp(db.data(), "FADB", 4) != 0) fail("fixed-array data block signature missing");
+                const uint64_t per_page = uint64_t(1) << page_bits;
+                if (nelmts <= per_page) {
+                    const std::vector<uint8_t> el = f.bytes(dblk + pre, (size_t)(nelmts * esz));
+                    for (uint64_t i = 0; i < nelmts; ++i) decode(el.data() + (size_t)(i * esz), o.chunks[(size_t)i]);
+                } else {
+                    const uint64_t npages = (nelmts + per_page - 1) / per_page;
+                    const size_t bm = (size_t)((npages + 7) / 8);
+                    const std::vector<uint8_t> bitmap = f.bytes(dblk + pre, bm);
+                    uint64_t at = dblk + pre + bm + 4;      // pages follow the block's checksum
+                    for (uint64_t pg = 0; pg < npages; ++pg) {
+                        const uint64_t n_here = std::min<uint64_t>(per_page, nelmts - pg * per_page);
+                        if (bitmap[(size_t)(pg / 8)] & (0x80u >> (pg % 8))) {
+                            const std::vector<uint8_t> el = f.bytes(at, (size_t)(n_here * esz));
+                            for (uint64_t i = 0; i < n_here; ++i) decode(el.data() + (size_t)(i * esz), o.chunks[(size_t)(pg * per_page + i)]);
+                        }
+                        at += n_here * esz + 4;              // elements + the page's checksum
+                    }
+                }
+            }
+        }
+    } else if (o.chunk_btree != UNDEF) {
         std::vector<std::pair<uint64_t, int>> stack;
         stack.push_back({o.chunk_btree, 0});
         const size_t key_sz = 8 + 8 * (size_t)(o.rank + 1);
@@ -666,6 +878,7 @@ void read_block_2d(const snpm_h5 &f, Object &o, uint64_t r0, uint64_t nr, uint64
         return;
     }
     const uint64_t ch_r = o.chunk_dims[0], ch_c = o.rank == 2 ? o.chunk_dims[1] : 1, gc = o.rank == 2 ? o.grid[1] : 1;
+    if (ch_r == 0 || ch_c == 0 || o.rank < 1 || o.rank > 2) fail("chunked dataset of rank %d with %llu x %llu chunks", o.rank, (unsigned long long)ch_r, (unsigned long long)ch_c);
     const size_t chunk_bytes = (size_t)(ch_r * ch_c * es);
     for (uint64_t ci = r0 / ch_r; ci <= (r0 + nr - 1) / ch_r; ++ci) {
         for (uint64_t cj = c0 / ch_c; cj <= (c0 + nc - 1) / ch_c; ++cj) {
@@ -907,9 +1120,9 @@ int snpm_h5_list(snpm_h5 *f, const char *group, char *buf, int64_t cap, int64_t 
     H5_TRY(f)
     std::lock_guard<std::mutex> lk(f->mu);
     Object *g = lookup(*f, group ? group : "");
-    if (g->is_dataset || g->btree == UNDEF) fail("%s is not a group", group);
+    if (!g->is_group()) fail("%s is not a group", group);
     std::vector<std::pair<std::string, uint64_t>> kids;
-    list_group(*f, g->btree, g->heap, kids);
+    group_members(*f, *g, kids);
     std::string all;
     for (auto &k : kids) all += k.first + "\n";
     if (needed) *needed = (int64_t)all.size() + 1;

@@ -9,7 +9,7 @@ The datasets are created exactly as the reference's writers do (pygwas/genotype.
 positions (i4) with attrs chrs / chr_regions, snps int8 lzf-compressed in chunks of (1000, num_accessions); core/makedb.py:64-81
 `save_as_hdf5_acc`: the same with gzip chunks of (num_snps, 1)), so the native reader (csrc/snpm_h5.cpp) is tested on
 files of the layout a user's all_chromosomes_binary.hdf5 / .acc.hdf5 have.  Expected contents are the .npz inputs
-(tests/golden/toy_db.npz) and, for the stress file, the arrays stored beside it in h5/stress_expected.npz.
+(tests/golden/toy_db.npz) and, for the stress file, the arrays stored beside it in h5/stress_expected.npz (latest_stress.hdf5 holds the same arrays).
 """
 import os
 
@@ -86,9 +86,46 @@ def main():
         g = f.create_group("grp")
         g.create_dataset("inner", data=np.arange(12, dtype="f8").reshape(3, 4))
     np.savez_compressed(os.path.join(OUT, "stress_expected.npz"), snps=snps, noise=noise, wide=wide, pos=pos)
-    # a file in the "latest" HDF5 file format (version-2 object headers, new chunk indexes): the native reader must refuse it
+    # files in the "latest" HDF5 file format (version-2 object headers, link messages, version-4 layouts with their own chunk
+    # indexes).  latest_format.hdf5: a small DB of the reference's layout (fixed-array index, one page)
     with h5py.File(os.path.join(OUT, "latest_format.hdf5"), "w", libver="latest") as f:
         f.create_dataset("snps", data=snps[:2000], compression="lzf", chunks=(1000, a))
+        f.create_dataset("accessions", data=np.array(["a%d" % i for i in range(a)], dtype="S"))
+        f.create_dataset("positions", data=pos[:2000])
+        f["positions"].attrs["chrs"] = np.array(["1"], dtype="S")
+        f["positions"].attrs["chr_regions"] = [(0, 2000)]
+    # latest_stress.hdf5: a PAGED fixed array (1763 chunks > 1024 per page) of filtered chunks with raw (incompressible) ones
+    # among them, an unfiltered chunked dataset, single-chunk datasets (filtered and not), a chunk that was never written, a
+    # nested group, variable-length strings, attributes; and two things the reader refuses by name: a dataset with an unlimited
+    # dimension (extensible-array index) and a group with dense link storage (more than 8 members)
+    with h5py.File(os.path.join(OUT, "latest_stress.hdf5"), "w", libver="latest") as f:
+        f.create_dataset("accessions", data=np.array(["acc_%d" % i for i in range(a)], dtype=object), dtype=h5py.string_dtype())
+        f.create_dataset("positions", data=pos, dtype="i4")
+        f["positions"].attrs["chrs"] = np.array(["Chr1", "Chr2"], dtype="S")
+        f["positions"].attrs["chr_regions"] = [(0, 40_000), (40_000, n)]
+        f.create_dataset("snps", data=snps, dtype="int8", compression="lzf", chunks=(40, a))          # 1763 chunks: two pages
+        f["snps"].attrs["data_format"] = "binary"
+        f["snps"].attrs["num_snps"] = n
+        f.create_dataset("noise", data=noise, chunks=(777, 2))                                         # chunked, no filter
+        f.create_dataset("wide_gzip", data=wide, compression="gzip", shuffle=True, chunks=(2500, 1135))   # ONE filtered chunk
+        x = f.create_group("extra")                    # (the root keeps 8 members: one more and its links move to dense storage)
+        x.create_dataset("one_plain_chunk", data=wide[:100], chunks=(100, 1135))                      # ONE unfiltered chunk
+        x.create_dataset("plain", data=wide[:10])                                                      # contiguous
+        x.create_dataset("tiny", data=np.arange(5, dtype="i8"))
+        holes = x.create_dataset("holes", shape=(3000, 4), dtype="int8", chunks=(1000, 4), compression="lzf", fillvalue=0)
+        holes[0:1000] = snps[0:1000, :4]
+        holes[2000:3000] = snps[2000:3000, :4]                                                         # chunk 1 never written
+        g = f.create_group("grp")
+        g.create_dataset("inner", data=np.arange(12, dtype="f8").reshape(3, 4))
+        g.create_group("deeper").create_dataset("leaf", data=np.arange(7, dtype="i2"))
+        x.create_dataset("growing", data=snps[:3000], maxshape=(None, a), chunks=(1000, a), compression="lzf")
+        many = f.create_group("many")
+        for i in range(12):
+            many.create_dataset("d%02d" % i, data=np.arange(3) + i)
+    # latest_unlimited.hdf5: a DB whose snps dataset can grow (extensible-array chunk index): the native reader refuses it by
+    # name and core/snp_genotype falls back to h5py where that is importable
+    with h5py.File(os.path.join(OUT, "latest_unlimited.hdf5"), "w", libver="latest") as f:
+        f.create_dataset("snps", data=snps[:2000], compression="lzf", chunks=(1000, a), maxshape=(None, a))
         f.create_dataset("accessions", data=np.array(["a%d" % i for i in range(a)], dtype="S"))
         f.create_dataset("positions", data=pos[:2000])
         f["positions"].attrs["chrs"] = np.array(["1"], dtype="S")

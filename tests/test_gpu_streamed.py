@@ -344,3 +344,40 @@ def test_packed_flat_panel_file_feeds_both_panel_kinds(case, golden_dir, tmp_pat
         assert type(g.panel()).__name__ == ("StreamedPanel" if budget_rows else "Panel")
         cmp_scores_table(open(o + ".scores.txt").read(), gold["scores.txt"])
         assert open(o + ".matches.json").read() == gold["matches.json"]
+
+
+def test_latest_format_hdf5_through_the_loader(golden_dir):
+    """a file in the "latest" HDF5 file format (version-2 object headers, a PAGED fixed-array index over 1763 lzf chunks of
+    (40, 8), raw chunks among them): the loader's threads decode its chunks into the staging slabs -- whole, as a column
+    range, as a row list, into an int8 and into a packed panel -- and a query on it equals the oracle"""
+    from snpmatch_amd import h5
+    want = np.load(os.path.join(golden_dir, "h5", "stress_expected.npz"))["snps"]
+    want = np.where(want < 0, -1, np.where(want > 2, 3, want)).astype(np.int8)     # a panel's canonical codes: missing -1, "matches nothing" 3
+    f = h5.File(os.path.join(golden_dir, "h5", "latest_stress.hdf5"))
+    store = engine.RowStore(h5=(f, "snps"))
+    ctx = make_ctx(SNPM_STAGE_MB=1)
+    p = engine.Panel.from_store(ctx, store, packed=False)
+    assert np.array_equal(p.download_rows(0, want.shape[0]), want)
+    p.free()
+    with pytest.raises(AssertionError, match="packed panel"):       # rows 10 000 - 13 000 hold arbitrary bytes: not packable
+        engine.Panel.from_store(ctx, store, packed=True)
+    rows = np.sort(np.random.default_rng(2).choice(want.shape[0], size=3000, replace=False)).astype(np.int64)
+    p = engine.Panel.from_store(ctx, store, packed=False, cols=(2, 7))
+    assert np.array_equal(p.download_rows(40_900, 200), want[40_900:41_100, 2:7])      # across the index's page border (chunk 1024)
+    store.load(p, (2, 7), rows, 10)
+    assert np.array_equal(p.download_rows(10, len(rows)), want[rows, 2:7])
+    p.free()
+    # the rows a packed panel can hold, as a row list into a packed panel, scored against the oracle
+    keep = np.concatenate([np.arange(0, 10_000), np.arange(13_000, want.shape[0])]).astype(np.int64)
+    p = engine.Panel(ctx, len(keep), 8, packed=True)
+    store.load(p, (0, 8), keep, 0)
+    assert np.array_equal(p.download_rows(0, len(keep)), want[keep])
+    sel = np.sort(np.random.default_rng(4).choice(len(keep), size=5000, replace=False)).astype(np.int64)
+    codes = np.where(want[keep][sel, 3] < 0, 0, want[keep][sel, 3]).astype(np.int8)
+    wei = synth.sample_weights(np.random.default_rng(5), codes, 0.8)
+    s, n = engine.Query(p, sel, wei).run(1000, False, engine.MODE_STRICT)
+    ws, wn = c_oracle.genotyper(want[keep], sel, wei, 1000, False)
+    assert np.array_equal(np.ascontiguousarray(s).view(np.uint64), np.ascontiguousarray(ws).view(np.uint64)) and np.array_equal(n, wn)
+    p.free()
+    ctx.close()
+    f.close()

@@ -137,16 +137,74 @@ def test_genotype_opens_the_reference_hdf5_and_makedb_native_converts_it(toy, tm
     assert np.array_equal(g2.g.positions, toy["positions"]) and np.array_equal(g2.g.chr_regions, toy["regions"])
 
 
-def test_latest_format_is_refused_and_h5py_is_the_fallback(monkeypatch):
-    """a file written with libver='latest' (version-2 object headers) is outside the native reader's scope: it says so, and
-    Genotype falls back to h5py where that is importable -- here a stand-in module that serves the expected arrays, so that the
-    fallback branch of core/snp_genotype._load_any runs (the test image has no h5py for the interpreter the tests use)"""
+def test_latest_file_format_reference_layout():
+    """libver='latest': version-2 object headers, link messages in the root group, a version-4 layout with a fixed-array chunk
+    index -- the same DB layout as the reference's writer, read natively and opened by core/snp_genotype.Genotype"""
+    from snpmatch_amd.core import snp_genotype
+    want = np.load(os.path.join(H5DIR, "stress_expected.npz"))
+    path = os.path.join(H5DIR, "latest_format.hdf5")
+    with h5.File(path) as f:
+        assert sorted(f.keys()) == ["accessions", "positions", "snps"]
+        assert f["snps"].shape == (2000, 8) and f["snps"].chunks == (1000, 8) and f["snps"].dtype == np.int8
+        assert np.array_equal(f["snps"][:], want["snps"][:2000])
+        assert np.array_equal(f["snps"][np.array([1999, 0, 1000, 999]), :], want["snps"][[1999, 0, 1000, 999]])
+        assert np.array_equal(f["positions"][:], want["pos"][:2000])
+        assert f["positions"].attrs["chrs"].astype("U").tolist() == ["1"]
+        assert f["positions"].attrs["chr_regions"].tolist() == [[0, 2000]]
+        assert f["accessions"][:].astype("U").tolist() == ["a%d" % i for i in range(8)]
+    g = snp_genotype.Genotype(path, None)
+    assert g.accessions.tolist() == ["a%d" % i for i in range(8)] and g.g.num_snps == 2000 and g.chrs.tolist() == ["1"]
+    assert np.array_equal(g.g.snps[np.array([1, 1999]), :], want["snps"][[1, 1999]])
+    assert hasattr(g.g, "h5_source")                       # served by the native reader (the loader threads read its chunks)
+
+
+def test_latest_file_format_stress():
+    """a paged fixed array (1763 filtered chunks, raw ones among them), unfiltered chunks, single-chunk datasets with and
+    without filters, a chunk that was never written, nested new-style groups, variable-length strings, attributes; an unlimited
+    dimension (extensible array) and a group of 12 members (dense link storage) are refused by name, the rest of the file
+    stays readable"""
+    want = np.load(os.path.join(H5DIR, "stress_expected.npz"))
+    with h5.File(os.path.join(H5DIR, "latest_stress.hdf5")) as f:
+        assert sorted(f.keys()) == ["accessions", "extra", "grp", "many", "noise", "positions", "snps", "wide_gzip"]
+        x = f["extra"]
+        assert sorted(x.keys()) == ["growing", "holes", "one_plain_chunk", "plain", "tiny"]
+        snps = f["snps"]
+        assert snps.shape == (70_500, 8) and snps.chunks == (40, 8)
+        assert np.array_equal(snps[:], want["snps"])
+        rows = np.sort(np.random.default_rng(1).choice(70_500, size=4000, replace=False))
+        assert np.array_equal(snps[rows, :], want["snps"][rows])
+        assert np.array_equal(snps[40_950:41_050, 1:6], want["snps"][40_950:41_050, 1:6])          # across the page border (chunk 1024)
+        assert np.array_equal(f["noise"][:], want["noise"]) and f["noise"].chunks == (777, 2)
+        assert np.array_equal(f["wide_gzip"][:], want["wide"]) and f["wide_gzip"].chunks == (2500, 1135)
+        assert np.array_equal(x["one_plain_chunk"][:], want["wide"][:100])
+        assert np.array_equal(x["plain"][:], want["wide"][:10]) and x["plain"].chunks is None
+        assert np.array_equal(x["tiny"][:], np.arange(5))
+        holes = x["holes"][:]
+        assert np.array_equal(holes[:1000], want["snps"][:1000, :4]) and np.array_equal(holes[2000:], want["snps"][2000:3000, :4])
+        assert not holes[1000:2000].any()                                                          # the unwritten chunk reads as the fill value
+        assert np.array_equal(f["positions"][:], want["pos"])
+        assert f["positions"].attrs["chr_regions"].tolist() == [[0, 40_000], [40_000, 70_500]]
+        assert f["snps"].attrs["num_snps"] == 70_500 and f["snps"].attrs["data_format"] in (b"binary", "binary")
+        assert f["accessions"][:].astype("U").tolist() == ["acc_%d" % i for i in range(8)]
+        assert np.array_equal(f["grp"]["inner"][:], np.arange(12.0).reshape(3, 4))
+        assert np.array_equal(f["grp"]["deeper"]["leaf"][:], np.arange(7)) and sorted(f["grp"].keys()) == ["deeper", "inner"]
+        with pytest.raises(IOError, match="extensible array"):
+            x["growing"][:]
+        with pytest.raises(IOError, match="dense link storage"):
+            f["many"].keys()
+        assert np.array_equal(x["tiny"][:], np.arange(5))                                          # the file is still usable
+
+
+def test_unsupported_index_falls_back_to_h5py(monkeypatch):
+    """a DB the native reader refuses (its snps dataset has an unlimited dimension: extensible-array chunk index): it says so,
+    and Genotype falls back to h5py where that is importable -- here a stand-in module that serves the expected arrays, so that
+    the fallback branch of core/snp_genotype._load_any runs (the test image has no h5py for the interpreter the tests use)"""
     import sys
     import types
     from snpmatch_amd.core import snp_genotype
-    path = os.path.join(H5DIR, "latest_format.hdf5")
-    with pytest.raises(IOError, match="latest|version-2|not supported"):
-        h5.File(path)
+    path = os.path.join(H5DIR, "latest_unlimited.hdf5")
+    with pytest.raises(IOError, match="extensible array"):
+        h5.File(path)["snps"][:]
     monkeypatch.setitem(sys.modules, "h5py", None)                  # import h5py -> ImportError
     with pytest.raises(IOError, match="h5py is not installed"):
         snp_genotype.Genotype(path, None)

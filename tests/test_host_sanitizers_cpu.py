@@ -52,7 +52,7 @@ def test_host_sources_under_asan_and_ubsan(tmp_path, golden_dir):
 
 
 def test_hdf5_reader_under_asan_and_ubsan(tmp_path, golden_dir):
-    """csrc/snpm_h5.cpp parses untrusted files: the three fixtures written by real h5py, then 120 randomly damaged copies of
+    """csrc/snpm_h5.cpp parses untrusted files: the six fixtures written by real h5py (both file format generations), then 180 randomly damaged copies of
     them (bytes overwritten, files cut short), under AddressSanitizer + UBSan.  Damage may produce errors, never a fault."""
     import numpy as np
     exe = str(tmp_path / "h5_asan_driver")
@@ -60,11 +60,12 @@ def test_hdf5_reader_under_asan_and_ubsan(tmp_path, golden_dir):
                            "-fno-sanitize-recover=all", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
                            os.path.join(ROOT, "tests", "h5_asan_driver.cpp"), os.path.join(CSRC, "snpm_h5.cpp"), "-lz", "-o", exe])
     h5dir = os.path.join(golden_dir, "h5")
-    good = [os.path.join(h5dir, n) for n in ("toy_db.hdf5", "toy_db.acc.hdf5", "stress.hdf5")]
+    good = [os.path.join(h5dir, n) for n in ("toy_db.hdf5", "toy_db.acc.hdf5", "stress.hdf5", "latest_format.hdf5",
+                                             "latest_stress.hdf5", "latest_unlimited.hdf5")]
     rng = np.random.default_rng(11)
     bad = []
-    for k in range(120):
-        raw = bytearray(open(good[k % 3], "rb").read())
+    for k in range(180):
+        raw = bytearray(open(good[k % 6], "rb").read())
         if k % 4 == 3:
             raw = raw[:int(rng.integers(16, len(raw)))]
         else:
@@ -81,9 +82,12 @@ def test_hdf5_reader_under_asan_and_ubsan(tmp_path, golden_dir):
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
     lines = r.stdout.strip().split("\n")
-    assert lines[-1] == "done" and len(lines) == 124
+    assert lines[-1] == "done" and len(lines) == 187
     assert lines[0].startswith("toy_db.hdf5 rc=0 objects=4") and lines[1].startswith("toy_db.acc.hdf5 rc=0 objects=4")
     assert lines[2].startswith("stress.hdf5 rc=0 objects=10")
+    assert lines[3].startswith("latest_format.hdf5 rc=0 objects=4")        # the "latest" file format: version-2 headers, fixed arrays
+    assert lines[4].startswith("latest_stress.hdf5 rc=0 objects=15")       # (its refused dataset and its dense group do not count)
+    assert lines[5].startswith("latest_unlimited.hdf5 rc=0 objects=3")     # root, accessions, positions: snps is refused by name
 
 
 def test_loader_building_blocks_under_tsan_and_asan(tmp_path):
