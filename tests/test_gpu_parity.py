@@ -492,6 +492,46 @@ def test_exact_mode_on_accession_major_copy():
     c.close()
 
 
+@pytest.mark.parametrize("forced", [1, 3, 17, 64])
+def test_reevaluation_on_the_accession_major_copy_many_shapes(forced):
+    """k_strict_sparse_T (flagged accessions re-scored on the accession-major packed copy): the first `forced` accessions are
+    re-evaluated (SNPM_DEBUG_REEVAL) and must carry the reference's fp64 bits -- chunk sizes that do not divide by 8, queries
+    shorter than one unrolled step, a ragged last chunk, int8 and packed panels, skip_hets, 1 to 64 columns per segment.
+    (An LDS-staged variant of this kernel was tried in round 3 and was slower: the pass is bound by the 24 B of weights per
+    row it has to read, 1.2 GB for 50M rows, not by how the lanes fetch them -- profiles/r03h_ab_sparse_T_dense.txt.)"""
+    for _ in (0,):
+        os.environ.update(SNPM_ACC_MAJOR_MIN_ROWS="0", SNPM_DEBUG_REEVAL=str(forced))
+        try:
+            c = engine.Context(0)
+        finally:
+            for k in ("SNPM_ACC_MAJOR_MIN_ROWS", "SNPM_DEBUG_REEVAL"):
+                del os.environ[k]
+        rng = np.random.default_rng(900 + forced)
+        sparse_runs = 0
+        for n, chunk in ((1, 1000), (13, 7), (9000, 1000), (20011, 1001), (4097, 7)):
+            n_acc = int(rng.choice([64, 300, 1135]))
+            db = rand_db(rng, n, n_acc)
+            for packed in (False, True):
+                panel = engine.Panel.from_host(c, db, packed=packed)
+                wei = rand_wei(rng, n)
+                q = engine.Query(panel, None, wei)
+                for skip in (False, True):
+                    want_s, want_n = c_oracle.genotyper(db, None, wei, chunk, skip)
+                    s, ni, info = q.run(chunk, skip, engine.MODE_EXACT, return_info=True)
+                    tag = (n, chunk, n_acc, packed, skip)
+                    assert info["all_integer_weights"] or info["n_strict_reeval"] >= min(forced, n_acc), (tag, info)
+                    if 0 < info["n_strict_reeval"] <= 64:                  # more: the dense tier re-scores every accession
+                        assert info["reeval_path"] == 1, (tag, info)
+                        sparse_runs += 1
+                    k = min(forced, n_acc)
+                    assert np.array_equal(bits(s)[:k], bits(want_s)[:k]), tag
+                    assert np.array_equal(ni, want_n) and np.array_equal(np.array(s, dtype=int), np.array(want_s, dtype=int)), tag
+                q.free()
+                panel.free()
+        assert sparse_runs >= 6 or forced == 64
+        c.close()
+
+
 # ------------------------------------------------------------------ packed (2 bits per call) panel format
 @pytest.mark.parametrize("n_snp,n_acc,n_match,chunk", [(4000, 1, 1000, 1000), (6000, 64, 3001, 1000), (20000, 1135, 7545, 1000),
                                                        (3000, 1250, None, 1000), (2100, 10000, None, 1000), (130, 17, 129, 7)])
