@@ -3,7 +3,7 @@
 One-off extended differential fuzz on the GPU box (not part of the test suite): the seeded fuzzers of tests/test_gpu_parity.py
 and tests/test_gpu_adversarial.py with OTHER seeds and more cases, on both LUT-tile sizes of the int8 fast pass.
 
-    python tools/fuzz_extended.py [n_cases] > gpurun_out/fuzz_extended.txt
+    python tools/fuzz_extended.py [n_cases [seed ...]] > gpurun_out/fuzz_extended.txt
 """
 import os
 import sys
@@ -18,6 +18,7 @@ import numpy as np  # noqa: E402
 
 def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+    SEEDS = tuple(int(a) for a in sys.argv[2:]) or (9001, 9002)
     from snpmatch_amd import engine
     import test_gpu_parity as tp
     import test_gpu_adversarial as ta
@@ -28,7 +29,7 @@ def main():
         ctx = engine.Context(0)
         for k in env:
             del os.environ[k]
-        for seed in (9001, 9002):
+        for seed in SEEDS:
             tp._fuzz_random_configurations(ctx, n_cases, seed)
             print("parity fuzz ok: %s, seed %d, %d cases (%.0f s)" % (label, seed, n_cases, time.time() - t0), flush=True)
         ctx.close()
