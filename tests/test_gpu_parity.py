@@ -580,8 +580,12 @@ def test_packed_phased_waves(max_parts):
     rng = np.random.default_rng(4711 + max_parts)
     # accessions -> dwords in the last wave -> phases: 512 -> 32 -> 2, 300 -> 19 -> 3, 250 -> 16 -> 4, 170 -> 11 -> 5,
     # 1184 -> 10 -> 6, 1135 -> 7 -> 8, 16 -> 1 -> 8, 1530 -> 32 -> 2, 2400 -> 22 -> 2; 513 / 1025 + 528: 33 dwords, not phased
-    for n_acc in (512, 300, 250, 170, 1184, 1135, 16, 1530, 2400, 513, 1553):
+    # 7300 -> 7 full waves + 9 dwords (one 8-wave block whose last wave has 7 phases), 9300 -> 9 full waves + 6 dwords (4-wave
+    # blocks: the third one holds a full wave, a phased wave and two idle ones)
+    for n_acc in (512, 300, 250, 170, 1184, 1135, 16, 1530, 2400, 513, 1553, 7300, 9300):
         n_snp = int(rng.choice([1, 5, 63, 64, 71, 1000, 16389, 40003] if not max_parts else [16389, 40003, 70001]))
+        if n_acc > 4096:
+            n_snp = min(n_snp, 16389)
         db = rand_db(rng, n_snp, n_acc)
         db[:, n_acc - 1] = -1                       # the last accession: no informative site
         panel = engine.Panel.from_host(c, db, packed=True)
