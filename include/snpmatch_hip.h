@@ -84,7 +84,8 @@ int         snpm_synchronize(snpm_ctx *ctx);
 int         snpm_device_mem_info(snpm_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
 
 /* ---------------------------------------------------------------- panel (DB genotype matrix in HBM) */
-/* SNP-major int8 [n_snp, pitch], pitch = n_acc rounded up to 256 B, pad bytes = -1.  1 <= n_acc <= 2^27 (SNPM_ERR_BADARG). */
+/* SNP-major int8 [n_snp, pitch], pitch = n_acc rounded up to 256 B (to 128 B where that saves 5 % of the row: read it with
+   snpm_panel_info), pad bytes = -1.  1 <= n_acc <= 2^27 (SNPM_ERR_BADARG). */
 int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out);
 /* Same panel with 2 bits per call (4 accessions per byte: 0 ref, 1 alt, 2 het, 3 missing): 4x less HBM
    capacity and traffic (the 10k x 50M panel is 125 GB and fits one MI355X).  Rows are uploaded as int8
@@ -96,7 +97,7 @@ int snpm_panel_free(snpm_panel *panel);
 int snpm_panel_info(const snpm_panel *panel, int64_t *n_snp, int64_t *n_acc, int64_t *pitch, void **device_ptr);
 /* Asynchronous upload of rows [row0, row0+nrows) from host memory (row stride host_pitch bytes,
    >= n_acc): rows are copied into double-buffered pinned staging slabs, sent with hipMemcpyAsync on a side
-   stream and written into the panel by a device kernel (256-B row pitch, codes canonicalised:
+   stream and written into the panel by a device kernel (the panel's row pitch, codes canonicalised:
    negative -> -1, >2 -> 3; 2-bit packing for packed panels).
    Returns once the last slab is enqueued; scoring calls wait for it on the device. */
 int snpm_panel_upload_rows(snpm_panel *panel, int64_t row0, int64_t nrows, const int8_t *host, int64_t host_pitch);

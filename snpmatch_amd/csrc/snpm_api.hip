@@ -108,6 +108,7 @@ struct snpm_ctx {
     int full_occupancy = 0;   // SNPM_FULL_OCCUPANCY=1: as many resident blocks as the occupancy API allows
     int bits_path = 1;     // SNPM_BITS=0: hard-call samples on packed panels go through k_fast_packed_q4 like any other
     int64_t pitch_align = 256;          // SNPM_PITCH_ALIGN: bytes a panel row is padded to (a multiple of 64; experiments)
+    bool pitch_align_forced = false;    // set by SNPM_PITCH_ALIGN: no per-width choice
     int64_t long_scan_rows = 2000000;   // SNPM_LONG_SCAN_ROWS: queries of at least this many rows walk LONG_TILE_ROWS-row tiles (int8 fast pass); -1: never
     // live panels of this context: snpm_destroy releases their device memory and orphans them (and their
     // queries), so that a panel / query handle freed AFTER its context is a harmless host-side delete
@@ -1329,7 +1330,10 @@ try {
     if (const char *s = getenv("SNPM_Q4_TILE_ROWS")) ctx->q4_tile_rows = atoi(s);
     if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
     if (const char *s = getenv("SNPM_BITS")) ctx->bits_path = atoi(s);
-    if (const char *s = getenv("SNPM_PITCH_ALIGN")) ctx->pitch_align = std::max<int64_t>(64, (atoll(s) + 63) / 64 * 64);
+    if (const char *s = getenv("SNPM_PITCH_ALIGN")) {
+        ctx->pitch_align = std::max<int64_t>(64, (atoll(s) + 63) / 64 * 64);
+        ctx->pitch_align_forced = true;
+    }
     if (const char *s = getenv("SNPM_LONG_SCAN_ROWS")) ctx->long_scan_rows = atoll(s) < 0 ? INT64_MAX : atoll(s);
     if (const char *s = getenv("SNPM_FULL_OCCUPANCY")) ctx->full_occupancy = atoi(s);
     if (const char *s = getenv("SNPM_OCC_CAP")) ctx->occ_cap = atoi(s);
@@ -1490,7 +1494,14 @@ try {
     // Round 3 tried whole 64-B sectors instead (SNPM_PITCH_ALIGN=64: lanes past the pitch are masked, 10 048 B per row move; all
     // tests pass): 1135 x 11M +3 %, 2500 x 50M +1 %, but 10 000 x 20M 0.816 -> 0.784 and 5000 x 40M 0.787 -> 0.740 of HBM peak
     // (profiles/r03e_ab_pitch.txt) -- a wave's 256-B read that straddles two 256-B units costs more than the padding saves.
-    const int64_t align = ctx->pitch_align;
+    // int8 panels whose 256-B padding would be 5 % of the row or more take whole 128-B cache lines instead (round 3,
+    // profiles/r03h_ab_pitch128.txt: the 1135 accessions of the 1001 Genomes panel 1280 -> 1152 B per row, 0.720 -> 0.740 of HBM
+    // peak and a tenth less HBM; 10 000 accessions would LOSE 0.3 % and keep their 10 240 B; packed panels measured no gain)
+    int64_t align = ctx->pitch_align;
+    if (!packed && !ctx->pitch_align_forced) {
+        const int64_t p256 = (n_acc + 255) / 256 * 256, p128 = (n_acc + 127) / 128 * 128;
+        if ((p256 - p128) * 20 >= p256) align = 128;
+    }
     p->pitch = packed ? (((n_acc + 3) / 4 + align - 1) / align) * align : ((n_acc + align - 1) / align) * align;
     // PREFETCH_PAD_ROWS extra rows: the fast pass prefetches (and never scores) a few rows past a part
     const size_t row_bytes = (size_t)(n_snp + PREFETCH_PAD_ROWS) * (size_t)p->pitch;

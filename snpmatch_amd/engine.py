@@ -316,7 +316,7 @@ def default_group(n_members=None):
 
 
 class Panel(object):
-    """int8 [n_snp, n_acc] genotype matrix in HBM (SNP-major, row pitch padded to 256 B)."""
+    """int8 [n_snp, n_acc] genotype matrix in HBM (SNP-major, row pitch padded to 256 B; to 128 B where that saves 5 % of the row)."""
 
     def __init__(self, ctx, n_snp, n_acc, packed=False):
         self.ctx = ctx
