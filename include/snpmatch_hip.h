@@ -93,6 +93,9 @@ int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **
    upload).  Every scoring entry point accepts either panel kind and returns identical results. */
 int snpm_panel_create_packed(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out);
 int snpm_panel_is_packed(const snpm_panel *panel, int *packed);
+/* Bytes per row a panel of n_acc accessions will have on this context (what snpm_panel_info reports afterwards): for callers
+   that size a panel to a memory budget before creating it. */
+int snpm_panel_row_pitch(snpm_ctx *ctx, int64_t n_acc, int packed, int64_t *pitch);
 int snpm_panel_free(snpm_panel *panel);
 int snpm_panel_info(const snpm_panel *panel, int64_t *n_snp, int64_t *n_acc, int64_t *pitch, void **device_ptr);
 /* Asynchronous upload of rows [row0, row0+nrows) from host memory (row stride host_pitch bytes,

@@ -194,8 +194,9 @@ class Genotype(object):
     # ------------------------------------------------------------------ device residency
     def panel(self, ctx=None, packed=None):
         """The DB matrix resident in HBM (created on first use; slabs go through pinned staging).
-        ``packed`` (default: environment SNPMATCH_PACKED=1) stores 2 bits per call instead of a byte --
-        same results, a quarter of the HBM; DBs with codes other than -1/0/1/2 stay int8.
+        ``packed``: True = 2 bits per call, False = a byte per call, None (default) = environment SNPMATCH_PACKED
+        ("1" / "0"; unset or "auto": packed when the DB's codes allow it -- same results bit for bit, a quarter of the HBM and of
+        the bytes over PCIe, the scans 2-3 x faster; DBs with codes other than -1/0/1/2 stay int8).
         Where the accession columns live:
           * under ``torch.distributed.run`` (``dist.job()``): this rank's accession shard on this rank's GPU;
           * several GPUs visible to ONE process (SNPMATCH_GPUS, default all): an ``engine.GroupPanel`` -- a shard per
@@ -204,7 +205,8 @@ class Genotype(object):
         from .. import dist, engine
         if self._panel is None or getattr(self._panel, "h", None) is None:
             if packed is None:
-                packed = os.environ.get("SNPMATCH_PACKED", "0") not in ("", "0")
+                env = os.environ.get("SNPMATCH_PACKED", "auto").strip().lower()
+                packed = None if env in ("", "auto") else env != "0"
             n_acc = len(self.accessions)
             job = dist.job()
             self._shard = job.bounds(n_acc) if job else None
@@ -243,20 +245,27 @@ class Genotype(object):
         n_loc = a1 - a0
 
         def need(pk):
-            width = (n_loc + 3) // 4 if pk else n_loc
-            return (store.n_snp + 32) * ((width + 255) // 256 * 256) + 256
+            return (store.n_snp + 32) * ctx.row_pitch(n_loc, pk) + 256
 
-        for pk in ([True] if packed else [False, True]):
+        # packed None (auto): the packed panel first -- it loads faster (a quarter of the bytes cross PCIe, packed by the host
+        # threads) and scans faster -- then int8; False: int8 first, packed only when int8 does not fit; True: packed
+        unpackable = False
+        for pk in ([True, False] if packed is None else [True] if packed else [False, True]):
             if need(pk) > budget:
                 continue
             try:
                 return engine.Panel.from_store(ctx, store, packed=pk, cols=(a0, a1))
             except AssertionError:
+                if not pk:
+                    raise
                 log.info("DB holds codes a packed panel cannot store; using the int8 panel")
+                unpackable = True
                 if packed and need(False) <= budget:
                     return engine.Panel.from_store(ctx, store, packed=False, cols=(a0, a1))
         log.info("DB shard of %.1f GB does not fit the HBM budget of %.1f GB: streaming SNP slabs", need(False) / 1e9, budget / 1e9)
-        if packed:
+        # slabs: packed when asked for, or when the file itself is packed; in auto mode an int8 source streams as int8 (a call
+        # code a packed panel refuses could otherwise surface in the middle of a job, slabs after the first are not probed)
+        if (packed or (packed is None and p2)) and not unpackable:
             try:
                 sp = engine.StreamedPanel(ctx, store, cols=(a0, a1), packed=True, budget_bytes=budget)
                 sp.store.load(sp.halves[0], sp.cols, (0, min(sp.rows_cap, store.n_snp)), 0)     # probe for codes a packed panel refuses

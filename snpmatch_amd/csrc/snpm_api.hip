@@ -1476,6 +1476,17 @@ int snpm_synchronize(snpm_ctx *ctx)
 }
 
 // ---------------------------------------------------------------------------------------------- panel
+// bytes per row of a panel of n_acc accessions (see panel_create_fmt for the measurements behind the rule)
+static int64_t panel_row_pitch(const snpm_ctx *ctx, int64_t n_acc, int packed)
+{
+    int64_t align = ctx->pitch_align;
+    if (!packed && !ctx->pitch_align_forced) {
+        const int64_t p256 = (n_acc + 255) / 256 * 256, p128 = (n_acc + 127) / 128 * 128;
+        if ((p256 - p128) * 20 >= p256) align = 128;
+    }
+    return packed ? (((n_acc + 3) / 4 + align - 1) / align) * align : ((n_acc + align - 1) / align) * align;
+}
+
 static int panel_create_fmt(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, int packed, snpm_panel **out)
 try {
     if (!ctx) return SNPM_ERR_BADARG;
@@ -1497,12 +1508,7 @@ try {
     // int8 panels whose 256-B padding would be 5 % of the row or more take whole 128-B cache lines instead (round 3,
     // profiles/r03h_ab_pitch128.txt: the 1135 accessions of the 1001 Genomes panel 1280 -> 1152 B per row, 0.720 -> 0.740 of HBM
     // peak and a tenth less HBM; 10 000 accessions would LOSE 0.3 % and keep their 10 240 B; packed panels measured no gain)
-    int64_t align = ctx->pitch_align;
-    if (!packed && !ctx->pitch_align_forced) {
-        const int64_t p256 = (n_acc + 255) / 256 * 256, p128 = (n_acc + 127) / 128 * 128;
-        if ((p256 - p128) * 20 >= p256) align = 128;
-    }
-    p->pitch = packed ? (((n_acc + 3) / 4 + align - 1) / align) * align : ((n_acc + align - 1) / align) * align;
+    p->pitch = panel_row_pitch(ctx, n_acc, packed);
     // PREFETCH_PAD_ROWS extra rows: the fast pass prefetches (and never scores) a few rows past a part
     const size_t row_bytes = (size_t)(n_snp + PREFETCH_PAD_ROWS) * (size_t)p->pitch;
     const size_t bytes = row_bytes + 256;                            // + the flag word d_other
@@ -1537,6 +1543,13 @@ int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **
 int snpm_panel_create_packed(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out)
 {
     return panel_create_fmt(ctx, n_snp, n_acc, 1, out);
+}
+
+int snpm_panel_row_pitch(snpm_ctx *ctx, int64_t n_acc, int packed, int64_t *pitch)
+{
+    if (!ctx || !pitch || n_acc < 1) return SNPM_ERR_BADARG;
+    *pitch = panel_row_pitch(ctx, n_acc, packed ? 1 : 0);
+    return SNPM_OK;
 }
 
 int snpm_panel_is_packed(const snpm_panel *p, int *packed)

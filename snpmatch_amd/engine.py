@@ -85,6 +85,12 @@ class Context(object):
     def synchronize(self):
         check(self.lib.snpm_synchronize(self.h), self.h)
 
+    def row_pitch(self, n_acc, packed=False):
+        """bytes per row of a panel of ``n_acc`` accessions on this context (before it is created)"""
+        out = C.c_int64(0)
+        check(self.lib.snpm_panel_row_pitch(self.h, int(n_acc), 1 if packed else 0, C.byref(out)), self.h)
+        return out.value
+
     def mem_info(self):
         """(free, total) device memory in bytes"""
         f, t = C.c_int64(0), C.c_int64(0)
@@ -1057,8 +1063,7 @@ class StreamedPanel(object):
         self.ctx, self.store = ctx, store
         self.cols = (0, store.n_acc) if cols is None else (int(cols[0]), int(cols[1]))
         self.n_snp, self.n_acc, self.packed = store.n_snp, self.cols[1] - self.cols[0], bool(packed)
-        acc_per_byte = 4 if packed else 1
-        pitch = ((self.n_acc + acc_per_byte - 1) // acc_per_byte + 255) // 256 * 256
+        pitch = ctx.row_pitch(self.n_acc, packed)
         if budget_bytes is None:
             budget_bytes = int(0.85 * ctx.mem_info()[0])
         self.rows_cap = int(budget_bytes // 2 // pitch) - 32             # the panel keeps 32 prefetch rows of its own

@@ -189,7 +189,8 @@ def test_group_of_streamed_members_matches_reference_files(golden_dir, tmp_path,
     from snpmatch_amd.core import snp_genotype
     monkeypatch.setenv("SNPMATCH_GPUS", "0,0")
     monkeypatch.setenv("SNPMATCH_GROUP_LOOPBACK", "1")
-    monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(2 * (1000 + 32) * 256 / 1e9))
+    monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(2 * (1000 + 32) * 128 / 1e9))       # int8 shards of 28 / 22 accessions: 128-B rows
+    monkeypatch.setenv("SNPMATCH_PACKED", "0")
     try:
         toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
         gold = json.load(open(os.path.join(golden_dir, "g2_inbred.json")))["inbred_skip0"]

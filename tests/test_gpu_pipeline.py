@@ -87,6 +87,17 @@ def cmp_window_table(got_text, want_text, strict_scores=None):
                 assert g[c] == w[c], (c, g, w)
 
 
+@pytest.fixture(autouse=True, params=["auto", "0"], ids=["db-packed-by-default", "db-int8"])
+def db_format(request, monkeypatch):
+    """every product-path test runs on both residency formats: the default (2-bit packed when the DB's codes allow it) and
+    SNPMATCH_PACKED=0 (the int8 panel); tests that set the variable themselves override this"""
+    if request.param == "auto":
+        monkeypatch.delenv("SNPMATCH_PACKED", raising=False)
+    else:
+        monkeypatch.setenv("SNPMATCH_PACKED", request.param)
+    return request.param
+
+
 @pytest.fixture(params=["certified", "strict"])
 def cross_mode(request, monkeypatch):
     """both window modes of ``cross``: the default (segmented fast pass + certificate) and SNPMATCH_CROSS_STRICT=1"""

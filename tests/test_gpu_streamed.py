@@ -41,9 +41,16 @@ def make_ctx(**env):
             del os.environ[k]
 
 
+def row_pitch(n_acc, packed=False):
+    """the library's row pitch (snpm_panel_row_pitch): 256-B padding, 128 B for int8 rows where that saves 5 % or more"""
+    if packed:
+        return ((n_acc + 3) // 4 + 255) // 256 * 256
+    p256, p128 = (n_acc + 255) // 256 * 256, (n_acc + 127) // 128 * 128
+    return p128 if (p256 - p128) * 20 >= p256 else p256
+
+
 def budget_for(rows_cap, n_acc, packed=False):
-    width = (n_acc + 3) // 4 if packed else n_acc
-    return 2 * (rows_cap + 32) * ((width + 255) // 256 * 256)
+    return 2 * (rows_cap + 32) * row_pitch(n_acc, packed)
 
 
 @pytest.fixture(scope="module")
@@ -171,6 +178,7 @@ def tiny_budget(monkeypatch):
     def set_rows(rows_cap, n_acc):
         monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(budget_for(rows_cap, n_acc) / 1e9))
     monkeypatch.setenv("SNPMATCH_GPUS", "1")
+    monkeypatch.setenv("SNPMATCH_PACKED", "0")          # the budgets below are sized for int8 slabs
     return set_rows
 
 
@@ -221,13 +229,15 @@ def test_product_path_streams_slabs_and_matches_reference_files(golden_dir, tmp_
 
 
 def test_residency_plan_prefers_whole_panels(tmp_path, monkeypatch):
-    """int8 whole -> packed whole -> slabs, by the budget; a DB with an odd call code skips the packed step"""
+    """SNPMATCH_PACKED=0: int8 whole -> packed whole -> slabs, by the budget; a DB with an odd call code skips the packed step.
+    Default (auto): packed whole first, int8 whole for a DB a packed panel cannot hold, int8 slabs when nothing fits whole."""
     monkeypatch.setenv("SNPMATCH_GPUS", "1")
+    monkeypatch.setenv("SNPMATCH_PACKED", "0")
     rng = np.random.default_rng(1)
     n, n_acc = 20_000, 1024
     db = rand_db(rng, n, n_acc)
     meta = (np.array(["a%d" % i for i in range(n_acc)]), np.arange(1, n + 1), np.array(["1"]), np.array([[0, n]]))
-    int8_bytes, packed_bytes = (n + 32) * 1024 + 256, (n + 32) * 256 + 256
+    int8_bytes, packed_bytes = (n + 32) * row_pitch(n_acc) + 256, (n + 32) * row_pitch(n_acc, True) + 256
 
     def plan(budget, snps=db):
         monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(budget / 1e9))
@@ -250,6 +260,10 @@ def test_residency_plan_prefers_whole_panels(tmp_path, monkeypatch):
     assert plan(int8_bytes - 1, odd) == ("StreamedPanel", False)
     monkeypatch.setenv("SNPMATCH_PACKED", "1")
     assert plan(packed_bytes - 1) == ("StreamedPanel", True)
+    monkeypatch.delenv("SNPMATCH_PACKED")                 # auto
+    assert plan(int8_bytes) == ("Panel", True) and plan(packed_bytes) == ("Panel", True)
+    assert plan(int8_bytes, odd) == ("Panel", False)      # unpackable: the int8 panel after the packed load refused
+    assert plan(packed_bytes - 1) == ("StreamedPanel", False) and plan(packed_bytes, odd) == ("StreamedPanel", False)
 
 
 def test_reference_hdf5_db_through_the_native_reader(golden_dir, tmp_path, monkeypatch):
@@ -281,7 +295,7 @@ def test_reference_hdf5_db_through_the_native_reader(golden_dir, tmp_path, monke
     ctx.close()
     for budget_rows in (None, 1000):
         if budget_rows:
-            monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(budget_for(budget_rows, 50) / 1e9))
+            monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(budget_for(budget_rows, 50, packed=True) / 1e9))     # too small for the packed DB whole
         g = snp_genotype.Genotype(path, None)
         out = str(tmp_path / ("h5_%s" % budget_rows))
         snpmatch.Genotyper(make_inputs(toy), g, out, run_genotyper=True)
@@ -337,7 +351,7 @@ def test_packed_flat_panel_file_feeds_both_panel_kinds(case, golden_dir, tmp_pat
     snp_genotype.save_native(path, toy["snps"], toy["accs"], toy["positions"], toy["chrs"], toy["regions"], packed=True)
     for budget_rows in (None, 1000):
         if budget_rows:
-            monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(budget_for(budget_rows, 50) / 1e9))
+            monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(budget_for(budget_rows, 50, packed=True) / 1e9))
         g = snp_genotype.Genotype(path, None)
         o = str(tmp_path / ("packedfile_%s" % budget_rows))
         snpmatch.Genotyper(make_inputs(toy), g, o, run_genotyper=True)
