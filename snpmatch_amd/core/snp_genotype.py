@@ -29,6 +29,7 @@ from . import parsers
 from .. import _lib
 
 log = logging.getLogger(__name__)
+GROUP_MIN_BYTES = 1 << 30          # DBs of at least this many calls are spread over the visible GPUs without being asked to
 chunk_size = 1000
 
 
@@ -218,11 +219,20 @@ class Genotype(object):
             group = None
             # several GPUs from one process: when asked for (SNPMATCH_GPUS), or by default for DBs of at least 1 GiB -- below
             # that one GPU loads and scores the DB faster than a communicator is set up
-            big = int(self.g.snps.shape[0]) * n_acc >= (1 << 30)
-            if ctx is None and (big or os.environ.get("SNPMATCH_GPUS", "") != ""):
+            big = int(self.g.snps.shape[0]) * n_acc >= GROUP_MIN_BYTES
+            asked = os.environ.get("SNPMATCH_GPUS", "") != ""
+            if ctx is None and (big or asked):
                 ids = engine.group_devices()
                 if ids is not None:
-                    group = engine.default_group(engine.GroupPanel.usable_members(n_acc, len(ids)))
+                    try:
+                        group = engine.default_group(engine.GroupPanel.usable_members(n_acc, len(ids)))
+                    except (RuntimeError, OSError) as e:
+                        # several GPUs were found but their communicator could not be formed (RCCL missing or unable to reach
+                        # a peer): a job that did not ask for them runs on one GPU, a job that did is told
+                        if asked:
+                            raise
+                        log.warning("the %d visible GPUs cannot form a group (%s): using one GPU", len(ids), e)
+                        group = None
             if group is not None:
                 self._panel = engine.GroupPanel.build(group, n_acc, lambda c, a0, a1: self._member_panel(c, a0, a1, packed))
             else:

@@ -263,3 +263,30 @@ def test_back_to_back_gathers_do_not_race():
         want_n = np.concatenate([np.full(b[1] - b[0], 7 + i) for i, b in enumerate(bounds)])
         assert np.array_equal(out["score"], want_s) and np.array_equal(out["ninfo"], want_n)
         group.free()
+
+
+def test_unrequested_group_that_cannot_form_falls_back_to_one_gpu(golden_dir, tmp_path, monkeypatch):
+    """several GPUs visible, a DB large enough to be spread over them, but the communicator cannot be formed (no RCCL, an
+    unreachable peer): a job that did not ask for the GPUs runs on one of them -- the reference's files -- and a job that
+    asked (SNPMATCH_GPUS) is told"""
+    from snpmatch_amd.core import snp_genotype
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    gold = json.load(open(os.path.join(golden_dir, "g2_inbred.json")))["inbred_skip0"]
+
+    def broken(n_members=None):
+        raise RuntimeError("ncclCommInitAll failed: unhandled system error")
+
+    monkeypatch.delenv("SNPMATCH_GPUS", raising=False)
+    monkeypatch.setattr(snp_genotype, "GROUP_MIN_BYTES", 0)
+    monkeypatch.setattr(engine, "group_devices", lambda: [0, 1])
+    monkeypatch.setattr(engine, "default_group", broken)
+    g = make_g(toy)
+    out = str(tmp_path / "fallback")
+    snpmatch.Genotyper(make_inputs(toy), g, out, run_genotyper=True)
+    assert isinstance(g.panel(), engine.Panel)
+    cmp_scores_table(open(out + ".scores.txt").read(), gold["scores.txt"])
+    assert open(out + ".matches.json").read() == gold["matches.json"]
+    monkeypatch.setenv("SNPMATCH_GPUS", "2")
+    with pytest.raises(RuntimeError, match="ncclCommInitAll"):
+        make_g(toy).panel()
+
