@@ -20,7 +20,7 @@ positions = np.concatenate([1 + (np.arange(bounds[c + 1] - bounds[c]) * int(g0.c
 regions = [(int(bounds[c]), int(bounds[c + 1])) for c in range(5)]
 t = time.perf_counter()
 ctx = engine.default_context()
-panel = engine.Panel(ctx, n_snp, n_acc)
+panel = engine.Panel(ctx, n_snp, n_acc, packed=os.environ.get("PACKED", "0") == "1")     # PACKED=1: the 2-bit panel (the drop-in classes' default residency)
 panel.fill_synthetic(1001)
 g = snp_genotype.Genotype.from_arrays(np.zeros((0, n_acc), dtype=np.int8), [str(i) for i in range(n_acc)], positions,
                                       ["1", "2", "3", "4", "5"], regions)
