@@ -437,7 +437,10 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
         n * pitch_bytes >= (int64_t(4) << 30))
         occ = std::min(occ, 2);
     if (ctx->occ_cap > 0) occ = std::min(occ, ctx->occ_cap);
-    int64_t resident = (int64_t)ctx->n_cu * occ * std::max(1, ctx->parts_mult);
+    // one-wave blocks of the int8 kernel (panels of up to 256 accessions): four times as many parts as resident blocks
+    // (256 x 100M rows 0.597 -> 0.754 of HBM peak with the 128-row tiles; two-wave blocks and wider: no gain)
+    const int narrow_mult = (bpl == 4 && g.wpb == 1 && occ_blocks_hint > 0 && ctx->parts_mult == 1) ? 4 : 1;
+    int64_t resident = (int64_t)ctx->n_cu * occ * std::max(1, ctx->parts_mult) * narrow_mult;
     int64_t n_parts = std::max<int64_t>(1, resident / g.n_colblocks);
     const int64_t n_tiles = std::max<int64_t>(1, (n + tile_rows - 1) / tile_rows);
     n_parts = std::min(n_parts, n_tiles);                    // part p scores tiles p, p+P, p+2P, ...
@@ -658,7 +661,10 @@ int fast_tile_rows(const snpm_query *q, bool bits)
 {
     const snpm_panel *p = q->panel;
     if (p->packed) return bits ? BITS_TILE_ROWS : Q4_TILE_ROWS * Q4_RUN;
-    const bool long_tiles = q->n >= p->ctx->long_scan_rows && pick_bpl(p->ctx, p->n_acc) == 4;
+    // (panels of one or two waves keep the 128-row tiles: their blocks are small, the 16 KB of a long tile would bound the
+    // resident blocks -- 256 accessions x 100M rows 0.528 -> 0.597 of HBM peak, 512 accessions 0.685 -> 0.773,
+    // profiles/r03j_ab_int8_narrow.txt)
+    const bool long_tiles = q->n >= p->ctx->long_scan_rows && pick_bpl(p->ctx, p->n_acc) == 4 && p->n_acc > 2 * WAVE * 4;
     return long_tiles ? LONG_TILE_ROWS : TILE_ROWS;
 }
 
