@@ -389,7 +389,7 @@ int pick_bpl(snpm_ctx *ctx, int64_t n_acc)
 }
 
 FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint, int bpl, int tile_rows = TILE_ROWS,
-                   int wpb_fixed = 0)
+                   int wpb_fixed = 0, int kernel_parts_mult = 1)
 {
     FastGeom g;
     g.bpl = bpl;
@@ -440,9 +440,17 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     // one-wave blocks of the int8 kernel (panels of up to 256 accessions): four times as many parts as resident blocks
     // (256 x 100M rows 0.597 -> 0.754 of HBM peak with the 128-row tiles; two-wave blocks and wider: no gain)
     const int narrow_mult = (bpl == 4 && g.wpb == 1 && occ_blocks_hint > 0 && ctx->parts_mult == 1) ? 4 : 1;
-    int64_t resident = (int64_t)ctx->n_cu * occ * std::max(1, ctx->parts_mult) * narrow_mult;
-    int64_t n_parts = std::max<int64_t>(1, resident / g.n_colblocks);
     const int64_t n_tiles = std::max<int64_t>(1, (n + tile_rows - 1) / tile_rows);
+    // kernel_parts_mult: k_fast_packed_q4 runs best with MORE parts than resident blocks (run_fast) -- as long as a part keeps
+    // sixteen tiles or so: every part costs a slot of partial sums to write and to add up, which on short scans outweighs the
+    // gain (1135 accessions x 11M rows with 16 parts per block: kernel 1.07 -> 1.09 ms, the step 1.11 -> 1.25 ms)
+    int kmult = 1;
+    if (ctx->parts_mult == 1 && kernel_parts_mult > 1 && g.wpb != 5) {       // (the one 5-wave block shape, 4097-5120 accessions: 2 / 4 parts per block lose 10 / 2 %, 8 gain 1 %)
+        const int64_t base_parts = std::max<int64_t>(1, (int64_t)ctx->n_cu * occ * narrow_mult / g.n_colblocks);
+        kmult = (int)std::max<int64_t>(1, std::min<int64_t>(kernel_parts_mult, n_tiles / (base_parts * 16)));
+    }
+    int64_t resident = (int64_t)ctx->n_cu * occ * std::max(1, ctx->parts_mult) * narrow_mult * kmult;
+    int64_t n_parts = std::max<int64_t>(1, resident / g.n_colblocks);
     n_parts = std::min(n_parts, n_tiles);                    // part p scores tiles p, p+P, p+2P, ...
     if (ctx->debug_max_parts > 0) n_parts = std::min<int64_t>(n_parts, ctx->debug_max_parts);   // tests: long parts
     n_parts = std::min<int64_t>(n_parts, 65535);             // grid.y
@@ -698,7 +706,15 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     else if (bpl == 16) occ = nt ? occ_b<16, true>(skip, gather, thr) : occ_b<16, false>(skip, gather, thr);
     else if (bpl == 8) occ = nt ? occ_b<8, true>(skip, gather, thr) : occ_b<8, false>(skip, gather, thr);
     else occ = nt ? occ_b<4, true>(skip, gather, thr) : occ_b<4, false>(skip, gather, thr);
-    FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl, tile_rows, wpb_fixed);
+    // Parts per resident block (round 3, profiles/r03j_ab_q4_parts_mult.txt, r03j_ab_parts_mult_all.txt): with as many parts as
+    // resident blocks every block of k_fast_packed_q4 walks its tiles in step with all the others -- the whole chip builds tables,
+    // then the whole chip looks up; eight times as many, shorter parts take the blocks out of step: 10 000 accessions 11.77 ->
+    // 10.50 ms per 20M SNPs (0.536 -> 0.601 of HBM peak on packed bytes), 8192: 0.644 -> 0.673, 4096: 0.628 -> 0.661, 2400: 0.448 ->
+    // 0.506, 1135: 0.393 -> 0.430, 512: 0.279 -> 0.332; on the whole 10 000 x 50M job 2 / 4 / 8 / 16 / 24 parts per block take
+    // 27.9 / 27.0 / 25.9 / 25.3 / 25.1 ms (r03j_ab_parts_mult_full.txt; 28.9 with one): sixteen.  k_fast_bits and the int8 k_fast keep
+    // one part per resident block (more: +1.5 % on 20M rows but -3 % on 50M for the bits kernel, -6 ... -1 % on every int8 shape).
+    const int kmult = (p16 && !bits) ? 16 : 1;
+    FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl, tile_rows, wpb_fixed, kmult);
     if (geom_out) *geom_out = g;
     q->last_kernel = bits ? "k_fast_bits" : (p16 ? "k_fast_packed_q4" : "k_fast");
     rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_slots * p->ld * sizeof(double));
@@ -1873,8 +1889,12 @@ try {
     const bool p16 = q->panel->packed != 0;
     const int bpl = p16 ? 16 : pick_bpl(ctx, q->panel->n_acc);
     // occ 1 -> the fewest, longest parts -> the largest bound; the tile size the run uses (the bound counts epochs of its tiles)
-    FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl, p16 ? std::min(BITS_TILE_ROWS, Q4_TILE_ROWS) : fast_tile_rows(q, false));
-    *bound = eref + efast_bound(q, g);
+    const int tile = p16 ? std::min(BITS_TILE_ROWS, Q4_TILE_ROWS) : fast_tile_rows(q, false);
+    FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl, tile);
+    // ... and the most, shortest parts a run may use (eight resident blocks per CU, the packed kernels' eight parts per
+    // block): the most partial sums to add up afterwards; the bound reported is the larger of the two
+    FastGeom g2 = fast_geom(ctx, q->panel->n_acc, q->n, 8, bpl, tile, 0, p16 ? 16 : 1);
+    *bound = eref + std::max(efast_bound(q, g), efast_bound(q, g2));
     return SNPM_OK;
 } SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
 
