@@ -94,6 +94,7 @@ struct snpm_ctx {
     // tunables (environment)
     int force_bpl = 0;
     int force_wpb = 0;
+    int part_min_tiles = 8;             // SNPM_PART_MIN_TILES: tiles a part keeps when k_fast_packed_q4 takes more parts than resident blocks
     int q4_tile_rows = 0;               // SNPM_Q4_TILE_ROWS: rows per LDS tile of k_fast_packed_q4 (0: by block size)
     int parts_mult = 1;
     int use_acc_major = 1;  // keep an accession-major packed copy (+25 % memory) for contiguous re-evaluation reads
@@ -442,12 +443,13 @@ FastGeom fast_geom(snpm_ctx *ctx, int64_t n_acc, int64_t n, int occ_blocks_hint,
     const int narrow_mult = (bpl == 4 && g.wpb == 1 && occ_blocks_hint > 0 && ctx->parts_mult == 1) ? 4 : 1;
     const int64_t n_tiles = std::max<int64_t>(1, (n + tile_rows - 1) / tile_rows);
     // kernel_parts_mult: k_fast_packed_q4 runs best with MORE parts than resident blocks (run_fast) -- as long as a part keeps
-    // sixteen tiles or so: every part costs a slot of partial sums to write and to add up, which on short scans outweighs the
-    // gain (1135 accessions x 11M rows with 16 parts per block: kernel 1.07 -> 1.09 ms, the step 1.11 -> 1.25 ms)
+    // eight tiles or so: every part costs a slot of partial sums to write and to add up, which on short scans outweighs the
+    // gain (1135 accessions x 11M rows with 16 parts per block: kernel 1.07 -> 1.09 ms, the step 1.11 -> 1.25 ms; 32 / 16 / 8 / 4
+    // tiles per part by the time of the whole step: profiles/r03j_ab_part_min_tiles.txt)
     int kmult = 1;
     if (ctx->parts_mult == 1 && kernel_parts_mult > 1 && g.wpb != 5) {       // (the one 5-wave block shape, 4097-5120 accessions: 2 / 4 parts per block lose 10 / 2 %, 8 gain 1 %)
         const int64_t base_parts = std::max<int64_t>(1, (int64_t)ctx->n_cu * occ * narrow_mult / g.n_colblocks);
-        kmult = (int)std::max<int64_t>(1, std::min<int64_t>(kernel_parts_mult, n_tiles / (base_parts * 16)));
+        kmult = (int)std::max<int64_t>(1, std::min<int64_t>(kernel_parts_mult, n_tiles / (base_parts * std::max(1, ctx->part_min_tiles))));
     }
     int64_t resident = (int64_t)ctx->n_cu * occ * std::max(1, ctx->parts_mult) * narrow_mult * kmult;
     int64_t n_parts = std::max<int64_t>(1, resident / g.n_colblocks);
@@ -1350,6 +1352,7 @@ try {
     if (const char *s = getenv("SNPM_PARTS_MULT")) ctx->parts_mult = std::max(1, atoi(s));
     if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
     if (const char *s = getenv("SNPM_Q4_TILE_ROWS")) ctx->q4_tile_rows = atoi(s);
+    if (const char *s = getenv("SNPM_PART_MIN_TILES")) ctx->part_min_tiles = std::max(1, atoi(s));
     if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
     if (const char *s = getenv("SNPM_BITS")) ctx->bits_path = atoi(s);
     if (const char *s = getenv("SNPM_PITCH_ALIGN")) {

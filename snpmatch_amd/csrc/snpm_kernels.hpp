@@ -524,7 +524,10 @@ constexpr int BITS_TILE_ROWS = 256;     // rows per tile of k_fast_bits (no LDS:
 constexpr int BITS_FLUSH_ROWS = 64;     // its bit-sliced counters (7 planes) are flushed into 16-bit counters every 64 rows
 constexpr int Q4_TILE_ROWS = 64;        // 16 four-row tables x 2 KiB = 32 KiB of LDS per block
 constexpr int Q4_G = 8;                 // rows per prefetch group (two tables)
-constexpr int Q4_RUN = 4;               // tiles a part scores in a row before it jumps ahead (the host's tile = Q4_RUN * Q4_TILE_ROWS rows)
+#ifndef SNPM_Q4_RUN
+#define SNPM_Q4_RUN 4
+#endif
+constexpr int Q4_RUN = SNPM_Q4_RUN;     // tiles a part scores in a row before it jumps ahead (the host's tile = Q4_RUN * Q4_TILE_ROWS rows)
 // Epoch sizes are coupled across three places: the 16-bit missing-call counters of the packed kernels (flushed once per
 // epoch), and the host's fast-pass error bound (efast_bound, snpm_api.hip), which counts at most EPOCH_TILES * TILE_ROWS
 // additions per term inside a part.  k_fast_packed_q4 adds pre-summed quads of rows (a quarter of its rows + 3 table additions
