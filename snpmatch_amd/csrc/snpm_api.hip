@@ -94,6 +94,7 @@ struct snpm_ctx {
     // tunables (environment)
     int force_bpl = 0;
     int force_wpb = 0;
+    int seg_blocks_per_cu = 0;          // SNPM_SEG_BLOCKS_PER_CU: parts of a segmented pass per CU and column block (0: 32 on int8 panels, 8 on packed ones)
     int part_min_tiles = 8;             // SNPM_PART_MIN_TILES: tiles a part keeps when k_fast_packed_q4 takes more parts than resident blocks
     int q4_tile_rows = 0;               // SNPM_Q4_TILE_ROWS: rows per LDS tile of k_fast_packed_q4 (0: by block size)
     int parts_mult = 1;
@@ -1054,7 +1055,10 @@ static int seg_plan(snpm_ctx *ctx, SegJob &j, SegPlan &pl)
         kmax = std::max<int64_t>(kmax, (len + j.chunk - 1) / j.chunk);
     }
     // enough parts to fill the chip a few times over
-    const int64_t want_blocks = std::max<int64_t>(1, (int64_t)ctx->n_cu * 8 / std::max<int64_t>(1, pl.g0.n_colblocks));
+    // (int8 panels: 32 parts per CU and column block, gathered batches of 64 samples 3.07 -> 2.72 ms with them; packed panels
+    // measure the same from 8 to 64 and keep 8 -- profiles/r03j_ab_seg_blocks.txt)
+    const int per_cu = ctx->seg_blocks_per_cu > 0 ? ctx->seg_blocks_per_cu : (q4 ? 8 : 32);
+    const int64_t want_blocks = std::max<int64_t>(1, (int64_t)ctx->n_cu * per_cu / std::max<int64_t>(1, pl.g0.n_colblocks));
     pl.tiles_per_part = std::max<int64_t>(2, std::min<int64_t>(EPOCH_TILES, (total_tiles + want_blocks - 1) / want_blocks));
     // [seg_off | slot0 | part_desc], built in pinned memory (the copy below is asynchronous)
     const int64_t max_parts = total_tiles / pl.tiles_per_part + n_seg + 1;
@@ -1353,6 +1357,7 @@ try {
     if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
     if (const char *s = getenv("SNPM_Q4_TILE_ROWS")) ctx->q4_tile_rows = atoi(s);
     if (const char *s = getenv("SNPM_PART_MIN_TILES")) ctx->part_min_tiles = std::max(1, atoi(s));
+    if (const char *s = getenv("SNPM_SEG_BLOCKS_PER_CU")) ctx->seg_blocks_per_cu = std::max(1, atoi(s));
     if (const char *s = getenv("SNPM_NT")) ctx->nt_loads = atoi(s);
     if (const char *s = getenv("SNPM_BITS")) ctx->bits_path = atoi(s);
     if (const char *s = getenv("SNPM_PITCH_ALIGN")) {
