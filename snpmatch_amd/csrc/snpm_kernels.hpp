@@ -51,6 +51,9 @@ namespace snpm {
 #ifndef SNPM_Q4_PHASES
 #define SNPM_Q4_PHASES 1                // k_fast_packed_q4: a last wave with <= 32 lanes inside the panel splits its lanes over row groups (see the kernel)
 #endif
+#ifndef SNPM_Q4_PROTO_ONE_BARRIER
+#define SNPM_Q4_PROTO_ONE_BARRIER 0
+#endif
 #ifndef SNPM_Q4_PROTO_QUAD
 #define SNPM_Q4_PROTO_QUAD 0            // 1: timing experiment only (results are wrong): k_fast_packed_q4 without its 4 x 16 transpose
 #endif
@@ -968,7 +971,9 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             }
             flush_planes();
             if (more) store_l4(ntr0, pre);
+#if !SNPM_Q4_PROTO_ONE_BARRIER                   // (1: timing experiment only, results are wrong -- what a second table set would save)
             __syncthreads();                      // every wave is done with this tile's tables; s_l4 holds the next rows
+#endif
             if (more) build_tables();
             __syncthreads();
         }
