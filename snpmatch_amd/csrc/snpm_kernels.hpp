@@ -51,6 +51,9 @@ namespace snpm {
 #ifndef SNPM_Q4_PHASES
 #define SNPM_Q4_PHASES 1                // k_fast_packed_q4: a last wave with <= 32 lanes inside the panel splits its lanes over row groups (see the kernel)
 #endif
+#ifndef SNPM_Q4_PROTO_NOLOAD
+#define SNPM_Q4_PROTO_NOLOAD 0
+#endif
 #ifndef SNPM_Q4_PROTO_ONE_BARRIER
 #define SNPM_Q4_PROTO_ONE_BARRIER 0
 #endif
@@ -646,6 +649,11 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     // in the scalar offset, the lane's bytes in the vector offset -- no per-load vector instruction (the saddr form of
     // global_load costs a v_mov per load here); gathered rows keep the global loads
     auto load_group = [&](uint32_t (&x)[G], int64_t r) {
+#if SNPM_Q4_PROTO_NOLOAD                         // timing experiment only (wrong results): the pass without its row loads
+#pragma unroll
+        for (int u = 0; u < G; ++u) x[u] = ((uint32_t)r + (uint32_t)u) * 2654435761u + lane_off * 40503u;
+        return;
+#endif
         if constexpr (!GATHER) {
             const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<int8_t *>(db + (row0 + r) * pitch), 0, (int)(G * pitch), 0x00020000);
