@@ -76,6 +76,7 @@ CASES = [
     (3000, 1250, None, 1000),
     (1500, 4097, None, 500),
     (2100, 10000, None, 1000),
+    (1300, 8192, None, 1000),          # a row pitch that would be a multiple of 8 KiB: padded by 256 B (panel_row_pitch)
     (130, 17, 129, 7),
 ]
 
@@ -534,7 +535,8 @@ def test_reevaluation_on_the_accession_major_copy_many_shapes(forced):
 
 # ------------------------------------------------------------------ packed (2 bits per call) panel format
 @pytest.mark.parametrize("n_snp,n_acc,n_match,chunk", [(4000, 1, 1000, 1000), (6000, 64, 3001, 1000), (20000, 1135, 7545, 1000),
-                                                       (3000, 1250, None, 1000), (2100, 10000, None, 1000), (130, 17, 129, 7)])
+                                                       (3000, 1250, None, 1000), (2100, 10000, None, 1000), (130, 17, 129, 7),
+                                                       (700, 32768, 301, 1000)])
 @pytest.mark.parametrize("skip", [False, True])
 def test_packed_panel_modes_vs_oracle(ctx, n_snp, n_acc, n_match, chunk, skip):
     rng = np.random.default_rng(n_snp * 17 + n_acc)
@@ -543,7 +545,8 @@ def test_packed_panel_modes_vs_oracle(ctx, n_snp, n_acc, n_match, chunk, skip):
         db[:, 2] = -1
         db[::5, 3] = -7                    # any negative value is "missing"
     panel = engine.Panel.from_host(ctx, db, packed=True)
-    assert panel.packed and panel.pitch == ((n_acc + 3) // 4 + 255) // 256 * 256
+    want_pitch = ((n_acc + 3) // 4 + 255) // 256 * 256
+    assert panel.packed and panel.pitch == want_pitch + (256 if want_pitch % 8192 == 0 else 0)     # multiples of 8 KiB are padded
     back = panel.download_rows(0, n_snp)
     assert np.array_equal(back, np.where(db < 0, -1, db))
     if n_match is None:
