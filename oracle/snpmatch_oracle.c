@@ -22,6 +22,7 @@
  *   score[a] = ((0 + A_ref[a]) + A_het[a]) + A_alt[a]
  *   ninfo[a] = (r1-r0) - #{rows: db[row,a] < 0}
  * with skip_hets: db==2 is treated as -1 (missing) for both score and ninfo.
+ * Panels of ONE accession (n_acc == 1): A_c is numpy's sum of a contiguous vector instead (np_sum_vector below).
  */
 #include <math.h>
 #include <stdint.h>
@@ -31,6 +32,41 @@
 static const int CAT_CODE[3] = {0, 2, 1};
 static const int CAT_COL[3]  = {0, 1, 2};
 
+/* numpy's DOUBLE_pairwise_sum (numpy/_core/src/umath/loops_utils.h.src), restated: fewer than 8 elements
+ * sequentially; up to 128 elements eight strided accumulators combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+ * and the tail added one by one; longer runs split at n/2 rounded down to a multiple of 8. */
+static double np_pairwise(const double *a, int64_t n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] = r[j] + a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+}
+
+/* np.sum of a contiguous fp64 vector as numpy 2.2 evaluates it: 8192-element buffer pieces, each summed
+ * pairwise, added in order onto 0.0 (pinned against np.sum and the reference in tests/test_oracle_golden.py). */
+static double np_sum_vector(const double *a, int64_t n)
+{
+    double res = 0.0;
+    for (int64_t c0 = 0; c0 < n; c0 += 8192)
+        res = res + np_pairwise(a + c0, n - c0 < 8192 ? n - c0 : 8192);
+    return res;
+}
+
 /* One matchGTsAccs call.  db: [n rows] gathered through row_idx (or dense when row_idx==NULL)
  * with row pitch `pitch` bytes; wei: [n,3] rows r0.. of the matched-weight array.
  * out_score/out_ninfo: [n_acc]; tmp: scratch [n_acc] doubles. */
@@ -39,11 +75,23 @@ static void match_call(const int8_t *db, int64_t pitch, const int64_t *row_idx, 
                        int64_t *out_ninfo, double *tmp)
 {
     for (int64_t a = 0; a < n_acc; ++a) { out_score[a] = 0.0; out_ninfo[a] = r1 - r0; }
+    /* ONE accession: the reference's [1, n] product is contiguous along the reduced axis, numpy sums it as a
+     * vector (pairwise inside 8192-element pieces), not row after row (snpmatch.py:85-87 with N_acc == 1) */
+    double *vec = NULL;
+    if (n_acc == 1 && r1 > r0) vec = (double *)malloc(sizeof(double) * (size_t)(r1 - r0));
     for (int c = 0; c < 3; ++c) {
         const int8_t code = (int8_t)CAT_CODE[c];
         const int col = CAT_COL[c];
         if (skip_hets && code == 2) {
             /* het rows became missing: A_het == 0, adding +0.0 leaves score unchanged */
+            continue;
+        }
+        if (vec) {
+            for (int64_t r = r0; r < r1; ++r) {
+                const int8_t *row = db + (row_idx ? row_idx[r] : r) * pitch;
+                vec[r - r0] = (row[0] == code) ? wei[3 * r + col] : 0.0;
+            }
+            out_score[0] = out_score[0] + np_sum_vector(vec, r1 - r0);
             continue;
         }
         for (int64_t a = 0; a < n_acc; ++a) tmp[a] = 0.0;
@@ -54,6 +102,7 @@ static void match_call(const int8_t *db, int64_t pitch, const int64_t *row_idx, 
         }
         for (int64_t a = 0; a < n_acc; ++a) out_score[a] = out_score[a] + tmp[a];
     }
+    free(vec);
     for (int64_t r = r0; r < r1; ++r) {
         const int8_t *row = db + (row_idx ? row_idx[r] : r) * pitch;
         if (skip_hets) {

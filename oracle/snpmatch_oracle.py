@@ -19,8 +19,13 @@ Each function cites the reference lines it follows (paths relative to
 
 Summation-order model (verified bit-for-bit against the reference on numpy
 2.2.6, see tests): ``matchGTsAccs`` reduces an F-ordered ``[N_acc, n]`` product
-over its strided axis, which numpy executes as plain row-after-row adds.  So for
-one call with ``n`` SNP rows::
+over its strided axis, which numpy executes as plain row-after-row adds
+(N_acc >= 2).  A panel of ONE accession is the exception: a ``[1, n]`` array is
+contiguous along the reduced axis too, and numpy then takes its contiguous-axis
+route -- ``A_c = np.sum`` of a vector: pairwise summation (leaves of <= 128
+elements with eight strided accumulators) inside 8192-element buffer pieces,
+the pieces added in order (``np_sum_restated`` below; goldens g1b / g2b / g5b).
+So for one call with ``n`` SNP rows and N_acc >= 2::
 
     A_c[a] = (((0 + t_c[0,a]) + t_c[1,a]) + ...) + t_c[n-1,a]     c in (ref, het, alt)
     score[a] = ((0 + A_ref[a]) + A_het[a]) + A_alt[a]
@@ -57,6 +62,14 @@ def match_gts_accs(wei, db, skip_hets_db=False):
         db = np.where(db == 2, np.int8(-1), db)
     n, n_acc = db.shape
     score = np.zeros(n_acc)
+    if n_acc == 1:
+        # ONE accession: the reference's [1, n] product is contiguous along the axis it reduces, and numpy sums a
+        # contiguous axis pairwise (8192-element buffer pieces added in order), not row after row
+        for code, col in CATEGORIES:                                          # :85-87
+            t = (db[:, 0] == code).astype(np.int64) * wei[:, col]
+            score = score + np_sum_restated(t)
+        ninfo = n - (db < 0).sum(axis=0).astype(np.int64)                     # :88
+        return score, ninfo
     for code, col in CATEGORIES:                                              # :85-87
         acc = np.zeros(n_acc)
         for s in range(n):

@@ -26,6 +26,8 @@ Outputs (all under tests/golden/):
   g5_cross.npz/json  per-window scores, get_window_data rows, np_test_identity, cross files' text
   g6_common.npz      get_common_positions edge cases
   g7_cross_*         F1-like and F2-like samples through the whole cross pipeline (interpreter cases >= 3)
+  g1b_single_acc.npz, g2b_g5b_single_acc.npz/json, toy_db_single.npz
+                     the same for panels of ONE accession (numpy sums a contiguous axis pairwise: another order)
 """
 import io
 import json
@@ -209,11 +211,11 @@ def g1_match():
 TOY_CHRLENS = [30427671, 19698289, 23459830, 18585056, 26975502]   # TAIR10 lengths (genome json)
 
 
-def build_toy(seed, n_acc=50, near=()):
+def build_toy(seed, n_acc=50, near=(), planted=17):
     rng = np.random.default_rng(seed)
     snps, accs, positions, chrs, regions = toy_db(rng, TOY_CHRLENS, 2000, n_acc, near_identical=near)
     s_chrs, s_pos, s_gt, s_wei, s_dp = toy_sample(rng, snps, positions, regions, TOY_CHRLENS,
-                                                  n_hit=2400, n_miss=600, planted=17, err=0.03)
+                                                  n_hit=2400, n_miss=600, planted=planted, err=0.03)
     return dict(snps=snps, accs=np.array(accs), positions=positions, chrs=np.array(chrs),
                 regions=np.array(regions), s_chrs=s_chrs, s_pos=s_pos, s_gt=s_gt, s_wei=s_wei, s_dp=s_dp)
 
@@ -375,6 +377,109 @@ def g5_cross():
     print("g5: cross captured (%d windows)" % (len(arrays["win_off_skip0"]) - 1))
 
 
+# ----------------------------------------------------------------------------- G1b / G2b / G5b: ONE accession
+def g1b_single_accession():
+    """Panels of one accession: numpy reduces the reference's [1, n] product along a contiguous axis, i.e. pairwise
+    inside 8192-element buffer pieces instead of row after row (core/snpmatch.py:85-87) -- its own fixtures, with their
+    own seeds, so that g1 ... g7 keep their bytes."""
+    rng = np.random.default_rng(701502)
+    out = {}
+    names = []
+    for n in (8, 9, 64, 129, 500, 1000, 2000, 8193, 20000):
+        db = rng.choice(DB_V, size=(n, 1), p=DB_P)
+        for kind in (("pl", "hard") if n <= 2000 else ("pl",)):
+            wei, _ = make_weights(rng, n, frac_pl=0.8 if kind == "pl" else 0.0)
+            key0 = "n%d_a1_%s" % (n, kind)
+            out[key0 + "_db"] = db
+            out[key0 + "_wei"] = wei
+            for skip in (False, True):
+                s, ni = ref_sm.matchGTsAccs(wei, db.copy(), skip)
+                key = key0 + "_%d" % int(skip)
+                names.append(key)
+                out[key + "_score"] = np.asarray(s, dtype=np.float64)
+                out[key + "_ninfo"] = np.asarray(ni, dtype=np.int64)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "g1b_single_acc.npz"), **out)
+    print("g1b: %d one-accession cases" % len(names))
+
+    def _append(self, other, ignore_index=False):
+        return pd.concat([self, other], ignore_index=ignore_index)
+    pd.DataFrame.append = _append             # pandas >= 2 (see module docstring)
+    toy = build_toy(1004, n_acc=1, planted=0)
+    np.savez_compressed(os.path.join(OUT, "toy_db_single.npz"), **toy)
+    res = {"note": "pandas2-append-shim"}
+    arrays = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for skip in (False, True):
+            # G2b: Genotyper end to end + the raw accumulators of its chunk loop
+            gt, files = run_inbred(toy, skip, False, tmp)
+            res["inbred_skip%d" % int(skip)] = files
+            score = np.zeros(1)
+            ninfo = np.zeros(1, dtype="uint32")
+            c0, c1 = gt.commonSNPs
+            for j in range(0, len(c0), 1000):
+                s, ni = ref_sm.matchGTsAccs(toy["s_wei"][c1[j:j + 1000]], toy["snps"][c0[j:j + 1000], :].copy(), skip)
+                score = score + s
+                ninfo = ninfo + ni
+            arrays["common_db"] = np.asarray(c0, dtype=np.int64)
+            arrays["common_sample"] = np.asarray(c1, dtype=np.int64)
+            arrays["score_skip%d" % int(skip)] = score
+            arrays["ninfo_skip%d" % int(skip)] = np.asarray(ninfo, dtype=np.int64)
+            assert np.array_equal(np.array(score, dtype=int), gt.result.scores)
+            # G5b: the cross pipeline's files and its per-window kernel outputs
+            g = make_genotype(toy["snps"].copy(), toy["accs"], toy["positions"], toy["chrs"], toy["regions"])
+            inputs = make_inputs(toy["s_chrs"], toy["s_pos"], toy["s_gt"], toy["s_wei"], toy["s_dp"])
+            outp = os.path.join(tmp, "cross%d" % int(skip))
+            stderr = sys.stderr
+            sys.stderr = io.StringIO()
+            try:
+                ref_cs.CrossIdentifier(inputs, g, "athaliana_tair10", 300000, outp, run_identifier=True, skip_db_hets=skip)
+            finally:
+                sys.stderr = stderr
+            files = {}
+            for suf in (".windowscore.txt", ".scores.txt", ".scores.txt.matches.json", ".matches.json"):
+                if os.path.exists(outp + suf):
+                    files[suf] = read_text(outp + suf)
+            res["cross_skip%d" % int(skip)] = files
+            genome = ref_genomes.Genome("athaliana_tair10")
+            wins_g = list(genome.get_bins_genome(g.g, 300000))
+            wins_s = list(genome.get_bins_arrays(inputs.chrs, inputs.pos, 300000))
+            rows_db, rows_s, off, w_score, w_ninfo = [], [], [0], [], []
+            for e_g, e_s in zip(wins_g, wins_s):
+                gp = g.g.positions[e_g[2]]
+                sp = inputs.pos[e_s[2]]
+                mdb = np.array(e_g[2], dtype=int)[np.where(np.in1d(gp, sp))[0]]
+                msm = np.array(e_s[2], dtype=int)[np.where(np.in1d(sp, gp))[0]]
+                rows_db.extend(mdb.tolist())
+                rows_s.extend(msm.tolist())
+                off.append(len(rows_db))
+                if len(mdb) > 0:
+                    s, ni = ref_sm.matchGTsAccs(inputs.wei[msm, ], toy["snps"][mdb, :].copy(), skip)
+                else:
+                    s, ni = np.zeros(1), np.zeros(1, dtype=int)
+                w_score.append(np.asarray(s, dtype=float))
+                w_ninfo.append(np.asarray(ni, dtype=np.int64))
+            arrays["win_off_skip%d" % int(skip)] = np.array(off, dtype=np.int64)
+            arrays["win_rows_db_skip%d" % int(skip)] = np.array(rows_db, dtype=np.int64)
+            arrays["win_rows_sample_skip%d" % int(skip)] = np.array(rows_s, dtype=np.int64)
+            arrays["win_score_skip%d" % int(skip)] = np.array(w_score)
+            arrays["win_ninfo_skip%d" % int(skip)] = np.array(w_ninfo)
+        # one long window (a cross with a large --binLen): more rows than one 8192-element buffer piece
+        rng = np.random.default_rng(701503)
+        n = 3 * 8192 + 77
+        db = rng.choice(DB_V, size=(n, 1), p=DB_P)
+        wei, _ = make_weights(rng, n)
+        arrays["long_db"], arrays["long_wei"] = db, wei
+        for skip in (False, True):
+            s, ni = ref_sm.matchGTsAccs(wei, db.copy(), skip)
+            arrays["long_score_skip%d" % int(skip)] = np.asarray(s, dtype=np.float64)
+            arrays["long_ninfo_skip%d" % int(skip)] = np.asarray(ni, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g2b_g5b_single_acc.npz"), **arrays)
+    with open(os.path.join(OUT, "g2b_g5b_single_acc.json"), "w") as fh:
+        json.dump(res, fh, indent=1, sort_keys=True)
+    print("g2b/g5b: one-accession inbred + cross captured (%d windows)" % (len(arrays["win_off_skip0"]) - 1))
+
+
 # ----------------------------------------------------------------------------- G6
 def g6_common():
     rng = np.random.default_rng(6)
@@ -499,5 +604,6 @@ if __name__ == "__main__":
     g5_cross()
     g6_common()
     g7_cross_cases()
+    g1b_single_accession()
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith((".npz", ".json"))}
     print(json.dumps(sizes, indent=1))

@@ -58,6 +58,57 @@ def test_match_golden_bitexact(golden_dir):
         assert np.array_equal(np.asarray(n), want_n), "graph " + name
 
 
+# ------------------------------------------------------------------ G1b / G2b / G5b: panels of ONE accession
+def test_single_accession_goldens_bitexact(golden_dir):
+    """numpy sums the reference's [1, n] product along a contiguous axis: pairwise inside 8192-element pieces, not row
+    after row (core/snpmatch.py:85-87 with N_acc == 1) -- both oracles follow that rule for one-column panels"""
+    g = np.load(os.path.join(golden_dir, "g1b_single_acc.npz"))
+    differs_from_sequential = 0
+    for name in g["names"]:
+        key0, skip = name[:-2], name.endswith("_1")
+        db, wei = g[key0 + "_db"], g[key0 + "_wei"]
+        assert db.shape[1] == 1
+        want_s, want_n = g[name + "_score"], g[name + "_ninfo"]
+        for tag, (s, n) in (("numpy", orc.match_gts_accs(wei, db, skip)), ("C", c_oracle.match(wei, db, skip)),
+                            ("graph", orc.match_gts_accs_graph(wei, db.copy(), skip))):
+            assert np.array_equal(bits(s), bits(want_s)), (tag, name)
+            assert np.array_equal(np.asarray(n), want_n), (tag, name)
+        # the row-after-row order (what every wider panel gets) really is another number for some of them
+        wide = np.concatenate([db, db], axis=1)
+        s2, _ = c_oracle.match(wei, wide, skip)
+        differs_from_sequential += int(bits(s2)[0] != bits(want_s)[0])
+        assert bits(s2)[0] == bits(s2)[1]
+    assert differs_from_sequential >= 8
+
+
+def test_single_accession_genotyper_and_windows_golden(golden_dir):
+    toy = np.load(os.path.join(golden_dir, "toy_db_single.npz"))
+    g = np.load(os.path.join(golden_dir, "g2b_g5b_single_acc.npz"))
+    assert toy["snps"].shape[1] == 1
+    c0, c1 = orc.get_common_positions(
+        np.repeat(toy["chrs"], [b - a for a, b in toy["regions"]]), toy["positions"], toy["s_chrs"], toy["s_pos"])
+    assert np.array_equal(c0, g["common_db"]) and np.array_equal(c1, g["common_sample"])
+    wei = toy["s_wei"][c1]
+    for skip in (0, 1):
+        s, n = orc.genotyper_scores(wei, toy["snps"][c0], 1000, bool(skip))
+        assert np.array_equal(bits(s), bits(g["score_skip%d" % skip])) and np.array_equal(n, g["ninfo_skip%d" % skip])
+        s, n = c_oracle.genotyper(toy["snps"], c0, wei, 1000, bool(skip))
+        assert np.array_equal(bits(s), bits(g["score_skip%d" % skip])) and np.array_equal(n, g["ninfo_skip%d" % skip])
+        off = g["win_off_skip%d" % skip]
+        rows_db, rows_s = g["win_rows_db_skip%d" % skip], g["win_rows_sample_skip%d" % skip]
+        ws, wn, _, _ = c_oracle.windows(toy["snps"], rows_db, toy["s_wei"][rows_s], off, bool(skip))
+        assert np.array_equal(bits(ws), bits(g["win_score_skip%d" % skip]))
+        assert np.array_equal(wn, g["win_ninfo_skip%d" % skip])
+        ws, wn = orc.window_scores(toy["s_wei"][rows_s], toy["snps"][rows_db], off, bool(skip))[:2]
+        assert np.array_equal(bits(ws), bits(g["win_score_skip%d" % skip]))
+        assert np.array_equal(wn, g["win_ninfo_skip%d" % skip])
+        # one window longer than numpy's 8192-element buffer
+        s, n = c_oracle.match(g["long_wei"], g["long_db"], bool(skip))
+        assert np.array_equal(bits(s), bits(g["long_score_skip%d" % skip])) and np.array_equal(n, g["long_ninfo_skip%d" % skip])
+        s, n = orc.match_gts_accs(g["long_wei"], g["long_db"], bool(skip))
+        assert np.array_equal(bits(s), bits(g["long_score_skip%d" % skip]))
+
+
 def test_match_asserts():
     with pytest.raises(AssertionError, match="same number of positions"):
         orc.match_gts_accs(np.ones((3, 3)), np.zeros((4, 2), dtype=np.int8))
