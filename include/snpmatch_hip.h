@@ -93,6 +93,11 @@ int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **
    upload).  Every scoring entry point accepts either panel kind and returns identical results. */
 int snpm_panel_create_packed(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out);
 int snpm_panel_is_packed(const snpm_panel *panel, int *packed);
+/* This panel holds only some accession columns (a rank's shard) of a DB of n_acc_total accessions.  Only n_acc_total == 1
+   against > 1 matters: for a panel of ONE accession numpy reduces the reference's [1, n] product along a contiguous axis, i.e.
+   pairwise inside 8192-element pieces, where every wider panel is summed row after row (core/snpmatch.py:85-87) -- the
+   reference-order kernels follow the rule of the width the reference would see.  Default: the panel's own n_acc. */
+int snpm_panel_set_total_accessions(snpm_panel *panel, int64_t n_acc_total);
 /* Bytes per row a panel of n_acc accessions will have on this context (what snpm_panel_info reports afterwards): for callers
    that size a panel to a memory budget before creating it. */
 int snpm_panel_row_pitch(snpm_ctx *ctx, int64_t n_acc, int packed, int64_t *pitch);

@@ -31,7 +31,7 @@ MODE_FAST = 2
 # every symbol include/snpmatch_hip.h declares (tests check that the .so exports all of them)
 SYMBOLS = [
     "snpm_version", "snpm_hip_build_version", "snpm_device_count", "snpm_init", "snpm_destroy", "snpm_last_error", "snpm_set_stream",
-    "snpm_synchronize", "snpm_device_mem_info", "snpm_panel_create", "snpm_panel_create_packed", "snpm_panel_is_packed", "snpm_panel_row_pitch", "snpm_panel_free", "snpm_panel_info", "snpm_panel_upload_rows", "snpm_panel_load_file", "snpm_panel_load_file_rows", "snpm_panel_load_file_rows_packed", "snpm_pack_rows_host",
+    "snpm_synchronize", "snpm_device_mem_info", "snpm_panel_create", "snpm_panel_create_packed", "snpm_panel_is_packed", "snpm_panel_set_total_accessions", "snpm_panel_row_pitch", "snpm_panel_free", "snpm_panel_info", "snpm_panel_upload_rows", "snpm_panel_load_file", "snpm_panel_load_file_rows", "snpm_panel_load_file_rows_packed", "snpm_pack_rows_host",
     "snpm_panel_upload_wait", "snpm_panel_download_rows", "snpm_panel_fill_synthetic", "snpm_query_create",
     "snpm_query_free", "snpm_query_bind_outputs", "snpm_query_run", "snpm_query_run_device", "snpm_query_error_bound",
     "snpm_query_run_windows", "snpm_query_run_windows_carry", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
@@ -144,6 +144,7 @@ def load():
     lib.snpm_panel_create_packed.argtypes = [p, i64, i64, pp]
     lib.snpm_panel_row_pitch.argtypes = [p, i64, C.c_int, C.POINTER(C.c_int64)]
     lib.snpm_panel_is_packed.argtypes = [p, C.POINTER(ci)]
+    lib.snpm_panel_set_total_accessions.argtypes = [p, i64]
     lib.snpm_panel_free.argtypes = [p]
     lib.snpm_panel_info.argtypes = [p, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), pp]
     lib.snpm_panel_upload_rows.argtypes = [p, i64, i64, p, i64]

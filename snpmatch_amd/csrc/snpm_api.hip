@@ -122,6 +122,8 @@ struct snpm_ctx {
 struct snpm_panel {
     snpm_ctx *ctx = nullptr;
     int64_t n_snp = 0, n_acc = 0;
+    int64_t n_acc_total = 0;            // accessions of the panel the REFERENCE would see (= n_acc unless this is one shard of a wider
+                                        // panel, snpm_panel_set_total_accessions): 1 selects numpy's vector summation (k_strict_single)
     int64_t pitch = 0;                  // bytes per SNP row (int8: >= n_acc; packed: >= n_acc / 4), multiple of ctx->pitch_align (256)
     int64_t ld = 0;                     // accessions per row rounded up to 256: leading dimension of result arrays
     int packed = 0;                     // 0 = int8 (one byte per call), 1 = 2 bits per call (4 accessions per byte)
@@ -813,6 +815,30 @@ bool ensure_acc_major(snpm_panel *p)
 // Dense: every accession, segments [seg0, seg0 + n_seg) -> ctx->ws_seg_* [n_seg, ld].  Segments are explicit
 // (d_seg_off: windows) or `chunk`-row pieces of the query.  gate (may be NULL): device count; the launch is a
 // no-op unless *gate > REEVAL_CAP.
+// A panel of ONE accession: the reference's per-call sums are numpy's vector sums (snpm_kernels_single.hpp)
+static inline bool single_accession(const snpm_panel *p) { return p->n_acc_total == 1; }
+
+// k_strict_single in place of the strict kernel of a site; tier / pairs / count as in the kernel's header
+static int launch_strict_single(snpm_ctx *ctx, const snpm_panel *p, const int64_t *d_row_idx, int64_t row0, const double *d_w,
+                                int skip, const int64_t *seg_off, int64_t chunk, int64_t n, int64_t seg0, int64_t n_seg,
+                                const int32_t *pairs, const int *count, int cap, int tier, int64_t kmax, dim3 grid,
+                                double *out_score, uint32_t *out_miss, int64_t ld)
+{
+    const bool gather = d_row_idx != nullptr;
+#define LAUNCH_SINGLE(S, G)                                                                                          \
+    hipLaunchKernelGGL((k_strict_single<S, G>), grid, dim3(SINGLE_THREADS), 0, ctx->stream, p->d, p->pitch, p->packed,  \
+                       d_row_idx, row0, d_w, seg_off, chunk, n, seg0, n_seg, pairs, count, cap, tier, kmax, out_score,  \
+                       out_miss, ld)
+    if (skip) {
+        if (gather) LAUNCH_SINGLE(true, true); else LAUNCH_SINGLE(true, false);
+    } else {
+        if (gather) LAUNCH_SINGLE(false, true); else LAUNCH_SINGLE(false, false);
+    }
+#undef LAUNCH_SINGLE
+    HIPCHK(ctx, hipGetLastError());
+    return SNPM_OK;
+}
+
 int launch_strict_dense(snpm_query *q, int skip, const int64_t *d_seg_off, int64_t chunk, int64_t seg0, int64_t n_seg,
                         const int *gate)
 {
@@ -822,6 +848,12 @@ int launch_strict_dense(snpm_query *q, int skip, const int64_t *d_seg_off, int64
     const bool gather = q->d_row_idx != nullptr;
     const int64_t *seg_off = d_seg_off ? d_seg_off + seg0 : nullptr;
     if (n_seg == 0) return SNPM_OK;
+    if (single_accession(p)) {
+        ProfScope ps(ctx, PK_STRICT);
+        return launch_strict_single(ctx, p, q->d_row_idx, q->row0, q->d_w, skip, seg_off, chunk, q->n, seg0, n_seg, nullptr, gate,
+                                    REEVAL_CAP, gate ? 2 : 0, 0, dim3((unsigned)std::min<int64_t>(n_seg, 65535)),
+                                    (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld);
+    }
     if (ctx->strict4) {
         // 4 columns per lane (one dword of an int8 panel, one byte of a packed panel)
         const int64_t lanes = (ncols + 3) / 4;
@@ -924,7 +956,14 @@ int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_c
         dim3 sgrid((unsigned)std::min<int64_t>((total + 255) / 256, (int64_t)ctx->n_cu * 8));     // grid-stride over (segment, column)
         const bool use_T = !q->transient_panel && q->n >= ctx->acc_major_min_rows && p->dT_state == 1;
         ProfScope ps(ctx, PK_STRICT);
-        if (use_T) {
+        if (single_accession(p)) {
+            // the only column that can be flagged is column 0; its segment sums land in slot 0 of the compact [n_seg, ld] rows
+            q->reeval_path = 2;
+            rc = launch_strict_single(ctx, p, q->d_row_idx, q->row0, q->d_w, skip, d_seg_off, chunk, q->n, 0, n_seg, nullptr, d_ncols,
+                                      REEVAL_CAP, 1, 0, dim3((unsigned)std::min<int64_t>(n_seg, 65535)),
+                                      (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld);
+            if (rc) return rc;
+        } else if (use_T) {
             q->reeval_path = 1;
 #define LAUNCH_SPARSE_T(S, G)                                                                                      \
     hipLaunchKernelGGL((k_strict_sparse_T<S, G>), sgrid, dim3(256), 0, ctx->stream, p->dT, p->pitchT, q->d_row_idx, \
@@ -1161,7 +1200,14 @@ static int seg_finish(snpm_ctx *ctx, const SegJob &j)
     snpm_panel *p = j.p;
     if (!j.certify || j.n_seg == 0) return SNPM_OK;
     const bool gather = j.d_row_idx != nullptr;
-    {
+    if (single_accession(p)) {
+        ProfScope ps(ctx, PK_STRICT);
+        int rc = launch_strict_single(ctx, p, j.d_row_idx, j.row0, j.d_w, j.skip, j.d_seg_off, j.chunk, j.n_total, 0, j.n_seg,
+                                      (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), j.cap, 0, j.kmax,
+                                      dim3((unsigned)std::min<int64_t>(std::max<int64_t>(j.kmax, 1), 1024), (unsigned)j.cap),
+                                      (double *)ctx->ws_pair_sums.p, nullptr, 0);
+        if (rc) return rc;
+    } else {
         ProfScope ps(ctx, PK_STRICT);
         dim3 grid((unsigned)((j.kmax + 255) / 256), (unsigned)j.cap);
 #define LAUNCH_PAIRS(S, G)                                                                                        \
@@ -1535,6 +1581,7 @@ try {
     p->ctx = ctx;
     p->n_snp = n_snp;
     p->n_acc = n_acc;
+    p->n_acc_total = n_acc;
     p->packed = packed ? 1 : 0;
     p->ld = ((n_acc + 255) / 256) * 256;
     // Row pitch: padded to 256 B, the width of a wave's read (10 000 accessions -> 10 240 B: 2.4 % of every pass is padding).
@@ -1592,6 +1639,14 @@ int snpm_panel_is_packed(const snpm_panel *p, int *packed)
 {
     if (!p || !packed) return SNPM_ERR_BADARG;
     *packed = p->packed;
+    return SNPM_OK;
+}
+
+int snpm_panel_set_total_accessions(snpm_panel *p, int64_t n_acc_total)
+{
+    if (!p || !p->ctx) return SNPM_ERR_BADARG;
+    CHECK_ARG(p->ctx, n_acc_total >= p->n_acc, "the whole panel cannot be narrower than this shard of it");
+    p->n_acc_total = n_acc_total;
     return SNPM_OK;
 }
 
@@ -1920,7 +1975,7 @@ static int enqueue_reevaluation(snpm_query *q, int skip, int64_t chunk)
 {
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
-    const bool want_T = ctx->use_acc_major && !q->transient_panel && q->n >= ctx->acc_major_min_rows;
+    const bool want_T = ctx->use_acc_major && !q->transient_panel && q->n >= ctx->acc_major_min_rows && !single_accession(p);
     if (want_T && p->dT_state == 0) {
         int64_t cnt = 0;
         int rc = read_count(q, &cnt);

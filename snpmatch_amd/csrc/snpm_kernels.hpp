@@ -2952,3 +2952,5 @@ k_calib_read(const uint32_t *__restrict__ p, int64_t n_dwords, uint32_t *__restr
 }
 
 }  // namespace snpm
+
+#include "snpm_kernels_single.hpp"

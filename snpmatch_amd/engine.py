@@ -324,7 +324,7 @@ def default_group(n_members=None):
 class Panel(object):
     """int8 [n_snp, n_acc] genotype matrix in HBM (SNP-major, row pitch padded to 256 B; to 128 B where that saves 5 % of the row)."""
 
-    def __init__(self, ctx, n_snp, n_acc, packed=False):
+    def __init__(self, ctx, n_snp, n_acc, packed=False, n_acc_total=None):
         self.ctx = ctx
         self.n_snp = int(n_snp)
         self.n_acc = int(n_acc)
@@ -333,6 +333,10 @@ class Panel(object):
         create = ctx.lib.snpm_panel_create_packed if packed else ctx.lib.snpm_panel_create
         check(create(ctx.h, self.n_snp, self.n_acc, C.byref(h)), ctx.h)
         self.h = h
+        if n_acc_total is not None and int(n_acc_total) != self.n_acc:
+            # a shard of a wider DB: the reference-order kernels follow the summation rule of the WHOLE panel's width
+            # (numpy sums a one-accession panel pairwise, core/snpmatch.py:85-87; every wider one row after row)
+            check(ctx.lib.snpm_panel_set_total_accessions(h, int(n_acc_total)), ctx.h)
         pitch = C.c_int64(0)
         dptr = C.c_void_p()
         check(ctx.lib.snpm_panel_info(h, None, None, C.byref(pitch), C.byref(dptr)), ctx.h)
@@ -351,7 +355,7 @@ class Panel(object):
     def from_store(cls, ctx, store, packed=False, cols=None):
         """the whole DB (or its columns ``cols``) resident: every row through the staging path"""
         a0, a1 = (0, store.n_acc) if cols is None else cols
-        p = cls(ctx, store.n_snp, a1 - a0, packed=packed)
+        p = cls(ctx, store.n_snp, a1 - a0, packed=packed, n_acc_total=store.n_acc)
         try:
             store.load(p, (a0, a1), None, 0, store.n_snp)
         except Exception:
@@ -1069,7 +1073,7 @@ class StreamedPanel(object):
         self.rows_cap = int(budget_bytes // 2 // pitch) - 32             # the panel keeps 32 prefetch rows of its own
         assert self.rows_cap >= 1, "HBM budget too small for a single row of this DB"
         self.rows_cap = min(self.rows_cap, max(self.n_snp, 1))
-        self.halves = [Panel(ctx, self.rows_cap, self.n_acc, packed=packed) for _ in range(2)]
+        self.halves = [Panel(ctx, self.rows_cap, self.n_acc, packed=packed, n_acc_total=store.n_acc) for _ in range(2)]
         ctx._children.add(self)
         self._pinned = {}
         self.loads = 0              # pieces loaded so far (tests / timing)
