@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="init the process group and all-gather even at N=1")
     ap.add_argument("--group-timeout", type=float, default=120.0,
                     help="seconds the ranks may take to join the library's RCCL group before all of them fall back to torch.distributed")
+    ap.add_argument("--degraded-reason", default="", help=argparse.SUPPRESS)      # set by a parent whose group join hung (see join_library_group)
+    ap.add_argument("--no-real-panel", action="store_true", help="skip the configs[1] / configs[2] legs (tools/bench_real_panel.py) after the headline")
     ap.add_argument("--collective", default="c-abi", choices=["c-abi", "torch"],
                     help="who runs the all-gather of the per-accession results at N>1: the library itself (snpm_group_*: RCCL "
                          "communicator inside libsnpmatch_hip.so, one packed all-gather) or torch.distributed")
@@ -182,9 +184,83 @@ def main():
     a0, n_loc, per = shards.a0, shards.n_local, shards.per
     mode = {"exact": engine.MODE_EXACT, "strict": engine.MODE_STRICT, "fast": engine.MODE_FAST}[args.mode]
 
+    # The collective of the path behind the C ABI (snpm_group_*): rank 0 makes the RCCL id, torch.distributed (already up
+    # for the barriers of the timing contract) carries its 128 bytes to the other ranks, every rank joins with its context.
+    # Joined BEFORE the panel is allocated, so that a process whose join hangs holds next to no HBM.
+    #   every rank joined          -> collective.transport = "c-abi-rccl"
+    #   a rank failed cleanly      -> every rank gathers through torch.distributed in this process: "torch-nccl-fallback" + reason
+    #   a rank is STUCK in the join -> nothing is measured in this process (a thread inside ncclCommInitRank holds the context):
+    #                                 every rank starts a fresh child with --collective torch, rank 0's child prints the line
+    #                                 (transport "torch-nccl-fallback", the reason, "degraded": true) and the parents leave with
+    #                                 exit code 3, so that the run is recorded as degraded, not as a normal one.
+    group = None
+    coll = {"transport": "none", "reason": None}
+    join_s = 0.0
+    if use_dist:
+        coll["transport"] = "torch-%s" % args.backend
+        if args.degraded_reason:
+            coll = {"transport": "torch-nccl-fallback", "reason": args.degraded_reason, "degraded": True}
+        if args.collective == "c-abi" and args.backend == "nccl":
+            status, why = 2, ""                 # 2 joined, 1 failed cleanly, 0 stuck
+            t_join = time.perf_counter()
+            try:
+                box = [engine.Group.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                made = {}
+
+                def join_group():
+                    try:
+                        if os.environ.get("SNPM_BENCH_SIMULATE_STUCK_JOIN") == str(rank):      # rehearsal of the stuck branch
+                            time.sleep(3600)
+                        made["group"] = engine.Group.from_rank(ctx, box[0], world, rank)
+                    except Exception as exc:          # noqa: BLE001
+                        made["error"] = exc
+
+                th = threading.Thread(target=join_group, daemon=True)
+                th.start()
+                th.join(args.group_timeout)
+                if th.is_alive():
+                    status, why = 0, "rank %d: snpm_group_create_rank (ncclCommInitRank) did not return within %.0f s" % (rank, args.group_timeout)
+                elif "error" in made:
+                    status, why = 1, "rank %d: snpm_group_create_rank failed: %s" % (rank, str(made["error"])[:200])
+                else:
+                    group = made["group"]
+                    assert group.shard(n_acc, rank) == (shards.a0, shards.a1), "the library and bench.py disagree about the shards"
+            except Exception as e:          # noqa: BLE001
+                status, why = 1, "rank %d: %s" % (rank, str(e)[:200])
+            join_s = time.perf_counter() - t_join
+            if why:
+                sys.stderr.write(why + "\n")
+            t = torch.tensor([status], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            worst = int(t.item())
+            reasons = [None] * world
+            dist.all_gather_object(reasons, why)
+            reason = "; ".join(r for r in reasons if r) or None
+            if worst == 2:
+                coll = {"transport": "c-abi-rccl", "reason": None,
+                        "how": "snpm_group_gather_scores: one ncclAllGather inside libsnpmatch_hip.so (%s)" % group.transport}
+            elif worst == 1:
+                if group is not None:
+                    group.free()
+                group = None
+                coll = {"transport": "torch-nccl-fallback", "reason": reason}
+            else:
+                # stuck: leave this process alone.  torch's process group goes first (the children form their own on the next port)
+                dist.barrier()
+                dist.destroy_process_group()
+                import subprocess
+                env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 1))
+                env.pop("SNPM_BENCH_SIMULATE_STUCK_JOIN", None)
+                cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + \
+                      ["--collective", "torch", "--degraded-reason", "library RCCL group join hung (%s); measured in a fresh process over torch.distributed" % reason]
+                child = subprocess.run(cmd, env=env, stdout=real_stdout if rank == 0 else subprocess.DEVNULL)
+                sys.stderr.write("rank %d: degraded run, child exit code %d\n" % (rank, child.returncode))
+                os._exit(3 if child.returncode == 0 else 4)
+
+
     # ---- slabs of this rank's shard (the same on every rank: sized for the widest shard)
-    acc_per_byte = 4 if args.packed else 1
-    pitch_max = ((per + acc_per_byte - 1) // acc_per_byte + 255) // 256 * 256
+    pitch_max = ctx.row_pitch(per, args.packed)          # the library's rule (128-B rows for narrow int8 panels, + 256 B at multiples of 8 KiB)
     if args.slabs > 0:
         rows_per_slab = -(-(-(-n_snp // args.slabs)) // chunk) * chunk
     else:
@@ -217,52 +293,6 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
-
-    # The collective of the path behind the C ABI (snpm_group_*): rank 0 makes the RCCL id, torch.distributed (already up
-    # for the barriers of the timing contract) carries its 128 bytes to the other ranks, every rank joins with its context.
-    # If any rank cannot form the group, all of them use torch.distributed for the gather instead (reported in `config`).
-    group = None
-    collective = "none"
-    stuck_threads = []
-    if use_dist:
-        collective = "torch.distributed (%s)" % args.backend
-        if args.collective == "c-abi" and args.backend == "nccl":
-            ok = 1
-            try:
-                box = [engine.Group.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                # ncclCommInitRank is collective: a rank that cannot reach its peers would wait for ever.  The driver's
-                # scaling run must end either way, so the join runs beside a watchdog; on a timeout every rank falls back
-                # to torch.distributed (the MIN below) and the process leaves through os._exit at the end.
-                made = {}
-
-                def join_group():
-                    try:
-                        made["group"] = engine.Group.from_rank(ctx, box[0], world, rank)
-                    except Exception as exc:          # noqa: BLE001
-                        made["error"] = exc
-
-                th = threading.Thread(target=join_group, daemon=True)
-                th.start()
-                th.join(args.group_timeout)
-                if th.is_alive():
-                    stuck_threads.append(th)
-                    raise TimeoutError("snpm_group_create_rank did not return within %.0f s" % args.group_timeout)
-                if "error" in made:
-                    raise made["error"]
-                group = made["group"]
-                assert group.shard(n_acc, rank) == (shards.a0, shards.a1), "the library and bench.py disagree about the shards"
-            except Exception as e:          # noqa: BLE001
-                sys.stderr.write("rank %d: snpm_group unavailable (%s)\n" % (rank, e))
-                ok = 0
-            t = torch.tensor([ok], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            if int(t.item()) == 1:
-                collective = "snpm_group_gather_scores: one ncclAllGather inside libsnpmatch_hip.so (%s)" % group.transport
-            else:
-                if group is not None:
-                    group.free()
-                group = None
 
     def gather_and_likelihood():
         if group is not None:
@@ -372,10 +402,23 @@ def main():
             gather_and_likelihood()
     ctx.profile(False)
     barrier()
+    per_rank = None
+    ranks_agree = None
     if use_dist:
+        mine = {"rank": rank, "ms_per_step": dt / args.steps * 1e3, "group_join_s": join_s, "acc": [int(a0), int(a0 + n_loc)]}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # every rank holds the full-length gathered vectors and the likelihoods computed from them: their bit patterns must
+        # be the same on all ranks (an all-gather that dropped or misplaced a shard shows up here, not only in the top hit)
+        torch.cuda.synchronize()
+        ck = (lik[:n_acc].view(torch.int64).sum() + lrt[:n_acc].view(torch.int64).sum() * 31).reshape(1).clone()
+        lo, hi = ck.clone(), ck.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_agree = bool(int(lo.item()) == int(hi.item()))
 
     # ---- the job once more INCLUDING the regeneration of every slab (what a panel larger than HBM really costs)
     end_to_end = None
@@ -416,10 +459,15 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc) and kernel == "fast" and not args.packed:
         try:
+            from snpmatch_amd import _lib
             for rec in json.load(open(pmc)).values():
                 if isinstance(rec, dict) and rec.get("n_acc") == n_loc and rec.get("n_snp") == rows_dom:
-                    traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_source = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes on this shape, not this run)"
+                    if rec.get("build_id") == _lib.build_id():
+                        traffic = rec.get("hbm_bytes_per_launch")
+                        traffic_source = "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes on this shape and this build, not this run)"
+                    else:       # a figure collected on other kernels says nothing about these
+                        traffic_source = "profiles/pmc_traffic.json holds this shape for build %s, the library is build %s: not reported" \
+                                         % (rec.get("build_id"), _lib.build_id())
         except Exception:
             traffic = None
 
@@ -480,7 +528,8 @@ def main():
                 "panel_format": "packed2" if args.packed else "int8", "slabs": slabs,
                 "sample": "planted accession %d, 2%% error, %s (generated on the device)"
                           % (PLANTED, "hard 0/1 calls" if args.hard_calls else "80% PL weights"),
-                "parallelism": "acc-shard x%d + all-gather (%s)" % (world, collective),
+                "parallelism": "acc-shard x%d + all-gather (%s)" % (world, coll["transport"]),
+                "collective": coll,
                 "timing": "per slab: regenerate (untimed), K timed scoring steps between barriers; plus K timed "
                           "certificate/gather/likelihood tails%s; ms_per_step = their sum / K"
                           % (" and K timed second-pass steps per slab for the flagged accessions" if second_pass else "")
@@ -502,8 +551,10 @@ def main():
             "cpu_baseline": cpu,
             "end_to_end": end_to_end,
             "checks": {"top_hit_is_planted": result_ok, "counts_match_cpu_port": parity,
-                       "strict_reevaluations": int(n_reeval), "second_pass_over_slabs": second_pass},
+                       "strict_reevaluations": int(n_reeval), "second_pass_over_slabs": second_pass, "ranks_agree": ranks_agree},
+            "per_rank": per_rank,
             "setup_s": t_setup,
+            "library_build_id": __import__("snpmatch_amd._lib", fromlist=["build_id"]).build_id(),
         }
         if args.packed:      # 0.25 B per comparison: the pass is VALU/LDS-issue-bound, the HBM fraction is informative only
             out["roofline"]["note"] = "packed panel: bound by VALU + LDS issue (DESIGN.md), not by HBM"
@@ -512,8 +563,7 @@ def main():
     if use_dist:
         dist.barrier()                  # rank 0 may have spent ~30 s in the CPU baseline
         dist.destroy_process_group()
-    if not stuck_threads:               # a thread still inside ncclCommInitRank holds the context
-        ctx.close()
+    ctx.close()
     if rank == 0:
         # Beside the headline (the int8 panel BASELINE.json names): the same job on the 2-bit packed panel, which fits one GPU
         # whole (125 GB).  A child process after this one has released its memory; a failure there only drops the extra field.
@@ -533,12 +583,31 @@ def main():
                     "note": "same job, same sample, 2 bits per call: results identical (tests), not the format the metric names"}}
             except Exception as e:          # noqa: BLE001
                 out["alternatives"] = {"packed2_panel_resident": {"error": str(e)[:200]}}
+        # The real-panel configurations (configs[1]: one 200k-SNP sample against 1135 x 11M resident -- gathered rows; a batch of 64;
+        # configs[2]: the 399 windows of `cross`), int8 and packed, as a child process: tools/bench_real_panel.py.  Informative
+        # legs beside the headline, each with its kernel, its HIP-event duration, algorithmic bytes and fraction of the HBM peak.
+        if world == 1 and not args.no_real_panel and whole_job and not profiled and not args.packed:
+            try:
+                import subprocess
+                child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_real_panel.py"), "--reps", "10"],
+                                       capture_output=True, text=True, timeout=300)
+                rp = json.loads(child.stdout.strip().splitlines()[-1])
+                keep = ("leg", "kernel", "wall_ms_per_call", "kernel_ms_per_call", "algorithmic_bytes_per_call", "achieved_GBs",
+                        "frac_of_hbm_peak", "bytes_counted", "int8_equivalent_GBs", "samples_per_s", "windows")
+                out["real_panel"] = {"workload": rp["workload"], "traffic": "profiles/r04_pmc_split_real_*.json (request-size split, separate --pmc passes)",
+                                     "formats": {f: {"row_pitch": v["row_pitch"], "panel_gb": v["panel_gb"],
+                                                     "legs": [{k: leg[k] for k in keep if k in leg} for leg in v["legs"]]}
+                                                 for f, v in rp["formats"].items()}}
+            except Exception as e:          # noqa: BLE001
+                out["real_panel"] = {"error": str(e)[:200]}
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
-    if stuck_threads:
-        os._exit(0)
+    if rank == 0 and (not out["checks"]["top_hit_is_planted"] or out["checks"]["ranks_agree"] is False):
+        sys.exit(5)                     # a wrong result is a failed run, whatever it measured
+    if args.degraded_reason:
+        sys.exit(0)                     # the parent turns this into its own exit code 3
 
 
 if __name__ == "__main__":

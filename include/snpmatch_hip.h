@@ -71,6 +71,9 @@ typedef struct snpm_group snpm_group;
 int         snpm_version(void);
 /* HIP version of the build (HIP_VERSION: major * 10000000 + minor * 100000 + patch); no GPU needed */
 int         snpm_hip_build_version(void);
+/* 12 hex digits: hash of the sources this library was built from (build_lib.sh).  Recorded measurements (profiles/pmc_traffic.json)
+   carry it; bench.py reports such a figure only for the build it was collected on. */
+const char *snpm_build_id(void);
 int         snpm_device_count(int *count);
 int         snpm_init(int device_id, snpm_ctx **out);
 int         snpm_destroy(snpm_ctx *ctx);

@@ -30,7 +30,7 @@ MODE_FAST = 2
 
 # every symbol include/snpmatch_hip.h declares (tests check that the .so exports all of them)
 SYMBOLS = [
-    "snpm_version", "snpm_hip_build_version", "snpm_device_count", "snpm_init", "snpm_destroy", "snpm_last_error", "snpm_set_stream",
+    "snpm_version", "snpm_hip_build_version", "snpm_build_id", "snpm_device_count", "snpm_init", "snpm_destroy", "snpm_last_error", "snpm_set_stream",
     "snpm_synchronize", "snpm_device_mem_info", "snpm_panel_create", "snpm_panel_create_packed", "snpm_panel_is_packed", "snpm_panel_set_total_accessions", "snpm_panel_row_pitch", "snpm_panel_free", "snpm_panel_info", "snpm_panel_upload_rows", "snpm_panel_load_file", "snpm_panel_load_file_rows", "snpm_panel_load_file_rows_packed", "snpm_pack_rows_host",
     "snpm_panel_upload_wait", "snpm_panel_download_rows", "snpm_panel_fill_synthetic", "snpm_query_create",
     "snpm_query_free", "snpm_query_bind_outputs", "snpm_query_run", "snpm_query_run_device", "snpm_query_error_bound",
@@ -132,6 +132,7 @@ def load():
     i64, p, dbl, ci = C.c_int64, C.c_void_p, C.c_double, C.c_int
     pp = C.POINTER(C.c_void_p)
     lib.snpm_version.restype = ci
+    lib.snpm_build_id.restype = C.c_char_p
     lib.snpm_device_count.argtypes = [C.POINTER(ci)]
     lib.snpm_init.argtypes = [ci, pp]
     lib.snpm_destroy.argtypes = [p]
@@ -233,6 +234,11 @@ def load():
         getattr(lib, name)
     _lib = lib
     return lib
+
+
+def build_id():
+    """hash of the sources the loaded library was built from (12 hex digits)"""
+    return load().snpm_build_id().decode()
 
 
 def check_group(rc, group_handle=None):

@@ -1204,14 +1204,14 @@ static int seg_finish(snpm_ctx *ctx, const SegJob &j)
         ProfScope ps(ctx, PK_STRICT);
         int rc = launch_strict_single(ctx, p, j.d_row_idx, j.row0, j.d_w, j.skip, j.d_seg_off, j.chunk, j.n_total, 0, j.n_seg,
                                       (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), j.cap, 0, j.kmax,
-                                      dim3((unsigned)std::min<int64_t>(std::max<int64_t>(j.kmax, 1), 1024), (unsigned)j.cap),
+                                      dim3((unsigned)std::min<int64_t>(std::max<int64_t>(j.kmax, 1), 1024), (unsigned)std::min(j.cap, 256)),
                                       (double *)ctx->ws_pair_sums.p, nullptr, 0);
         if (rc) return rc;
     } else {
         ProfScope ps(ctx, PK_STRICT);
-        dim3 grid((unsigned)((j.kmax + 255) / 256), (unsigned)j.cap);
+        dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(j.kmax, 1), 256), (unsigned)std::min(j.cap, 512));   // a wave per (pair, chunk); both axes walk
 #define LAUNCH_PAIRS(S, G)                                                                                        \
-    hipLaunchKernelGGL((k_strict_pairs<S, G>), grid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->packed, j.d_row_idx,     \
+    hipLaunchKernelGGL((k_strict_pairs<S, G>), grid, dim3(WAVE), 0, ctx->stream, p->d, p->pitch, p->packed, j.d_row_idx,     \
                        j.row0, j.d_w, j.d_seg_off, j.chunk, (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), \
                        j.cap, j.kmax, (double *)ctx->ws_pair_sums.p)
         if (j.skip) {
@@ -1223,7 +1223,7 @@ static int seg_finish(snpm_ctx *ctx, const SegJob &j)
         HIPCHK(ctx, hipGetLastError());
     }
     ProfScope ps(ctx, PK_SCAN);
-    hipLaunchKernelGGL(k_scan_pairs, dim3((unsigned)j.cap), dim3(64), 0, ctx->stream, (const double *)ctx->ws_pair_sums.p,
+    hipLaunchKernelGGL(k_scan_pairs, dim3((unsigned)std::min(j.cap, 1024)), dim3(64), 0, ctx->stream, (const double *)ctx->ws_pair_sums.p,
                        j.d_seg_off, j.chunk, (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), j.cap, j.kmax,
                        j.d_score, j.ldo);
     HIPCHK(ctx, hipGetLastError());
@@ -1358,6 +1358,11 @@ int snpm_version(void) { return 100; }
 // HIP version the library was built against, as hipcc's headers encode it (major * 10000000 + minor * 100000 + patch): the
 // binding compares its major number with the HIP runtime it is about to share with PyTorch
 int snpm_hip_build_version(void) { return HIP_VERSION; }
+
+#ifndef SNPM_BUILD_ID
+#define SNPM_BUILD_ID "unknown"
+#endif
+const char *snpm_build_id(void) { return SNPM_BUILD_ID; }
 
 int snpm_device_count(int *count)
 {

@@ -66,6 +66,9 @@ namespace snpm {
 #ifndef SNPM_FAST_G
 #define SNPM_FAST_G 4                   // rows per prefetch group of the int8 fast pass (two groups in flight)
 #endif
+#ifndef SNPM_FAST_G_GATHER
+#define SNPM_FAST_G_GATHER SNPM_FAST_G  // the same for the gathered-row instantiations (row lists of samples, windows, batches)
+#endif
 #ifndef SNPM_FAST_MIN_WAVES
 #define SNPM_FAST_MIN_WAVES 6
 #endif
@@ -324,7 +327,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     constexpr int NDW = BPL / 4;
     constexpr int EPL = BPL;
     // rows per prefetch group: 4 (G*32 B = half a 256-B LUT block); 8-row groups spill at the 80-VGPR budget and measured no gain
-    constexpr int G = SNPM_FAST_G;
+    constexpr int G = GATHER ? SNPM_FAST_G_GATHER : SNPM_FAST_G;
     __shared__ __attribute__((aligned(256))) double s_lut[2][TR * 4];
 
     const int tid = threadIdx.x;
@@ -1551,49 +1554,51 @@ __global__ void k_reduce_seg(const double *__restrict__ part_score, const uint32
     }
 }
 
+// One WAVE per (flagged pair, chunk of its segment): the lanes fetch 64 rows' calls and weights at once, then every lane adds
+// them in row order from broadcast values (v_readlane) -- the reference's three sequential per-category sums with the loads
+// of 64 rows in flight instead of one dependent gather per row.  (Round 3 gave every chunk ONE lane: a window of `cross` is a
+// single chunk, so a flagged (window, accession) pair walked its ~500 gathered rows on one lane -- 0.24 ms of a 0.06-ms pass.)
+//   grid.x walks the chunks of a segment, grid.y the flagged pairs (both bounded: no pair flagged = a launch of microseconds)
 template <bool SKIP, bool GATHER>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64)
 k_strict_pairs(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx, int64_t row0,
                const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk,
                const int32_t *__restrict__ pairs, const int *__restrict__ count, int cap, int64_t kmax,
                double *__restrict__ sums)
 {
     const int np = *count < cap ? *count : cap;
-    const int pr = blockIdx.y;
-    if (pr >= np) return;
-    const int64_t sg = pairs[2 * pr], col = pairs[2 * pr + 1];
-    const int64_t s0 = seg_off[sg], s1 = seg_off[sg + 1];
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t r0 = s0 + k * chunk;
-    if (r0 >= s1 && !(k == 0)) return;
-    const int64_t r1 = (r0 + chunk < s1) ? r0 + chunk : s1;
-    double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
-    constexpr int U = 8;
-    int64_t r = r0;
-    for (; r + U <= r1; r += U) {
-        int b[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t prow = GATHER ? row_idx[r + u] : (row0 + r + u);
-            b[u] = code_at(db, pitch, prow, col, packed);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double w0 = w[3 * (r + u) + 0], w1 = w[3 * (r + u) + 1], w2 = w[3 * (r + u) + 2];
-            a_ref = add_sel(a_ref, b[u] == 0, w0);
-            if (!SKIP) a_het = add_sel(a_het, b[u] == 2, w1);
-            a_alt = add_sel(a_alt, b[u] == 1, w2);
+    const int lane = threadIdx.x;
+    for (int pr = blockIdx.y; pr < np; pr += gridDim.y) {
+        const int64_t sg = pairs[2 * pr], col = pairs[2 * pr + 1];
+        const int64_t s0 = seg_off[sg], s1 = seg_off[sg + 1];
+        int64_t K = (s1 - s0 + chunk - 1) / chunk;
+        if (K < 1) K = 1;                                  // an empty segment: one matchGTsAccs call on no rows
+        for (int64_t k = blockIdx.x; k < K; k += gridDim.x) {
+            const int64_t r0 = s0 + k * chunk;
+            const int64_t r1 = (r0 + chunk < s1) ? r0 + chunk : s1;
+            double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
+            for (int64_t rb = r0; rb < r1; rb += WAVE) {
+                const int64_t r = rb + lane;
+                int b = -1;
+                double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+                if (r < r1) {
+                    const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
+                    b = code_at(db, pitch, prow, col, packed);
+                    w0 = w[3 * r + 0];
+                    w1 = w[3 * r + 1];
+                    w2 = w[3 * r + 2];
+                }
+                const int cnt = (int)((r1 - rb < WAVE) ? (r1 - rb) : WAVE);
+                for (int i = 0; i < cnt; ++i) {
+                    const int bi = __shfl(b, i);
+                    a_ref = add_sel(a_ref, bi == 0, __shfl(w0, i));
+                    if (!SKIP) a_het = add_sel(a_het, bi == 2, __shfl(w1, i));
+                    a_alt = add_sel(a_alt, bi == 1, __shfl(w2, i));
+                }
+            }
+            if (lane == 0) sums[(int64_t)pr * kmax + k] = ((0.0 + a_ref) + a_het) + a_alt;
         }
     }
-    for (; r < r1; ++r) {
-        const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
-        const int b = code_at(db, pitch, prow, col, packed);
-        const double w0 = w[3 * r + 0], w1 = w[3 * r + 1], w2 = w[3 * r + 2];
-        a_ref = add_sel(a_ref, b == 0, w0);
-        if (!SKIP) a_het = add_sel(a_het, b == 2, w1);
-        a_alt = add_sel(a_alt, b == 1, w2);
-    }
-    sums[(int64_t)pr * kmax + k] = ((0.0 + a_ref) + a_het) + a_alt;
 }
 
 // one wave per pair: lanes fetch 64 chunk sums at a time, lane 0 adds them in order; then score[seg, acc] = total
@@ -1604,8 +1609,7 @@ k_scan_pairs(const double *__restrict__ sums, const int64_t *__restrict__ seg_of
 {
     __shared__ double tile[64];
     const int np = *count < cap ? *count : cap;
-    const int pr = blockIdx.x;
-    if (pr >= np) return;
+    for (int pr = blockIdx.x; pr < np; pr += gridDim.x) {
     const int64_t sg = pairs[2 * pr], col = pairs[2 * pr + 1];
     const int64_t len = seg_off[sg + 1] - seg_off[sg];
     int64_t K = (len + chunk - 1) / chunk;
@@ -1621,6 +1625,8 @@ k_scan_pairs(const double *__restrict__ sums, const int64_t *__restrict__ seg_of
         __syncthreads();
     }
     if (threadIdx.x == 0) score[sg * ldo + col] = s;
+    __syncthreads();
+    }
 }
 
 // totals over the segments in order (TotScoreList += ScoreList per window, core/csmatch.py:88-90) from [n_seg, ldo]
@@ -1638,7 +1644,25 @@ __global__ void k_tot_seg(const double *__restrict__ score, const int64_t *__res
     if (a >= n_acc) return;
     double t = 0.0;
     int64_t m = 0;
-    for (int64_t s = 0; s < n_seg; ++s) {
+    // the additions stay in window order; the loads of 16 windows are requested together (one dependent load per window made
+    // the 399 windows of a `cross` cost 0.13 ms)
+    constexpr int U = 16;
+    int64_t s = 0;
+    for (; s + U <= n_seg; s += U) {
+        double v[U];
+        int64_t c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            v[u] = score[(s + u) * ldo + a];
+            c[u] = ninfo[(s + u) * ldo + a];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            t = t + v[u];
+            m += c[u];
+        }
+    }
+    for (; s < n_seg; ++s) {
         t = t + score[s * ldo + a];
         m += ninfo[s * ldo + a];
     }

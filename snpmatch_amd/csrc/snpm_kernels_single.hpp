@@ -132,8 +132,7 @@ k_strict_single(const int8_t *__restrict__ db, int64_t pitch, int packed, const 
     uint32_t miss = 0;
     if (pairs) {
         const int np = *count < cap ? *count : cap;
-        const int pr = blockIdx.y;
-        if (pr >= np) return;
+        for (int pr = blockIdx.y; pr < np; pr += gridDim.y) {
         const int64_t sg = pairs[2 * pr];
         const int64_t s0 = seg_off[sg], s1 = seg_off[sg + 1];
         int64_t K = (s1 - s0 + chunk - 1) / chunk;
@@ -143,6 +142,7 @@ k_strict_single(const int8_t *__restrict__ db, int64_t pitch, int packed, const 
             const int64_t r1 = (r0 + chunk < s1) ? r0 + chunk : s1;
             single_call<SKIP, GATHER>(db, pitch, packed, row_idx, row0, w, r0, r1, sm_code, sm_val, &sm_miss, score, miss);
             if (threadIdx.x == 0) out_score[(int64_t)pr * kmax + k] = score;
+        }
         }
         return;
     }

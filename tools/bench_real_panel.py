@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""
+The real-panel configurations of BASELINE.json as bench legs: configs[1] (1001 Genomes shape, 1135 accessions x 11M SNPs
+resident, one 200k-SNP sample: the GATHERED access shape of Genotyper.genotyper, core/snpmatch.py:218-225), the same for a
+batch of 64 samples whose inputs already are in HBM, and configs[2] (the 399 windows of `snpmatch cross` at 300 kb,
+core/csmatch.py:80-95) -- on the int8 panel and on the 2-bit packed panel (the drop-in classes' default residency).
+
+bench.py runs this as a child process after the headline job and puts the JSON it prints under "real_panel"; run alone
+(optionally under rocprofv3) it is the workload of the profiles/r04_real_panel_* summaries.
+
+Per leg: the scoring kernel's name, its average duration from HIP events on the library's stream (snpm_profile_*), the
+ALGORITHMIC bytes of one launch = matched rows x (row bytes + 24 B of fp64 weights + 8 B of row index), where a row is
+n_acc bytes (int8) or n_acc / 4 bytes (packed), and the fraction of the 8 TB/s HBM peak those bytes per second are.  Packed
+legs also state the int8-equivalent rate (what an int8 panel would have had to stream for the same comparisons): that
+figure may exceed the chip's bandwidth and is labelled as such.
+
+usage: tools/bench_real_panel.py [--formats int8,packed] [--reps 20] [--batch 64] [--json-only]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from snpmatch_amd import engine, synth  # noqa: E402
+from snpmatch_amd.core import genomes  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+N_SNP, N_ACC, SEED, PLANTED, N_MATCH = 11_000_000, 1135, 1001, 417, 200_000
+
+
+def tair10_layout(n_snp):
+    """DB positions spread over the five TAIR10 chromosomes in proportion to their lengths"""
+    g0 = genomes.Genome("athaliana_tair10")
+    frac = np.cumsum(g0.chrlen) / g0.chrlen.sum()
+    bounds = np.concatenate([[0], np.round(frac * n_snp).astype(np.int64)])
+    positions = np.concatenate([1 + (np.arange(bounds[c + 1] - bounds[c]) * int(g0.chrlen[c] - 1)) // int(bounds[c + 1] - bounds[c])
+                                for c in range(5)])
+    return g0, bounds, positions
+
+
+def window_offsets(g0, bounds, positions, rows, bin_len=300000):
+    """offsets of the 300-kb windows (core/genomes.py:111-116: [1 + k b, (k + 1) b]) inside the sorted matched-row list"""
+    off = [0]
+    for c in range(5):
+        lo, hi = np.searchsorted(rows, bounds[c]), np.searchsorted(rows, bounds[c + 1])
+        pos = positions[rows[lo:hi]]
+        nb = len(range(1, int(g0.chrlen[c]), bin_len))
+        edges = np.searchsorted(pos, 1 + bin_len * np.arange(1, nb + 1), side="left")
+        off.extend((lo + edges).tolist())
+    return np.asarray(off, dtype=np.int64)
+
+
+def kernel_leg(ctx, name, run, n_launch_rows, row_bytes, reps, kernel="fast"):
+    """time `run` reps times; kernel = average HIP-event duration of the scoring kernel per launch"""
+    run()
+    ctx.synchronize()
+    ctx.profile(True)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    launches, ms = ctx.profile_read(kernel)
+    parts = {k: ctx.profile_read(k) for k in ("lut", "fast", "reduce", "strict", "scan", "likelihood")}
+    ctx.profile(False)
+    per_call_ms = ms / reps                       # a call may take several launches (runs of a batch)
+    alg = float(n_launch_rows) * (row_bytes + 24.0 + 8.0)
+    rate = alg / (per_call_ms * 1e-3) / 1e9 if per_call_ms > 0 else 0.0
+    return {"leg": name, "wall_ms_per_call": wall * 1e3, "kernel_ms_per_call": per_call_ms, "kernel_launches_per_call": launches / reps,
+            "algorithmic_bytes_per_call": alg, "achieved_GBs": rate, "frac_of_hbm_peak": rate / HBM_PEAK_GBS,
+            "other_kernels_ms_per_call": {k: v[1] / reps for k, v in parts.items() if v[0] and k != kernel}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--formats", default="int8,packed")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--n-snp", type=int, default=N_SNP)
+    ap.add_argument("--n-match", type=int, default=N_MATCH)
+    args = ap.parse_args()
+    import torch
+
+    n_snp, n_match, B = args.n_snp, args.n_match, args.batch
+    ctx = engine.Context(0)
+    g0, bounds, positions = tair10_layout(n_snp)
+    rng = np.random.default_rng(5)
+    samples = []
+    for b in range(B):
+        rows = np.sort(rng.choice(n_snp, size=n_match, replace=False)).astype(np.int64)
+        acc = PLANTED if b == 0 else (b * 7) % N_ACC
+        col = synth.panel_rows(SEED, rows, acc // 4 * 4, 4)[:, acc % 4]
+        samples.append((rows, synth.planted_sample(rng, col, 0.02)[1], acc))
+    rows0, wei0, _ = samples[0]
+    win_off = window_offsets(g0, bounds, positions, rows0)
+    off = np.concatenate([[0], np.cumsum([len(r) for r, _, _ in samples])]).astype(np.int64)
+    cat_rows = np.concatenate([r for r, _, _ in samples])
+    cat_wei = np.concatenate([w for _, w, _ in samples])
+    out = {"workload": "configs[1] / configs[2]: synthetic %d accessions x %d SNPs resident (seed %d), %d-SNP samples (planted accession, 2%% "
+                       "error, 80%% PL weights), %d windows of 300 kb" % (N_ACC, n_snp, SEED, n_match, len(win_off) - 1),
+           "hbm_peak_GBs": HBM_PEAK_GBS, "formats": {}}
+    for fmt in args.formats.split(","):
+        packed = fmt == "packed"
+        t0 = time.perf_counter()
+        panel = engine.Panel(ctx, n_snp, N_ACC, packed=packed)
+        panel.fill_synthetic(SEED)
+        ctx.synchronize()
+        row_bytes = N_ACC / 4.0 if packed else float(N_ACC)
+        legs = []
+        # (1) ONE gathered 200k-row sample per call, inputs from host memory: query + run + likelihood (what Genotyper.genotyper does)
+        lik_top = [None]
+
+        def one_sample():
+            q = engine.Query(panel, rows0, wei0)
+            s, n = q.run(1000, False, engine.MODE_EXACT)
+            lik, _ = ctx.likelihood(s, n, truncate=True)
+            lik_top[0] = int(np.nanargmin(lik))
+            q.free()
+
+        leg = kernel_leg(ctx, "single_sample_200k_gathered_rows", one_sample, n_match, row_bytes, args.reps)
+        assert lik_top[0] == PLANTED
+        leg["kernel"] = "k_fast_packed_q4<GATHER>" if packed else "k_fast<GATHER>"
+        legs.append(leg)
+        # (2) the same sample, query kept: the scoring alone (kernel + reduce + certificate), results to the host
+        q = engine.Query(panel, rows0, wei0)
+        leg = kernel_leg(ctx, "single_sample_200k_rerun_resident_query", lambda: q.run(1000, False, engine.MODE_EXACT), n_match, row_bytes, args.reps)
+        leg["kernel"] = q.last_kernel()
+        legs.append(leg)
+        # (3) configs[2]: the 399 windows of that sample in one segmented pass (fast + per-(window, accession) certificate)
+        leg = kernel_leg(ctx, "cross_399_windows_certified", lambda: q.run_windows(win_off, False, totals=True, fast=True), n_match,
+                         row_bytes, args.reps)
+        leg["kernel"] = "k_fast_packed_q4<GATHER, SEG>" if packed else "k_fast<GATHER, SEG>"
+        leg["windows"] = int(len(win_off) - 1)
+        legs.append(leg)
+        leg = kernel_leg(ctx, "cross_399_windows_reference_order", lambda: q.run_windows(win_off, False, totals=True, fast=False), n_match,
+                         row_bytes, max(2, args.reps // 4), kernel="strict")
+        leg["kernel"] = "k_strict4<GATHER>"
+        legs.append(leg)
+        q.free()
+        # (4) B samples per call, inputs already in HBM
+        d_rows = torch.as_tensor(cat_rows, device="cuda:0")
+        d_wei = torch.as_tensor(cat_wei, device="cuda:0")
+        torch.cuda.synchronize()
+        dev = (d_rows.data_ptr(), d_wei.data_ptr(), off)
+        res = [None]
+
+        def batch():
+            res[0] = engine.score_batch(panel, None, device=dev)
+
+        leg = kernel_leg(ctx, "batch_%d_samples_inputs_in_hbm" % B, batch, B * n_match, row_bytes, max(2, args.reps // 2))
+        leg["kernel"] = "k_fast_packed_q4<GATHER, SEG>" if packed else "k_fast<GATHER, SEG>"
+        leg["samples_per_s"] = B / (leg["wall_ms_per_call"] * 1e-3)
+        assert [int(np.nanargmin(res[0]["lik"][b])) for b in range(B)] == [s[2] for s in samples]
+        legs.append(leg)
+        for leg in legs:
+            if packed:
+                leg["bytes_counted"] = "packed bytes (n_acc / 4 per row): the bytes the kernel moves"
+                leg["int8_equivalent_GBs"] = leg["achieved_GBs"] * (N_ACC + 32.0) / (row_bytes + 32.0)
+                leg["int8_equivalent_note"] = "what an int8 panel would stream for the same comparisons; NOT a bandwidth (may exceed 8 TB/s)"
+            else:
+                leg["bytes_counted"] = "int8 bytes (n_acc per row)"
+            leg["comparisons_per_s"] = leg["algorithmic_bytes_per_call"] / (row_bytes + 32.0) * N_ACC / (leg["kernel_ms_per_call"] * 1e-3) \
+                if leg["kernel_ms_per_call"] > 0 else None
+        out["formats"][fmt] = {"panel_gb": n_snp * panel.pitch / 1e9, "row_pitch": panel.pitch, "setup_s": time.perf_counter() - t0, "legs": legs}
+        del d_rows, d_wei
+        panel.free()
+        torch.cuda.empty_cache()
+    ctx.close()
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -5,5 +5,5 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p tools/ab
 ${HIPCC:-/opt/rocm/bin/hipcc} -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off \
-    -pthread -Iinclude -Isnpmatch_amd/csrc "$@" \
+    -pthread -Iinclude -Isnpmatch_amd/csrc -DSNPM_BUILD_ID=\"variant-$name\" "$@" \
     -o tools/ab/libsnpmatch_hip_$name.so snpmatch_amd/csrc/snpm_api.hip snpmatch_amd/csrc/snpm_vcf.cpp snpmatch_amd/csrc/snpm_host.cpp snpmatch_amd/csrc/snpm_h5.cpp -lz

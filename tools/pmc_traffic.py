@@ -38,7 +38,14 @@ calib_fetch = sum(fetch["k_calib_read"]) / len(fetch["k_calib_read"]) * 1024.0
 factor = calib_bytes / calib_fetch
 kf = sum(fetch["k_fast"]) / len(fetch["k_fast"]) * 1024.0
 kw = sum(write["k_fast"]) / len(write["k_fast"]) * 1024.0
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from snpmatch_amd import _lib
+    build_id = _lib.build_id()
+except Exception:          # noqa: BLE001
+    build_id = None
 res = {
+    "build_id": build_id,
     "n_acc": n_acc, "n_snp": n_snp, "panel_format": "packed2" if packed else "int8",
     "sample": "hard calls" if os.environ.get("PMC_HARD", "0") == "1" else "80% PL weights",
     "calibration": {"kernel": "k_calib_read", "known_bytes": calib_bytes, "FETCH_SIZE_bytes_raw": calib_fetch,

@@ -82,7 +82,13 @@ for _ in range(NB):
     out2 = engine.score_batch(panel, None, device=dev)
 dt = time.perf_counter() - t0
 kf = ctx.profile_read("fast")
-print("batches of %3d, HBM  : %7.0f samples/s (%.3f ms per sample); k_fast<SEG> %.3f ms per batch = %.0f GB/s"
-      % (B, B * NB / dt, dt / B / NB * 1e3, kf[1] / max(kf[0], 1),
-         B * n_match * (n_acc + 32.0) / (kf[1] / max(kf[0], 1) * 1e-3) / 1e9), flush=True)
+k_ms = kf[1] / NB                      # a batch may take several launches (runs)
+row_bytes = n_acc / 4.0 if panel.packed else float(n_acc)
+moved = B * n_match * (row_bytes + 32.0) / (k_ms * 1e-3) / 1e9
+print("batches of %3d, HBM  : %7.0f samples/s (%.3f ms per sample); %s %.3f ms per batch = %.0f GB/s of %s bytes (row + 24 B weights + "
+      "8 B index)%s"
+      % (B, B * NB / dt, dt / B / NB * 1e3, "k_fast_packed_q4<GATHER, SEG>" if panel.packed else "k_fast<GATHER, SEG>", k_ms, moved,
+         "packed" if panel.packed else "int8",
+         "; int8-equivalent %.0f GB/s (not a bandwidth: what an int8 panel would have streamed)"
+         % (B * n_match * (n_acc + 32.0) / (k_ms * 1e-3) / 1e9) if panel.packed else ""), flush=True)
 assert np.array_equal(out2["ninfo"], out["ninfo"]) and np.array_equal(out2["score"].astype(np.int64), out["score"].astype(np.int64))
