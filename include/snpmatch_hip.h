@@ -211,6 +211,19 @@ int snpm_query_run_windows_fast(snpm_query *query, const int64_t *win_off, int64
                                 double *score, int64_t *ninfo, double *tot_score, int64_t *tot_ninfo, int64_t *info);
 
 /* ---------------------------------------------------------------- many samples per call */
+/* ONE sample against a resident panel in ONE call: Genotyper.genotyper (core/snpmatch.py:207-241: gather of the matched weight rows
+   :221, chunk loop :218-225) followed by GenotyperOutput's truncation and likelihoods (:96, :106-117).  row_idx [n]: matched DB rows;
+   wei [n_wei, 3]: the sample's weights; sample_idx [n] (or NULL = rows 0..n-1): row of wei for each matched SNP -- the library's host
+   threads gather wei[sample_idx] straight into a pinned slab, check the indices and derive the weight properties on the way (no
+   device pass, no read-back), the slab goes up, LUT / fast pass / reduce + certificate / gated reference-order tiers / likelihood
+   are enqueued back to back, and score, ninfo, lik, lrt [n_acc each] (lik / lrt of the TRUNCATED counts; both NULL = skip) return
+   in one copy after one synchronisation.  mode / chunk / skip_hets as snpm_query_run; info (may be NULL) as there.
+   SNPM_ERR_BADARG (-> AssertionError) for indices outside the panel / the weights and non-finite weights, SNPM_ERR_DOMAIN when a
+   count exceeds its informative sites (the reference's assert, :43). */
+int snpm_genotype_once(snpm_panel *panel, const int64_t *row_idx, const double *wei, const int64_t *sample_idx, int64_t n_wei,
+                       int64_t n, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo, double *lik,
+                       double *lrt, int64_t *info);
+
 /* B samples against one resident panel.  The reference scores one sample per process (core/snpmatch.py:256-268); here
    sample b owns entries [sample_off[b], sample_off[b+1]) of the concatenated row list (int64, panel rows matched by the
    sample = commonSNPs[0]) and weights (float64 [N,3] = inputs.wei[commonSNPs[1]]); device_inputs != 0: both are DEVICE

@@ -32,7 +32,9 @@ def ratio_or_nan(num, den):
 
 
 def mean_depth(dp):
-    """mean sequencing depth of the sample; BED inputs carry the string "NA" -> NaN"""
+    """mean sequencing depth of the sample; BED inputs carry the string "NA" -> NaN (a float is taken as the mean itself)"""
+    if isinstance(dp, float):
+        return dp
     try:
         arr = np.asarray(dp, dtype=float)
     except (TypeError, ValueError):
@@ -47,6 +49,39 @@ def scores_frame(accs, matches, ninfo, fractions, likelihood, lrt, num_snps, dp)
     """one row per accession, columns in the order of ``*.scores.txt`` (written without header)"""
     data = dict(zip(SCORE_COLUMNS, (accs, matches, ninfo, fractions, likelihood, lrt, num_snps, mean_depth(dp))))
     return pd.DataFrame(data, columns=list(SCORE_COLUMNS))
+
+
+def _csv_float(x):
+    """a float as ``DataFrame.to_csv`` writes it: shortest round-trip text, empty for NaN"""
+    x = float(x)
+    return "" if x != x else repr(x)
+
+
+def write_scores_table(path, accs, matches, ninfo, fractions, likelihood, lrt, num_snps, dp):
+    """``*.scores.txt`` (core/snpmatch.py:122-138: tab-separated, no header, no index) written directly -- the bytes
+    ``scores_frame(...).to_csv(path, header=None, sep="\t", index=None)`` would write (checked against pandas in
+    tests/test_host_logic_cpu.py), at a tenth of its cost for a 1135-accession table.  Accession names that would need CSV
+    quoting go through pandas."""
+    accs = [str(a) for a in np.asarray(accs).tolist()]
+    if any(("\t" in a) or ('"' in a) or ("\n" in a) or ("\r" in a) for a in accs):
+        scores_frame(accs, matches, ninfo, fractions, likelihood, lrt, num_snps, dp).to_csv(path, header=None, sep="\t", index=None)
+        return
+    tail = "\t%s\t%s\n" % (_csv_value(num_snps), _csv_float(mean_depth(dp)))
+    m = np.asarray(matches).tolist()
+    n = np.asarray(ninfo).tolist()
+    f = np.asarray(fractions, dtype=float).tolist()
+    li = np.asarray(likelihood, dtype=float).tolist()
+    lr = np.asarray(lrt, dtype=float).tolist()
+    with open(path, "w") as fh:
+        fh.write("".join("%s\t%s\t%s\t%s\t%s\t%s%s" % (accs[i], _csv_value(m[i]), _csv_value(n[i]), _csv_float(f[i]), _csv_float(li[i]),
+                                                       _csv_float(lr[i]), tail) for i in range(len(accs))))
+
+
+def _csv_value(v):
+    """an integer or float scalar as ``to_csv`` writes it"""
+    if isinstance(v, (int, np.integer)):
+        return str(int(v))
+    return _csv_float(v)
 
 
 def inbred_case(n_top, mean_top_fraction, overlap, prob_thres, overlap_thres=0.5):

@@ -51,6 +51,16 @@ def parseGT(snpGT):
     else:
         die("unable to parse the format of GT in vcf!")
     text = snpGT.astype("U")
+    if text.dtype == np.dtype("<U3") and text.flags.c_contiguous:
+        # three-character calls ('0/1', '1|1', './.'): compare the code points as integers instead of 200k strings four times
+        cp = text.view(np.uint32).reshape(len(text), 3)
+        a, mid, b = cp[:, 0], cp[:, 1], cp[:, 2]
+        ok = mid == ord(sep)
+        one_a, one_b, zero_a, zero_b = a == ord("1"), b == ord("1"), a == ord("0"), b == ord("0")
+        codes[ok & one_a & one_b] = 1
+        codes[ok & ((zero_a & one_b) | (one_a & zero_b))] = 2
+        codes[ok & (a == ord(".")) & (b == ord("."))] = -1
+        return codes
     for pattern, code in ((("1", "1"), 1), (("0", "1"), 2), (("1", "0"), 2), ((".", "."), -1)):
         codes[text == sep.join(pattern)] = code
     return codes
@@ -150,18 +160,26 @@ class ParseInputs(object):
 
     def filter_chr_names(self):
         """``g_chrs``: chromosome names without a (case-insensitive) 'chr'; ``g_chrs_ids``: their distinct
-        values in order of first appearance.  The regex runs on the distinct names only."""
+        values in order of first appearance; ``g_chr_codes``: the position of every SNP's chromosome in ``g_chrs_ids``
+        (integers: what the position intersection compares).  A sorted input names each chromosome in one run, so the
+        distinct names are taken from the run heads and the regex runs on those only."""
         if len(self.chrs) == 0:
             self.g_chrs = self.g_chrs_ids = np.zeros(0, dtype="U1")
+            self.g_chr_codes = np.zeros(0, dtype=np.int64)
             return
-        uniq, first, inv = np.unique(self.chrs, return_index=True, return_inverse=True)
-        bare = np.array([re.sub("chr", "", c, flags=re.IGNORECASE) for c in uniq.tolist()], dtype="str")
-        self.g_chrs = bare[inv]
-        ids = []
-        for k in np.argsort(first, kind="stable"):        # 'Chr1' and 'chr1' are the same chromosome
+        c = self.chrs
+        starts = np.concatenate([[0], np.flatnonzero(c[1:] != c[:-1]) + 1]) if len(c) > 1 else np.zeros(1, dtype=np.int64)
+        lens = np.diff(np.concatenate([starts, [len(c)]]))
+        uniq, first_h, inv_h = np.unique(c[starts], return_index=True, return_inverse=True)
+        bare = np.array([re.sub("chr", "", x, flags=re.IGNORECASE) for x in uniq.tolist()], dtype="str")
+        ids, code_of = [], np.zeros(len(uniq), dtype=np.int64)
+        for k in np.argsort(starts[first_h], kind="stable"):        # 'Chr1' and 'chr1' are the same chromosome
             if bare[k] not in ids:
                 ids.append(bare[k])
+            code_of[k] = ids.index(bare[k])
+        self.g_chrs = np.repeat(bare[inv_h], lens)
         self.g_chrs_ids = np.array(ids, dtype=self.g_chrs.dtype)
+        self.g_chr_codes = np.repeat(code_of[inv_h], lens)
 
     def load_snp_info(self, snpCHR, snpPOS, snpGT, snpWEI, DPmean):
         self.chrs = np.array(snpCHR, dtype="str")

@@ -293,14 +293,23 @@ class Genotype(object):
             cache[ci] = bool(len(pos) < 2 or np.all(pos[1:] > pos[:-1]))
         return cache[ci]
 
-    def get_positions_idxs(self, commonSNPsCHR, commonSNPsPOS):
+    def get_positions_idxs(self, commonSNPsCHR, commonSNPsPOS, _parsed=None):
         """(db_row_idx, sample_idx) of the positions present in both; core/snp_genotype.py:43-44.
         Same result as ``get_common_positions(chromosomes, positions, ...)`` without materialising one
-        chromosome string per DB row: the DB side is walked region by region (pygwas chr_regions)."""
-        ins = parsers.ParseInputs("")
-        ins.load_snp_info(snpCHR=commonSNPsCHR, snpPOS=commonSNPsPOS, snpGT="", snpWEI=np.nan, DPmean=0)
-        ins.filter_chr_names()
-        db_ids = np.array([re.sub("chr", "", c, flags=re.IGNORECASE) for c in self.g.chrs.astype("U").tolist()], dtype="str")
+        chromosome string per DB row: the DB side is walked region by region (pygwas chr_regions).
+        ``_parsed``: the ``ParseInputs`` these arrays belong to, when its chromosome names are already filtered
+        (``Genotyper`` / ``CrossIdentifier`` call ``filter_chr_names`` on construction): nothing is copied or re-derived."""
+        if _parsed is not None and getattr(_parsed, "g_chr_codes", None) is not None and len(_parsed.g_chr_codes) == len(commonSNPsPOS):
+            ins = _parsed
+        else:
+            ins = parsers.ParseInputs("")
+            ins.load_snp_info(snpCHR=commonSNPsCHR, snpPOS=commonSNPsPOS, snpGT="", snpWEI=np.nan, DPmean=0)
+            ins.filter_chr_names()
+        db_ids = self.__dict__.get("_db_chr_ids")
+        if db_ids is None:                       # once per DB object
+            db_ids = self._db_chr_ids = np.array([re.sub("chr", "", c, flags=re.IGNORECASE) for c in self.g.chrs.astype("U").tolist()], dtype="str")
+        sample_ids = ins.g_chrs_ids.tolist()
+        sample_pos = np.ascontiguousarray(ins.pos, dtype=np.int64)
         positions = self.__dict__.get("_positions_i64")
         if positions is None:                    # one int64 copy per DB object (HDF5 stores int32)
             positions = self._positions_i64 = np.ascontiguousarray(self.g.positions, dtype=np.int64)
@@ -315,9 +324,12 @@ class Genotype(object):
             if regions[ci][1] <= regions[ci][0] or cid not in ins.g_chrs_ids:
                 continue
             s, e = int(regions[ci][0]), int(regions[ci][1])
-            ix2 = np.where(ins.g_chrs == cid)[0]
-            p1 = np.asarray(positions[s:e], dtype=int)
-            p2 = np.asarray(ins.pos[ix2], dtype=int)
+            ix2 = np.flatnonzero(ins.g_chr_codes == sample_ids.index(cid))
+            p1 = positions[s:e]
+            if len(ix2) and ix2[-1] - ix2[0] + 1 == len(ix2):       # one run of the sorted input: a view, no gather
+                p2 = sample_pos[ix2[0]:ix2[-1] + 1]
+            else:
+                p2 = sample_pos[ix2]
             # native sorted merge (strictly increasing inputs); the DB side is verified once per chromosome, after
             # which a short sample list is located by galloping search instead of a walk over every DB position
             merged = _lib.intersect_sorted(p1, p2, a_verified=self._region_is_increasing(ci, p1))

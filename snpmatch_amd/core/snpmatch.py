@@ -112,6 +112,13 @@ class GenotyperOutput(object):
                                     truncate=False, amin=fixed_top)
 
     def get_likelihoods(self, amin="calc"):
+        # Genotyper's one-call path (snpm_genotype_once) brings the likelihoods of these very counts back with them: they are
+        # used as long as scores / ninfo still are the arrays they were computed from
+        pre = getattr(self, "_device_likelihoods", None)
+        if pre is not None and isinstance(amin, str) and amin == "calc" and np.array_equal(pre[0], self.scores) \
+                and np.array_equal(pre[1], self.ninfo):
+            self.likelis, self.lrts = pre[2], pre[3]
+            return
         self.likelis, self.lrts = self.calculate_likelihoods(self.scores, self.ninfo, amin)
 
     def _refresh(self):
@@ -120,11 +127,12 @@ class GenotyperOutput(object):
 
     def print_out_table(self, outFile):
         self._refresh()
-        table = _report.scores_frame(self.accs, self.scores, self.ninfo, self.probabilies, self.likelis, self.lrts,
-                                     self.num_snps, self.dp)
+        dp_mean = _report.mean_depth(self.dp)        # once: a pass over the sample's depth column
         if outFile:
-            table.to_csv(outFile, header=None, sep="\t", index=None)
-        return table
+            _report.write_scores_table(outFile, self.accs, self.scores, self.ninfo, self.probabilies, self.likelis, self.lrts,
+                                       self.num_snps, dp_mean)
+        return _report.scores_frame(self.accs, self.scores, self.ninfo, self.probabilies, self.likelis, self.lrts,
+                                    self.num_snps, dp_mean)
 
     def print_json_output(self, outFile):
         self._refresh()
@@ -155,7 +163,7 @@ class Genotyper(object):
             self.write_genotyper_output(self.result)
 
     def get_common_positions(self):
-        self.commonSNPs = self.g.get_positions_idxs(self.inputs.chrs, self.inputs.pos)
+        self.commonSNPs = self.g.get_positions_idxs(self.inputs.chrs, self.inputs.pos, _parsed=self.inputs)
 
     def genotyper(self, filter_pos_ix=None, mask_acc_ix=None):
         """One pass over the matched SNPs.  ``filter_pos_ix``: restrict to these DB rows;
@@ -172,10 +180,18 @@ class Genotyper(object):
         n_matched = len(db_rows)
         # the reference walks the matched SNPs in chunk_size-row matchGTsAccs calls; here that is one query
         # against the HBM-resident panel whose counts are certified identical to that loop's
-        query = self.g.panel().query(db_rows, self.inputs.wei[sample_rows, ])
-        scores, ninfo = query.run(self.chunk_size, self._skip_db_hets, engine.MODE_EXACT)
-        query.free()
+        panel = self.g.panel()
         job = dist.job()
+        once = None
+        if type(panel) is engine.Panel and job is None:
+            # the whole matrix resident on one GPU: ONE library call gathers the matched weight rows (:221), scores them and returns
+            # counts and likelihoods together (snpm_genotype_once)
+            once = panel.genotype_once(db_rows, self.inputs.wei, sample_rows, self.chunk_size, self._skip_db_hets, engine.MODE_EXACT)
+            scores, ninfo = once["score"], once["ninfo"]
+        else:
+            query = panel.query(db_rows, self.inputs.wei[sample_rows, ])
+            scores, ninfo = query.run(self.chunk_size, self._skip_db_hets, engine.MODE_EXACT)
+            query.free()
         if job is not None:          # this rank scored its accession shard: one all-gather makes the vectors whole
             scores, ninfo = job.gather_scores(scores, ninfo, self.num_lines)
         log.info("Done analysing %s positions", n_matched)
@@ -185,7 +201,11 @@ class Genotyper(object):
             assert type(mask_acc_ix) is np.ndarray, "provide a numpy array of accessions indices to mask"
             shown = np.setdiff1d(np.arange(self.num_lines), mask_acc_ix)
             accs, scores, ninfo = accs[shown], scores[shown], ninfo[shown]
-        return GenotyperOutput(accs, scores, ninfo, overlap, n_matched, self.inputs.dp)
+            once = None              # the minimum of another accession set: GenotyperOutput asks the device again
+        out = GenotyperOutput(accs, scores, ninfo, overlap, n_matched, self.inputs.dp)
+        if once is not None:
+            out._device_likelihoods = (out.scores.copy(), out.ninfo.copy(), once["lik"], once["lrt"])
+        return out
 
     def write_genotyper_output(self, result):
         log.info("writing score file!")

@@ -2954,6 +2954,25 @@ k_f1_finish(const double *__restrict__ chunk_sum, const uint32_t *__restrict__ m
     }
 }
 
+// snpm_genotype_once: (score, ninfo, likelihood, lrt) of one sample and the two status words (re-evaluated accessions, y > n
+// flag of k_likelihood) in ONE buffer of 8-byte words [4 * n_acc + 2], copied back in one piece
+__global__ void k_once_pack(const double *__restrict__ score, const int64_t *__restrict__ ninfo, const double *__restrict__ lik,
+                            const double *__restrict__ lrt, const int *__restrict__ count, const int *__restrict__ domain_flag,
+                            int64_t n_acc, int64_t *__restrict__ out)
+{
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a == 0) {
+        out[4 * n_acc] = count ? (int64_t)*count : 0;
+        out[4 * n_acc + 1] = domain_flag ? (int64_t)*domain_flag : 0;
+    }
+    if (a >= n_acc) return;
+    out[a] = __double_as_longlong(score[a]);
+    out[n_acc + a] = ninfo[a];
+    out[2 * n_acc + a] = lik ? __double_as_longlong(lik[a]) : 0;
+    out[3 * n_acc + a] = lrt ? __double_as_longlong(lrt[a]) : 0;
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // PMC calibration: reads `n_dwords` dwords exactly once with the access shape of k_fast (one dword
 // per lane, 256 contiguous bytes per wave instruction, non-temporal), so that FETCH_SIZE can be

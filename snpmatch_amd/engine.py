@@ -367,6 +367,31 @@ class Panel(object):
         """the matched SNPs of one sample against this panel (``GroupPanel`` / ``StreamedPanel`` offer the same call)"""
         return Query(self, row_idx, wei, row0=row0)
 
+    def genotype_once(self, row_idx, wei, sample_idx=None, chunk=1000, skip_hets=False, mode=MODE_EXACT, likelihoods=True):
+        """ONE sample in ONE call (snpm_genotype_once): ``row_idx`` int64 [n] matched DB rows, ``wei`` float64 [n_wei, 3] the
+        sample's weights, ``sample_idx`` int64 [n] the weight row of each matched SNP (None: rows 0..n-1).  Returns a dict with
+        score / ninfo (and lik / lrt of the truncated counts) [n_acc] and the re-evaluation counters of ``Query.run``."""
+        ctx = self.ctx
+        row_idx = np.ascontiguousarray(row_idx, dtype=np.int64)
+        wei = np.asarray(wei)
+        assert wei.ndim == 2 and wei.shape[1] == 3, "SNP weights should be a np.array with  shape == n,3"
+        wei = np.ascontiguousarray(wei, dtype=np.float64)
+        if sample_idx is not None:
+            sample_idx = np.ascontiguousarray(sample_idx, dtype=np.int64)
+            assert len(sample_idx) == len(row_idx), "please provide same number of positions for both sample and db"
+        else:
+            assert len(wei) == len(row_idx), "please provide same number of positions for both sample and db"
+        out = {"score": np.empty(self.n_acc, dtype=np.float64), "ninfo": np.empty(self.n_acc, dtype=np.int64)}
+        if likelihoods:
+            out["lik"] = np.empty(self.n_acc, dtype=np.float64)
+            out["lrt"] = np.empty(self.n_acc, dtype=np.float64)
+        info = np.zeros(4, dtype=np.int64)
+        check(ctx.lib.snpm_genotype_once(self.h, ptr(row_idx), ptr(wei), ptr(sample_idx), len(wei), len(row_idx), int(chunk),
+                                         int(bool(skip_hets)), int(mode), ptr(out["score"]), ptr(out["ninfo"]), ptr(out.get("lik")),
+                                         ptr(out.get("lrt")), ptr(info)), ctx.h)
+        out["n_strict_reeval"], out["all_integer_weights"], out["reeval_path"] = int(info[0]), bool(info[1]), int(info[2])
+        return out
+
     def upload_rows(self, row0, rows):
         rows = np.ascontiguousarray(rows, dtype=np.int8)
         assert rows.ndim == 2 and rows.shape[1] == self.n_acc

@@ -1,0 +1,129 @@
+"""
+snpm_genotype_once (-m gpu): one sample against a resident panel in ONE library call -- the host threads gather the matched
+weight rows, the weight properties come from that pass, counts and likelihoods return in one copy.  Everything it returns must
+equal the three-call path (Query + run + likelihood) and the C oracle (Genotyper.genotyper, core/snpmatch.py:207-241).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import snpmatch_oracle as orc
+from snpmatch_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = engine.Context(0)
+    yield c
+    c.close()
+
+
+def rand_db(rng, n, n_acc):
+    return rng.choice(np.array([-1, 0, 1, 2], dtype=np.int8), size=(n, n_acc), p=[0.05, 0.60, 0.33, 0.02])
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("n_snp,n_acc,n_match,n_in", [(20000, 1135, 7545, 10000), (6000, 64, 3001, 3001), (4000, 1, 1000, 1500),
+                                                       (130, 17, 129, 200), (300000, 300, 250000, 260000)])
+def test_once_equals_three_calls_and_oracle(ctx, packed, n_snp, n_acc, n_match, n_in):
+    rng = np.random.default_rng(n_snp + n_acc + int(packed))
+    db = rand_db(rng, n_snp, n_acc)
+    panel = engine.Panel.from_host(ctx, db, packed=packed)
+    rows = np.sort(rng.choice(n_snp, size=n_match, replace=False)).astype(np.int64)
+    codes = rng.choice(np.array([0, 1, 2], dtype=np.int8), size=n_in, p=[0.6, 0.35, 0.05])
+    for frac_pl in (0.8, 0.0):                                   # PL-weighted and hard-call samples (k_fast_bits on packed panels)
+        wei_all = synth.sample_weights(rng, codes, frac_pl)
+        sidx = np.sort(rng.choice(n_in, size=n_match, replace=False)).astype(np.int64)
+        wei = wei_all[sidx]
+        for skip in (False, True):
+            want_s, want_n = c_oracle.genotyper(db, rows, wei, 1000, skip)
+            q = engine.Query(panel, rows, wei)
+            s3, n3 = q.run(1000, skip, engine.MODE_EXACT)
+            lik3, lrt3 = ctx.likelihood(s3, n3, truncate=True)
+            q.free()
+            out = panel.genotype_once(rows, wei_all, sidx, 1000, skip, engine.MODE_EXACT)
+            assert np.array_equal(out["ninfo"], want_n) and np.array_equal(out["score"].astype(int), want_s.astype(int))
+            assert np.array_equal(bits(out["score"]), bits(s3))              # the same kernels in the same geometry
+            assert np.array_equal(bits(out["lik"]), bits(lik3)) and np.array_equal(bits(out["lrt"]), bits(lrt3))
+            assert out["all_integer_weights"] == (frac_pl == 0.0)
+            lik_o, lrt_o = orc.calculate_likelihoods(want_s.astype(int), want_n)
+            ok = ~np.isnan(lik_o)
+            assert np.array_equal(np.isnan(out["lik"]), ~ok) and np.allclose(out["lik"][ok], lik_o[ok], rtol=1e-12, atol=0)
+            # reference order: the reference's fp64 bits; without sample_idx the weights are taken row for row
+            out = panel.genotype_once(rows, wei, None, 1000, skip, engine.MODE_STRICT, likelihoods=False)
+            assert np.array_equal(bits(out["score"]), bits(want_s)) and np.array_equal(out["ninfo"], want_n) and "lik" not in out
+    panel.free()
+
+
+def test_once_forced_reevaluation_and_refusals(golden_dir):
+    os.environ["SNPM_DEBUG_REEVAL"] = "3"
+    try:
+        c = engine.Context(0)
+    finally:
+        del os.environ["SNPM_DEBUG_REEVAL"]
+    rng = np.random.default_rng(99)
+    db = rand_db(rng, 9000, 300)
+    panel = engine.Panel.from_host(c, db)
+    rows = np.arange(9000, dtype=np.int64)
+    wei = synth.sample_weights(rng, rng.choice(np.array([0, 1, 2], dtype=np.int8), size=9000), 0.8)
+    want_s, want_n = c_oracle.genotyper(db, None, wei, 1000, False)
+    out = panel.genotype_once(rows, wei)
+    assert out["n_strict_reeval"] >= 3 and np.array_equal(bits(out["score"][:3]), bits(want_s[:3]))     # re-scored in reference order
+    assert np.array_equal(out["ninfo"], want_n) and np.array_equal(out["score"].astype(int), want_s.astype(int))
+    # refusals with the reference's messages
+    with pytest.raises(AssertionError, match="outside the panel"):
+        panel.genotype_once(np.array([1, 9000], dtype=np.int64), wei[:2])
+    with pytest.raises(AssertionError, match="outside the panel"):
+        panel.genotype_once(np.array([1, 2], dtype=np.int64), wei[:2], np.array([0, 5], dtype=np.int64))
+    with pytest.raises(AssertionError, match="same number of positions"):
+        panel.genotype_once(rows[:10], wei[:9])
+    bad = wei[:100].copy()
+    bad[7, 1] = np.nan
+    with pytest.raises(AssertionError, match="finite"):
+        panel.genotype_once(rows[:100], bad)
+    heavy = wei[:100].copy() * 3.0                               # counts above the informative sites: the reference's assert (:43)
+    with pytest.raises(AssertionError, match="greater than n"):
+        panel.genotype_once(rows[:100], heavy)
+    # an empty match list is a valid (if useless) sample
+    out = panel.genotype_once(np.zeros(0, dtype=np.int64), np.zeros((0, 3)))
+    assert np.all(out["ninfo"] == 0) and np.all(out["score"] == 0) and np.all(np.isnan(out["lik"]))
+    panel.free()
+    c.close()
+
+
+def test_genotyper_uses_the_one_call_path(ctx, golden_dir, tmp_path, monkeypatch):
+    """Genotyper on a resident single-GPU panel goes through snpm_genotype_once and writes the reference's files"""
+    import json
+    from snpmatch_amd.core import parsers, snp_genotype, snpmatch
+    toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
+    gold = json.load(open(os.path.join(golden_dir, "g2_inbred.json")))
+    g = snp_genotype.Genotype.from_arrays(toy["snps"], toy["accs"], toy["positions"], toy["chrs"], toy["regions"])
+    calls = []
+    real = engine.Panel.genotype_once
+    monkeypatch.setattr(engine.Panel, "genotype_once", lambda self, *a, **k: calls.append(1) or real(self, *a, **k))
+    inp = parsers.ParseInputs("")
+    inp.load_snp_info(toy["s_chrs"], toy["s_pos"], toy["s_gt"], toy["s_wei"], toy["s_dp"])
+    out = str(tmp_path / "once")
+    gt = snpmatch.Genotyper(inp, g, out, run_genotyper=True)
+    assert calls and hasattr(gt.result, "_device_likelihoods")
+    want = gold["inbred_skip0"]
+    assert open(out + ".matches.json").read() == want["matches.json"]
+    got = [l.split("\t") for l in open(out + ".scores.txt").read().strip().split("\n")]
+    ref = [l.split("\t") for l in want["scores.txt"].strip().split("\n")]
+    for a, b in zip(got, ref):
+        assert a[:4] == b[:4] and a[6:] == b[6:]
+        assert abs(float(a[4]) - float(b[4])) <= 1e-12 * abs(float(b[4])) and abs(float(a[5]) - float(b[5])) <= 1e-12 * abs(float(b[5]))
+    # changing the counts afterwards invalidates the cached likelihoods
+    gt.result.scores = gt.result.scores.copy()
+    gt.result.scores[0] -= 1
+    gt.result.get_likelihoods()
+    lik, _ = snpmatch.GenotyperOutput.calculate_likelihoods(gt.result.scores, gt.result.ninfo)
+    assert np.array_equal(bits(gt.result.likelis), bits(lik))

@@ -74,6 +74,30 @@ def test_parse_gt_and_chr_names():
     ins.filter_chr_names()
     assert ins.g_chrs.tolist() == ["2", "2", "1", "1", "M"]
     assert ins.g_chrs_ids.tolist() == ["2", "1", "M"]           # order of first appearance
+    assert ins.g_chr_codes.tolist() == [0, 0, 1, 1, 2]
+    # unsorted input (a chromosome in several runs) and the plain per-string route give the same three arrays
+    rng = np.random.default_rng(8)
+    names = rng.choice(np.array(["Chr1", "chr1", "2", "CHR2", "Pt", "chrM", "3"]), size=500)
+    ins.load_snp_info(names, np.arange(500), "", np.nan, 0)
+    ins.filter_chr_names()
+    import re
+    bare = np.array([re.sub("chr", "", c, flags=re.IGNORECASE) for c in names.tolist()])
+    assert np.array_equal(ins.g_chrs, bare)
+    first_seen = []
+    for c in bare.tolist():
+        if c not in first_seen:
+            first_seen.append(c)
+    assert ins.g_chrs_ids.tolist() == first_seen
+    assert np.array_equal(ins.g_chrs_ids[ins.g_chr_codes], bare)
+    # the integer route of parseGT (three-character calls) equals the string route on every call text that occurs
+    calls = np.array(["0/0", "1/1", "0/1", "1/0", "./.", "1/2", "2/1", "0/.", "./1", "0|1", "1|1"])
+    mixed = rng.choice(calls[:9], size=300)
+    mixed[0] = "0/1"
+    slow = np.zeros(300, dtype=np.int8)
+    for pat, code in (("1/1", 1), ("0/1", 2), ("1/0", 2), ("./.", -1)):
+        slow[mixed == pat] = code
+    assert np.array_equal(parsers.parseGT(mixed), slow)
+    assert parsers.parseGT(np.array(["0/1", "10/1", "1/1"])).tolist() == [2, 0, 1]      # wider strings: the string route
 
 
 def _same_calls(a, b):

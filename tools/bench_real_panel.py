@@ -123,9 +123,25 @@ def main():
             lik_top[0] = int(np.nanargmin(lik))
             q.free()
 
-        leg = kernel_leg(ctx, "single_sample_200k_gathered_rows", one_sample, n_match, row_bytes, args.reps)
+        leg = kernel_leg(ctx, "single_sample_200k_three_calls", one_sample, n_match, row_bytes, args.reps)
         assert lik_top[0] == PLANTED
         leg["kernel"] = "k_fast_packed_q4<GATHER>" if packed else "k_fast<GATHER>"
+        leg["note"] = "round 3's path: snpm_query_create + snpm_query_run + snpm_likelihood, weights gathered by the caller"
+        legs.append(leg)
+        # (1b) the same sample through snpm_genotype_once: the library gathers wei_all[sample_idx] itself (what Genotyper.genotyper
+        # hands over: the whole sample's weights + the matched positions), counts and likelihoods come back in one copy
+        n_in = n_match + n_match // 4                            # a sample with 25 % of its SNPs absent from the DB
+        sidx = np.sort(rng.choice(n_in, size=n_match, replace=False)).astype(np.int64)
+        wei_all = np.zeros((n_in, 3))
+        wei_all[sidx] = wei0
+
+        def one_call():
+            lik_top[0] = int(np.nanargmin(panel.genotype_once(rows0, wei_all, sidx, 1000, False, engine.MODE_EXACT)["lik"]))
+
+        leg = kernel_leg(ctx, "single_sample_200k_one_call", one_call, n_match, row_bytes, args.reps)
+        assert lik_top[0] == PLANTED
+        leg["kernel"] = "k_fast_packed_q4<GATHER>" if packed else "k_fast<GATHER>"
+        leg["note"] = "snpm_genotype_once: host-thread gather into a pinned slab, one upload, one copy back (Genotyper.genotyper's path)"
         legs.append(leg)
         # (2) the same sample, query kept: the scoring alone (kernel + reduce + certificate), results to the host
         q = engine.Query(panel, rows0, wei0)
