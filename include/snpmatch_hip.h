@@ -398,14 +398,20 @@ int snpm_profile_read(snpm_ctx *ctx, const char *kernel, int64_t *launches, doub
 /* ---------------------------------------------------------------- sample input: VCF text (host only, no GPU) */
 /* Single pass over a (plain or gzip) VCF: what ParseInputs.read_vcf (core/parsers.py:178-213, scikit-allel in
    the reference) extracts for sample column `sample_index`: CHROM, POS, the GT text as written, the first three
-   PL values (-1 where absent) and INFO/DP (-1 where absent).  SNPM_ERR_STATE = the file holds something this
-   reader does not want to interpret (odd numbers, CRLF, very wide records): use the generic reader. */
+   PL values (-1 where absent) and INFO/DP (-1 where absent).  The calling thread reads (and inflates) the file in blocks of
+   whole lines, a team of threads (the process's cores, at most 16; SNPM_VCF_THREADS) parses the blocks, file order is kept.
+   SNPM_ERR_STATE = the file holds something this reader does not want to interpret (odd numbers, CRLF, very wide records):
+   use the generic reader. */
 typedef struct snpm_vcf snpm_vcf;
 int snpm_vcf_parse(const char *path, int sample_index, snpm_vcf **out);
-/* flags: bit 0 some FORMAT has GT, bit 1 some record has PL, bit 2 some record has INFO/DP */
+/* flags: bit 0 some FORMAT has GT, bit 1 some record has PL, bit 2 some record has INFO/DP, bit 3 CHROM / GT text is pure ASCII */
 int snpm_vcf_dims(const snpm_vcf *vcf, int64_t *n_records, int *chr_width, int *gt_width, int *flags, int *n_samples);
 /* chr [n * chr_width] and gt [n * gt_width]: NUL-padded fixed-width bytes; pos [n]; pl [n * 3]; dp [n] */
 int snpm_vcf_fill(const snpm_vcf *vcf, char *chr, int64_t *pos, char *gt, double *pl, int64_t *dp);
+/* The same with CHROM / GT as fixed-width UTF-32 (numpy '<U{width}': one code point per uint32_t, zero padded: no per-string
+   conversion on the Python side) and called [n] = 0 where the genotype is './.' or '.|.' (the records ParseInputs.read_vcf
+   drops, core/parsers.py:141-157).  SNPM_ERR_STATE when the text is not ASCII (flag bit 3). */
+int snpm_vcf_fill_u32(const snpm_vcf *vcf, uint32_t *chr, int64_t *pos, uint32_t *gt, double *pl, int64_t *dp, uint8_t *called);
 const char *snpm_vcf_sample_name(const snpm_vcf *vcf, int i);
 int snpm_vcf_free(snpm_vcf *vcf);
 

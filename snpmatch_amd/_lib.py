@@ -37,7 +37,7 @@ SYMBOLS = [
     "snpm_query_run_windows", "snpm_query_run_windows_carry", "snpm_score_dense_host", "snpm_likelihood", "snpm_likelihood_device",
     "snpm_binom_identity", "snpm_binom_sf_host", "snpm_intersect_sorted", "snpm_panel_segregating",
     "snpm_query_f1_pairs", "snpm_intersect_sorted_search",
-    "snpm_vcf_parse", "snpm_vcf_dims", "snpm_vcf_fill", "snpm_vcf_sample_name", "snpm_vcf_free",
+    "snpm_vcf_parse", "snpm_vcf_dims", "snpm_vcf_fill", "snpm_vcf_fill_u32", "snpm_vcf_sample_name", "snpm_vcf_free",
     "snpm_debug_stream_read", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
     "snpm_panel_fill_synthetic_rows", "snpm_sample_synthetic", "snpm_query_create_device", "snpm_query_last_reeval",
     "snpm_query_last_kernel", "snpm_carry_create", "snpm_carry_reset", "snpm_carry_free", "snpm_carry_set_columns", "snpm_carry_bind_outputs", "snpm_panel_segregating_first", "snpm_query_gather_columns", "snpm_query_run_windows_fast", "snpm_score_batch", "snpm_score_batch_coded", "snpm_genotype_once", "snpm_host_alloc", "snpm_host_free",
@@ -224,6 +224,7 @@ def load():
     lib.snpm_vcf_parse.argtypes = [C.c_char_p, ci, pp]
     lib.snpm_vcf_dims.argtypes = [p, C.POINTER(i64), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     lib.snpm_vcf_fill.argtypes = [p, p, p, p, p, p]
+    lib.snpm_vcf_fill_u32.argtypes = [p, p, p, p, p, p, p]
     lib.snpm_vcf_sample_name.argtypes = [p, ci]
     lib.snpm_vcf_sample_name.restype = C.c_char_p
     lib.snpm_vcf_free.argtypes = [p]
@@ -296,8 +297,9 @@ def intersect_sorted(a, b, a_verified=False):
 
 
 def vcf_parse(path, sample_index=0):
-    """native single-pass VCF reader (snpm_vcf_*): dict with chr, pos, gt, pl, dp, flags, sample names; None when
-    the library declines the file (the caller then uses the Python reader)"""
+    """native VCF reader (snpm_vcf_*: blocks of lines parsed by a team of threads): dict with chr, pos, gt, pl, dp, flags, sample
+    names; None when the library declines the file (the caller then uses the Python reader).  ``chr`` / ``gt`` arrive as numpy
+    unicode arrays filled by the library (UTF-32, no conversion pass), ``called`` marks the records whose genotype is not './.' / '.|.'."""
     lib = load()
     h = C.c_void_p()
     rc = lib.snpm_vcf_parse(os.fsencode(path), int(sample_index), C.byref(h))
@@ -309,16 +311,26 @@ def vcf_parse(path, sample_index=0):
         n, cw, gw, flags, ns = C.c_int64(0), C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
         lib.snpm_vcf_dims(h, C.byref(n), C.byref(cw), C.byref(gw), C.byref(flags), C.byref(ns))
         n = n.value
-        chrom = np.zeros(n, dtype="S%d" % cw.value)
-        gt = np.zeros(n, dtype="S%d" % gw.value)
-        pos = np.zeros(n, dtype=np.int64)
-        dp = np.zeros(n, dtype=np.int64)
-        pl = np.zeros((n, 3), dtype=np.float64)
-        lib.snpm_vcf_fill(h, ptr(chrom), ptr(pos), ptr(gt), ptr(pl), ptr(dp))
+        pos = np.empty(n, dtype=np.int64)
+        dp = np.empty(n, dtype=np.int64)
+        pl = np.empty((n, 3), dtype=np.float64)
+        called = None
+        if flags.value & 8:
+            chrom = np.empty(n, dtype="<U%d" % cw.value)
+            gt = np.empty(n, dtype="<U%d" % gw.value)
+            called = np.empty(n, dtype=np.uint8)
+            rc = lib.snpm_vcf_fill_u32(h, ptr(chrom), ptr(pos), ptr(gt), ptr(pl), ptr(dp), ptr(called))
+            assert rc == SNPM_OK
+            called = called.view(np.bool_)
+        else:
+            chrom = np.zeros(n, dtype="S%d" % cw.value)
+            gt = np.zeros(n, dtype="S%d" % gw.value)
+            lib.snpm_vcf_fill(h, ptr(chrom), ptr(pos), ptr(gt), ptr(pl), ptr(dp))
+            chrom, gt = chrom.astype("U"), gt.astype("U")
         names = [lib.snpm_vcf_sample_name(h, i).decode() for i in range(ns.value)]
     finally:
         lib.snpm_vcf_free(h)
-    return {"chr": chrom, "pos": pos, "gt": gt, "pl": pl, "dp": dp, "names": names,
+    return {"chr": chrom, "pos": pos, "gt": gt, "pl": pl, "dp": dp, "names": names, "called": called,
             "has_gt": bool(flags.value & 1), "has_pl": bool(flags.value & 2), "has_dp": bool(flags.value & 4)}
 
 

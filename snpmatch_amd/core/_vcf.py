@@ -55,11 +55,12 @@ def _read_calls_native(path, sample):
     return {
         "samples": np.array(raw["names"][sample:sample + 1], dtype="U"),
         "has_gt": raw["has_gt"] or n == 0,
-        "chr": raw["chr"].astype("U"),
-        "pos": raw["pos"].astype(int),
-        "gt": raw["gt"].astype("U").reshape(n, 1),
+        "chr": raw["chr"],                         # unicode arrays filled by the library: no conversion pass
+        "pos": raw["pos"],
+        "gt": raw["gt"].reshape(n, 1),
         "pl": raw["pl"].reshape(n, 1, 3) if raw["has_pl"] else None,
-        "dp": raw["dp"].astype(int) if raw["has_dp"] else None,
+        "dp": raw["dp"] if raw["has_dp"] else None,
+        "called": raw["called"],                   # bool [n] (or None): genotype is not './.' / '.|.'
     }
 
 
@@ -96,6 +97,7 @@ def read_calls(path, samples=(0,), native=True):
             pls.append(row_pl)
     n, s = len(chrom), len(samples)
     return {
+        "called": None,
         "samples": np.array([names[i] for i in samples if i < len(names)], dtype="U"),
         "has_gt": any_gt or n == 0,
         "chr": np.array(chrom, dtype="U"),

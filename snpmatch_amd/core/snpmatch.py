@@ -280,6 +280,8 @@ def parse_inputs_once(in_file, log_debug):
     if job is None:
         return parsers.ParseInputs(inFile=in_file, logDebug=log_debug)
     inputs = parsers.ParseInputs(inFile=in_file, logDebug=log_debug) if job.is_writer else None
+    if inputs is not None:
+        inputs.wait_for_cache()      # the cache is written in the background: complete before the other ranks look for it
     job.barrier()
     return inputs if inputs is not None else parsers.ParseInputs(inFile=in_file, logDebug=log_debug)
 

@@ -10,7 +10,7 @@ import shutil
 
 import numpy as np
 
-from snpmatch_amd.core import parsers
+from snpmatch_amd.core import _vcf, parsers
 
 
 def test_vcf_parse_reference_pins(golden_dir, tmp_path):
@@ -153,3 +153,22 @@ def test_native_vcf_reader_equals_python_reader(golden_dir, tmp_path):
     empty = tmp_path / "empty.vcf"
     empty.write_text(head)
     _same_calls(_vcf.read_calls(str(empty), native=True), _vcf.read_calls(str(empty), native=False))
+
+
+def test_native_vcf_reader_in_many_blocks_on_several_threads(golden_dir, tmp_path, monkeypatch):
+    """the native reader cuts the file into blocks of whole lines parsed by a team of threads: with 8-KiB blocks the sample file
+    becomes hundreds of blocks, and the records must come back in file order, equal to the Python reader's, for any team size"""
+    import gzip
+    import shutil
+    src = os.path.join(golden_dir, "701_501.filter.vcf.gz")
+    plain = str(tmp_path / "s.vcf")
+    with gzip.open(src, "rb") as fi, open(plain, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    want = _vcf.read_calls(plain, (0,), native=False)
+    for threads, block_kb in (("1", "8"), ("4", "8"), ("16", "4"), ("3", "4096")):
+        monkeypatch.setenv("SNPM_VCF_THREADS", threads)
+        monkeypatch.setenv("SNPM_VCF_BLOCK_KB", block_kb)
+        for path in (plain, src):
+            got = _vcf.read_calls(path, (0,))
+            assert got["called"] is not None and np.array_equal(got["called"], (want["gt"][:, 0] != "./.") & (want["gt"][:, 0] != ".|."))
+            _same_calls(got, want)
