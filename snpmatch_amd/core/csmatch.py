@@ -7,9 +7,9 @@ Public surface follows the reference module ``snpmatch.core.csmatch`` (core/csma
 ``chunk_size``.
 
 The reference scores window after window (one ``matchGTsAccs`` call each, :80-90).  Here the matched DB
-rows of ALL windows form one device query with a segment per window -- by default the segmented streaming
-pass with its certificate (counts exact, float scores to ~1e-12), with SNPMATCH_CROSS_STRICT=1 the
-reference-order kernel (fp64 bit-exact) -- the per-window likelihoods / minima / ratios are one
+rows of ALL windows form one device query with a segment per window -- by default the reference-order kernel
+(fp64 window scores with the reference's bits: ``windowscore.txt`` byte-identical), with SNPMATCH_CROSS_FAST=1 the
+segmented streaming pass with its certificate (counts exact, float scores to ~1e-12) -- the per-window likelihoods / minima / ratios are one
 ``k_likelihood`` launch with a row per window, and the binomial identity test runs on the device as well.  The window table and the
 JSON interpretation are host glue (``_report``); the 45 in-silico F1s of the ten best accessions are one
 more device call (``k_f1_*``, numpy's summation order).
@@ -151,13 +151,17 @@ class CrossIdentifier(object):
         n_matched = int(offsets[-1])
 
         query = self.g.panel().query(db_rows, self.inputs.wei[sample_rows, ])
-        # default: the segmented streaming pass with the certificate per (window, accession) and for the totals -- snps_match,
-        # snps_info, num_amb, the totals and every file derived from them identical to the reference's, the float columns of
-        # windowscore.txt (score, likelihood) equal to ~1e-12 relative (north_star asks for 1e-6).  SNPMATCH_CROSS_STRICT=1
-        # (or SNPMATCH_CROSS_FAST=0): every window in reference order instead -- fp64 window scores with the reference's bits,
-        # the "score" column byte-identical -- at the speed of the reference-order kernel (0.70 instead of 0.78 of HBM peak).
-        strict = (os.environ.get("SNPMATCH_CROSS_STRICT", "0") not in ("", "0")) or os.environ.get("SNPMATCH_CROSS_FAST", "1") == "0"
+        # default (round 4): every window in the reference's summation order -- fp64 window scores with the reference's
+        # bits, windowscore.txt byte-identical, which is what a drop-in is diffed against; at the 1001-Genomes shape the two
+        # modes cost the same (0.41 against 0.46 ms for 399 windows, profiles/r04b_real_panel_legs_one_call.json).
+        # SNPMATCH_CROSS_FAST=1: the segmented streaming pass with the certificate per (window, accession) and for the totals --
+        # snps_match, snps_info, num_amb, the totals and every file derived from them identical, the float columns of
+        # windowscore.txt (score, likelihood) equal to ~1e-12 relative (north_star asks for 1e-6): the faster mode on wide panels.
+        # SNPMATCH_CROSS_STRICT=1 (round 3's switch) still forces the reference order.
+        strict = (os.environ.get("SNPMATCH_CROSS_STRICT", "0") not in ("", "0")) or \
+                 (os.environ.get("SNPMATCH_CROSS_FAST", "0") in ("", "0"))
         fast = not strict
+        log.info("window scoring mode: %s", "segmented fast pass + certificate (SNPMATCH_CROSS_FAST)" if fast else "reference order")
         w_score, w_ninfo, tot_score, tot_ninfo = query.run_windows(offsets, self._skip_db_hets, fast=fast)
         query.free()
         job = dist.job()

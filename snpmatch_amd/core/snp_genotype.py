@@ -276,13 +276,16 @@ class Genotype(object):
         # slabs: packed when asked for, or when the file itself is packed; in auto mode an int8 source streams as int8 (a call
         # code a packed panel refuses could otherwise surface in the middle of a job, slabs after the first are not probed)
         if (packed or (packed is None and p2)) and not unpackable:
+            sp = None
             try:
                 sp = engine.StreamedPanel(ctx, store, cols=(a0, a1), packed=True, budget_bytes=budget)
                 sp.store.load(sp.halves[0], sp.cols, (0, min(sp.rows_cap, store.n_snp)), 0)     # probe for codes a packed panel refuses
                 return sp
-            except AssertionError:
-                log.info("DB holds codes a packed panel cannot store; streaming int8 slabs")
-                sp.free()
+            except AssertionError as e:
+                # (the constructor itself asserts when the budget holds no row: then there is nothing to free)
+                log.info("packed slabs not usable (%s); streaming int8 slabs", e)
+                if sp is not None:
+                    sp.free()
         return engine.StreamedPanel(ctx, store, cols=(a0, a1), packed=False, budget_bytes=budget)
 
     # ------------------------------------------------------------------ position intersection (a5)

@@ -1961,15 +1961,17 @@ try {
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, q->cert_eref(), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const double eref = *(const double *)ctx->h_pinned;
-    const bool p16 = q->panel->packed != 0;
-    const int bpl = p16 ? 16 : pick_bpl(ctx, q->panel->n_acc);
-    // occ 1 -> the fewest, longest parts -> the largest bound; the tile size the run uses (the bound counts epochs of its tiles)
-    const int tile = p16 ? std::min(BITS_TILE_ROWS, Q4_TILE_ROWS) : fast_tile_rows(q, false);
-    FastGeom g = fast_geom(ctx, q->panel->n_acc, q->n, 1, bpl, tile);
-    // ... and the most, shortest parts a run may use (eight resident blocks per CU, the packed kernels' eight parts per
-    // block): the most partial sums to add up afterwards; the bound reported is the larger of the two
-    FastGeom g2 = fast_geom(ctx, q->panel->n_acc, q->n, 8, bpl, tile, 0, p16 ? 16 : 1);
-    *bound = eref + std::max(efast_bound(q, g), efast_bound(q, g2));
+    // The fast pass's share, bounded over EVERY geometry a run may pick (two probe geometries did not dominate the
+    // one run_fast chooses from the measured occupancy, its part multipliers and block shapes): a term passes through at most
+    // min(n, rows of an epoch) additions inside a part, REDUCE_GROUP in its group and one per group afterwards, and there are
+    // at most (parts + epochs) / REDUCE_GROUP + 1 groups with parts <= 16 resident blocks x 16 parts each per CU and an epoch
+    // never shorter than EPOCH_TILES tiles of 16 rows.
+    const double u = 1.1102230246251565e-16;
+    const int64_t epoch_adds = (int64_t)EPOCH_TILES * 255;                                  // the longest tile any kernel walks
+    const int64_t max_parts = (int64_t)ctx->n_cu * 16 * 16;
+    const int64_t max_slots = max_parts + q->n / ((int64_t)EPOCH_TILES * 16) + 2;
+    const double m = (double)(std::min<int64_t>(q->n, epoch_adds) + REDUCE_GROUP + (max_slots + REDUCE_GROUP - 1) / REDUCE_GROUP + 3);
+    *bound = eref + (q->wsum * (m * u / (1.0 - m * u))) * 1.0000001;
     return SNPM_OK;
 } SNPM_GUARD(((q && q->panel) ? q->panel->ctx : nullptr))
 

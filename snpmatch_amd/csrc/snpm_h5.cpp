@@ -697,18 +697,25 @@ void index_chunks(const snpm_h5 &f, Object &o)
             }
         }
     } else if (o.chunk_btree != UNDEF) {
+        // (node, level the parent expects: -1 = the root, any).  A child must sit exactly one level below its parent (a node
+        // that names itself or an ancestor as its child is refused there), and the walk visits at most a small multiple of the
+        // dataset's chunk count of nodes: a damaged or crafted file ends in an error, not in unbounded work.
         std::vector<std::pair<uint64_t, int>> stack;
-        stack.push_back({o.chunk_btree, 0});
+        stack.push_back({o.chunk_btree, -1});
         const size_t key_sz = 8 + 8 * (size_t)(o.rank + 1);
+        const uint64_t max_nodes = 2 * (uint64_t)o.chunks.size() + 64;
+        uint64_t visited = 0;
         while (!stack.empty()) {
             const uint64_t node = stack.back().first;
-            const int depth = stack.back().second;
+            const int expect = stack.back().second;
             stack.pop_back();
-            if (depth > 64) fail("chunk B-tree too deep");
+            if (++visited > max_nodes) fail("chunk B-tree holds more nodes than the dataset has chunks");
             uint8_t nh[8];
             f.read(node, nh, 8);
             if (memcmp(nh, "TREE", 4) != 0 || nh[4] != 1) fail("chunk B-tree node signature missing");
             const int level = nh[5], used = nh[6] | (nh[7] << 8);
+            if (expect >= 0 && level != expect) fail("chunk B-tree node at the wrong level");
+            if (level > 64) fail("chunk B-tree too deep");
             const std::vector<uint8_t> b = f.bytes(node + 8, (size_t)(2 * f.so) + (size_t)used * (key_sz + f.so) + key_sz);
             Cursor c(b.data(), b.size());
             c.skip((size_t)(2 * f.so));
@@ -725,7 +732,7 @@ void index_chunks(const snpm_h5 &f, Object &o)
                 }
                 c.u(8);                                     // offset in the element-size dimension (0)
                 ch.addr = c.u(f.so);
-                if (level > 0) stack.push_back({ch.addr, depth + 1});
+                if (level > 0) stack.push_back({ch.addr, level - 1});
                 else if (inside) o.chunks[(size_t)idx] = ch;
             }
         }
@@ -814,6 +821,8 @@ const uint8_t *load_chunk(const snpm_h5 &f, const Object &o, size_t index, size_
     if (ch.addr == UNDEF) {                                 // never written: the fill value (0)
         memset(cb.data.data(), 0, chunk_bytes);
     } else {
+        // the stored size comes from the file: checked against the file before a buffer of that size is made
+        if (ch.addr + f.base > f.file_size || ch.size > f.file_size - (ch.addr + f.base)) fail("chunk %zu lies outside the file", index);
         cb.tmp.resize(ch.size);
         f.read(ch.addr, cb.tmp.data(), ch.size);
         std::vector<uint8_t> *cur = &cb.tmp, *other = &cb.data;

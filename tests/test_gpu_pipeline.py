@@ -71,10 +71,11 @@ def test_refine_matches_reference_files(golden_dir, tmp_path):
 
 def cmp_window_table(got_text, want_text, strict_scores=None):
     """acc, snps_match, snps_info, identical, num_amb, window_index identical; likelihood within RTOL; the "score" column
-    (float window score / informative sites) identical as text in the reference-order mode (SNPMATCH_CROSS_STRICT=1),
-    within RTOL in the default certified mode"""
+    (float window score / informative sites) identical as text in the reference-order mode (the default),
+    within RTOL in the certified fast mode (SNPMATCH_CROSS_FAST=1)"""
     if strict_scores is None:
-        strict_scores = os.environ.get("SNPMATCH_CROSS_STRICT", "0") not in ("", "0")
+        strict_scores = (os.environ.get("SNPMATCH_CROSS_STRICT", "0") not in ("", "0")) or \
+                        (os.environ.get("SNPMATCH_CROSS_FAST", "0") in ("", "0"))
     got = [l.split("\t") for l in got_text.strip().split("\n")]
     want = [l.split("\t") for l in want_text.strip().split("\n")]
     assert got[0] == want[0]
@@ -100,11 +101,13 @@ def db_format(request, monkeypatch):
 
 @pytest.fixture(params=["certified", "strict"])
 def cross_mode(request, monkeypatch):
-    """both window modes of ``cross``: the default (segmented fast pass + certificate) and SNPMATCH_CROSS_STRICT=1"""
+    """both window modes of ``cross``: the default (reference order, byte-identical window scores) and SNPMATCH_CROSS_FAST=1
+    (segmented fast pass + certificate)"""
+    monkeypatch.delenv("SNPMATCH_CROSS_STRICT", raising=False)
     if request.param == "strict":
-        monkeypatch.setenv("SNPMATCH_CROSS_STRICT", "1")
+        monkeypatch.delenv("SNPMATCH_CROSS_FAST", raising=False)
     else:
-        monkeypatch.delenv("SNPMATCH_CROSS_STRICT", raising=False)
+        monkeypatch.setenv("SNPMATCH_CROSS_FAST", "1")
     return request.param
 
 
