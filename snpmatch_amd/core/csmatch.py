@@ -41,8 +41,12 @@ def _window_segments_sorted(genome, db, sample, bin_len):
     window of a matched position is (pos - 1) // bin_len.  Returns None when the inputs are not of that form."""
     bin_len = int(bin_len)
     db_ids = genomes._bare(db.chrs)
-    names, inverse = np.unique(np.asarray(sample.chrs, dtype="str"), return_inverse=True)
-    smp_ids = genomes._bare(names)
+    codes = getattr(sample, "g_chr_codes", None)
+    if codes is not None and len(codes) == len(sample.chrs):       # filter_chr_names already named every SNP's chromosome
+        smp_ids, inverse = genomes._bare(sample.g_chrs_ids), codes      # (lower-cased like the genome's ids; 'Chr1' / 'chr1' share a code)
+    else:
+        names, inverse = np.unique(np.asarray(sample.chrs, dtype="str"), return_inverse=True)
+        smp_ids = genomes._bare(names)
     genome._check(db_ids, "genotype hdf5 file")
     genome._check(np.unique(smp_ids), "given SNPs")
     db_pos = db.__dict__.get("_positions_i64")
@@ -198,7 +202,7 @@ class CrossIdentifier(object):
             snpmatch_result.get_probabilities()
         log.info("simulating F1s for top 10 accessions")
         best = np.argsort(-snpmatch_result.probabilies)[0:10]
-        db_rows, sample_rows = self.g.get_positions_idxs(self.inputs.chrs, self.inputs.pos)
+        db_rows, sample_rows = self.g.get_positions_idxs(self.inputs.chrs, self.inputs.pos, _parsed=self.inputs)
         # all pairs in one device call (k_f1_*): per pair np.sum(W[alt, 2]) + np.sum(W[ref, 0]) + np.sum(W[het, 1])
         # with numpy's summation order, so the float scores printed below carry the reference's digits
         query = self.g.panel().query(db_rows, self.inputs.wei[sample_rows, ])
