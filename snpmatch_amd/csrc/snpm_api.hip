@@ -103,6 +103,7 @@ struct snpm_ctx {
     int64_t acc_major_min_rows = 1000000;   // ... once a query is long enough for the strided path to hurt
     int strict4 = 1;           // dense strict scoring with 4 columns per lane (SNPM_STRICT4=0: one column per lane)
     int debug_max_parts = 0;   // SNPM_DEBUG_MAX_PARTS=k: cap the parts of the fast pass (tests of multi-epoch parts)
+    int packed_split = 1;   // SNPM_PACKED_SPLIT=0: packed panels keep whole rows at a 256-B pitch (round 3's layout)
     int debug_reeval = 0;   // SNPM_DEBUG_REEVAL=k: also re-evaluate accessions 0..k-1 (to time that path)
     int stage_threads = 8;  // host threads filling the pinned staging slabs (default: the cores of this process, at most 16)
     int nt_loads = 1;      // panel bytes are read once: non-temporal loads (+5-8% measured)
@@ -126,6 +127,10 @@ struct snpm_panel {
     int64_t n_acc_total = 0;            // accessions of the panel the REFERENCE would see (= n_acc unless this is one shard of a wider
                                         // panel, snpm_panel_set_total_accessions): 1 selects numpy's vector summation (k_strict_single)
     int64_t pitch = 0;                  // bytes per SNP row (int8: >= n_acc; packed: >= n_acc / 4), multiple of ctx->pitch_align (256)
+                                        // -- or, for a SPLIT packed panel, main part + tail part (e.g. 256 + 32): what a row costs in HBM
+    int64_t kpitch = 0;                 // what the kernels stride rows by: pitch, or the main part's pitch (a multiple of 256, may be 0)
+    int64_t tail_pitch = 0, tail_off = 0;   // split packed panels: bytes per row of the tail matrix / its offset from d (else 0)
+    int64_t desc = 0;                   // the kernels' layout descriptor (snpm_k_common.hpp; 0 for int8 panels)
     int64_t ld = 0;                     // accessions per row rounded up to 256: leading dimension of result arrays
     int packed = 0;                     // 0 = int8 (one byte per call), 1 = 2 bits per call (4 accessions per byte)
     int8_t *d = nullptr;
@@ -541,8 +546,9 @@ int launch_p16_t(snpm_query *q, const FastGeom &g, int *occ_out, int threads)
     dim3 grid((unsigned)g.n_colblocks, (unsigned)g.n_parts);
     dim3 block(WAVE * g.wpb);
     ProfScope ps(ctx, PK_FAST);
-    hipLaunchKernelGGL((k_fast_packed_q4<SKIP, GATHER, NT, false, TR>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx,
-                       q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, p->n_acc);
+    hipLaunchKernelGGL((k_fast_packed_q4<SKIP, GATHER, NT, false, TR>), grid, block, 0, ctx->stream, p->d, p->kpitch, q->d_row_idx,
+                       q->row0, q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, p->n_acc,
+                       p->desc);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }
@@ -576,8 +582,8 @@ int launch_bits_t(snpm_query *q, const FastGeom &g, int *occ_out, int threads)
     }
     ProfScope ps(ctx, PK_FAST);
     hipLaunchKernelGGL((k_fast_bits<SKIP, GATHER, NT>), dim3((unsigned)g.n_colblocks, (unsigned)g.n_parts), dim3(WAVE * g.wpb), 0,
-                       ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, q->n, (const uint8_t *)q->d_wbits,
-                       (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, p->n_acc);
+                       ctx->stream, p->d, p->kpitch, q->d_row_idx, q->row0, q->n, (const uint8_t *)q->d_wbits,
+                       (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, p->n_acc, p->desc);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }
@@ -794,8 +800,8 @@ bool ensure_acc_major(snpm_panel *p)
     if (hipMemsetAsync(ctx->ws_flags.p, 0, sizeof(int), ctx->stream) != hipSuccess) return false;
     if (p->packed) {
         dim3 grid((unsigned)((p->n_snp + PTP_ROWS - 1) / PTP_ROWS), (unsigned)((p->n_acc + PTP_COLS - 1) / PTP_COLS));
-        hipLaunchKernelGGL(k_pack_transpose_packed, grid, dim3(256), 0, ctx->stream, (const uint8_t *)p->d, p->pitch, p->n_snp,
-                           p->n_acc, p->dT, p->pitchT);
+        hipLaunchKernelGGL(k_pack_transpose_packed, grid, dim3(256), 0, ctx->stream, (const uint8_t *)p->d, p->kpitch, p->n_snp,
+                           p->n_acc, p->dT, p->pitchT, p->desc);
     } else {
         dim3 grid((unsigned)((p->n_snp + PT_ROWS - 1) / PT_ROWS), (unsigned)((p->n_acc + PT_COLS - 1) / PT_COLS));
         hipLaunchKernelGGL(k_pack_transpose, grid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->n_snp, p->n_acc, p->dT,
@@ -827,7 +833,7 @@ static int launch_strict_single(snpm_ctx *ctx, const snpm_panel *p, const int64_
 {
     const bool gather = d_row_idx != nullptr;
 #define LAUNCH_SINGLE(S, G)                                                                                          \
-    hipLaunchKernelGGL((k_strict_single<S, G>), grid, dim3(SINGLE_THREADS), 0, ctx->stream, p->d, p->pitch, p->packed,  \
+    hipLaunchKernelGGL((k_strict_single<S, G>), grid, dim3(SINGLE_THREADS), 0, ctx->stream, p->d, p->kpitch, p->desc,  \
                        d_row_idx, row0, d_w, seg_off, chunk, n, seg0, n_seg, pairs, count, cap, tier, kmax, out_score,  \
                        out_miss, ld)
     if (skip) {
@@ -865,9 +871,9 @@ int launch_strict_dense(snpm_query *q, int skip, const int64_t *d_seg_off, int64
 #define LAUNCH_STRICT4(S, G)                                                                                     \
     do {                                                                                                         \
         if (p->packed)                                                                                           \
-            hipLaunchKernelGGL((k_strict4<S, G, true>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
+            hipLaunchKernelGGL((k_strict4<S, G, true>), grid4, dim3(t4), 0, ctx->stream, p->d, p->kpitch, q->d_row_idx, q->row0, \
                                q->d_w, seg_off, chunk, q->n, seg0, n_seg, ncols, (double *)ctx->ws_seg_score.p,  \
-                               (uint32_t *)ctx->ws_seg_miss.p, ld, (const int *)nullptr, gate, REEVAL_CAP);      \
+                               (uint32_t *)ctx->ws_seg_miss.p, ld, (const int *)nullptr, gate, REEVAL_CAP, p->desc); \
         else                                                                                                     \
             hipLaunchKernelGGL((k_strict4<S, G, false>), grid4, dim3(t4), 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0, \
                                q->d_w, seg_off, chunk, q->n, seg0, n_seg, ncols, (double *)ctx->ws_seg_score.p,  \
@@ -886,7 +892,7 @@ int launch_strict_dense(snpm_query *q, int skip, const int64_t *d_seg_off, int64
     dim3 grid((unsigned)(gate ? std::min<int64_t>(n_seg, 2048) : n_seg), (unsigned)((ncols + thr - 1) / thr));
     ProfScope ps(ctx, PK_STRICT);
 #define LAUNCH_STRICT(S, G)                                                                                       \
-    hipLaunchKernelGGL((k_strict<S, G>), grid, dim3(thr), 0, ctx->stream, p->d, p->pitch, p->packed, q->d_row_idx, q->row0,  \
+    hipLaunchKernelGGL((k_strict<S, G>), grid, dim3(thr), 0, ctx->stream, p->d, p->kpitch, p->desc, q->d_row_idx, q->row0,  \
                        q->d_w, seg_off, chunk, q->n, seg0, n_seg, (const int32_t *)nullptr, ncols,                \
                        (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld, gate, REEVAL_CAP)
     if (skip) {
@@ -979,7 +985,7 @@ int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_c
         } else {
             q->reeval_path = 2;
 #define LAUNCH_SPARSE(S, G)                                                                                        \
-    hipLaunchKernelGGL((k_strict_sparse<S, G>), sgrid, dim3(256), 0, ctx->stream, p->d, p->pitch, p->packed, q->d_row_idx, \
+    hipLaunchKernelGGL((k_strict_sparse<S, G>), sgrid, dim3(256), 0, ctx->stream, p->d, p->kpitch, p->desc, q->d_row_idx, \
                        q->row0, q->d_w, d_seg_off, chunk, q->n, n_seg, d_cols, d_ncols, REEVAL_CAP, \
                        (double *)ctx->ws_seg_score.p, (uint32_t *)ctx->ws_seg_miss.p, ld)
             if (skip) {
@@ -1031,8 +1037,8 @@ static int launch_q4_seg(snpm_ctx *ctx, const SegJob &j, dim3 grid, dim3 block, 
     ProfScope ps(ctx, PK_FAST);
     const int tr = q4_tile_rows(ctx, (int)(block.x / WAVE));
 #define LAUNCH_SEG_TR(S, G, TR)                                                                                   \
-    hipLaunchKernelGGL((k_fast_packed_q4<S, G, NT, true, TR>), grid, block, 0, ctx->stream, p->d, p->pitch, j.d_row_idx, j.row0, \
-                       n_parts, j.d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, p->n_acc, d_desc)
+    hipLaunchKernelGGL((k_fast_packed_q4<S, G, NT, true, TR>), grid, block, 0, ctx->stream, p->d, p->kpitch, j.d_row_idx, j.row0, \
+                       n_parts, j.d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, p->n_acc, p->desc, d_desc)
 #define LAUNCH_SEG(S, G)                                                                                          \
     do {                                                                                                          \
         if (tr == 16) LAUNCH_SEG_TR(S, G, 16);                                                                    \
@@ -1212,7 +1218,7 @@ static int seg_finish(snpm_ctx *ctx, const SegJob &j)
         ProfScope ps(ctx, PK_STRICT);
         dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(j.kmax, 1), 256), (unsigned)std::min(j.cap, 512));   // a wave per (pair, chunk); both axes walk
 #define LAUNCH_PAIRS(S, G)                                                                                        \
-    hipLaunchKernelGGL((k_strict_pairs<S, G>), grid, dim3(WAVE), 0, ctx->stream, p->d, p->pitch, p->packed, j.d_row_idx,     \
+    hipLaunchKernelGGL((k_strict_pairs<S, G>), grid, dim3(WAVE), 0, ctx->stream, p->d, p->kpitch, p->desc, j.d_row_idx,     \
                        j.row0, j.d_w, j.d_seg_off, j.chunk, (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), \
                        j.cap, j.kmax, (double *)ctx->ws_pair_sums.p)
         if (j.skip) {
@@ -1423,6 +1429,7 @@ try {
     if (const char *s = getenv("SNPM_ACC_MAJOR")) ctx->use_acc_major = atoi(s);
     if (const char *s = getenv("SNPM_ACC_MAJOR_MIN_ROWS")) ctx->acc_major_min_rows = atoll(s);
     if (const char *s = getenv("SNPM_DEBUG_REEVAL")) ctx->debug_reeval = atoi(s);
+    if (const char *s = getenv("SNPM_PACKED_SPLIT")) ctx->packed_split = atoi(s) != 0;
     if (const char *s = getenv("SNPM_STRICT4")) ctx->strict4 = atoi(s);
     if (const char *s = getenv("SNPM_DEBUG_MAX_PARTS")) ctx->debug_max_parts = atoi(s);
     ctx->stage_threads = default_stage_threads();
@@ -1559,8 +1566,33 @@ int snpm_synchronize(snpm_ctx *ctx)
 
 // ---------------------------------------------------------------------------------------------- panel
 // bytes per row of a panel of n_acc accessions (see panel_create_fmt for the measurements behind the rule)
+// SPLIT layout of a packed panel (snpm_k_common.hpp): the whole 256-B column blocks of a row form the main matrix, its ragged
+// tail (<= 128 B, padded to a power of two) a matrix of its own -- chosen when that saves >= 5 % of the row against padding the
+// tail to 256 B.  1135 accessions: 256 + 32 B per row instead of 512; 512 / 256 / 128 accessions: a 128 / 64 / 32-B pitch.
+// main / tail = 0 / 0: whole rows (panel_row_pitch below).
+static void packed_split_of(const snpm_ctx *ctx, int64_t n_acc, int64_t *main_pitch, int64_t *tail_pitch)
+{
+    *main_pitch = *tail_pitch = 0;
+    if (!ctx->packed_split || ctx->pitch_align_forced) return;
+    if (const char *e = getenv("SNPM_PACKED_SPLIT"))               // also read per panel: one process may hold both layouts (tests)
+        if (atoi(e) == 0) return;
+    const int64_t row_bytes = (n_acc + 3) / 4;
+    const int64_t main = row_bytes / 256 * 256, rem = row_bytes - main;
+    if (rem == 0 || rem > 128) return;
+    int64_t tp = 4;
+    while (tp < rem) tp <<= 1;
+    if ((256 - tp) * 20 < main + 256) return;
+    *main_pitch = main;
+    *tail_pitch = tp;
+}
+
 static int64_t panel_row_pitch(const snpm_ctx *ctx, int64_t n_acc, int packed)
 {
+    if (packed) {
+        int64_t mp, tp;
+        packed_split_of(ctx, n_acc, &mp, &tp);
+        if (tp) return mp + tp;
+    }
     int64_t align = ctx->pitch_align;
     if (!packed && !ctx->pitch_align_forced) {
         const int64_t p256 = (n_acc + 255) / 256 * 256, p128 = (n_acc + 127) / 128 * 128;
@@ -1598,8 +1630,25 @@ try {
     // profiles/r03h_ab_pitch128.txt: the 1135 accessions of the 1001 Genomes panel 1280 -> 1152 B per row, 0.720 -> 0.740 of HBM
     // peak and a tenth less HBM; 10 000 accessions would LOSE 0.3 % and keep their 10 240 B; packed panels measured no gain)
     p->pitch = panel_row_pitch(ctx, n_acc, packed);
+    p->kpitch = p->pitch;
     // PREFETCH_PAD_ROWS extra rows: the fast pass prefetches (and never scores) a few rows past a part
-    const size_t row_bytes = (size_t)(n_snp + PREFETCH_PAD_ROWS) * (size_t)p->pitch;
+    size_t row_bytes = (size_t)(n_snp + PREFETCH_PAD_ROWS) * (size_t)p->pitch;
+    if (packed) {
+        int64_t mp, tp;
+        packed_split_of(ctx, n_acc, &mp, &tp);
+        if (tp) {               // main matrix, then (256-B aligned) the tail matrix; phased waves read up to 64 rows past a part
+            const size_t rows_alloc = (size_t)(n_snp + PREFETCH_PAD_ROWS + 64);
+            p->kpitch = mp;
+            p->tail_pitch = tp;
+            p->tail_off = (int64_t)(((rows_alloc * (size_t)mp) + 255) / 256 * 256);
+            row_bytes = (size_t)p->tail_off + (rows_alloc * (size_t)tp + 255) / 256 * 256;
+            int lg = 0;
+            while (((int64_t)1 << lg) < tp) ++lg;
+            p->desc = 1 | ((int64_t)(lg + 1) << 1) | ((p->tail_off / 256) << 8);
+        } else {
+            p->desc = 1;
+        }
+    }
     const size_t bytes = row_bytes + 256;                            // + the flag word d_other
     hipError_t e = hipMalloc((void **)&p->d, bytes);
     if (e != hipSuccess) {
@@ -1717,7 +1766,7 @@ int snpm_panel_download_rows(snpm_panel *p, int64_t row0, int64_t nrows, int8_t 
         const int64_t nr = std::min(slab, nrows - r);
         const int64_t total = nr * p->n_acc;
         hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                           (const uint8_t *)p->d + (row0 + r) * p->pitch, p->pitch, nr, p->n_acc,
+                           (const uint8_t *)p->d, p->kpitch, p->desc, row0 + r, nr, p->n_acc,
                            (int8_t *)ctx->ws_stage_dev.p, p->n_acc);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1742,7 +1791,7 @@ int snpm_panel_fill_synthetic_rows(snpm_panel *p, uint64_t seed, int64_t snp0, i
     const unsigned gy = (unsigned)std::min<int64_t>(nrows, 2048);
     if (p->packed) {
         hipLaunchKernelGGL(k_synth_packed, dim3((unsigned)((p->pitch + thr - 1) / thr), gy), dim3(thr), 0, ctx->stream,
-                           (uint8_t *)p->d + row0 * p->pitch, p->pitch, nrows, p->n_acc, seed, snp0, acc0);
+                           (uint8_t *)p->d, p->kpitch, p->desc, row0, nrows, p->n_acc, seed, snp0, acc0);
     } else {
         hipLaunchKernelGGL(k_synth, dim3((unsigned)((p->pitch / 4 + thr - 1) / thr), gy), dim3(thr), 0, ctx->stream,
                            (uint32_t *)(p->d + row0 * p->pitch), p->pitch, nrows, p->n_acc, seed, snp0, acc0);
@@ -2872,8 +2921,8 @@ static int panel_segregating(snpm_panel *p, const int32_t *cols, int64_t ncols, 
     if (ncols > 0)
         HIPCHK(ctx, hipMemcpyAsync(ctx->ws_cols.p, cols, (size_t)ncols * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     uint8_t *d_mask = (uint8_t *)ctx->ws_tmp_ninfo.p, *d_first = d_mask + p->n_snp;
-    hipLaunchKernelGGL(k_segregating, dim3((unsigned)((p->n_snp + 255) / 256)), dim3(256), 0, ctx->stream, p->d, p->pitch,
-                       p->packed, p->n_snp, (const int32_t *)ctx->ws_cols.p, (int)ncols, d_mask, first ? d_first : (uint8_t *)nullptr);
+    hipLaunchKernelGGL(k_segregating, dim3((unsigned)((p->n_snp + 255) / 256)), dim3(256), 0, ctx->stream, p->d, p->kpitch,
+                       p->desc, p->n_snp, (const int32_t *)ctx->ws_cols.p, (int)ncols, d_mask, first ? d_first : (uint8_t *)nullptr);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(mask, d_mask, (size_t)p->n_snp, hipMemcpyDeviceToHost, ctx->stream));
     if (first) HIPCHK(ctx, hipMemcpyAsync(first, d_first, (size_t)p->n_snp, hipMemcpyDeviceToHost, ctx->stream));
@@ -2913,7 +2962,7 @@ try {
     if ((rc = ensure(ctx, ctx->ws_cols, (size_t)ncols * sizeof(int32_t)))) return rc;
     if ((rc = ensure(ctx, ctx->ws_tmp_ninfo, (size_t)ncols * (size_t)stride))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->ws_cols.p, acc_idx, (size_t)ncols * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_f1_gather, dim3((unsigned)(stride / 256)), dim3(256), 0, ctx->stream, p->d, p->pitch, p->packed,
+    hipLaunchKernelGGL(k_f1_gather, dim3((unsigned)(stride / 256)), dim3(256), 0, ctx->stream, p->d, p->kpitch, p->desc,
                        (const int64_t *)q->d_row_idx, q->row0, n, (const int32_t *)ctx->ws_cols.p, ncols,
                        (uint8_t *)ctx->ws_tmp_ninfo.p, stride);
     HIPCHK(ctx, hipGetLastError());
@@ -2984,7 +3033,7 @@ try {
 
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_f1_gather, dim3((unsigned)(stride / 256)), dim3(256), 0, st, p->d, p->pitch, p->packed,
+    hipLaunchKernelGGL(k_f1_gather, dim3((unsigned)(stride / 256)), dim3(256), 0, st, p->d, p->kpitch, p->desc,
                        (const int64_t *)q->d_row_idx, q->row0, n, (const int32_t *)d_tab, n_sel, d_codes, stride);
     HIPCHK(ctx, hipGetLastError());
     const int32_t *d_pairs = d_tab + n_sel;

@@ -60,6 +60,28 @@ constexpr int EPOCH_TILES = 64;         // k_fast writes its partial sums out (a
 constexpr int REDUCE_GROUP = 64;        // k_reduce_groups adds this many partials sequentially per group
 constexpr int PREFETCH_PAD_ROWS = 32;   // rows the fast pass may read (never score) past the last row of a part
 
+// Layout descriptor of a 2-bit packed panel (snpm_panel::desc; 0 for int8 panels), passed to every kernel that reads or writes one:
+//   bit 0        the panel is packed (4 accessions per byte)
+//   bits 1..7    0: every row is one run of `pitch` bytes (row-major);  t + 1: SPLIT layout -- the first `pitch` bytes of a row (a
+//                multiple of 256, possibly 0) lie in the main matrix at `db` with rows `pitch` bytes apart, the remaining bytes of
+//                the row (its ragged tail, <= 128 of them) in a second matrix with rows of 2^t bytes
+//   bits 8..     where that tail matrix starts: (desc >> 8) * 256 bytes behind `db`
+// A 1135-accession panel (284 B per row) is then 256 + 32 = 288 B per row instead of a 512-B pitch: a dense scan fetches the
+// bytes it uses (round 3: 388 B per 284-B row), and panels of <= 512 accessions get a 32 / 64 / 128-B pitch.  The column blocks of
+// the packed kernels are 256 B wide, so a wave (and a 256-thread block of k_strict4) lies entirely in one of the two matrices.
+__host__ __device__ __forceinline__ int64_t pk_tail_pitch(int64_t desc)
+{
+    const int t = (int)((desc >> 1) & 0x7F);
+    return t ? (int64_t)1 << (t - 1) : 0;
+}
+__host__ __device__ __forceinline__ int64_t pk_tail_off(int64_t desc) { return (desc >> 8) * 256; }
+// offset from `db` of byte b (0 <= b < pitch + tail pitch) of packed row prow
+__host__ __device__ __forceinline__ int64_t pk_off(int64_t pitch, int64_t desc, int64_t prow, int64_t b)
+{
+    const int64_t tp = pk_tail_pitch(desc);
+    return (tp && b >= pitch) ? pk_tail_off(desc) + prow * tp + (b - pitch) : prow * pitch + b;
+}
+
 typedef __attribute__((address_space(3))) const double lds_cdouble;
 typedef double f64x2_t __attribute__((ext_vector_type(2)));
 

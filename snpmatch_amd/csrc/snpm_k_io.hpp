@@ -7,11 +7,13 @@ namespace snpm {
 // packed panel upload: int8 rows (staging slab on the device, row stride src_pitch) -> 2 bits per call.
 // One thread per output byte.  Codes outside {-1 (any negative), 0, 1, 2} cannot be encoded: *bad |= 1.
 __global__ void k_pack_rows(const int8_t *__restrict__ src, int64_t src_pitch, int64_t nrows, int64_t n_acc,
-                            uint8_t *__restrict__ dst, int64_t dst_pitch, int *__restrict__ bad)
+                            uint8_t *__restrict__ db, int64_t pitch, int64_t desc, int64_t row0, int *__restrict__ bad)
 {
+    // db / pitch / desc: the packed panel (row-major or split, snpm_k_common.hpp); rows row0 .. row0 + nrows - 1 are written
+    const int64_t row_bytes = pitch + pk_tail_pitch(desc);
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nrows * dst_pitch) return;
-    const int64_t r = i / dst_pitch, b = i - r * dst_pitch;
+    if (i >= nrows * row_bytes) return;
+    const int64_t r = i / row_bytes, b = i - r * row_bytes;
     uint32_t out = 0;
     int saw = 0;
 #pragma unroll
@@ -23,7 +25,7 @@ __global__ void k_pack_rows(const int8_t *__restrict__ src, int64_t src_pitch, i
         out |= (uint32_t)(v < 0 ? 3 : (v & 3)) << (2 * f);
     }
     if (saw) atomicOr(bad, 1);
-    dst[i] = (uint8_t)out;
+    db[pk_off(pitch, desc, row0 + r, b)] = (uint8_t)out;
 }
 
 // int8 panel upload: tightly staged rows (row stride src_pitch) -> panel rows (256-B pitch), codes
@@ -50,13 +52,13 @@ __global__ void k_repitch_canon(const int8_t *__restrict__ src, int64_t src_pitc
 }
 
 // packed rows -> int8 (download / checks): one thread per accession byte of the destination
-__global__ void k_unpack_rows(const uint8_t *__restrict__ src, int64_t src_pitch, int64_t nrows, int64_t n_acc,
+__global__ void k_unpack_rows(const uint8_t *__restrict__ db, int64_t pitch, int64_t desc, int64_t row0, int64_t nrows, int64_t n_acc,
                               int8_t *__restrict__ dst, int64_t dst_pitch)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrows * n_acc) return;
     const int64_t r = i / n_acc, a = i - r * n_acc;
-    const int v = (src[r * src_pitch + (a >> 2)] >> (2 * (int)(a & 3))) & 3;
+    const int v = (db[pk_off(pitch, desc, row0 + r, a >> 2)] >> (2 * (int)(a & 3))) & 3;
     dst[r * dst_pitch + a] = (int8_t)(v == 3 ? -1 : v);
 }
 
@@ -119,11 +121,12 @@ k_synth(uint32_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n_acc, 
 
 // packed counterpart of k_synth: the same values, one byte (= one accession quad) per thread and row
 __global__ void __launch_bounds__(256)
-k_synth_packed(uint8_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n_acc, uint64_t seed,
+k_synth_packed(uint8_t *__restrict__ db, int64_t pitch, int64_t desc, int64_t row0, int64_t n_snp, int64_t n_acc, uint64_t seed,
                int64_t snp0, int64_t acc0)
 {
+    // rows row0 .. row0 + n_snp - 1 of the packed panel (db, pitch, desc) <- SNPs snp0 ..; one thread per row byte
     const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= pitch) return;
+    if (q >= pitch + pk_tail_pitch(desc)) return;
     for (int64_t row = blockIdx.y; row < n_snp; row += gridDim.y) {
         const uint64_t rh = splitmix64(seed ^ ((uint64_t)(snp0 + row) * 0xD6E8FEB86659FD93ull));
         const uint32_t v = synth_quad_row(rh, (uint64_t)((acc0 >> 2) + q));
@@ -134,7 +137,7 @@ k_synth_packed(uint8_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n
             const bool pad = (q * 4 + f) >= n_acc;
             out |= ((c == 0xffu || pad) ? 3u : c) << (2 * f);
         }
-        db[row * pitch + q] = (uint8_t)out;
+        db[pk_off(pitch, desc, row0 + row, q)] = (uint8_t)out;
     }
 }
 

@@ -57,7 +57,7 @@ template <bool SKIP, bool GATHER, bool NT, bool SEG = false, int TR_ = Q4_TILE_R
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, SNPM_Q4_MIN_WAVES)
 k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
                  const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
-                 int64_t n_acc, const int64_t *__restrict__ part_desc = nullptr)
+                 int64_t n_acc, int64_t desc = 0, const int64_t *__restrict__ part_desc = nullptr)
 {
     constexpr int G = Q4_G;
     constexpr int TR = TR_;
@@ -83,7 +83,15 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     // lanes that had been inactive there and wrote garbage counts; tests/test_gpu_batch.py::test_dense_windows_on_narrow_packed_panels).
     auto tid_now = [&]() -> int { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; };
     const int64_t dw_first = (int64_t)blockIdx.x * nthr + __builtin_amdgcn_readfirstlane(tid & ~(WAVE - 1));   // first dword of my wave (scalar)
-    const int64_t dw_end = (pitch / 4 < (n_acc + 15) / 16) ? pitch / 4 : (n_acc + 15) / 16;   // dwords of a row that hold accessions
+    // SPLIT layout (desc, snpm_k_common.hpp): a wave past the main part's columns reads the tail matrix -- its own base, its own
+    // (narrow) pitch, dwords counted from the tail's first one.  All wave-uniform: scalar registers.
+    const int64_t tail_p = pk_tail_pitch(desc);
+    const bool tail_wave = tail_p != 0 && dw_first * 4 >= pitch;
+    const int8_t *dbw = tail_wave ? db + pk_tail_off(desc) : db;
+    const int64_t pw = tail_wave ? tail_p : pitch;
+    const int64_t dw0 = tail_wave ? pitch / 4 : 0;
+    const int64_t row_dwords = (pitch + tail_p) / 4;
+    const int64_t dw_end = (row_dwords < (n_acc + 15) / 16) ? row_dwords : (n_acc + 15) / 16;   // dwords of a row that hold accessions
     int ph_t = 0, ph = 1;                               // wave-uniform
     if (SNPM_Q4_PHASES && dw_first < dw_end && dw_end - dw_first <= WAVE / 2) {
         ph_t = (int)(dw_end - dw_first);
@@ -97,14 +105,14 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         const int t = tid_now();
         return phased ? dw_first + ((t & (WAVE - 1)) - phj * ph_t) : (int64_t)blockIdx.x * nthr + t;
     };
-    auto lane_inside = [&](int phj, int64_t dw) -> bool { return phased ? (phj < ph) : (dw * 4 < pitch && dw * 16 < ld); };
+    auto lane_inside = [&](int phj, int64_t dw) -> bool { return phased ? (phj < ph) : (dw < row_dwords && dw * 16 < ld); };
     bool lane_on;
     uint32_t lane_off;                                  // byte offset of my dword in a row (+ the first row of my phase's group: 32 bits hold 56 rows of <= 2^25 bytes)
     {
         const int phj = my_phase();
         const int64_t dw = my_dword(phj);
         lane_on = lane_inside(phj, dw);
-        lane_off = lane_on ? (uint32_t)(dw * 4) + (uint32_t)(phj * G) * (uint32_t)pitch : 0u;
+        lane_off = lane_on ? (uint32_t)((dw - dw0) * 4) + (uint32_t)(phj * G) * (uint32_t)pw : 0u;
     }
     const bool wave_on = __any(lane_on) != 0;           // wave-uniform
     const int64_t p = SEG ? (int64_t)blockIdx.y + (int64_t)gridDim.y * blockIdx.z : (int64_t)blockIdx.y;
@@ -134,7 +142,7 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
     asm volatile("" : "+v"(three));
     auto load = [&](int64_t rr) -> uint32_t {
         const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
-        const int8_t *rowbase = db + prow * pitch;
+        const int8_t *rowbase = dbw + prow * pw;
         uint32_t off = lane_off;
         asm volatile("" : "+v"(off));                     // keeps the saddr form of the load (see k_fast)
         const uint32_t *ptr = reinterpret_cast<const uint32_t *>(rowbase + off);
@@ -151,10 +159,10 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
 #endif
         if constexpr (!GATHER) {
             const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<int8_t *>(db + (row0 + r) * pitch), 0, (int)(G * pitch), 0x00020000);
+                const_cast<int8_t *>(dbw + (row0 + r) * pw), 0, (int)(G * pw), 0x00020000);
 #pragma unroll
             for (int u = 0; u < G; ++u)
-                x[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, lane_off, (int)(u * pitch), NT ? 2 : 0);
+                x[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, lane_off, (int)(u * pw), NT ? 2 : 0);
         } else {
 #pragma unroll
             for (int u = 0; u < G; ++u) x[u] = load(r + u);
@@ -376,7 +384,7 @@ k_fast_packed_q4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
             if constexpr (GATHER) {
                 x[u] = 0u;
                 if (on) {
-                    const uint32_t *ptr = reinterpret_cast<const uint32_t *>(db + row_idx[tr + grp * G + u] * pitch + my_dword(ph_j) * 4);
+                    const uint32_t *ptr = reinterpret_cast<const uint32_t *>(dbw + row_idx[tr + grp * G + u] * pw + (my_dword(ph_j) - dw0) * 4);
                     x[u] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
                 }
             } else {
@@ -512,7 +520,7 @@ template <bool SKIP, bool GATHER, bool NT>
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, 6)
 k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
             const uint8_t *__restrict__ wbits, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
-            int64_t n_acc)
+            int64_t n_acc, int64_t desc = 0)
 {
     // Rows are requested in groups of 4 (two register sets: 4 to 8 row loads in flight per lane) and counted in groups of 8;
     // 256-row tiles.  Measured with the arithmetic stripped (tools/micro/read_patterns.hip, this panel's 2560-B rows,
@@ -529,7 +537,14 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
     constexpr int PH_MAX = 8;
     const int lane = tid & (WAVE - 1);
     const int64_t dw_first = (int64_t)blockIdx.x * nthr + __builtin_amdgcn_readfirstlane(tid - lane);   // first dword of my wave (scalar)
-    const int64_t dw_end = (pitch / 4 < (n_acc + 15) / 16) ? pitch / 4 : (n_acc + 15) / 16;   // dwords of a row that hold accessions
+    // SPLIT layout (desc): a wave past the main part's columns reads the tail matrix (see k_fast_packed_q4)
+    const int64_t tail_p = pk_tail_pitch(desc);
+    const bool tail_wave = tail_p != 0 && dw_first * 4 >= pitch;
+    const int8_t *dbw = tail_wave ? db + pk_tail_off(desc) : db;
+    const int64_t pw = tail_wave ? tail_p : pitch;
+    const int64_t dw0 = tail_wave ? pitch / 4 : 0;
+    const int64_t row_dwords = (pitch + tail_p) / 4;
+    const int64_t dw_end = (row_dwords < (n_acc + 15) / 16) ? row_dwords : (n_acc + 15) / 16;   // dwords of a row that hold accessions
     int ph_t = 0, ph = 1;                               // wave-uniform
     if (SNPM_Q4_PHASES && dw_first < dw_end && dw_end - dw_first <= WAVE / 2) {
         ph_t = (int)(dw_end - dw_first);
@@ -538,9 +553,9 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
     const bool phased = ph > 1;
     const int ph_j = phased ? lane / ph_t : 0;           // my phase
     const int64_t my_dw = phased ? dw_first + (lane - ph_j * ph_t) : (int64_t)blockIdx.x * nthr + tid;
-    const int64_t byte0 = my_dw * 4;
-    const int64_t col0 = byte0 * 4;
-    const bool lane_on = phased ? (ph_j < ph) : (byte0 < pitch && col0 < ld);
+    const int64_t byte0 = (my_dw - dw0) * 4;            // my byte inside a row of the matrix my wave reads
+    const int64_t col0 = my_dw * 16;
+    const bool lane_on = phased ? (ph_j < ph) : (my_dw < row_dwords && col0 < ld);
     const int64_t p = blockIdx.y;
     const int64_t P = gridDim.y;
     const int64_t n_tiles_total = (n + TR - 1) / TR;
@@ -552,10 +567,10 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
     for (int i = 0; i < 8; ++i) hit16[i] = miss16[i] = 0;
 
     // phased lanes: + the first row of my phase's group
-    const uint32_t lane_off = lane_on ? (uint32_t)byte0 + (uint32_t)(ph_j * 8) * (uint32_t)pitch : 0u;
+    const uint32_t lane_off = lane_on ? (uint32_t)byte0 + (uint32_t)(ph_j * 8) * (uint32_t)pw : 0u;
     auto load = [&](int64_t rr) -> uint32_t {
         const int64_t prow = GATHER ? row_idx[rr] : (row0 + rr);
-        const int8_t *rowbase = db + prow * pitch;
+        const int8_t *rowbase = dbw + prow * pw;
         uint32_t off = lane_off;
         asm volatile("" : "+v"(off));
         const uint32_t *ptr = reinterpret_cast<const uint32_t *>(rowbase + off);
@@ -565,10 +580,10 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
     auto load_rows = [&](uint32_t (&x)[4], int64_t r) {
         if constexpr (!GATHER) {
             const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<int8_t *>(db + (row0 + r) * pitch), 0, (int)(4 * pitch), 0x00020000);
+                const_cast<int8_t *>(dbw + (row0 + r) * pw), 0, (int)(4 * pw), 0x00020000);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                x[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, lane_off, (int)(u * pitch), NT ? 2 : 0);
+                x[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rows, lane_off, (int)(u * pw), NT ? 2 : 0);
         } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u) x[u] = load(r + u);
@@ -759,7 +774,7 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
                     if constexpr (GATHER) {
                         x[u] = 0u;
                         if (on) {
-                            const uint32_t *ptr = reinterpret_cast<const uint32_t *>(db + row_idx[tr0 + grp * 8 + u] * pitch + byte0);
+                            const uint32_t *ptr = reinterpret_cast<const uint32_t *>(dbw + row_idx[tr0 + grp * 8 + u] * pw + byte0);
                             x[u] = NT ? __builtin_nontemporal_load(ptr) : *ptr;
                         }
                     } else {

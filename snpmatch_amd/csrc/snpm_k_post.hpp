@@ -121,7 +121,7 @@ __global__ void k_binom_identity(const double *__restrict__ x, const int64_t *__
 // ------------------------------------------------------------------------------------------------
 // --refine support (identify_segregating_snps, core/snp_genotype.py:188-211): mask[row] = 1 when the
 // informative (non-negative) calls of the listed accessions in that SNP row are not all identical.
-__global__ void k_segregating(const int8_t *__restrict__ db, int64_t pitch, int packed, int64_t n_snp,
+__global__ void k_segregating(const int8_t *__restrict__ db, int64_t pitch, int64_t packed, int64_t n_snp,
                               const int32_t *__restrict__ cols, int ncols, uint8_t *__restrict__ mask,
                               uint8_t *__restrict__ first_out)
 {
@@ -161,7 +161,7 @@ constexpr int F1_MAX_SEL = 32;
 // codes[c][s] = call of selected accession c at matched SNP s (0 ref, 1 alt, 2 het, 3 other, 0xFF missing);
 // rows n..stride-1 are padding (missing)
 __global__ void __launch_bounds__(256)
-k_f1_gather(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx, int64_t row0,
+k_f1_gather(const int8_t *__restrict__ db, int64_t pitch, int64_t packed, const int64_t *__restrict__ row_idx, int64_t row0,
             int64_t n, const int32_t *__restrict__ acc, int n_sel, uint8_t *__restrict__ codes, int64_t stride)
 {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

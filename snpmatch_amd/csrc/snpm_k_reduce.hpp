@@ -127,10 +127,10 @@ __device__ __forceinline__ double add_sel(double acc, bool match, double w) { re
 
 // genotype code of (row, accession) in either panel format: int8 -> the byte (negative = missing);
 // packed -> 2-bit field, 3 = missing (returned as -1)
-__device__ __forceinline__ int code_at(const int8_t *__restrict__ db, int64_t pitch, int64_t prow, int64_t col, int packed)
+__device__ __forceinline__ int code_at(const int8_t *__restrict__ db, int64_t pitch, int64_t prow, int64_t col, int64_t packed)
 {
-    if (packed) {
-        const int v = (((const uint8_t *)db)[prow * pitch + (col >> 2)] >> (2 * (int)(col & 3))) & 3;
+    if (packed) {               // `packed` is the panel's layout descriptor (snpm_k_common.hpp): row-major or split rows
+        const int v = (((const uint8_t *)db)[pk_off(pitch, packed, prow, col >> 2)] >> (2 * (int)(col & 3))) & 3;
         return v == 3 ? -1 : v;
     }
     return db[prow * pitch + col];      // (a non-temporal load here: 3.80 -> 3.69 ms for the second pass of the N = 1 bench: not worth a variant)
@@ -258,7 +258,7 @@ __global__ void k_reduce_seg(const double *__restrict__ part_score, const uint32
 //   grid.x walks the chunks of a segment, grid.y the flagged pairs (both bounded: no pair flagged = a launch of microseconds)
 template <bool SKIP, bool GATHER>
 __global__ void __launch_bounds__(64)
-k_strict_pairs(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx, int64_t row0,
+k_strict_pairs(const int8_t *__restrict__ db, int64_t pitch, int64_t packed, const int64_t *__restrict__ row_idx, int64_t row0,
                const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk,
                const int32_t *__restrict__ pairs, const int *__restrict__ count, int cap, int64_t kmax,
                double *__restrict__ sums)

@@ -10,7 +10,7 @@ namespace snpm {
 //   out_score [n_seg, ld] fp64 = ((0 + A_ref) + A_het) + A_alt, out_miss [n_seg, ld] u32
 template <bool SKIP, bool GATHER>
 __global__ void __launch_bounds__(256)
-k_strict(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx, int64_t row0,
+k_strict(const int8_t *__restrict__ db, int64_t pitch, int64_t packed, const int64_t *__restrict__ row_idx, int64_t row0,
          const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
          int64_t n_seg, const int32_t *__restrict__ cols, int64_t ncols, double *__restrict__ out_score,
          uint32_t *__restrict__ out_miss, int64_t ld, const int *__restrict__ gate, int gate_cap)
@@ -88,7 +88,7 @@ __device__ __forceinline__ void
 strict4_segments(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
                  const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
                  int64_t n_seg, int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
-                 int64_t c0, const uint4 *lut)
+                 int64_t c0, const uint4 *lut, uint32_t coff_sub = 0u)
 {
     for (int64_t seg = blockIdx.x; seg < n_seg; seg += gridDim.x) {          // one pass unless the launch is gated (see k_strict)
     int64_t r0, r1;
@@ -243,7 +243,9 @@ strict4_segments(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__
         return PACKED ? (uint32_t) * reinterpret_cast<const uint8_t *>(ptr) : *reinterpret_cast<const uint32_t *>(ptr);
     };
     // row address = wave-uniform row base + the lane's 32-bit offset (global_load with a scalar base: no address VALU)
-    const uint32_t coff = (uint32_t)(PACKED ? c0 / 4 : c0);
+    // (coff_sub: a block of a SPLIT packed panel that lies in the tail matrix -- db / pitch are that matrix's, the lane's byte
+    // counts from the tail's first byte)
+    const uint32_t coff = (uint32_t)(PACKED ? c0 / 4 : c0) - coff_sub;
     int64_t r = r0;
     if constexpr ((!PACKED || MASKS) && SNPM_STRICT_EXEC) {
         // Batches of SB rows, two register sets: the next batch is requested before the current one is scored (up to
@@ -324,7 +326,7 @@ __global__ void __launch_bounds__(256)
 k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0,
           const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
           int64_t n_seg, int64_t ncols, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
-          const int *__restrict__ other_codes, const int *__restrict__ gate, int gate_cap)
+          const int *__restrict__ other_codes, const int *__restrict__ gate, int gate_cap, int64_t desc = 0)
 {
     if (dense_tier_off(gate, gate_cap)) return;
     const int64_t c0 = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) * 4;
@@ -333,6 +335,15 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
         for (uint32_t e = threadIdx.x; e < 256u; e += blockDim.x) s_lut[e] = strict_lut_entry<SKIP>(e);
         __syncthreads();
         if (c0 >= ncols) return;
+        // split layout: a block covers blockDim.x (64 / 128 / 256, dividing 256) consecutive row bytes, so it lies in the main
+        // matrix or in the tail matrix as a whole (block-uniform)
+        const int64_t tp = pk_tail_pitch(desc);
+        const int64_t byte0 = (int64_t)blockIdx.y * blockDim.x;
+        if (tp && byte0 >= pitch) {
+            strict4_segments<SKIP, GATHER, true, true>(db + pk_tail_off(desc), tp, row_idx, row0, w, seg_off, chunk, n, seg0, n_seg, ncols,
+                                                       out_score, out_miss, ld, c0, s_lut, (uint32_t)pitch);
+            return;
+        }
         strict4_segments<SKIP, GATHER, true, true>(db, pitch, row_idx, row0, w, seg_off, chunk, n, seg0, n_seg, ncols,
                                                    out_score, out_miss, ld, c0, s_lut);
         return;
@@ -355,7 +366,7 @@ k_strict4(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restric
 // Same arithmetic and order as k_strict.  out_* [n_seg, ld].
 template <bool SKIP, bool GATHER>
 __global__ void __launch_bounds__(256)
-k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx,
+k_strict_sparse(const int8_t *__restrict__ db, int64_t pitch, int64_t packed, const int64_t *__restrict__ row_idx,
                 int64_t row0, const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n,
                 int64_t n_seg, const int32_t *__restrict__ cols, const int *__restrict__ d_ncols, int cap,
                 double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)
@@ -455,7 +466,7 @@ constexpr int PTP_ROWS = 256;
 constexpr int PTP_COLS = 256;
 __global__ void __launch_bounds__(256)
 k_pack_transpose_packed(const uint8_t *__restrict__ db, int64_t pitch, int64_t n_snp, int64_t n_acc,
-                        uint8_t *__restrict__ dT, int64_t pitchT)
+                        uint8_t *__restrict__ dT, int64_t pitchT, int64_t desc)
 {
     __shared__ uint32_t tile[PTP_ROWS][PTP_COLS / 16 + 1];     // 16 dwords of 16 calls per row (+1: conflict-free columns)
     const int64_t snp0 = (int64_t)blockIdx.x * PTP_ROWS;
@@ -466,7 +477,8 @@ k_pack_transpose_packed(const uint8_t *__restrict__ db, int64_t pitch, int64_t n
         const int64_t row = snp0 + r;
         const int64_t byte = acc0 / 4 + (t & 15) * 4;
         uint32_t v = 0xffffffffu;                                // rows / bytes past the end: missing
-        if (row < n_snp && byte < pitch) v = *reinterpret_cast<const uint32_t *>(db + row * pitch + byte);
+        // (a dword of four row bytes never straddles the main / tail boundary of a split panel: both parts are multiples of 4 bytes)
+        if (row < n_snp && byte < pitch + pk_tail_pitch(desc)) v = *reinterpret_cast<const uint32_t *>(db + pk_off(pitch, desc, row, byte));
         tile[r][t & 15] = v;
     }
     __syncthreads();

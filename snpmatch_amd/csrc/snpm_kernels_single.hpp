@@ -21,7 +21,7 @@ constexpr int SINGLE_LEAVES = NP_SUM_CHUNK / 8;     // leaf candidates of one bu
 // One call over rows [r0, r1) of the matched list, evaluated by the whole block; thread 0 returns the call's score and
 // missing count.  sm_code [8192], sm_val [3][1024], sm_miss [1] are the block's LDS.
 template <bool SKIP, bool GATHER>
-__device__ __forceinline__ void single_call(const int8_t *__restrict__ db, int64_t pitch, int packed,
+__device__ __forceinline__ void single_call(const int8_t *__restrict__ db, int64_t pitch, int64_t packed,
                                             const int64_t *__restrict__ row_idx, int64_t row0, const double *__restrict__ w,
                                             int64_t r0, int64_t r1, int8_t *sm_code, double (*sm_val)[SINGLE_LEAVES],
                                             uint32_t *sm_miss, double &score, uint32_t &miss)
@@ -118,7 +118,7 @@ __device__ __forceinline__ void single_call(const int8_t *__restrict__ db, int64
 //       out_score [pair * kmax + k] (k_scan_pairs adds them in order).  grid.x walks the pieces.
 template <bool SKIP, bool GATHER>
 __global__ void __launch_bounds__(SINGLE_THREADS)
-k_strict_single(const int8_t *__restrict__ db, int64_t pitch, int packed, const int64_t *__restrict__ row_idx, int64_t row0,
+k_strict_single(const int8_t *__restrict__ db, int64_t pitch, int64_t packed, const int64_t *__restrict__ row_idx, int64_t row0,
                 const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk, int64_t n, int64_t seg0,
                 int64_t n_seg, const int32_t *__restrict__ pairs, const int *__restrict__ count, int cap, int tier,
                 int64_t kmax, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld)

@@ -218,10 +218,11 @@ int fill_rows(snpm_ctx *ctx, const RowSource &src, int64_t n_acc, bool pack, int
 
 // ---------------------------------------------------------------------------------------------- the staging pipeline
 // host-packed rows (tight, src_pitch bytes) -> packed panel rows (256-B pitch, pad bytes 0xFF = four missing calls)
-__global__ void k_repitch_packed(const uint8_t *__restrict__ src, int64_t src_pitch, int64_t nrows, uint32_t *__restrict__ dst,
-                                 int64_t dst_pitch)
+__global__ void k_repitch_packed(const uint8_t *__restrict__ src, int64_t src_pitch, int64_t nrows, uint8_t *__restrict__ db,
+                                 int64_t pitch, int64_t desc, int64_t row0)
 {
-    const int64_t dwords_per_row = dst_pitch / 4;
+    // db / pitch / desc: the packed panel (row-major or split rows, snpm_k_common.hpp); one thread per destination dword
+    const int64_t dwords_per_row = (pitch + snpm::pk_tail_pitch(desc)) / 4;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrows * dwords_per_row) return;
     const int64_t r = i / dwords_per_row, d = i - r * dwords_per_row;
@@ -231,7 +232,7 @@ __global__ void k_repitch_packed(const uint8_t *__restrict__ src, int64_t src_pi
         const int64_t b = d * 4 + j;
         out |= (uint32_t)(b < src_pitch ? src[r * src_pitch + b] : 0xffu) << (8 * j);
     }
-    dst[i] = out;
+    *reinterpret_cast<uint32_t *>(db + snpm::pk_off(pitch, desc, row0 + r, d * 4)) = out;
 }
 
 // packed staged rows (tight, src_pitch bytes) -> int8 panel rows (256-B pitch): one thread per destination dword = one source byte;
@@ -323,14 +324,14 @@ int stage_rows(snpm_panel *p, int64_t row0, int64_t nrows, const RowSource &src)
             const int64_t total = nr * (p->pitch / 4);
             hipLaunchKernelGGL(k_repitch_canon, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream,
                                scratch, spitch, nr, n_acc, (uint32_t *)(p->d + (row0 + r) * p->pitch), p->pitch, p->d_other);
-        } else if (host_pack) {
+        } else if (host_pack) {             // (packed panels: p->pitch = bytes per row, kpitch / desc = how they lie in memory)
             const int64_t total = nr * (p->pitch / 4);
             hipLaunchKernelGGL(k_repitch_packed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream,
-                               (const uint8_t *)scratch, spitch, nr, (uint32_t *)(p->d + (row0 + r) * p->pitch), p->pitch);
+                               (const uint8_t *)scratch, spitch, nr, (uint8_t *)p->d, p->kpitch, p->desc, row0 + r);
         } else {
             const int64_t total = nr * p->pitch;
             hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->copy_stream, scratch,
-                               spitch, nr, n_acc, (uint8_t *)p->d + (row0 + r) * p->pitch, p->pitch, (int *)ctx->ws_flags2.p);
+                               spitch, nr, n_acc, (uint8_t *)p->d, p->kpitch, p->desc, row0 + r, (int *)ctx->ws_flags2.p);
         }
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipEventRecord(ctx->ld_done[which], ctx->copy_stream));

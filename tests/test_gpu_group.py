@@ -191,6 +191,9 @@ def test_group_of_streamed_members_matches_reference_files(golden_dir, tmp_path,
     monkeypatch.setenv("SNPMATCH_GROUP_LOOPBACK", "1")
     monkeypatch.setenv("SNPM_HBM_BUDGET_GB", repr(2 * (1000 + 32) * 128 / 1e9))       # int8 shards of 28 / 22 accessions: 128-B rows
     monkeypatch.setenv("SNPMATCH_PACKED", "0")
+    # (with the split layout of round 4 a 28-accession packed panel has 8-B rows and would fit this budget whole: the scenario
+    # -- nothing fits, int8 slabs are streamed -- needs round 3's 256-B packed rows)
+    monkeypatch.setenv("SNPM_PACKED_SPLIT", "0")
     try:
         toy = np.load(os.path.join(golden_dir, "toy_db.npz"))
         gold = json.load(open(os.path.join(golden_dir, "g2_inbred.json")))["inbred_skip0"]

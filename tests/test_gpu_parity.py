@@ -545,8 +545,16 @@ def test_packed_panel_modes_vs_oracle(ctx, n_snp, n_acc, n_match, chunk, skip):
         db[:, 2] = -1
         db[::5, 3] = -7                    # any negative value is "missing"
     panel = engine.Panel.from_host(ctx, db, packed=True)
-    want_pitch = ((n_acc + 3) // 4 + 255) // 256 * 256
-    assert panel.packed and panel.pitch == want_pitch + (256 if want_pitch % 8192 == 0 else 0)     # multiples of 8 KiB are padded
+    # bytes per row: whole 256-B column blocks + the ragged tail at a power-of-two pitch (split layout) where that saves >= 5 % of
+    # the row, else rows padded to 256 B (+ 256 B at multiples of 8 KiB)
+    row = (n_acc + 3) // 4
+    tail = 4
+    while tail < row % 256:
+        tail *= 2
+    split = 0 < row % 256 <= 128 and (256 - tail) * 20 >= row // 256 * 256 + 256 and os.environ.get("SNPM_PACKED_SPLIT", "1") != "0"
+    want_pitch = (row // 256 * 256 + tail) if split else (row + 255) // 256 * 256
+    assert panel.packed and panel.pitch == want_pitch + (256 if (not split and want_pitch % 8192 == 0) else 0)
+    assert panel.pitch == ctx.row_pitch(n_acc, True)
     back = panel.download_rows(0, n_snp)
     assert np.array_equal(back, np.where(db < 0, -1, db))
     if n_match is None:
