@@ -581,7 +581,8 @@ int launch_bits_t(snpm_query *q, const FastGeom &g, int *occ_out, int threads)
         return SNPM_OK;
     }
     ProfScope ps(ctx, PK_FAST);
-    hipLaunchKernelGGL((k_fast_bits<SKIP, GATHER, NT>), dim3((unsigned)g.n_colblocks, (unsigned)g.n_parts), dim3(WAVE * g.wpb), 0,
+    // grid = (parts, column blocks): the part is the fast block index (XCD balance, see the kernel)
+    hipLaunchKernelGGL((k_fast_bits<SKIP, GATHER, NT>), dim3((unsigned)g.n_parts, (unsigned)g.n_colblocks), dim3(WAVE * g.wpb), 0,
                        ctx->stream, p->d, p->kpitch, q->d_row_idx, q->row0, q->n, (const uint8_t *)q->d_wbits,
                        (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld, p->n_acc, p->desc);
     HIPCHK(ctx, hipGetLastError());

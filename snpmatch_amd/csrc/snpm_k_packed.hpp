@@ -536,7 +536,13 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
     // counts (1024 and 1040 accessions x 40M rows took 1.7 and 3.3 ms: the nearly empty wave cost as much as the full one).
     constexpr int PH_MAX = 8;
     const int lane = tid & (WAVE - 1);
-    const int64_t dw_first = (int64_t)blockIdx.x * nthr + __builtin_amdgcn_readfirstlane(tid - lane);   // first dword of my wave (scalar)
+    // Grid = (parts, column blocks): the PART is the fast block index.  Workgroups are dealt to the eight XCDs round-robin in
+    // linear block order; with the column block as the fast index (rounds 1-3) a panel of two column blocks put every block of the
+    // full column on the four even XCDs and the light tail blocks on the four odd ones -- 1040 ... 2048 accessions scanned at half
+    // the chip (1024 accessions x 40M rows 1.72 ms, 1040 accessions 2.9 ms).
+    // (same-box A/B of the two orders on nine widths: profiles/r04_bits_grid_order_ab.txt)
+    const int64_t cb = blockIdx.y;
+    const int64_t dw_first = cb * nthr + __builtin_amdgcn_readfirstlane(tid - lane);   // first dword of my wave (scalar)
     // SPLIT layout (desc): a wave past the main part's columns reads the tail matrix (see k_fast_packed_q4)
     const int64_t tail_p = pk_tail_pitch(desc);
     const bool tail_wave = tail_p != 0 && dw_first * 4 >= pitch;
@@ -552,12 +558,12 @@ k_fast_bits(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restr
     }
     const bool phased = ph > 1;
     const int ph_j = phased ? lane / ph_t : 0;           // my phase
-    const int64_t my_dw = phased ? dw_first + (lane - ph_j * ph_t) : (int64_t)blockIdx.x * nthr + tid;
+    const int64_t my_dw = phased ? dw_first + (lane - ph_j * ph_t) : cb * nthr + tid;
     const int64_t byte0 = (my_dw - dw0) * 4;            // my byte inside a row of the matrix my wave reads
     const int64_t col0 = my_dw * 16;
     const bool lane_on = phased ? (ph_j < ph) : (my_dw < row_dwords && col0 < ld);
-    const int64_t p = blockIdx.y;
-    const int64_t P = gridDim.y;
+    const int64_t p = blockIdx.x;
+    const int64_t P = gridDim.x;
     const int64_t n_tiles_total = (n + TR - 1) / TR;
 
     uint32_t hit16[8], miss16[8];       // [d]: accession d (low half) and d + 8 (high half)
