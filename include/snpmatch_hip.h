@@ -90,7 +90,9 @@ int         snpm_device_mem_info(snpm_ctx *ctx, int64_t *free_bytes, int64_t *to
 /* SNP-major int8 [n_snp, pitch], pitch = n_acc rounded up to 256 B (to 128 B where that saves 5 % of the row, + 256 B where it
    would be a multiple of 8 KiB: read it with snpm_panel_info / snpm_panel_row_pitch), pad bytes = -1.  1 <= n_acc <= 2^27 (SNPM_ERR_BADARG). */
 int snpm_panel_create(snpm_ctx *ctx, int64_t n_snp, int64_t n_acc, snpm_panel **out);
-/* Same panel with 2 bits per call (4 accessions per byte: 0 ref, 1 alt, 2 het, 3 missing): 4x less HBM
+/* Same panel with 2 bits per call (4 accessions per byte: 0 ref, 1 alt, 2 het, 3 missing; rows either whole at a 256-B pitch or
+   SPLIT -- the whole 256-B column blocks of a row in a main matrix, its ragged tail at a narrow pitch of its own -- where that saves
+   5 % of the row: snpm_panel_row_pitch / snpm_panel_info report main + tail bytes per row; SNPM_PACKED_SPLIT=0 keeps whole rows): 4x less HBM
    capacity and traffic (the 10k x 50M panel is 125 GB and fits one MI355X).  Rows are uploaded as int8
    exactly like an int8 panel and packed on the device; codes > 2 cannot be stored (SNPM_ERR_BADARG from the
    upload).  Every scoring entry point accepts either panel kind and returns identical results. */
