@@ -61,18 +61,24 @@ def kernel_leg(ctx, name, run, n_launch_rows, row_bytes, reps, kernel="fast"):
     ctx.synchronize()
     ctx.profile(True)
     ctx.profile_reset()
+    each = []
     t0 = time.perf_counter()
     for _ in range(reps):
+        t1 = time.perf_counter()
         run()
+        each.append(time.perf_counter() - t1)
     ctx.synchronize()
-    wall = (time.perf_counter() - t0) / reps
+    mean_wall = (time.perf_counter() - t0) / reps
+    wall = float(np.median(each))          # the median: once per few hundred launches the HIP runtime stalls a call for tens of ms
+    if os.environ.get("BENCH_REAL_PANEL_TRACE"):
+        sys.stderr.write("%s: %s ms\n" % (name, " ".join("%.2f" % (t * 1e3) for t in each)))
     launches, ms = ctx.profile_read(kernel)
     parts = {k: ctx.profile_read(k) for k in ("lut", "fast", "reduce", "strict", "scan", "likelihood")}
     ctx.profile(False)
     per_call_ms = ms / reps                       # a call may take several launches (runs of a batch)
     alg = float(n_launch_rows) * (row_bytes + 24.0 + 8.0)
     rate = alg / (per_call_ms * 1e-3) / 1e9 if per_call_ms > 0 else 0.0
-    return {"leg": name, "wall_ms_per_call": wall * 1e3, "kernel_ms_per_call": per_call_ms, "kernel_launches_per_call": launches / reps,
+    return {"leg": name, "wall_ms_per_call": wall * 1e3, "wall_ms_mean": mean_wall * 1e3, "wall_ms_max": max(each) * 1e3, "kernel_ms_per_call": per_call_ms, "kernel_launches_per_call": launches / reps,
             "algorithmic_bytes_per_call": alg, "achieved_GBs": rate, "frac_of_hbm_peak": rate / HBM_PEAK_GBS,
             "other_kernels_ms_per_call": {k: v[1] / reps for k, v in parts.items() if v[0] and k != kernel}}
 
