@@ -225,6 +225,13 @@ int snpm_query_run_windows_fast(snpm_query *query, const int64_t *win_off, int64
 int snpm_genotype_once(snpm_panel *panel, const int64_t *row_idx, const double *wei, const int64_t *sample_idx, int64_t n_wei,
                        int64_t n, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo, double *lik,
                        double *lrt, int64_t *info);
+/* The same call with DICTIONARY-CODED weights: wei[r, c] = table[codes[3 r + c]], codes uint16 [n_wei, 3], table fp64 [table_len <= 65536]
+   (as snpm_score_batch_coded).  A VCF sample's weights are exp(-PL / 10) of small integer PLs (core/parsers.py:141-151): the caller
+   computes the table with its own libm, so the device weights carry the fp64 path's bits; the matched rows travel as 32-bit
+   indices (n_snp < 2^31), 10 instead of 32 bytes per matched SNP cross PCIe.  A code >= table_len is SNPM_ERR_BADARG. */
+int snpm_genotype_once_coded(snpm_panel *panel, const int64_t *row_idx, const uint16_t *codes, const double *table, int64_t table_len,
+                             const int64_t *sample_idx, int64_t n_wei, int64_t n, int64_t chunk, int skip_hets, int mode,
+                             double *score, int64_t *ninfo, double *lik, double *lrt, int64_t *info);
 
 /* B samples against one resident panel.  The reference scores one sample per process (core/snpmatch.py:256-268); here
    sample b owns entries [sample_off[b], sample_off[b+1]) of the concatenated row list (int64, panel rows matched by the

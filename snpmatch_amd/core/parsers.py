@@ -83,6 +83,23 @@ def _one_hot_weights(gt_text):
     return wei
 
 
+def _weight_codes(pl, no_pl, wei):
+    """Dictionary codes of a VCF sample's weights: (codes uint16 [n, 3], table float64) with ``table[codes] == wei`` bit for bit,
+    or None.  The weights are exp(-PL / 10) of integer PLs (rows without PL: one-hot 0 / 1), so a few hundred table entries
+    describe them all; the one-call scoring path then sends 6 instead of 24 bytes of weights per SNP to the GPU
+    (``snpm_genotype_once_coded``).  The table is made with the same numpy expression as the weights and the identity is
+    verified here, once, at parse time."""
+    if pl.size == 0 or pl.min() < -1 or pl.max() > 60000 or not np.array_equal(pl, np.floor(pl)):
+        return None
+    k = int(pl.max()) + 1
+    table = np.concatenate([np.exp(np.arange(k, dtype=float) / (-10)), [0.0], np.exp(np.array([-1.0]) / (-10))])
+    codes = np.where(pl < 0, k + 1, pl).astype(np.uint16)          # a PL of -1 inside a partly present triple: exp(0.1), as the reference computes it
+    codes[no_pl] = np.where(wei[no_pl] == 1.0, 0, k).astype(np.uint16)     # one-hot rows: 1.0 = exp(0) = table[0], 0.0 = table[k]
+    if not np.array_equal(table[codes].view(np.uint64), np.ascontiguousarray(wei).view(np.uint64)):
+        return None
+    return codes, table
+
+
 class ParseInputs(object):
 
     def __init__(self, inFile, logDebug=True, outFile="parser"):
@@ -105,6 +122,7 @@ class ParseInputs(object):
             else:
                 die("input file type %s not supported" % os.path.splitext(inFile)[1])
             self.load_snp_info(*fields)
+            self._adopt_codes(getattr(self, "_pending_codes", None))
             self.save_snp_info(prefix, background=True)
             self.case_interpret_inputs(prefix + ".stats.json")
             log.info("parsed %d SNP calls", len(self.chrs))
@@ -113,6 +131,28 @@ class ParseInputs(object):
     def _load_npz(self, path):
         z = np.load(path)
         self.load_snp_info(z['chr'], z['pos'], z['gt'], z['wei'], z['dp'])
+        if 'wei_codes' in z.files and 'wei_table' in z.files:       # written by this package's parser; verified, not trusted
+            codes, table = z['wei_codes'], z['wei_table']
+            if codes.shape == self.wei.shape and codes.dtype == np.uint16 and len(table) and int(codes.max(initial=0)) < len(table) and \
+                    np.array_equal(table[codes].view(np.uint64), np.ascontiguousarray(self.wei).view(np.uint64)):
+                self._adopt_codes((codes, table))
+
+    def _adopt_codes(self, pair):
+        """dictionary codes of ``self.wei`` (``_weight_codes``): used by ``Genotyper``'s one-call path as long as ``self.wei`` still
+        is the array they describe -- which is made read-only, so that an in-place edit cannot leave them stale (assign a new array
+        to ``wei`` to change weights: the codes are dropped)."""
+        self._wei_codes = self._wei_table = self._wei_coded_for = None
+        if pair is None:
+            return
+        self._wei_codes, self._wei_table = np.ascontiguousarray(pair[0], dtype=np.uint16), np.ascontiguousarray(pair[1], dtype=np.float64)
+        self.wei.flags.writeable = False
+        self._wei_coded_for = self.wei
+
+    def weight_codes(self):
+        """(codes, table) when they still describe ``self.wei``, else None"""
+        if getattr(self, "_wei_codes", None) is not None and self._wei_coded_for is self.wei and not self.wei.flags.writeable:
+            return self._wei_codes, self._wei_table
+        return None
 
     def case_interpret_inputs(self, outFile):
         """``<prefix>.stats.json``: SNPs per chromosome, depth, heterozygosity, low-SNP warning"""
@@ -158,11 +198,13 @@ class ParseInputs(object):
         else:
             called = np.flatnonzero((gt != './.') & (gt != '.|.'))
         gt = gt[called]
+        self._pending_codes = None
         if 'wei' in calls:
             pl = calls['wei'][called, 0]
             no_pl = np.all(pl == -1, axis=1)
             wei = np.exp(pl / (-10))
             wei[no_pl] = _one_hot_weights(gt[no_pl])
+            self._pending_codes = _weight_codes(pl, no_pl, wei)
         else:
             wei = _one_hot_weights(gt)
         return (calls['chr'][called], calls['pos'][called], gt, wei, calls['dp'][called])
@@ -203,6 +245,8 @@ class ParseInputs(object):
         ``wait_for_cache`` earlier (an accession-sharded job's other ranks load the file)."""
         log.info("caching the parse as %s.npz", outFile)
         arrays = dict(chr=self.chrs, pos=self.pos, gt=self.gt, wei=self.wei, dp=self.dp)
+        if self.weight_codes() is not None:             # extra keys: the reference's loader reads its five by name
+            arrays.update(wei_codes=self._wei_codes, wei_table=self._wei_table)
         if not background:
             np.savez(outFile, **arrays)
             return

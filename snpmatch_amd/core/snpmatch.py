@@ -186,7 +186,12 @@ class Genotyper(object):
         if type(panel) is engine.Panel and job is None:
             # the whole matrix resident on one GPU: ONE library call gathers the matched weight rows (:221), scores them and returns
             # counts and likelihoods together (snpm_genotype_once)
-            once = panel.genotype_once(db_rows, self.inputs.wei, sample_rows, self.chunk_size, self._skip_db_hets, engine.MODE_EXACT)
+            coded = self.inputs.weight_codes() if hasattr(self.inputs, "weight_codes") else None
+            if coded is not None and panel.n_snp < 2 ** 31:         # a parsed VCF: 6 instead of 24 bytes of weights per SNP to the GPU
+                once = panel.genotype_once(db_rows, coded[0], sample_rows, self.chunk_size, self._skip_db_hets, engine.MODE_EXACT,
+                                           table=coded[1])
+            else:
+                once = panel.genotype_once(db_rows, self.inputs.wei, sample_rows, self.chunk_size, self._skip_db_hets, engine.MODE_EXACT)
             scores, ninfo = once["score"], once["ninfo"]
         else:
             query = panel.query(db_rows, self.inputs.wei[sample_rows, ])

@@ -24,16 +24,22 @@ struct OnceProps {          // per task of the fill
 
 }  // namespace
 
-int snpm_genotype_once(snpm_panel *p, const int64_t *row_idx, const double *wei, const int64_t *sample_idx, int64_t n_wei,
-                       int64_t n, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo, double *lik,
-                       double *lrt, int64_t *info)
-try {
+// codes != NULL: the sample's weights as dictionary codes, wei[r, c] = table[codes[3 r + c]] (snpm_genotype_once_coded)
+static int genotype_once_impl(snpm_panel *p, const int64_t *row_idx, const double *wei, const uint16_t *codes, const double *table,
+                              int64_t table_len, const int64_t *sample_idx, int64_t n_wei, int64_t n, int64_t chunk, int skip_hets,
+                              int mode, double *score, int64_t *ninfo, double *lik, double *lrt, int64_t *info)
+{
     CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
+    const bool coded = codes != nullptr;
+    if (coded) {
+        CHECK_ARG(ctx, table != nullptr && table_len >= 1 && table_len <= 65536, "weight table of 1 .. 65536 entries expected");
+        CHECK_ARG(ctx, p->n_snp < ((int64_t)1 << 31), "coded samples travel with 32-bit row indices");
+    }
     CHECK_ARG(ctx, n >= 0 && n_wei >= 0, "n must be >= 0");
     CHECK_ARG(ctx, chunk >= 1, "chunk must be >= 1");
     CHECK_ARG(ctx, mode == SNPM_MODE_EXACT || mode == SNPM_MODE_STRICT || mode == SNPM_MODE_FAST, "unknown mode");
-    CHECK_ARG(ctx, n == 0 || (row_idx && wei), "please provide same number of positions for both sample and db");
+    CHECK_ARG(ctx, n == 0 || (row_idx && (wei || coded)), "please provide same number of positions for both sample and db");
     CHECK_ARG(ctx, sample_idx || n <= n_wei, "please provide same number of positions for both sample and db");
     CHECK_ARG(ctx, score && ninfo && ((lik == nullptr) == (lrt == nullptr)), "score / ninfo outputs missing, or only one likelihood output");
     if (info) info[0] = info[1] = info[2] = info[3] = 0;
@@ -57,19 +63,53 @@ try {
     q->row0 = 0;
 
     // ---- 1 + 2: fill the pinned slab [rows int64 | weights fp64 x 3] with the pool, pieces go up behind the fill
-    const size_t row_bytes = (size_t)n * sizeof(int64_t), wei_bytes = (size_t)n * 3 * sizeof(double);
+    // plain: [rows int64 | weights fp64 x 3] = 32 B per matched SNP; coded: [rows int32 | codes uint16 x 3] = 10 B
+    const size_t row_bytes = ((size_t)n * (coded ? sizeof(int32_t) : sizeof(int64_t)) + 7) / 8 * 8;
+    const size_t wei_bytes = (size_t)n * 3 * (coded ? sizeof(uint16_t) : sizeof(double));
     const size_t out_words = 4 * na + 2;
     rc = ensure_pinned(ctx, std::max<size_t>(row_bytes + wei_bytes + 64, out_words * sizeof(int64_t)));
     if (rc) return rc;
     int64_t *h_rows = (int64_t *)ctx->h_pinned;
+    int32_t *h_rows32 = (int32_t *)ctx->h_pinned;
     double *h_wei = (double *)((char *)ctx->h_pinned + row_bytes);
+    uint16_t *h_codes = (uint16_t *)((char *)ctx->h_pinned + row_bytes);
+    int32_t *d_rows32 = nullptr;
+    uint16_t *d_codes = nullptr;
+    if (coded && n > 0) {
+        // the table on the device: uploaded when it is not the one of the previous call
+        if ((rc = ensure(ctx, ctx->ws_once_table, 65536 * sizeof(double)))) return rc;
+        if (ctx->once_table.size() != (size_t)table_len || memcmp(ctx->once_table.data(), table, (size_t)table_len * sizeof(double)) != 0) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));         // a previous call's expansion may still read the old table / staging copy
+            ctx->once_table.assign(table, table + table_len);
+            HIPCHK(ctx, hipMemcpyAsync(ctx->ws_once_table.p, ctx->once_table.data(), (size_t)table_len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (query_alloc(q, (void **)&d_rows32, row_bytes) != hipSuccess || query_alloc(q, (void **)&d_codes, wei_bytes) != hipSuccess)
+            return set_err(ctx, SNPM_ERR_OOM, "query allocation failed");
+    }
     HostPool *pool = host_pool(ctx);
-    const int64_t piece = 4096;                                    // rows per task
+    const int64_t piece = coded ? 8192 : 4096;                     // rows per task
     const int n_tasks = (int)((n + piece - 1) / piece);
     std::vector<OnceProps> props((size_t)std::max(n_tasks, 1));
     const int64_t n_snp = p->n_snp;
     // weight properties with integer tests on the bit patterns (no libm call per weight: this loop runs once per matched SNP)
     auto bits_of = [](double v) -> uint64_t { uint64_t b; memcpy(&b, &v, 8); return b; };
+    auto flags_of = [&](double v) -> uint32_t {          // bit 0 fractional, 1 not 0 / 1, 2 non-finite, 3 huge
+        const uint64_t b = bits_of(v), mag = b & 0x7FFFFFFFFFFFFFFFull;
+        const double a = fabs(v);
+        return (uint32_t)(a < 9.0e15 && (double)(int64_t)a != a) | ((uint32_t)(!(mag == 0 || b == 0x3FF0000000000000ull)) << 1) |
+               ((uint32_t)(mag >= 0x7FF0000000000000ull) << 2) | ((uint32_t)(!(a < 9.0e15)) << 3);
+    };
+    // coded samples: the properties of every table entry once, then one small lookup per weight
+    std::vector<uint32_t> tab_flags;
+    std::vector<double> tab_abs;
+    if (coded) {
+        tab_flags.resize((size_t)table_len);
+        tab_abs.resize((size_t)table_len);
+        for (int64_t k = 0; k < table_len; ++k) {
+            tab_flags[(size_t)k] = flags_of(table[k]);
+            tab_abs[(size_t)k] = fabs(table[k]);
+        }
+    }
     auto fill = [&](int t) {
         const int64_t i0 = (int64_t)t * piece, i1 = std::min<int64_t>(n, i0 + piece);
         OnceProps pr;
@@ -78,24 +118,43 @@ try {
         for (int64_t i = i0; i < i1; ++i) {
             const int64_t r = row_idx[i];
             if ((uint64_t)r >= (uint64_t)n_snp && pr.bad_row < 0) pr.bad_row = i;
-            h_rows[i] = r;
+            if (coded) h_rows32[i] = (int32_t)r;
+            else h_rows[i] = r;
             int64_t s = sample_idx ? sample_idx[i] : i;
             if ((uint64_t)s >= (uint64_t)n_wei) {                  // a sample index outside the weight array: reported like a bad row
                 if (pr.bad_row < 0) pr.bad_row = i;
                 s = 0;
             }
             double m = 0.0;
+            if (coded) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double v = wei[3 * s + c];
-                h_wei[3 * i + c] = v;
-                const uint64_t b = bits_of(v), mag = b & 0x7FFFFFFFFFFFFFFFull;
-                any_nonfinite |= (uint64_t)(mag >= 0x7FF0000000000000ull);
-                any_not01 |= (uint64_t)(!(mag == 0 || b == 0x3FF0000000000000ull));
-                const double a = fabs(v);
-                any_huge |= (uint64_t)(!(a < 9.0e15));             // beyond 2^53 every double is an integer, but sums of them are not exact
-                any_frac |= (uint64_t)(a < 9.0e15 && (double)(int64_t)a != a);
-                m = a > m ? a : m;
+                for (int c = 0; c < 3; ++c) {
+                    const uint16_t k = codes[3 * s + c];
+                    h_codes[3 * i + c] = k;
+                    if ((int64_t)k >= table_len) {                 // a code outside the table: reported like a bad index
+                        if (pr.bad_row < 0) pr.bad_row = i;
+                        continue;
+                    }
+                    const uint32_t f = tab_flags[k];
+                    any_frac |= f & 1u;
+                    any_not01 |= (f >> 1) & 1u;
+                    any_nonfinite |= (f >> 2) & 1u;
+                    any_huge |= (f >> 3) & 1u;
+                    m = tab_abs[k] > m ? tab_abs[k] : m;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const double v = wei[3 * s + c];
+                    h_wei[3 * i + c] = v;
+                    const uint32_t f = flags_of(v);
+                    any_frac |= f & 1u;
+                    any_not01 |= (f >> 1) & 1u;
+                    any_nonfinite |= (f >> 2) & 1u;
+                    any_huge |= (f >> 3) & 1u;
+                    const double a = fabs(v);
+                    m = a > m ? a : m;
+                }
             }
             wsum += m;
         }
@@ -119,6 +178,9 @@ try {
     std::atomic<int> upload_error{0};
     auto upload_piece = [&](int k) -> bool {
         const int64_t i0 = (int64_t)k * kTasksPerPiece * piece, i1 = std::min<int64_t>(n, i0 + (int64_t)kTasksPerPiece * piece);
+        if (coded)
+            return hipMemcpyAsync(d_rows32 + i0, h_rows32 + i0, (size_t)(i1 - i0) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                   hipMemcpyAsync(d_codes + 3 * i0, h_codes + 3 * i0, (size_t)(i1 - i0) * 3 * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
         if (hipMemcpyAsync(q->d_row_idx + i0, h_rows + i0, (size_t)(i1 - i0) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(q->d_w + 3 * i0, h_wei + 3 * i0, (size_t)(i1 - i0) * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
             return false;
@@ -158,7 +220,7 @@ try {
     if (bad_at >= 0 || (flags & 4) || upload_error.load()) {
         (void)hipStreamSynchronize(ctx->stream);                   // pieces already on their way read the slab
         if (bad_at >= 0)
-            return set_err(ctx, SNPM_ERR_BADARG, "row index %lld at %lld outside the panel (n_snp %lld), or a sample index outside the weights",
+            return set_err(ctx, SNPM_ERR_BADARG, "row index %lld at %lld outside the panel (n_snp %lld), or a sample index / weight code outside the weights",
                            (long long)row_idx[bad_at], (long long)bad_at, (long long)n_snp);
         if (flags & 4) return set_err(ctx, SNPM_ERR_BADARG, "SNP weights must be finite (a NaN or infinite weight was given)");
         return set_err(ctx, SNPM_ERR_HIP, "upload of the sample failed");
@@ -166,6 +228,14 @@ try {
     if (!overlapped)
         for (int k = 0; k < n_pieces; ++k)
             if (!upload_piece(k)) return set_err(ctx, SNPM_ERR_HIP, "upload of the sample failed");
+    if (coded && n > 0) {          // widen the row list, expand the codes: the query then looks like any other
+        if ((rc = ensure(ctx, ctx->ws_flags2, 64))) return rc;
+        hipLaunchKernelGGL(k_check_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, q->d_row_idx, (const int32_t *)d_rows32, n,
+                           p->n_snp, (int *)ctx->ws_flags2.p);
+        hipLaunchKernelGGL(k_expand_codes, dim3((unsigned)((3 * n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint16_t *)d_codes,
+                           (const double *)ctx->ws_once_table.p, 3 * n, q->d_w);
+        HIPCHK(ctx, hipGetLastError());
+    }
     HIPCHK(ctx, hipMemsetAsync(q->d_row_idx + n, 0, PREFETCH_PAD_ROWS * sizeof(int64_t), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(q->d_cert, 0, 16, ctx->stream));
     q->wsum = (double)tot * 1.0000001;                  // the same margin as the device sum of query_finish_setup
@@ -221,4 +291,23 @@ try {
         info[2] = n_flag > REEVAL_CAP ? 3 : (n_flag > 0 ? q->reeval_path : 0);
     }
     return SNPM_OK;
+}
+
+int snpm_genotype_once(snpm_panel *p, const int64_t *row_idx, const double *wei, const int64_t *sample_idx, int64_t n_wei,
+                       int64_t n, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo, double *lik,
+                       double *lrt, int64_t *info)
+try {
+    return genotype_once_impl(p, row_idx, wei, nullptr, nullptr, 0, sample_idx, n_wei, n, chunk, skip_hets, mode, score, ninfo, lik, lrt, info);
+} SNPM_GUARD((p ? p->ctx : nullptr))
+
+// The same call with DICTIONARY-CODED weights: wei[r, c] = table[codes[3 r + c]] (codes uint16 [n_wei, 3], table fp64 [table_len]).
+// A VCF sample's weights are exp(-PL / 10) of small integer PLs (core/parsers.py:141-151): the caller computes the table with its
+// own libm, so the device weights carry the fp64 path's bits, and 10 instead of 32 bytes per matched SNP cross PCIe.
+int snpm_genotype_once_coded(snpm_panel *p, const int64_t *row_idx, const uint16_t *codes, const double *table, int64_t table_len,
+                             const int64_t *sample_idx, int64_t n_wei, int64_t n, int64_t chunk, int skip_hets, int mode,
+                             double *score, int64_t *ninfo, double *lik, double *lrt, int64_t *info)
+try {
+    if (p && p->ctx && !codes) return set_err(p->ctx, SNPM_ERR_BADARG, "weight codes missing");
+    return genotype_once_impl(p, row_idx, nullptr, codes, table, table_len, sample_idx, n_wei, n, chunk, skip_hets, mode, score, ninfo, lik,
+                              lrt, info);
 } SNPM_GUARD((p ? p->ctx : nullptr))

@@ -367,15 +367,17 @@ class Panel(object):
         """the matched SNPs of one sample against this panel (``GroupPanel`` / ``StreamedPanel`` offer the same call)"""
         return Query(self, row_idx, wei, row0=row0)
 
-    def genotype_once(self, row_idx, wei, sample_idx=None, chunk=1000, skip_hets=False, mode=MODE_EXACT, likelihoods=True):
+    def genotype_once(self, row_idx, wei, sample_idx=None, chunk=1000, skip_hets=False, mode=MODE_EXACT, likelihoods=True, table=None):
         """ONE sample in ONE call (snpm_genotype_once): ``row_idx`` int64 [n] matched DB rows, ``wei`` float64 [n_wei, 3] the
-        sample's weights, ``sample_idx`` int64 [n] the weight row of each matched SNP (None: rows 0..n-1).  Returns a dict with
-        score / ninfo (and lik / lrt of the truncated counts) [n_acc] and the re-evaluation counters of ``Query.run``."""
+        sample's weights, ``sample_idx`` int64 [n] the weight row of each matched SNP (None: rows 0..n-1).  With ``table``
+        (float64 [<= 65536]) ``wei`` holds uint16 codes instead, weight = table[code] (snpm_genotype_once_coded: 10 instead of 32
+        bytes per matched SNP over PCIe).  Returns a dict with score / ninfo (and lik / lrt of the truncated counts) [n_acc] and
+        the re-evaluation counters of ``Query.run``."""
         ctx = self.ctx
         row_idx = np.ascontiguousarray(row_idx, dtype=np.int64)
         wei = np.asarray(wei)
         assert wei.ndim == 2 and wei.shape[1] == 3, "SNP weights should be a np.array with  shape == n,3"
-        wei = np.ascontiguousarray(wei, dtype=np.float64)
+        wei = np.ascontiguousarray(wei, dtype=np.float64 if table is None else np.uint16)
         if sample_idx is not None:
             sample_idx = np.ascontiguousarray(sample_idx, dtype=np.int64)
             assert len(sample_idx) == len(row_idx), "please provide same number of positions for both sample and db"
@@ -386,9 +388,16 @@ class Panel(object):
             out["lik"] = np.empty(self.n_acc, dtype=np.float64)
             out["lrt"] = np.empty(self.n_acc, dtype=np.float64)
         info = np.zeros(4, dtype=np.int64)
-        check(ctx.lib.snpm_genotype_once(self.h, ptr(row_idx), ptr(wei), ptr(sample_idx), len(wei), len(row_idx), int(chunk),
-                                         int(bool(skip_hets)), int(mode), ptr(out["score"]), ptr(out["ninfo"]), ptr(out.get("lik")),
-                                         ptr(out.get("lrt")), ptr(info)), ctx.h)
+        if table is not None:
+            table = np.ascontiguousarray(table, dtype=np.float64)
+            assert table.ndim == 1 and 1 <= len(table) <= 65536
+            check(ctx.lib.snpm_genotype_once_coded(self.h, ptr(row_idx), ptr(wei), ptr(table), len(table), ptr(sample_idx), len(wei),
+                                                   len(row_idx), int(chunk), int(bool(skip_hets)), int(mode), ptr(out["score"]),
+                                                   ptr(out["ninfo"]), ptr(out.get("lik")), ptr(out.get("lrt")), ptr(info)), ctx.h)
+        else:
+            check(ctx.lib.snpm_genotype_once(self.h, ptr(row_idx), ptr(wei), ptr(sample_idx), len(wei), len(row_idx), int(chunk),
+                                             int(bool(skip_hets)), int(mode), ptr(out["score"]), ptr(out["ninfo"]), ptr(out.get("lik")),
+                                             ptr(out.get("lrt")), ptr(info)), ctx.h)
         out["n_strict_reeval"], out["all_integer_weights"], out["reeval_path"] = int(info[0]), bool(info[1]), int(info[2])
         return out
 

@@ -127,3 +127,70 @@ def test_genotyper_uses_the_one_call_path(ctx, golden_dir, tmp_path, monkeypatch
     gt.result.get_likelihoods()
     lik, _ = snpmatch.GenotyperOutput.calculate_likelihoods(gt.result.scores, gt.result.ninfo)
     assert np.array_equal(bits(gt.result.likelis), bits(lik))
+
+
+def test_coded_one_call_equals_fp64_one_call(ctx, golden_dir, tmp_path):
+    """snpm_genotype_once_coded (weights as uint16 codes into a table, rows as 32-bit indices) returns what the fp64 form returns,
+    bit for bit; Genotyper takes it for a parsed VCF and writes the same files as with plain weights"""
+    import shutil
+    from snpmatch_amd.core import parsers, snp_genotype, snpmatch
+    rng = np.random.default_rng(77)
+    n_snp, n_acc, n_in, n_match = 50000, 1135, 30000, 24000
+    db = rand_db(rng, n_snp, n_acc)
+    pl = rng.integers(0, 256, size=(n_in, 3)).astype(float)
+    pl[rng.random(n_in) < 0.1] = -1.0                      # rows without PL: one-hot
+    pl[5, 1] = -1.0                                        # a partly missing triple: exp(0.1), as the reference computes it
+    no_pl = np.all(pl == -1, axis=1)
+    wei = np.exp(pl / (-10))
+    hot = np.zeros((int(no_pl.sum()), 3))
+    hot[np.arange(len(hot)), rng.integers(0, 3, len(hot))] = 1.0
+    wei[no_pl] = hot
+    pair = parsers._weight_codes(pl, no_pl, wei)
+    assert pair is not None
+    codes, table = pair
+    rows = np.sort(rng.choice(n_snp, size=n_match, replace=False)).astype(np.int64)
+    sidx = np.sort(rng.choice(n_in, size=n_match, replace=False)).astype(np.int64)
+    for packed in (False, True):
+        panel = engine.Panel.from_host(ctx, db, packed=packed)
+        for skip in (False, True):
+            for mode in (engine.MODE_EXACT, engine.MODE_STRICT):
+                a = panel.genotype_once(rows, wei, sidx, 1000, skip, mode)
+                b = panel.genotype_once(rows, codes, sidx, 1000, skip, mode, table=table)
+                for k in ("score", "ninfo", "lik", "lrt"):
+                    assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), (packed, skip, mode, k)
+                assert a["all_integer_weights"] == b["all_integer_weights"] is False
+        want_s, want_n = c_oracle.genotyper(db, rows, wei[sidx], 1000, False)
+        b = panel.genotype_once(rows, codes, sidx, 1000, False, engine.MODE_STRICT, table=table)
+        assert np.array_equal(bits(b["score"]), bits(want_s)) and np.array_equal(b["ninfo"], want_n)
+        hard = np.where(wei[no_pl] == 1.0, 0, len(table) - 2).astype(np.uint16)         # an all-hard-call sample through the codes
+        h = panel.genotype_once(rows[:len(hard)], hard, None, 1000, False, engine.MODE_EXACT, table=table)
+        hw, hn = c_oracle.genotyper(db, rows[:len(hard)], wei[no_pl], 1000, False)
+        assert h["all_integer_weights"] and np.array_equal(bits(h["score"]), bits(hw)) and np.array_equal(h["ninfo"], hn)
+        with pytest.raises(AssertionError, match="outside"):
+            panel.genotype_once(rows[:4], np.full((4, 3), len(table), dtype=np.uint16), None, table=table)
+        panel.free()
+    # the product: Genotyper on the sample VCF (codes from the parser) writes what it writes with plain weights
+    toy_vcf = str(tmp_path / "s.vcf.gz")
+    shutil.copy(os.path.join(golden_dir, "701_501.filter.vcf.gz"), toy_vcf)
+    inp = parsers.ParseInputs(toy_vcf)
+    assert inp.weight_codes() is not None
+    rng = np.random.default_rng(3)
+    order = np.lexsort((inp.pos, inp.chrs))
+    chrs, pos = inp.chrs[order], inp.pos[order]
+    regions, start = [], 0
+    names = []
+    for c in np.unique(chrs):
+        k = int(np.sum(chrs == c))
+        regions.append((start, start + k))
+        names.append(c)
+        start += k
+    snps = rand_db(rng, len(pos), 40)
+    g = snp_genotype.Genotype.from_arrays(snps, [str(i) for i in range(40)], pos, names, regions)
+    out_a, out_b = str(tmp_path / "coded"), str(tmp_path / "plain")
+    snpmatch.Genotyper(inp, g, out_a, run_genotyper=True)
+    plain = parsers.ParseInputs("")
+    plain.load_snp_info(inp.chrs, inp.pos, inp.gt, inp.wei, inp.dp)
+    assert plain.weight_codes() is None
+    snpmatch.Genotyper(plain, g, out_b, run_genotyper=True)
+    for suf in (".scores.txt", ".matches.json"):
+        assert open(out_a + suf).read() == open(out_b + suf).read()

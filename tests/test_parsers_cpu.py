@@ -9,6 +9,7 @@ import os
 import shutil
 
 import numpy as np
+import pytest
 
 from snpmatch_amd.core import _vcf, parsers
 
@@ -172,3 +173,37 @@ def test_native_vcf_reader_in_many_blocks_on_several_threads(golden_dir, tmp_pat
             got = _vcf.read_calls(path, (0,))
             assert got["called"] is not None and np.array_equal(got["called"], (want["gt"][:, 0] != "./.") & (want["gt"][:, 0] != ".|."))
             _same_calls(got, want)
+
+
+def test_vcf_weights_carry_dictionary_codes(golden_dir, tmp_path):
+    """a parsed VCF keeps (codes, table) with table[codes] == wei bit for bit (what Genotyper's one-call path uploads instead of the
+    fp64 triples); the cache round-trips them, an edit of the weights drops them"""
+    import gzip
+    import shutil
+    src = os.path.join(golden_dir, "701_501.filter.vcf.gz")
+    vcf = str(tmp_path / "s.vcf.gz")
+    shutil.copy(src, vcf)
+    p = parsers.ParseInputs(vcf)
+    p.wait_for_cache()
+    pair = p.weight_codes()
+    assert pair is not None
+    codes, table = pair
+    assert codes.dtype == np.uint16 and codes.shape == p.wei.shape == (7545, 3)
+    assert np.array_equal(table[codes].view(np.uint64), p.wei.view(np.uint64))
+    assert table[0] == 1.0 and 0.0 in table and not p.wei.flags.writeable
+    with pytest.raises(ValueError):
+        p.wei[0, 0] = 0.5                                  # in-place edits cannot leave the codes stale
+    q = parsers.ParseInputs(vcf)                           # from the .npz cache
+    assert q.weight_codes() is not None and np.array_equal(q.weight_codes()[0], codes) and np.array_equal(q.wei, p.wei)
+    q.wei = q.wei.copy()                                   # a new weight array: no codes any more
+    assert q.weight_codes() is None
+    hard = parsers.ParseInputs("")
+    hard.load_snp_info(["1"], [5], ["0/0"], np.array([[1.0, 0.0, 0.0]]), 3)
+    assert hard.weight_codes() is None                     # nothing parsed, nothing coded
+    # fractional or huge PLs are not coded
+    assert parsers._weight_codes(np.array([[0.0, 10.5, 200.0]]), np.array([False]), np.exp(np.array([[0.0, 10.5, 200.0]]) / -10)) is None
+    assert parsers._weight_codes(np.array([[0.0, 70000.0, 200.0]]), np.array([False]), np.exp(np.array([[0.0, 70000.0, 200.0]]) / -10)) is None
+    both = parsers._weight_codes(np.array([[0.0, -1.0, 30.0], [-1.0, -1.0, -1.0]]), np.array([False, True]),
+                                 np.array([[1.0, np.exp(0.1), np.exp(-3.0)], [0.0, 1.0, 0.0]]))
+    if both is not None:                                   # (exp(0.1) as a one-element array may round differently: then no codes)
+        assert np.array_equal(both[1][both[0]].view(np.uint64), np.array([[1.0, np.exp(0.1), np.exp(-3.0)], [0.0, 1.0, 0.0]]).view(np.uint64))

@@ -149,6 +149,20 @@ def main():
         leg["kernel"] = "k_fast_packed_q4<GATHER>" if packed else "k_fast<GATHER>"
         leg["note"] = "snpm_genotype_once: host-thread gather into a pinned slab, one upload, one copy back (Genotyper.genotyper's path)"
         legs.append(leg)
+        # (1c) ... and with the weights as dictionary codes, as ParseInputs keeps them for a parsed VCF (exp(-PL / 10) of integer PLs):
+        # 10 instead of 32 bytes per matched SNP cross PCIe (snpm_genotype_once_coded)
+        tab = engine.pl_table(256)
+        tab = np.concatenate([tab, [0.0]])
+        codes_all = engine.weight_codes(wei_all, tab)
+        if codes_all is not None:
+            def one_call_coded():
+                lik_top[0] = int(np.nanargmin(panel.genotype_once(rows0, codes_all, sidx, 1000, False, engine.MODE_EXACT, table=tab)["lik"]))
+
+            leg = kernel_leg(ctx, "single_sample_200k_one_call_coded_weights", one_call_coded, n_match, row_bytes, args.reps)
+            assert lik_top[0] == PLANTED
+            leg["kernel"] = "k_fast_packed_q4<GATHER>" if packed else "k_fast<GATHER>"
+            leg["note"] = "snpm_genotype_once_coded: what Genotyper.genotyper calls for a sample parsed from a VCF"
+            legs.append(leg)
         # (2) the same sample, query kept: the scoring alone (kernel + reduce + certificate), results to the host
         q = engine.Query(panel, rows0, wei0)
         leg = kernel_leg(ctx, "single_sample_200k_rerun_resident_query", lambda: q.run(1000, False, engine.MODE_EXACT), n_match, row_bytes, args.reps)

@@ -15,3 +15,10 @@ for i in range(8):
     t0 = time.perf_counter()
     out = panel.genotype_once(rows, wall, sidx)
     print("wall %.3f ms top %d" % ((time.perf_counter() - t0) * 1e3, int(np.nanargmin(out["lik"]))), flush=True)
+tab = np.concatenate([engine.pl_table(256), [0.0]])
+codes = engine.weight_codes(wall, tab)
+print("coded weights:", codes is not None)
+for i in range(8):
+    t0 = time.perf_counter()
+    out = panel.genotype_once(rows, codes, sidx, table=tab)
+    print("coded wall %.3f ms top %d" % ((time.perf_counter() - t0) * 1e3, int(np.nanargmin(out["lik"]))), flush=True)
