@@ -30,7 +30,8 @@ def test_vcf_parse_reference_pins(golden_dir, tmp_path):
     np.testing.assert_array_equal(snps.wei[0], np.exp(np.array([0.0, 9.0, 87.0]) / (-10)))
     assert snps.wei.shape == (7545, 3) and snps.dp[0] == 3
     assert np.all((snps.wei > 0) & (snps.wei <= 1))
-    # cache + stats files, as the reference writes them (core/parsers.py:85-86, 96-116)
+    # cache + stats files, as the reference writes them (core/parsers.py:85-86, 96-116); the cache is written by a background thread
+    snps.wait_for_cache()
     assert os.path.isfile(str(vcf) + ".snpmatch.npz")
     stats = json.load(open(str(vcf) + ".snpmatch.stats.json"))
     assert stats["num_of_snps"] == 7545 and stats["interpretation"]["case"] == 0
