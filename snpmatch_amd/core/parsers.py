@@ -100,6 +100,19 @@ def _weight_codes(pl, no_pl, wei):
     return codes, table
 
 
+def _hard_call_codes(wei):
+    """(codes, table) of a sample whose weights are all 0.0 or 1.0 (BED input, a VCF without PL, :118-127), else None: the same
+    compact form for ``snpm_genotype_once_coded`` -- one pass over the weights"""
+    wei = np.asarray(wei)
+    if wei.ndim != 2 or wei.shape[1] != 3 or wei.size == 0 or wei.dtype != np.float64:
+        return None
+    wei = np.ascontiguousarray(wei)
+    ones = wei == 1.0
+    if not np.all(ones | (wei.view(np.uint64) == 0)):          # +0.0 only: the table holds its bits
+        return None
+    return ones.astype(np.uint16), np.array([0.0, 1.0])
+
+
 class ParseInputs(object):
 
     def __init__(self, inFile, logDebug=True, outFile="parser"):
@@ -122,7 +135,7 @@ class ParseInputs(object):
             else:
                 die("input file type %s not supported" % os.path.splitext(inFile)[1])
             self.load_snp_info(*fields)
-            self._adopt_codes(getattr(self, "_pending_codes", None))
+            self._adopt_codes(getattr(self, "_pending_codes", None) or _hard_call_codes(self.wei))
             self.save_snp_info(prefix, background=True)
             self.case_interpret_inputs(prefix + ".stats.json")
             log.info("parsed %d SNP calls", len(self.chrs))
@@ -136,6 +149,8 @@ class ParseInputs(object):
             if codes.shape == self.wei.shape and codes.dtype == np.uint16 and len(table) and int(codes.max(initial=0)) < len(table) and \
                     np.array_equal(table[codes].view(np.uint64), np.ascontiguousarray(self.wei).view(np.uint64)):
                 self._adopt_codes((codes, table))
+        else:                                                       # a cache the reference wrote: hard calls are coded on the spot
+            self._adopt_codes(_hard_call_codes(np.ascontiguousarray(self.wei)))
 
     def _adopt_codes(self, pair):
         """dictionary codes of ``self.wei`` (``_weight_codes``): used by ``Genotyper``'s one-call path as long as ``self.wei`` still

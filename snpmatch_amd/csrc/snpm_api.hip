@@ -67,6 +67,12 @@ struct snpm_ctx {
     Buf ws_wprops, ws_epart;            // partial sums of k_wprops / k_eref
     Buf ws_once, ws_once_table;         // packed results of snpm_genotype_once; the weight table of its coded form
     std::vector<double> once_table;     // host image of ws_once_table
+    std::vector<uint8_t> once_code_flags;   // per code: bit 0 a fractional / huge entry, 1 neither 0 nor 1, 2 NaN / infinite, 3 past the table
+    std::vector<double> once_code_abs;  // per code: |entry| (0 for codes past the table and non-finite entries)
+    Buf ws_once_state;                  // {ticket, bad-input bits} of k_once_prep / k_once_finish: zero between calls
+    bool once_state_clean = false;
+    int once_fused = 1;                 // SNPM_ONCE_FUSED=0: snpm_genotype_once keeps the unfused kernels and copies of its first version
+    int once_zero_copy = -1;            // SNPM_ONCE_ZEROCOPY: 1 the fused form reads the pinned slab in place, 0 it goes through the copy engine; unset: coded samples (10 B per SNP) in place, fp64 samples (32 B) through the copy engine behind the fill
     Buf ws_seg_desc, ws_eseg, ws_pairs, ws_pair_sums, ws_bscore, ws_bninfo, ws_blut, ws_brows, ws_brows32, ws_bw, ws_bcodes;   // segmented / batched scoring
     int64_t *h_desc = nullptr;          // pinned host image of ws_seg_desc
     size_t h_desc_cap = 0;
@@ -169,6 +175,7 @@ struct snpm_query {
     void *d_cert = nullptr;
     int64_t eref_chunk = -1, eref_after = -1;   // what d_cert->eref currently holds
     bool count_valid = false;           // the last run was a certified one (count / cols are meaningful)
+    bool cert_count_clean = false;      // the flag count is already zero (k_once_prep cleared it): run_fast skips its fill, once
     std::vector<snpm_ctx::Cached> owned;   // every device buffer of this query with its capacity
     const char *last_kernel = "";       // scoring kernel of the last run (reports)
     int reeval_path = 0;                // sparse re-evaluation reads: 1 = accession-major copy, 2 = SNP-major (strided)
@@ -457,6 +464,8 @@ try {
     if (const char *s = getenv("SNPM_DEBUG_REEVAL")) ctx->debug_reeval = atoi(s);
     if (const char *s = getenv("SNPM_PACKED_SPLIT")) ctx->packed_split = atoi(s) != 0;
     if (const char *s = getenv("SNPM_STRICT4")) ctx->strict4 = atoi(s);
+    if (const char *s = getenv("SNPM_ONCE_FUSED")) ctx->once_fused = atoi(s) != 0;
+    if (const char *s = getenv("SNPM_ONCE_ZEROCOPY")) ctx->once_zero_copy = atoi(s) != 0;
     if (const char *s = getenv("SNPM_DEBUG_MAX_PARTS")) ctx->debug_max_parts = atoi(s);
     ctx->stage_threads = default_stage_threads();
     if (const char *s = getenv("SNPM_STAGE_THREADS")) ctx->stage_threads = std::max(1, atoi(s));

@@ -123,7 +123,8 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
         rc = ensure_eref(q, cert.chunk, cert.chunks_after);
         if (rc) return rc;
     }
-    HIPCHK(ctx, hipMemsetAsync(q->cert_count(), 0, sizeof(int), ctx->stream));
+    if (!q->cert_count_clean) HIPCHK(ctx, hipMemsetAsync(q->cert_count(), 0, sizeof(int), ctx->stream));
+    q->cert_count_clean = false;
     q->count_valid = cert.on;
     if (q->n > 0) {
         if (g.n_epochs > 1) {

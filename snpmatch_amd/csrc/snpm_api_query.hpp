@@ -202,7 +202,9 @@ try {
 // they have anything to do (see dense_tier_off / the sparse kernels), so the host never waits for the flag count.
 // The accession-major copy is built the first time something is flagged on a long query -- the one case that
 // reads the count back (once per panel).
-static int enqueue_reevaluation(snpm_query *q, int skip, int64_t chunk)
+// dense_tier = false (snpm_genotype_once): the > REEVAL_CAP tier is left to the caller, who sees the count with its results and
+// runs run_strict_chain only then -- two launches that almost never have work stay out of a short sample's critical path.
+static int enqueue_reevaluation(snpm_query *q, int skip, int64_t chunk, bool dense_tier = true)
 {
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
@@ -213,11 +215,8 @@ static int enqueue_reevaluation(snpm_query *q, int skip, int64_t chunk)
         if (rc) return rc;
         if (cnt >= 1 && cnt <= REEVAL_CAP) (void)ensure_acc_major(p);
     }
-    int rc = run_strict_sparse(q, skip, chunk, q->cert_cols(), q->cert_count(), nullptr);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_patch, dim3(1), dim3(REEVAL_CAP), 0, ctx->stream, (const double *)ctx->ws_tmp_score.p,
-                       (const int32_t *)q->cert_cols(), (const int *)q->cert_count(), REEVAL_CAP, q->d_score);
-    HIPCHK(ctx, hipGetLastError());
+    int rc = run_strict_sparse(q, skip, chunk, q->cert_cols(), q->cert_count(), nullptr, nullptr, 0, q->d_score);
+    if (rc || !dense_tier) return rc;
     // more than REEVAL_CAP flagged (many exact-integer scores, e.g. clonal accessions): everything in reference order
     return run_strict_chain(q, skip, chunk, q->cert_count(), nullptr, nullptr, q->d_score, q->d_ninfo);
 }
@@ -457,11 +456,8 @@ try {
                        (const double *)q->d_score, p->n_acc, (const double *)d_etot, e_extra, ctx->debug_reeval,
                        q->cert_cols(), q->cert_count(), REEVAL_CAP);
     HIPCHK(ctx, hipGetLastError());
-    rc = run_strict_sparse(q, skip, maxlen, q->cert_cols(), q->cert_count(), nullptr, j.d_seg_off, n_win);
+    rc = run_strict_sparse(q, skip, maxlen, q->cert_cols(), q->cert_count(), nullptr, j.d_seg_off, n_win, q->d_score);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_patch, dim3(1), dim3(REEVAL_CAP), 0, ctx->stream, (const double *)ctx->ws_tmp_score.p,
-                       (const int32_t *)q->cert_cols(), (const int *)q->cert_count(), REEVAL_CAP, q->d_score);
-    HIPCHK(ctx, hipGetLastError());
     rc = ensure_pinned(ctx, 64);
     if (rc) return rc;
     int *h_cnt = (int *)ctx->h_pinned;

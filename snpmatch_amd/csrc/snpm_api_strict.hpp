@@ -126,8 +126,9 @@ int run_strict_chain(snpm_query *q, int skip, int64_t chunk, const int *gate, co
 // Sparse tier: reference-order chunk sums of the accessions listed on the device (d_cols, *d_ncols <= REEVAL_CAP;
 // the kernels do nothing for other counts) -> ws_seg_score [n_seg, REEVAL_CAP] -> chain of additions ->
 // ws_tmp_score [REEVAL_CAP].  carry (may be NULL): compact totals of earlier slabs, continued by the chain.
+// patch_score (may be NULL): the totals also replace patch_score[d_cols[i]] (k_patch inside the chain's kernel: one launch less).
 int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_cols, const int *d_ncols, const double *carry,
-                      const int64_t *d_seg_off = nullptr, int64_t n_seg_explicit = 0)
+                      const int64_t *d_seg_off = nullptr, int64_t n_seg_explicit = 0, double *patch_score = nullptr)
 {
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
@@ -181,7 +182,7 @@ int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_c
     }
     ProfScope ps(ctx, PK_SCAN);
     hipLaunchKernelGGL(k_scan_few, dim3(1), dim3(256), 0, ctx->stream, (const double *)ctx->ws_seg_score.p, n_seg, ld,
-                       d_ncols, REEVAL_CAP, (double *)ctx->ws_tmp_score.p, carry);
+                       d_ncols, REEVAL_CAP, (double *)ctx->ws_tmp_score.p, carry, d_cols, patch_score);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }

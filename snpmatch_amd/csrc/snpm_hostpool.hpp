@@ -9,6 +9,7 @@
 
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -26,15 +27,20 @@ namespace {
 // ---------------------------------------------------------------------------------------------- host thread pool
 class HostPool {
 public:
+    // Workers SPIN for a short while (SNPM_POOL_SPIN_US, default 400 us) for the next run() before they block on the condition
+    // variable, and so does the caller for the last task of a run: a sleeping thread takes 30-50 us to wake, which was most of
+    // the 0.1 ms a 200k-SNP sample's staging fill took (snpm_genotype_once: calls follow each other within that window when
+    // samples are scored in a row).  Long waits still sleep.
     explicit HostPool(int n)
     {
+        if (const char *e = getenv("SNPM_POOL_SPIN_US")) spin_us_ = atoi(e) > 0 ? atoi(e) : 0;
         for (int i = 0; i < n; ++i) threads_.emplace_back([this] { loop(); });
     }
     ~HostPool()
     {
         {
             std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
+            stop_.store(true, std::memory_order_release);
         }
         cv_work_.notify_all();
         for (auto &t : threads_) t.join();
@@ -53,17 +59,35 @@ public:
             fn_ = &fn;
             n_tasks_ = n_tasks;
             next_ = 0;
-            pending_ = n_tasks;
-            ++gen_;
+            pending_.store(n_tasks, std::memory_order_relaxed);
+            gen_.fetch_add(1, std::memory_order_release);
         }
         cv_work_.notify_all();
         work();
-        std::unique_lock<std::mutex> lk(m_);
-        cv_done_.wait(lk, [this] { return pending_ == 0; });
+        if (!spin_until([this] { return pending_.load(std::memory_order_acquire) == 0; })) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_done_.wait(lk, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+        }
+        std::lock_guard<std::mutex> lk(m_);            // (also: the last worker has left its notify)
         fn_ = nullptr;
     }
 
 private:
+    template <class Pred>
+    bool spin_until(Pred done) const
+    {
+        if (spin_us_ <= 0) return done();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            for (int i = 0; i < 64; ++i) {
+                if (done()) return true;
+#if defined(__x86_64__)
+                _mm_pause();
+#endif
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) return done();
+        }
+    }
     void work()
     {
         for (;;) {
@@ -76,9 +100,9 @@ private:
                 fn = fn_;
             }
             (*fn)(t);
-            {
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> lk(m_);
-                if (--pending_ == 0) cv_done_.notify_all();
+                cv_done_.notify_all();
             }
         }
     }
@@ -86,12 +110,13 @@ private:
     {
         uint64_t seen = 0;
         for (;;) {
-            {
+            auto news = [&] { return stop_.load(std::memory_order_acquire) || gen_.load(std::memory_order_acquire) != seen; };
+            if (!spin_until(news)) {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_work_.wait(lk, [&] { return stop_ || gen_ != seen; });
-                if (stop_) return;
-                seen = gen_;
+                cv_work_.wait(lk, news);
             }
+            if (stop_.load(std::memory_order_acquire)) return;
+            seen = gen_.load(std::memory_order_acquire);
             work();
         }
     }
@@ -99,9 +124,11 @@ private:
     std::mutex m_;
     std::condition_variable cv_work_, cv_done_;
     const std::function<void(int)> *fn_ = nullptr;
-    int n_tasks_ = 0, next_ = 0, pending_ = 0;
-    uint64_t gen_ = 0;
-    bool stop_ = false;
+    int n_tasks_ = 0, next_ = 0;
+    std::atomic<int> pending_{0};
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<bool> stop_{false};
+    int spin_us_ = 400;
 };
 
 // Copy into a pinned staging slab with non-temporal stores: the slab is read next by the DMA engine, not by this core, so the

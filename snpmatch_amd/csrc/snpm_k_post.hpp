@@ -416,5 +416,56 @@ __global__ void k_once_pack(const double *__restrict__ score, const int64_t *__r
     out[3 * n_acc + a] = lrt ? __double_as_longlong(lrt[a]) : 0;
 }
 
+// The same in one launch with the likelihoods (k_likelihood of ONE row on the truncated counts, nanmin, ratio: core/snpmatch.py:
+// 96, 106-117) and written straight into `out` -- which may be the pinned host slab: no copy engine, no fill of the flag word
+// (profiles/r04_once_timeline_*).  ONE block.  state[1] = bad-input bits of k_once_prep (read, reported in word 4 n_acc + 1 bits
+// 1-2, cleared for the next call); lik_tmp [n_acc] device scratch (the ratio pass re-reads the likelihoods: not from the host).
+__global__ void __launch_bounds__(1024)
+k_once_finish(const double *__restrict__ score, const int64_t *__restrict__ ninfo, int64_t n_acc, int want_lik,
+              const int *__restrict__ count, unsigned *__restrict__ state, double *__restrict__ lik_tmp, int64_t *__restrict__ out)
+{
+    __shared__ double s_min[16];
+    __shared__ double s_top;
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    double mn = __builtin_inf();
+    int bad = 0;
+    for (int64_t i = threadIdx.x; i < n_acc; i += blockDim.x) {
+        const double y = score[i];
+        const int64_t ni = ninfo[i];
+        out[i] = __double_as_longlong(y);
+        out[n_acc + i] = ni;
+        double l = 0.0;
+        if (want_lik) {
+            l = likeli_one(trunc(y), (double)ni, &bad);
+            lik_tmp[i] = l;
+            if (l == l && l < mn) mn = l;
+        }
+        out[2 * n_acc + i] = want_lik ? __double_as_longlong(l) : 0;
+    }
+    if (bad) atomicOr(&s_bad, 1);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(mn, o);
+        mn = other < mn ? other : mn;
+    }
+    if ((threadIdx.x & 63) == 0) s_min[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = __builtin_inf();
+        const int nw = (blockDim.x + 63) >> 6;
+        for (int k = 0; k < nw; ++k) m = s_min[k] < m ? s_min[k] : m;
+        if (m == __builtin_inf()) m = __builtin_nan("");      // all-NaN: np.nanmin -> nan
+        s_top = m;
+        out[4 * n_acc] = count ? (int64_t)*count : 0;
+        out[4 * n_acc + 1] = (int64_t)(s_bad & 1) | ((int64_t)(state[1] & 3u) << 1);
+        state[1] = 0u;
+    }
+    __syncthreads();
+    const double top = s_top;
+    for (int64_t i = threadIdx.x; i < n_acc; i += blockDim.x)
+        out[3 * n_acc + i] = want_lik ? __double_as_longlong((top <= 0.0) ? __builtin_nan("") : lik_tmp[i] / top) : 0;
+}
 
 }  // namespace snpm

@@ -129,4 +129,104 @@ __global__ void k_expand_codes(const uint16_t *__restrict__ codes, const double 
     if (i < n3) wei[i] = table[codes[i]];
 }
 
+// ------------------------------------------------------------------------------------------------
+// snpm_genotype_once: everything between "the sample lies in the staging slab" and the fast pass in ONE launch (it was eight:
+// k_check_rows, k_expand_codes, two fills, k_build_lut, k_eref, k_efinish, the fill of the flag count -- 4.8 us each on a
+// path whose scoring kernel takes 53 us, profiles/r04_once_timeline_before.txt).  The slab is read where it lies: src_rows /
+// src_wei may be the PINNED HOST slab itself (no copy engine in the path: a copy costs ~25 us before it moves a byte) or a
+// device staging copy of it.
+//   block b walks the chunks k = b, b + grid, ... of `chunk` rows, as k_eref does -- same rows per thread, same order of
+//   additions, so the bound is the one k_eref / k_efinish leave: per row it checks the row index (outside the panel: row 0,
+//   bad |= 1), expands the weight codes (CODED: wei = table[code], a code outside the table: bad |= 2) and writes rows [n]
+//   int64, w [n, 3], lut [n, 4] (k_build_lut's entries); weights go through LDS in sub-tiles of ONCE_SUB rows so that every
+//   source byte crosses the bus once, in full dwords.  Block 0 also clears the prefetch pad behind the row list and the
+//   flag count.  The LAST block to finish (ticket counter) adds the partials up in k_efinish's order and resets the ticket.
+constexpr int ONCE_SUB = 1024;
+constexpr int64_t ONCE_MAX_CHUNK = 4096;        // longer chunks (few blocks, long walks) take the unfused kernels
+
+template <bool CODED>
+__global__ void __launch_bounds__(256)
+k_once_prep(const void *src_rows, const void *src_wei, const double *__restrict__ table, int table_len,
+            int64_t n, int64_t n_snp, int64_t chunk, int skip_hets, int64_t *rows, double *w,      // fp64 samples: src_rows == rows, src_wei == w (in place)
+            double *__restrict__ lut, double *__restrict__ partial, double *__restrict__ eref, int *__restrict__ cert_count,
+            unsigned *__restrict__ state /* [0] ticket, [1] bad */, int pad_rows)
+{
+    __shared__ double sm[4];
+    __shared__ __attribute__((aligned(16))) double s_w[CODED ? (ONCE_SUB * 3 / 4 + 2) : ONCE_SUB * 3];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    const int64_t K = (n + chunk - 1) / chunk;
+    if (blockIdx.x == 0) {
+        for (int i = tid; i < pad_rows; i += 256) rows[n + i] = 0;
+        if (tid == 0) *cert_count = 0;
+    }
+    int bad = 0;
+    double acc = 0.0;                                     // meaningful in thread 0
+    for (int64_t k = blockIdx.x; k < K; k += gridDim.x) {
+        const int64_t r0 = k * chunk, r1 = (r0 + chunk < n) ? r0 + chunk : n;
+        double s = 0.0;
+        for (int64_t t0 = r0; t0 < r1; t0 += ONCE_SUB) {
+            const int64_t t1 = (t0 + ONCE_SUB < r1) ? t0 + ONCE_SUB : r1;
+            __syncthreads();                              // the previous sub-tile has been consumed
+            int shift = 0;                                // CODED: first code of the sub-tile inside its first staged dword (0 or 1)
+            if constexpr (CODED) {
+                const int64_t b0 = 6 * t0, b1 = 6 * t1, a0 = b0 & ~(int64_t)3;
+                const int n_dw = (int)((b1 - a0 + 3) / 4);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(src_wei) + a0);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(s_w);
+                for (int e = tid; e < n_dw; e += 256) dst[e] = src[e];
+                shift = (int)((b0 - a0) / 2);
+            } else {
+                const double *src = reinterpret_cast<const double *>(src_wei) + 3 * t0;
+                const int n_el = (int)(3 * (t1 - t0));
+                for (int e = tid; e < n_el; e += 256) s_w[e] = src[e];
+            }
+            __syncthreads();
+            for (int64_t r = t0 + tid; r < t1; r += 256) {
+                int64_t prow = CODED ? (int64_t)reinterpret_cast<const int32_t *>(src_rows)[r] : reinterpret_cast<const int64_t *>(src_rows)[r];
+                if (prow < 0 || prow >= n_snp) { prow = 0; bad |= 1; }
+                double w0, w1, w2;
+                const int l = (int)(r - t0);
+                if constexpr (CODED) {
+                    const uint16_t *c = reinterpret_cast<const uint16_t *>(s_w) + shift + 3 * l;
+                    int c0 = c[0], c1 = c[1], c2 = c[2];
+                    if (c0 >= table_len || c1 >= table_len || c2 >= table_len) {
+                        bad |= 2;
+                        c0 = c0 < table_len ? c0 : 0; c1 = c1 < table_len ? c1 : 0; c2 = c2 < table_len ? c2 : 0;
+                    }
+                    w0 = table[c0]; w1 = table[c1]; w2 = table[c2];
+                } else {
+                    w0 = s_w[3 * l]; w1 = s_w[3 * l + 1]; w2 = s_w[3 * l + 2];
+                }
+                rows[r] = prow;
+                w[3 * r] = w0; w[3 * r + 1] = w1; w[3 * r + 2] = w2;
+                double4 e;
+                e.x = w0; e.y = w2; e.z = skip_hets ? 0.0 : w1; e.w = 0.0;
+                reinterpret_cast<double4 *>(lut)[r] = e;
+                s += fmax(fabs(w0), fmax(fabs(w1), fabs(w2)));
+            }
+        }
+        s = block_sum_256(s, sm);
+        acc += s * (double)((r1 - r0) + 3 + (K - k));
+    }
+    if (bad) atomicOr(&state[1], (unsigned)bad);
+    if (tid == 0) {
+        partial[blockIdx.x] = acc;
+        __threadfence();
+        s_last = (atomicAdd(&state[0], 1u) == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    double v = 0.0;
+    for (int i = tid; i < (int)gridDim.x; i += 256) v += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = block_sum_256(v, sm);
+    if (tid == 0) {
+        const double u = 1.1102230246251565e-16;
+        const double mmax = (double)(chunk + 3 + K);
+        eref[0] = (v * u / (1.0 - mmax * u)) * 1.0000001;
+        state[0] = 0u;
+    }
+}
+
 }  // namespace snpm

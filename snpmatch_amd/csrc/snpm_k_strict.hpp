@@ -624,7 +624,8 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 
 __global__ void __launch_bounds__(256)
 k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, const int *__restrict__ d_ncols, int cap,
-           double *__restrict__ tot_score, const double *__restrict__ carry)
+           double *__restrict__ tot_score, const double *__restrict__ carry, const int32_t *__restrict__ patch_cols = nullptr,
+           double *__restrict__ patch_score = nullptr)
 {
     __shared__ __attribute__((aligned(16))) double tile[2][SCAN_TILE_ELEMS + 2 * WAVE];
     const int ncols = *d_ncols;
@@ -688,7 +689,10 @@ k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, cons
         }
         __syncthreads();
     }
-    if ((int)threadIdx.x < ncols) tot_score[threadIdx.x] = s;
+    if ((int)threadIdx.x < ncols) {
+        tot_score[threadIdx.x] = s;
+        if (patch_score) patch_score[patch_cols[threadIdx.x]] = s;        // k_patch fused in: the totals replace the fast-pass scores
+    }
 }
 #undef SCAN_READ8
 #undef SCAN_WAIT8

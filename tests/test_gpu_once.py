@@ -194,3 +194,74 @@ def test_coded_one_call_equals_fp64_one_call(ctx, golden_dir, tmp_path):
     snpmatch.Genotyper(plain, g, out_b, run_genotyper=True)
     for suf in (".scores.txt", ".matches.json"):
         assert open(out_a + suf).read() == open(out_b + suf).read()
+
+
+def _ctx_with(**env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return engine.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def test_fused_and_unfused_forms_of_the_call_agree():
+    """the short form of snpm_genotype_once (k_once_prep + k_once_finish; by default coded samples are read in place from the pinned
+    slab and fp64 samples go through the copy engine behind the fill), both transports forced for both kinds of sample, and the
+    first version's kernels and copies return the same bits -- plain and coded,
+    with forced sparse-tier and dense-tier re-evaluations, and with a chunk above the fused form's limit"""
+    from snpmatch_amd.core import parsers
+    rng = np.random.default_rng(2024)
+    n_snp, n_acc, n_in, n_match = 40000, 300, 30000, 21001
+    db = rand_db(rng, n_snp, n_acc)
+    pl = rng.integers(0, 200, size=(n_in, 3)).astype(float)
+    pl[rng.random(n_in) < 0.2] = -1.0
+    no_pl = np.all(pl == -1, axis=1)
+    wei = np.exp(pl / (-10))
+    hot = np.zeros((int(no_pl.sum()), 3))
+    hot[np.arange(len(hot)), rng.integers(0, 3, len(hot))] = 1.0
+    wei[no_pl] = hot
+    codes, table = parsers._weight_codes(pl, no_pl, wei)
+    rows = np.sort(rng.choice(n_snp, size=n_match, replace=False)).astype(np.int64)
+    sidx = np.sort(rng.choice(n_in, size=n_match, replace=False)).astype(np.int64)
+    for reeval in (0, 3, 100):                     # 100 > the sparse tier's 64: the deferred dense tier
+        forms = {"fused": _ctx_with(SNPM_DEBUG_REEVAL=reeval), "copies": _ctx_with(SNPM_DEBUG_REEVAL=reeval, SNPM_ONCE_ZEROCOPY=0),
+                 "in-place": _ctx_with(SNPM_DEBUG_REEVAL=reeval, SNPM_ONCE_ZEROCOPY=1),
+                 "unfused": _ctx_with(SNPM_DEBUG_REEVAL=reeval, SNPM_ONCE_FUSED=0)}
+        res = {}
+        for name, c in forms.items():
+            for packed in (False, True):
+                panel = engine.Panel.from_host(c, db, packed=packed)
+                for chunk in (1000, 333, 5000):
+                    for skip in (False, True):
+                        a = panel.genotype_once(rows, wei, sidx, chunk, skip, engine.MODE_EXACT)
+                        b = panel.genotype_once(rows, codes, sidx, chunk, skip, engine.MODE_EXACT, table=table)
+                        for k in ("score", "ninfo", "lik", "lrt"):
+                            assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), (name, packed, chunk, skip, k)
+                        assert a["n_strict_reeval"] >= reeval and b["n_strict_reeval"] >= reeval
+                        res[(name, packed, chunk, skip)] = a
+                if reeval == 100 and not packed:
+                    want_s, want_n = c_oracle.genotyper(db, rows, wei[sidx], 1000, False)
+                    assert np.array_equal(bits(res[(name, False, 1000, False)]["score"]), bits(want_s))      # every accession in reference order
+                    assert np.array_equal(res[(name, False, 1000, False)]["ninfo"], want_n)
+                # a bad code / a bad row are refused by every form
+                with pytest.raises(AssertionError, match="outside"):
+                    panel.genotype_once(rows[:4], np.full((4, 3), len(table), dtype=np.uint16), None, table=table)
+                with pytest.raises(AssertionError, match="outside the panel"):
+                    panel.genotype_once(np.array([1, n_snp], dtype=np.int64), codes[:2], None, table=table)
+                # ... and the call after a refusal is a normal one
+                again = panel.genotype_once(rows, codes, sidx, 1000, False, engine.MODE_EXACT, table=table)
+                assert np.array_equal(bits(again["score"]), bits(res[(name, packed, 1000, False)]["score"]))
+                panel.free()
+        for key, a in res.items():
+            if key[0] == "fused":
+                continue
+            f = res[("fused",) + key[1:]]
+            for k in ("score", "ninfo", "lik", "lrt"):
+                assert np.array_equal(a[k].view(np.uint64), f[k].view(np.uint64)), (key, k)
+        for c in forms.values():
+            c.close()

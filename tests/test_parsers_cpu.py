@@ -62,6 +62,11 @@ def test_bed_parse_reference_pins(golden_dir, tmp_path):
     # the reference crashes on BED depth "NA" (np.nanmean("NA")); here the stats file reports NaN
     stats = json.load(open(str(bed) + ".snpmatch.stats.json"))
     assert stats["num_of_snps"] == 10000 and np.isnan(stats["depth"])
+    # hard calls carry the two-entry dictionary form of their weights (Genotyper's one-call path uploads it instead of the fp64 triples)
+    pair = snps.weight_codes()
+    assert pair is not None and pair[1].tolist() == [0.0, 1.0] and pair[0].dtype == np.uint16
+    assert np.array_equal(pair[1][pair[0]].view(np.uint64), snps.wei.view(np.uint64))
+    assert parsers._hard_call_codes(np.array([[1.0, 0.5, 0.0]])) is None and parsers._hard_call_codes(np.array([[1.0, -0.0, 0.0]])) is None
 
 
 def test_parse_gt_and_chr_names():

@@ -56,11 +56,10 @@ def window_offsets(g0, bounds, positions, rows, bin_len=300000):
 
 
 def kernel_leg(ctx, name, run, n_launch_rows, row_bytes, reps, kernel="fast"):
-    """time `run` reps times; kernel = average HIP-event duration of the scoring kernel per launch"""
+    """time `run` reps times (wall clock, the library's event profiling off), then reps times more with it on: kernel = average
+    HIP-event duration of the scoring kernel per launch (the events cost a short call 0.03-0.06 ms of wall time)"""
     run()
     ctx.synchronize()
-    ctx.profile(True)
-    ctx.profile_reset()
     each = []
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -72,6 +71,11 @@ def kernel_leg(ctx, name, run, n_launch_rows, row_bytes, reps, kernel="fast"):
     wall = float(np.median(each))          # the median: once per few hundred launches the HIP runtime stalls a call for tens of ms
     if os.environ.get("BENCH_REAL_PANEL_TRACE"):
         sys.stderr.write("%s: %s ms\n" % (name, " ".join("%.2f" % (t * 1e3) for t in each)))
+    ctx.profile(True)
+    ctx.profile_reset()
+    for _ in range(reps):
+        run()
+    ctx.synchronize()
     launches, ms = ctx.profile_read(kernel)
     parts = {k: ctx.profile_read(k) for k in ("lut", "fast", "reduce", "strict", "scan", "likelihood")}
     ctx.profile(False)

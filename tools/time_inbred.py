@@ -54,3 +54,24 @@ with tempfile.TemporaryDirectory() as tmp:
         r = ci.window_genotyper(os.path.join(tmp, "c.windowscore.txt"))
         t1 = time.perf_counter()
         print("cross  rep%d: window_genotyper %.3f s (%d windows, %d table rows)" % (rep, t1 - t0, 399, len(ci.windows_data)))
+    if os.environ.get("PROFILE") == "1":             # where the host time of the warm runs goes (cProfile, 5 runs each)
+        import cProfile
+        import pstats
+
+        def inbred_once():
+            gt = snpmatch.Genotyper(inp, g, os.path.join(tmp, "o"), run_genotyper=False)
+            gt.get_common_positions()
+            gt.write_genotyper_output(gt.genotyper())
+
+        def cross_once():
+            ci = csmatch.CrossIdentifier(inp, g, "athaliana_tair10", 300000, os.path.join(tmp, "c"), run_identifier=False)
+            ci.window_genotyper(os.path.join(tmp, "c.windowscore.txt"))
+
+        for name, fn in (("inbred", inbred_once), ("cross", cross_once)):
+            pr = cProfile.Profile()
+            pr.enable()
+            for _ in range(5):
+                fn()
+            pr.disable()
+            print("== cProfile, 5 warm runs of %s" % name)
+            pstats.Stats(pr).sort_stats("cumulative").print_stats(35)
