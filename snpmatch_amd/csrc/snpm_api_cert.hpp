@@ -107,6 +107,11 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     // 27.9 / 27.0 / 25.9 / 25.3 / 25.1 ms (r03j_ab_parts_mult_full.txt; 28.9 with one): sixteen.  k_fast_bits and the int8 k_fast keep
     // one part per resident block (more: +1.5 % on 20M rows but -3 % on 50M for the bits kernel, -6 ... -1 % on every int8 shape).
     const int kmult = (p16 && !bits) ? 16 : 1;
+    // GATHERED rows on an int8 panel, blocks of 5, 6 or 7 waves (1025-1792 accessions: the 1001 Genomes width): 4 / 3 / 3 resident
+    // blocks per CU instead of the 5 / 4 / 4 the occupancy query allows -- a 1M-row sample takes 0.205 instead of 0.267 ms on 1135
+    // accessions (5.66 vs 4.35 TB/s), 0.277 instead of 0.327 ms on 1500, 0.299 instead of 0.345 ms on 1700; 200k rows and blocks of
+    // 1-4 or 8 waves do not care (profiles/r04_gather_occupancy.txt)
+    if (gather && !p16 && bpl == 4 && g0.wpb >= 5 && g0.wpb <= 7 && !ctx->full_occupancy) occ = std::min(occ, g0.wpb == 5 ? 4 : 3);
     FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl, tile_rows, wpb_fixed, kmult);
     if (geom_out) *geom_out = g;
     q->last_kernel = bits ? "k_fast_bits" : (p16 ? "k_fast_packed_q4" : "k_fast");
