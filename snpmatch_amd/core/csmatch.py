@@ -59,15 +59,17 @@ def _window_segments_sorted(genome, db, sample, bin_len):
         n_win = len(range(1, int(genome.chrlen[chr_ix]), bin_len))
         chrom.append(np.full(n_win, chr_ix, dtype=int))
         where = np.flatnonzero(db_ids == cid)
-        mine = np.flatnonzero(np.isin(inverse, np.flatnonzero(smp_ids == cid)))
+        wanted = np.flatnonzero(smp_ids == cid)
+        mine = np.flatnonzero(inverse == wanted[0] if len(wanted) == 1 else np.isin(inverse, wanted))
         if len(where) == 0 or len(mine) == 0 or n_win == 0:
             counts.append(np.zeros(n_win, dtype=np.int64))
             continue
         row0, row1 = int(db.chr_regions[where[0]][0]), int(db.chr_regions[where[0]][1])
-        p1, p2 = db_pos[row0:row1], smp_pos[mine]
+        one_run = int(mine[-1]) - int(mine[0]) + 1 == len(mine)
+        p1, p2 = db_pos[row0:row1], (smp_pos[int(mine[0]):int(mine[-1]) + 1] if one_run else smp_pos[mine])
         if cid not in increasing:
             increasing[cid] = bool(len(p1) == 0 or (p1[0] >= 1 and np.all(p1[1:] > p1[:-1])))
-        if not increasing[cid] or int(mine[-1]) - int(mine[0]) + 1 != len(mine) or p2[0] < 1:
+        if not increasing[cid] or not one_run or p2[0] < 1:
             return None
         hit = _lib.intersect_sorted(p1, p2, a_verified=True)
         if hit is None:                                    # sample positions not strictly increasing

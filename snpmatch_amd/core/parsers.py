@@ -34,21 +34,23 @@ def die(msg):
     sys.exit(1)
 
 
-def parseGT(snpGT):
+def _gt_separator(head):
+    """'|' or '/' as the genotype text ``head`` uses it, None for anything else"""
+    head = str(head)
+    return "|" if "|" in head else ("/" if "/" in head else None)
+
+
+def parseGT(snpGT, _sep=None):
     """genotype text -> int8 codes: 0 hom-ref, 1 hom-alt, 2 het, -1 no call (anything else stays 0).
     The separator ('/' or '|') is taken from the first entry; purely numeric input is returned as codes."""
     snpGT = np.asarray(snpGT)
     codes = np.zeros(len(snpGT), dtype="int8")
     if len(codes) == 0:
         return codes
-    head = str(snpGT[0])
-    if "|" in head:
-        sep = "|"
-    elif "/" in head:
-        sep = "/"
-    elif head.isdigit():
-        return np.array(np.copy(snpGT), dtype="int8")
-    else:
+    sep = _sep or _gt_separator(snpGT[0])
+    if sep is None:
+        if str(snpGT[0]).isdigit():
+            return np.array(np.copy(snpGT), dtype="int8")
         die("unable to parse the format of GT in vcf!")
     text = snpGT.astype("U")
     if text.dtype == np.dtype("<U3") and text.flags.c_contiguous:
@@ -162,6 +164,22 @@ class ParseInputs(object):
         self._wei_codes, self._wei_table = np.ascontiguousarray(pair[0], dtype=np.uint16), np.ascontiguousarray(pair[1], dtype=np.float64)
         self.wei.flags.writeable = False
         self._wei_coded_for = self.wei
+
+    def gt_codes_of(self, rows):
+        """``parseGT(self.gt[rows])`` without gathering or re-parsing 200k strings per call: the whole column is parsed once per
+        separator (``parseGT`` reads the separator from the FIRST entry it is given, here ``self.gt[rows[0]]``) and kept while
+        ``self.gt`` is the same array.  None when that first entry has no separator (the caller parses the text itself)."""
+        rows = np.asarray(rows)
+        if len(rows) == 0 or len(self.gt) == 0:
+            return np.zeros(0, dtype="int8")
+        sep = _gt_separator(self.gt[int(rows[0])])
+        if sep is None:
+            return None
+        cache = self.__dict__.setdefault("_gt_code_cache", {})
+        hit = cache.get(sep)
+        if hit is None or hit[0] is not self.gt:
+            hit = cache[sep] = (self.gt, parseGT(self.gt, _sep=sep))
+        return hit[1][rows]
 
     def weight_codes(self):
         """(codes, table) when they still describe ``self.wei``, else None"""

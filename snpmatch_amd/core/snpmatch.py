@@ -216,7 +216,8 @@ class Genotyper(object):
         log.info("writing score file!")
         result.print_out_table(self.outFile + '.scores.txt')
         result.print_json_output(self.outFile + ".matches.json")
-        getHeterozygosity(self.inputs.gt[self.commonSNPs[1]], self.outFile + ".matches.json")
+        codes = self.inputs.gt_codes_of(self.commonSNPs[1]) if hasattr(self.inputs, "gt_codes_of") else None
+        getHeterozygosity(self.inputs.gt[self.commonSNPs[1]] if codes is None else codes, self.outFile + ".matches.json", _codes=codes)
         return result
 
     def filter_tophits(self):
@@ -240,9 +241,10 @@ class Genotyper(object):
         self.result_fine.print_out_table(self.outFile + ".refined.scores.txt")
 
 
-def getHeterozygosity(snpGT, outFile='default'):
-    """fraction of heterozygous calls among ``snpGT``; also recorded in the JSON file when one is given"""
-    n_het = int(np.count_nonzero(parsers.parseGT(snpGT) == 2))
+def getHeterozygosity(snpGT, outFile='default', _codes=None):
+    """fraction of heterozygous calls among ``snpGT``; also recorded in the JSON file when one is given
+    (``_codes``: the calls already as ``parseGT`` codes)"""
+    n_het = int(np.count_nonzero((parsers.parseGT(snpGT) if _codes is None else _codes) == 2))
     het = get_fraction(n_het, len(snpGT))
     if outFile != 'default':
         _report.update_json(outFile, percent_heterozygosity=het)

@@ -10,6 +10,20 @@
 #include <vector>
 
 #include "snpmatch_hip.h"
+#include "snpm_hostpool.hpp"
+
+namespace {
+// one persistent pool for the context-free host entry points (threads are made on first use; their workers spin briefly for
+// the next call -- the five chromosomes of a sample follow each other within microseconds -- before they sleep)
+HostPool &shared_pool()
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = (unsigned)CPU_COUNT(&set);
+    static HostPool pool((int)std::max(0, std::min<int>((int)(hw ? hw : 1), 16) - 1));
+    return pool;
+}
+}  // namespace
 
 extern "C" {
 
@@ -66,10 +80,8 @@ int snpm_intersect_sorted_search(const int64_t *a, int64_t na, const int64_t *b,
     // Every probe of a long DB list is a cache miss of its own (a 200k-SNP sample against 11M DB positions: ~55 rows apart),
     // so the walk is cut into ranges of b that run on their own threads (each finds its start by a binary search) and the
     // per-range hit lists are closed up afterwards: the same pairs in the same order as the single walk.
-    unsigned hw = std::thread::hardware_concurrency();
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) hw = (unsigned)CPU_COUNT(&set);
-    const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 16), nb / 4096));
+    HostPool &pool = shared_pool();
+    const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)(pool.size() + 1), nb / 2048));   // ranges, handed out dynamically
     if (n_thr <= 1) {
         *n_out = gallop_range(a, na, b, 0, nb, 0, ia, ib);
         return SNPM_OK;
@@ -81,10 +93,7 @@ int snpm_intersect_sorted_search(const int64_t *a, int64_t na, const int64_t *b,
         const int64_t lo = (j0 < j1) ? (int64_t)(std::lower_bound(a, a + na, b[j0]) - a) : 0;
         cnt[(size_t)t] = gallop_range(a, na, b, j0, j1, lo, ia, ib);
     };
-    std::vector<std::thread> thr;
-    for (int t = 1; t < n_thr; ++t) thr.emplace_back(work, t);
-    work(0);
-    for (auto &th : thr) th.join();
+    pool.run(n_thr, work);
     int64_t k = cnt[0];
     for (int t = 1; t < n_thr; ++t) {
         const int64_t j0 = start[(size_t)t];
