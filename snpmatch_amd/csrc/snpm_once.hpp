@@ -24,6 +24,34 @@ struct OnceProps {          // per task of the fill
 
 }  // namespace
 
+// The weight table of the coded form on the device (uploaded when it is not the one of the previous call) and, with it, the
+// properties of every code: a flag byte and |entry| (65536 of each; codes past the table carry bit 3).  BOTH forms of the call
+// go through here: the per-code tables always describe ctx->once_table.
+static int once_set_table(snpm_ctx *ctx, const double *table, int64_t table_len)
+{
+    int rc = ensure(ctx, ctx->ws_once_table, 65536 * sizeof(double));
+    if (rc) return rc;
+    if (ctx->once_table.size() == (size_t)table_len && ctx->once_code_flags.size() == 65536 &&
+        memcmp(ctx->once_table.data(), table, (size_t)table_len * sizeof(double)) == 0)
+        return SNPM_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));         // a previous call's expansion may still read the old table / staging copy
+    ctx->once_table.assign(table, table + table_len);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->ws_once_table.p, ctx->once_table.data(), (size_t)table_len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    ctx->once_code_flags.assign(65536, (uint8_t)8);
+    ctx->once_code_abs.assign(65536, 0.0);
+    for (int64_t k = 0; k < table_len; ++k) {
+        const double v = table[k], a = fabs(v);
+        uint64_t b;
+        memcpy(&b, &v, 8);
+        const uint64_t mag = b & 0x7FFFFFFFFFFFFFFFull;
+        ctx->once_code_flags[(size_t)k] = (uint8_t)((uint32_t)((a < 9.0e15 && (double)(int64_t)a != a) || !(a < 9.0e15)) |
+                                                    ((uint32_t)(!(mag == 0 || b == 0x3FF0000000000000ull)) << 1) |
+                                                    ((uint32_t)(mag >= 0x7FF0000000000000ull) << 2));
+        ctx->once_code_abs[(size_t)k] = (mag < 0x7FF0000000000000ull) ? a : 0.0;
+    }
+    return SNPM_OK;
+}
+
 // ---- the short form of the call (default; SNPM_ONCE_FUSED=0 or a chunk above ONCE_MAX_CHUNK take genotype_once_impl's body) ----
 // GPU timeline of a coded 200k-SNP sample before: 2 copies up (67 us with their gaps), 15 kernels and fills of ~4.8 us each around
 // the 53 us of k_fast, 1 copy back = 224 us (profiles/r04_once_timeline_before.txt).  Here: the slab stays in pinned host memory
@@ -71,27 +99,7 @@ static int genotype_once_fused(snpm_panel *p, const int64_t *row_idx, const doub
         HIPCHK(ctx, hipMemsetAsync(ctx->ws_once_state.p, 0, 64, ctx->stream));
         ctx->once_state_clean = true;
     }
-    if (coded) {
-        if ((rc = ensure(ctx, ctx->ws_once_table, 65536 * sizeof(double)))) return rc;
-        if (ctx->once_table.size() != (size_t)table_len || memcmp(ctx->once_table.data(), table, (size_t)table_len * sizeof(double)) != 0) {
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            ctx->once_table.assign(table, table + table_len);
-            HIPCHK(ctx, hipMemcpyAsync(ctx->ws_once_table.p, ctx->once_table.data(), (size_t)table_len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-            // the properties of every code, once per table (a byte each; codes past the table: bit 3)
-            ctx->once_code_flags.assign(65536, (uint8_t)8);
-            ctx->once_code_abs.assign(65536, 0.0);
-            for (int64_t k = 0; k < table_len; ++k) {
-                const double v = table[k], a = fabs(v);
-                uint64_t b;
-                memcpy(&b, &v, 8);
-                const uint64_t mag = b & 0x7FFFFFFFFFFFFFFFull;
-                ctx->once_code_flags[(size_t)k] = (uint8_t)((uint32_t)((a < 9.0e15 && (double)(int64_t)a != a) || !(a < 9.0e15)) |
-                                                            ((uint32_t)(!(mag == 0 || b == 0x3FF0000000000000ull)) << 1) |
-                                                            ((uint32_t)(mag >= 0x7FF0000000000000ull) << 2));
-                ctx->once_code_abs[(size_t)k] = (mag < 0x7FF0000000000000ull) ? a : 0.0;
-            }
-        }
-    }
+    if (coded && (rc = once_set_table(ctx, table, table_len))) return rc;
 
     // ---- fill: the pool gathers the matched rows into the slab
     HostPool *pool = host_pool(ctx);
@@ -381,13 +389,7 @@ static int genotype_once_impl(snpm_panel *p, const int64_t *row_idx, const doubl
     int32_t *d_rows32 = nullptr;
     uint16_t *d_codes = nullptr;
     if (coded && n > 0) {
-        // the table on the device: uploaded when it is not the one of the previous call
-        if ((rc = ensure(ctx, ctx->ws_once_table, 65536 * sizeof(double)))) return rc;
-        if (ctx->once_table.size() != (size_t)table_len || memcmp(ctx->once_table.data(), table, (size_t)table_len * sizeof(double)) != 0) {
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));         // a previous call's expansion may still read the old table / staging copy
-            ctx->once_table.assign(table, table + table_len);
-            HIPCHK(ctx, hipMemcpyAsync(ctx->ws_once_table.p, ctx->once_table.data(), (size_t)table_len * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        }
+        if ((rc = once_set_table(ctx, table, table_len))) return rc;
         if (query_alloc(q, (void **)&d_rows32, row_bytes) != hipSuccess || query_alloc(q, (void **)&d_codes, wei_bytes) != hipSuccess)
             return set_err(ctx, SNPM_ERR_OOM, "query allocation failed");
     }

@@ -265,3 +265,29 @@ def test_fused_and_unfused_forms_of_the_call_agree():
                 assert np.array_equal(a[k].view(np.uint64), f[k].view(np.uint64)), (key, k)
         for c in forms.values():
             c.close()
+
+
+def test_code_properties_follow_the_table_across_both_forms(ctx):
+    """the per-code property tables of the fused form describe the table of the LAST coded call, whichever form made it (found by
+    the fuzzer: a hard-call table, then the same fractional table through the unfused form (chunk above its limit) and the fused
+    one -- the second call used to keep the first table's "all integers" verdict and counted 1.0 weights only)"""
+    rng = np.random.default_rng(4242)
+    n_snp, n_acc, n = 6000, 300, 2700
+    db = rand_db(rng, n_snp, n_acc)
+    rows = np.sort(rng.choice(n_snp, size=n, replace=False)).astype(np.int64)
+    calls = rng.choice(np.array([0, 1, 2], dtype=np.int8), size=n)
+    hard = synth.sample_weights(rng, calls, 0.0)
+    soft = synth.sample_weights(rng, calls, 1.0)
+    for packed in (False, True):
+        panel = engine.Panel.from_host(ctx, db, packed=packed)
+        for first_chunk in (5000, 1000):                       # unfused / fused form makes the fractional table current
+            t_h, inv_h = np.unique(hard.ravel(), return_inverse=True)
+            t_s, inv_s = np.unique(soft.ravel(), return_inverse=True)
+            a = panel.genotype_once(rows, inv_h.reshape(hard.shape).astype(np.uint16), None, 1000, False, engine.MODE_EXACT, table=t_h)
+            assert a["all_integer_weights"]
+            panel.genotype_once(rows, inv_s.reshape(soft.shape).astype(np.uint16), None, first_chunk, False, engine.MODE_EXACT, table=t_s)
+            b = panel.genotype_once(rows, inv_s.reshape(soft.shape).astype(np.uint16), None, 7, False, engine.MODE_EXACT, table=t_s)
+            want_s, want_n = c_oracle.genotyper(db, rows, soft, 7, False)
+            assert not b["all_integer_weights"]
+            assert np.array_equal(b["ninfo"], want_n) and np.array_equal(b["score"].astype(int), want_s.astype(int))
+        panel.free()

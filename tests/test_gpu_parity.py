@@ -741,6 +741,23 @@ def _fuzz_random_configurations(ctx, n_cases, seed):
             want = c_oracle.windows(db, rows, wei, off, skip)
             assert np.array_equal(bits(got[0]), bits(want[0])) and np.array_equal(got[1], want[1]), tag
             assert np.array_equal(bits(got[2]), bits(want[2])) and np.array_equal(got[3], want[3]), tag
+        if rows is not None and type(panel) is engine.Panel and hasattr(panel, "genotype_once") and np.all(wei <= 1.0):
+            # the one-call form of the same sample (snpm_genotype_once: k_once_prep / k_once_finish), plain and dictionary-coded
+            # (weights above 1 can push a count above its informative sites: that call asserts like the reference's likeliTest)
+            table, inv = np.unique(wei.ravel(), return_inverse=True)
+            for coded in (False, True):
+                if coded and len(table) > 65536:
+                    continue
+                args = (rows, inv.reshape(wei.shape).astype(np.uint16) if coded else wei, None, chunk, skip)
+                kw = {"table": table} if coded else {}
+                once = panel.genotype_once(*args, engine.MODE_STRICT, **kw)
+                assert np.array_equal(bits(once["score"]), bits(want_s)) and np.array_equal(once["ninfo"], want_n), tag
+                once = panel.genotype_once(*args, engine.MODE_EXACT, **kw)
+                assert np.array_equal(once["ninfo"], want_n) and np.array_equal(once["score"].astype(int), want_s.astype(int)), tag
+                assert np.array_equal(bits(once["score"]), bits(s)), tag             # the three-call path's kernels in its geometry
+                lik_o, _ = orc.calculate_likelihoods(want_s.astype(int), want_n)
+                ok = ~np.isnan(lik_o)
+                assert np.array_equal(np.isnan(once["lik"]), ~ok) and np.allclose(once["lik"][ok], lik_o[ok], rtol=1e-12, atol=0), tag
         q.free()
         panel.free()
 
