@@ -18,10 +18,11 @@ rm -rf $out/prof_bench
 echo "== PMC traffic of the headline slab"
 bash tools/collect_pmc.sh slab_10000x20019000 10000 20019000 > $out/pmc_headline.log 2>&1; echo "rc=$?"; tail -3 $out/pmc_headline.log
 cp gpurun_out/pmc_slab_10000x20019000/pmc_traffic.json $out/pmc_traffic.json 2>/dev/null
-echo "== one-call path phases"
-{ echo "# snpm_genotype_once on 1135 x 11M int8, one 200k-SNP sample (tools/debug/r04_once_trace.py); SNPM_ONCE_PIECE_TASKS = fill tasks (4096 rows) per upload piece"
-  for pt in 4 12 25 64; do echo "== piece tasks $pt"; SNPM_ONCE_PIECE_TASKS=$pt python tools/debug/r04_once_trace.py 2>&1 | grep -v amdgpu | tail -6; done; } > $out/once_phases.txt
-tail -4 $out/once_phases.txt
+echo "== one-call path: phases of its forms, GPU timeline"
+python tools/debug/r04_once_trace.py 2>&1 | grep -v amdgpu > $out/once_forms.txt; grep "coded wall" $out/once_forms.txt | head -8 | tail -3
+bash tools/debug/r04_once_timeline.sh > /dev/null 2>&1; cp gpurun_out/r04t/once_timeline.txt $out/once_timeline.txt 2>/dev/null
+echo "== warm inbred / cross runs"
+{ echo "== int8 panel"; python tools/time_inbred.py 2>&1 | grep -v amdgpu; echo "== 2-bit packed panel"; PACKED=1 python tools/time_inbred.py 2>&1 | grep -v amdgpu; } > $out/time_inbred.txt; grep rep1 $out/time_inbred.txt
 python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/r04z/bench_default.json").read().strip().splitlines()[-1])
