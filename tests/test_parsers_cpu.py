@@ -213,3 +213,55 @@ def test_vcf_weights_carry_dictionary_codes(golden_dir, tmp_path):
                                  np.array([[1.0, np.exp(0.1), np.exp(-3.0)], [0.0, 1.0, 0.0]]))
     if both is not None:                                   # (exp(0.1) as a one-element array may round differently: then no codes)
         assert np.array_equal(both[1][both[0]].view(np.uint64), np.array([[1.0, np.exp(0.1), np.exp(-3.0)], [0.0, 1.0, 0.0]]).view(np.uint64))
+
+
+def _write_bgzf(path, data, member=65280, eof=True):
+    """``data`` as a BGZF file (what bgzip / bcftools write): gzip members of at most ``member`` text bytes, each with its
+    compressed size in a 'BC' extra subfield; the empty end-of-file member last"""
+    import struct
+    import zlib
+    with open(path, "wb") as fh:
+        pieces = [data[i:i + member] for i in range(0, len(data), member)] + ([b""] if eof else [])
+        for piece in pieces:
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            raw = co.compress(piece) + co.flush()
+            fh.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25))
+            fh.write(raw + struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece)))
+
+
+def test_native_vcf_reader_inflates_bgzf_members_side_by_side(golden_dir, tmp_path, monkeypatch):
+    """a bgzipped VCF (independent gzip members) is inflated by a team of threads, batch by batch: same records as the plain
+    file for any member size, batch size and team size; gzip's own reader agrees on the file; damaged members are refused"""
+    import gzip
+    from snpmatch_amd import _lib
+    src = os.path.join(golden_dir, "701_501.filter.vcf.gz")
+    data = gzip.open(src, "rb").read()
+    plain = str(tmp_path / "s.vcf")
+    open(plain, "wb").write(data)
+    want = _vcf.read_calls(plain, (0,), native=False)
+    bg = str(tmp_path / "s.bgzf.vcf.gz")
+    for member, batch_kb, threads, block_kb in ((65280, "16384", "8", "4096"), (4000, "1", "4", "8"), (517, "3", "16", "4"),
+                                                (65280, "70", "1", "64"), (30000, "64", "3", "8")):
+        _write_bgzf(bg, data, member)
+        assert gzip.open(bg, "rb").read() == data                   # a valid multi-member gzip file
+        monkeypatch.setenv("SNPM_VCF_BGZF_BATCH_KB", batch_kb)
+        monkeypatch.setenv("SNPM_VCF_THREADS", threads)
+        monkeypatch.setenv("SNPM_VCF_BLOCK_KB", block_kb)
+        _same_calls(_vcf.read_calls(bg, (0,), native=True), want)
+        monkeypatch.setenv("SNPM_VCF_BGZF", "0")                    # the one-stream path on the same file
+        _same_calls(_vcf.read_calls(bg, (0,), native=True), want)
+        monkeypatch.delenv("SNPM_VCF_BGZF")
+    for k in ("SNPM_VCF_BGZF_BATCH_KB", "SNPM_VCF_THREADS", "SNPM_VCF_BLOCK_KB"):
+        monkeypatch.delenv(k)
+    _write_bgzf(bg, data, 65280, eof=False)                          # no end-of-file member: still every record
+    _same_calls(_vcf.read_calls(bg, (0,), native=True), want)
+    # damage: a flipped byte inside a member's data (CRC / inflate error), a truncated file, trailing bytes that are no member
+    _write_bgzf(bg, data, 20000)
+    raw = bytearray(open(bg, "rb").read())
+    bad = bytes(raw[:5000]) + bytes([raw[5000] ^ 0x55]) + bytes(raw[5001:])
+    open(bg, "wb").write(bad)
+    assert _lib.vcf_parse(bg, 0) is None
+    open(bg, "wb").write(bytes(raw[:len(raw) // 2]))
+    assert _lib.vcf_parse(bg, 0) is None
+    open(bg, "wb").write(bytes(raw) + b"garbage-that-is-no-member")
+    assert _lib.vcf_parse(bg, 0) is None

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""ParseInputs on a synthetic single-sample VCF of N records (plain and gzip): the sample-ingestion step in front of the scoring
+"""ParseInputs on a synthetic single-sample VCF of N records (plain, gzip and BGZF): the sample-ingestion step in front of the scoring
 (core/parsers.py:141-157, 178-213).  usage: tools/time_parse.py [n_records=1000000]"""
 import gzip
 import os
@@ -44,7 +44,21 @@ try:
         shutil.copyfileobj(fi, fo)
     print("%d records: %s %.0f MB, %s %.0f MB; SNPM_VCF_THREADS=%s" % (n, os.path.basename(plain), os.path.getsize(plain) / 1e6,
                                                                     os.path.basename(gz), os.path.getsize(gz) / 1e6, os.environ.get("SNPM_VCF_THREADS", "default")))
-    for path in (plain, gz):
+    # the same text as bgzip / bcftools write it: independent gzip members of <= 64 KiB (inflated side by side by the native reader)
+    import struct
+    import zlib
+    bgz = os.path.join(tmp, "sample.bgzf.vcf.gz")
+    with open(plain, "rb") as fi, open(bgz, "wb") as fo:
+        while True:
+            piece = fi.read(65280)
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            raw = co.compress(piece) + co.flush()
+            fo.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(raw) + 25))
+            fo.write(raw + struct.pack("<II", zlib.crc32(piece) & 0xFFFFFFFF, len(piece)))
+            if not piece:
+                break
+    print("%s %.0f MB" % (os.path.basename(bgz), os.path.getsize(bgz) / 1e6))
+    for path in (plain, gz, bgz):
         for rep in range(4):
             for f in (path + ".snpmatch.npz", path + ".snpmatch.stats.json"):
                 if os.path.exists(f):
