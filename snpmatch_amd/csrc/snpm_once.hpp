@@ -1,16 +1,18 @@
-// snpm_once.hpp -- ONE sample against a resident panel in ONE call: snpm_genotype_once.
+// snpm_once.hpp -- ONE sample against a resident panel in ONE call: snpm_genotype_once / snpm_genotype_once_coded.
 //
 // Genotyper.genotyper (core/snpmatch.py:207-241) for a single sample used to be three synchronising ABI calls from Python --
 // snpm_query_create (two pageable uploads, a device pass over the weights and a read-back of its flags), snpm_query_run (two
 // copies back), snpm_likelihood (two copies up, two back) -- plus a numpy gather of the sample's matched weight rows in front:
-// 0.55-0.7 ms per 200k-SNP sample around 0.06 ms of scoring (profiles/r04_real_panel_*).  Here:
-//   1. the host thread pool gathers wei[sample_idx[i]] and the row list straight into ONE pinned slab and, on the way, checks
-//      the row indices and collects the weight properties the kernels are chosen by (sum of max |w|, all-integer, hard 0/1,
-//      finite) -- no device pass over the weights, no read-back before the launch decisions;
-//   2. the slab goes up piece by piece behind the fill (copy stream), the compute stream waits for the last piece;
-//   3. LUT, fast pass, ordered reduce + certificate, the gated reference-order tiers, likelihood / nanmin / ratio (on the
-//      truncated counts, as GenotyperOutput does, :96, :106-117) are enqueued back to back;
-//   4. (score, ninfo, likelihood, lrt, #re-evaluated) are packed into one buffer and come back in ONE copy, one synchronisation.
+// 0.55-0.7 ms per 200k-SNP sample around 0.06 ms of scoring (profiles/r04_real_panel_*).  Two forms live here:
+//   genotype_once_fused (default)  the host thread pool gathers wei[sample_idx[i]] / the weight codes and the row list into ONE
+//      pinned slab, collecting the weight properties the kernels are chosen by on the way; k_once_prep reads the slab where it
+//      lies (or what the copy engine brought behind the fill) and prepares everything the scoring needs in one launch; fast pass,
+//      reduce + certificate, the sparse tier, k_once_finish (likelihood / nanmin / ratio of the truncated counts, :96, :106-117,
+//      + status) written straight into the slab: seven launches, one synchronisation.
+//   genotype_once_impl's own body (SNPM_ONCE_FUSED=0, chunk > ONCE_MAX_CHUNK, n == 0)  the first version: the slab goes up in
+//      pieces behind the fill, row check / code expansion / LUT / error bound / tiers / likelihood as separate launches of the
+//      query path, one packed copy back.
+// Both return the same bits (tests/test_gpu_once.py).
 // Included by snpm_api.hip inside its extern "C" block.
 
 namespace {
