@@ -55,12 +55,24 @@ def _window_segments_sorted(genome, db, sample, bin_len):
     increasing = db.__dict__.setdefault("_increasing_chr", {})
     smp_pos = np.ascontiguousarray(sample.pos, dtype=np.int64)
     per_db, per_sample, counts, chrom = [], [], [], []
+    # a sample sorted by chromosome names each one in ONE run of `inverse`: the runs are found once (one pass over the codes
+    # instead of one per chromosome); anything else takes the per-chromosome membership tests
+    inverse = np.asarray(inverse)
+    cuts = np.flatnonzero(inverse[1:] != inverse[:-1]) + 1 if len(inverse) > 1 else np.zeros(0, dtype=np.int64)
+    run_start = np.concatenate(([0], cuts)).astype(np.int64) if len(inverse) else np.zeros(0, dtype=np.int64)
+    run_end = np.concatenate((cuts, [len(inverse)])).astype(np.int64) if len(inverse) else np.zeros(0, dtype=np.int64)
+    run_code = inverse[run_start] if len(inverse) else np.zeros(0, dtype=np.int64)
+    runs_are_chromosomes = len(np.unique(run_code)) == len(run_code)
     for chr_ix, cid in enumerate(genome.chrs_ids):
         n_win = len(range(1, int(genome.chrlen[chr_ix]), bin_len))
         chrom.append(np.full(n_win, chr_ix, dtype=int))
         where = np.flatnonzero(db_ids == cid)
         wanted = np.flatnonzero(smp_ids == cid)
-        mine = np.flatnonzero(inverse == wanted[0] if len(wanted) == 1 else np.isin(inverse, wanted))
+        if runs_are_chromosomes and len(wanted) == 1:
+            k = np.flatnonzero(run_code == wanted[0])
+            mine = np.arange(run_start[k[0]], run_end[k[0]]) if len(k) else np.zeros(0, dtype=np.int64)
+        else:
+            mine = np.flatnonzero(inverse == wanted[0] if len(wanted) == 1 else np.isin(inverse, wanted))
         if len(where) == 0 or len(mine) == 0 or n_win == 0:
             counts.append(np.zeros(n_win, dtype=np.int64))
             continue
@@ -180,8 +192,12 @@ class CrossIdentifier(object):
         filled = np.flatnonzero(np.diff(offsets) > 0)                     # empty windows produce no rows
         if len(filled):
             dev = engine.default_context()
-            sc = np.ascontiguousarray(w_score[filled][:, shown])
-            ni = np.ascontiguousarray(w_ninfo[filled][:, shown])
+            if mask_acc_ix is None:               # every accession shown: one row selection, no column gather
+                sc = np.ascontiguousarray(w_score if len(filled) == len(w_score) else w_score[filled])
+                ni = np.ascontiguousarray(w_ninfo if len(filled) == len(w_ninfo) else w_ninfo[filled])
+            else:
+                sc = np.ascontiguousarray(w_score[filled][:, shown])
+                ni = np.ascontiguousarray(w_ninfo[filled][:, shown])
             lik, lrt = dev.likelihood(sc, ni)                              # one device row per window
             same = dev.binom_identity(sc.ravel(), ni.ravel(), self.error_rate, 0.05).reshape(sc.shape)
             self.windows_data = _report.window_table(filled + 1, accs, sc, ni, lik, lrt, same, snpmatch.lr_thres)

@@ -14,7 +14,7 @@ wall = np.zeros((n_in, 3)); wall[sidx] = wei
 tab = np.concatenate([engine.pl_table(256), [0.0]])
 codes = engine.weight_codes(wall, tab)
 forms = [("default", {}), ("zero-copy", {"SNPM_ONCE_ZEROCOPY": "1"}), ("copies", {"SNPM_ONCE_ZEROCOPY": "0"}), ("unfused", {"SNPM_ONCE_FUSED": "0"})]
-only = os.environ.get("ONCE_FORMS")
+only = os.environ.get("ONCE_FORMS") or (sys.argv[1] if len(sys.argv) > 1 else None)      # (rocprofv3 takes the program itself after --: the selection as an argument)
 for name, env in forms:
     if only and name not in only.split(","):
         continue

@@ -15,9 +15,11 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $out/p
 python tools/kernel_trace_by_shape.py --phase-marker k_synth $out/prof_bench > $out/bench_kernel_by_shape.csv
 find $out/prof_bench -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/bench_kernel_stats.csv
 rm -rf $out/prof_bench
+if [ "${SKIP_PMC:-0}" != 1 ]; then
 echo "== PMC traffic of the headline slab"
 bash tools/collect_pmc.sh slab_10000x20019000 10000 20019000 > $out/pmc_headline.log 2>&1; echo "rc=$?"; tail -3 $out/pmc_headline.log
 cp gpurun_out/pmc_slab_10000x20019000/pmc_traffic.json $out/pmc_traffic.json 2>/dev/null
+fi
 echo "== one-call path: phases of its forms, GPU timeline"
 python tools/debug/r04_once_trace.py 2>&1 | grep -v amdgpu > $out/once_forms.txt; grep "coded wall" $out/once_forms.txt | head -8 | tail -3
 bash tools/debug/r04_once_timeline.sh > /dev/null 2>&1; cp gpurun_out/r04t/once_timeline.txt $out/once_timeline.txt 2>/dev/null
