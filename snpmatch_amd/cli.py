@@ -41,6 +41,13 @@ def snpmatch_inbred(args):
     snpmatch.potatoGenotyper(args)
 
 
+def snpmatch_inbred_batch(args):
+    from .core import snpmatch
+    for f in args['inFiles']:
+        check_file(f)
+    snpmatch.potatoGenotyperBatch(args)
+
+
 def snpmatch_cross(args):
     from .core import csmatch
     check_file(args['inFile'])
@@ -74,6 +81,19 @@ def get_options(description, version_message):
     common(inbred, "identify_inbred")
     inbred.add_argument("--refine", action="store_true", dest="refine", default=False, help="Refine scores for indistinguishable lines")
     inbred.set_defaults(func=snpmatch_inbred)
+
+    # not in the reference (which starts a process, and opens the DB, per sample): many samples against ONE resident DB
+    batch = sub.add_parser('inbred-batch', help="`inbred` for many samples: the DB is loaded once, samples are scored a batch per device call")
+    batch.add_argument("-i", "--input_files", dest="inFiles", nargs='+', required=True, help="VCF/BED files, one sample each")
+    batch.add_argument("-d", "--hdf5_file", default=None, dest="hdf5File", help="Path to SNP matrix (as for inbred)")
+    batch.add_argument("-e", "--hdf5_acc_file", default=None, dest="hdf5accFile", help="Path to SNP matrix chunked column-wise (optional for flat panels)")
+    batch.add_argument("--skip_db_hets", action="store_true", dest="skip_db_hets", default=False,
+                       help="Replace heterozygous calls in DB with nan during the analysis.")
+    batch.add_argument("-v", "--verbose", action="store_true", dest="logDebug", default=False, help="Show verbose debugging output")
+    batch.add_argument("-o", "--output", dest="outFile", default="identify_inbred",
+                       help="Output prefix: sample <name>.vcf writes <prefix>.<name>.scores.txt / .matches.json")
+    batch.add_argument("--batch_size", dest="batchSize", default=64, type=int, help="samples per device call")
+    batch.set_defaults(func=snpmatch_inbred_batch)
 
     cross = sub.add_parser('cross', help="SNPmatch on the crosses (F2s and F3s) of A. thaliana")
     common(cross, "identify_cross")

@@ -15,6 +15,7 @@ Division of labour
     ``*.scores.txt`` / ``*.matches.json``.
 """
 import logging
+import os
 import sys
 
 import numpy as np
@@ -261,7 +262,7 @@ def genotype_batch(inputs_list, g, out_files, skip_db_hets=False, chunk_size=100
     samples, common = [], []
     for inputs in inputs_list:
         inputs.filter_chr_names()
-        db_rows, sample_rows = g.get_positions_idxs(inputs.chrs, inputs.pos)
+        db_rows, sample_rows = g.get_positions_idxs(inputs.chrs, inputs.pos, _parsed=inputs)
         common.append((db_rows, sample_rows))
         samples.append((db_rows, inputs.wei[sample_rows, ]))
     res = engine.score_batch(g.panel(), samples, chunk_size, skip_db_hets, engine.MODE_EXACT, likelihoods=False)
@@ -276,9 +277,34 @@ def genotype_batch(inputs_list, g, out_files, skip_db_hets=False, chunk_size=100
                               n_matched, inputs.dp)
         out.print_out_table(out_files[b] + '.scores.txt')
         out.print_json_output(out_files[b] + ".matches.json")
-        getHeterozygosity(inputs.gt[common[b][1]], out_files[b] + ".matches.json")
+        codes = inputs.gt_codes_of(common[b][1]) if hasattr(inputs, "gt_codes_of") else None
+        getHeterozygosity(inputs.gt[common[b][1]] if codes is None else codes, out_files[b] + ".matches.json", _codes=codes)
         results.append(out)
     return results
+
+
+def potatoGenotyperBatch(args):
+    """entry point of ``snpmatch_amd inbred-batch`` (args: inFiles, hdf5File, hdf5accFile, outFile, logDebug, skip_db_hets,
+    batchSize): what ``potatoGenotyper`` writes for every sample, with the DB loaded once and ``batchSize`` samples per device
+    call.  Sample ``<dir>/<name>.<ext>`` writes ``<outFile>.<name>.scores.txt`` / ``.matches.json``."""
+    log.info("loading database files")
+    g = snp_genotype.Genotype(args['hdf5File'], args['hdf5accFile'])
+    files = list(args['inFiles'])
+    names = []
+    for f in files:
+        base = os.path.basename(f)
+        for ext in (".vcf.gz", ".vcf", ".bed", ".npz"):
+            if base.endswith(ext):
+                base = base[:-len(ext)]
+                break
+        names.append(base)
+    assert len(set(names)) == len(names), "sample file names must be distinct (they name the outputs)"
+    step = max(1, int(args.get('batchSize', 64) or 64))
+    for b0 in range(0, len(files), step):
+        inputs = [parse_inputs_once(f, args['logDebug']) for f in files[b0:b0 + step]]
+        log.info("scoring samples %d .. %d of %d", b0 + 1, b0 + len(inputs), len(files))
+        genotype_batch(inputs, g, ["%s.%s" % (args['outFile'], n) for n in names[b0:b0 + step]], skip_db_hets=args['skip_db_hets'])
+    log.info("finished!")
 
 
 def parse_inputs_once(in_file, log_debug):

@@ -182,6 +182,54 @@ def test_cli_inbred_and_cross(golden_dir, tmp_path):
     assert r.returncode == 1 and "input file does not exist" in r.stderr
 
 
+def test_cli_inbred_batch_writes_what_inbred_writes(golden_dir, tmp_path):
+    """`python -m snpmatch_amd inbred-batch`: three samples (a parsed .npz, the sample VCF, the sample BED) against one resident
+    DB, two per device call -- every sample's files equal what a single `inbred` run writes for it"""
+    import shutil
+    from snpmatch_amd.core import parsers
+    vcf = str(tmp_path / "s1.vcf.gz")
+    shutil.copy(os.path.join(golden_dir, "701_501.filter.vcf.gz"), vcf)
+    bed = str(tmp_path / "s2.bed")
+    shutil.copy(os.path.join(golden_dir, "701_502.filter.bed"), bed)
+    a, b = parsers.ParseInputs(vcf), parsers.ParseInputs(bed)
+    a.wait_for_cache()
+    b.wait_for_cache()
+    # a DB over the union of both samples' positions, 40 random accessions
+    chrs = np.concatenate([a.chrs, np.array(["Chr" + c if not str(c).lower().startswith("chr") else c for c in b.chrs])])
+    pos = np.concatenate([a.pos, b.pos])
+    key = np.unique(np.array([("%s\t%09d" % (str(c).lower().replace("chr", ""), p)) for c, p in zip(chrs, pos)]))
+    k_chr = np.array([k.split("\t")[0] for k in key])
+    k_pos = np.array([int(k.split("\t")[1]) for k in key])
+    names = sorted(set(k_chr.tolist()))
+    regions, start = [], 0
+    for c in names:
+        n = int(np.sum(k_chr == c))
+        regions.append((start, start + n))
+        start += n
+    rng = np.random.default_rng(11)
+    snps = rng.choice(np.array([-1, 0, 1, 2], dtype=np.int8), size=(len(key), 40), p=[0.05, 0.6, 0.33, 0.02])
+    db = str(tmp_path / "union.snpm")
+    snp_genotype.save_native(db, snps, np.array([str(i) for i in range(40)]), k_pos, np.array(names), np.array(regions))
+    third = str(tmp_path / "s3.npz")
+    np.savez(third, chr=a.chrs[::2], pos=a.pos[::2], gt=a.gt[::2], wei=a.wei[::2], dp=a.dp[::2])
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    out = str(tmp_path / "batch")
+    r = subprocess.run([sys.executable, "-m", "snpmatch_amd", "inbred-batch", "-i", vcf, bed, third, "-d", db, "-o", out, "--batch_size", "2"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for f, name in ((vcf, "s1"), (bed, "s2"), (third, "s3")):
+        single = str(tmp_path / ("single_" + name))
+        r = subprocess.run([sys.executable, "-m", "snpmatch_amd", "inbred", "-i", f, "-d", db, "-o", single],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert open("%s.%s.matches.json" % (out, name)).read() == open(single + ".matches.json").read(), name
+        cmp_scores_table(open("%s.%s.scores.txt" % (out, name)).read(), open(single + ".scores.txt").read())
+    # two inputs that would write the same files are refused
+    r = subprocess.run([sys.executable, "-m", "snpmatch_amd", "inbred-batch", "-i", vcf, vcf, "-d", db, "-o", out],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "distinct" in r.stderr
+
+
 @pytest.mark.parametrize("kind", ["f1", "f2", "f2hom"])
 def test_cross_interpreter_cases_match_reference(golden_dir, tmp_path, kind, cross_mode):
     """F1-like / F2-like samples: the whole cross pipeline incl. cross_interpreter (cases 5 and 6)."""
