@@ -166,14 +166,18 @@ class Genotyper(object):
     def get_common_positions(self):
         self.commonSNPs = self.g.get_positions_idxs(self.inputs.chrs, self.inputs.pos, _parsed=self.inputs)
 
-    def genotyper(self, filter_pos_ix=None, mask_acc_ix=None):
+    def genotyper(self, filter_pos_ix=None, mask_acc_ix=None, _filter_mask=None):
         """One pass over the matched SNPs.  ``filter_pos_ix``: restrict to these DB rows;
-        ``mask_acc_ix``: leave these accessions out of the returned result."""
+        ``mask_acc_ix``: leave these accessions out of the returned result.
+        (``_filter_mask``: the same restriction as a flag per DB row, ``filter_tophits``' shortcut.)"""
         self.get_common_positions()
         db_rows, sample_rows = self.commonSNPs
-        if filter_pos_ix is not None:
-            assert type(filter_pos_ix) is np.ndarray, "provide np array for indices to be considered"
-            sel = np.flatnonzero(np.isin(db_rows, filter_pos_ix))
+        if filter_pos_ix is not None or _filter_mask is not None:
+            if _filter_mask is not None:
+                sel = np.flatnonzero(np.asarray(_filter_mask)[db_rows])
+            else:
+                assert type(filter_pos_ix) is np.ndarray, "provide np array for indices to be considered"
+                sel = np.flatnonzero(np.isin(db_rows, filter_pos_ix))
             if len(sel) < 100:
                 log.info("#positions in segregating sites are are too little: %s" % len(sel))
             db_rows, sample_rows = db_rows[sel], sample_rows[sel]
@@ -235,9 +239,11 @@ class Genotyper(object):
             log.info("too many lines are indistinguishable, skipping refining likelihoods step")
             return None
         log.info("refining likelihoods for only indistinguishable lines")
-        segregating = self.g.identify_segregating_snps(top)
         others = np.flatnonzero(self.result.lrts >= lr_thres)
-        self.result_fine = self.genotyper(filter_pos_ix=segregating, mask_acc_ix=others)
+        if hasattr(self.g, "segregating_mask"):
+            self.result_fine = self.genotyper(mask_acc_ix=others, _filter_mask=self.g.segregating_mask(top))
+        else:
+            self.result_fine = self.genotyper(filter_pos_ix=self.g.identify_segregating_snps(top), mask_acc_ix=others)
         log.info("writing output: %s" % self.outFile + ".refined.scores.txt")
         self.result_fine.print_out_table(self.outFile + ".refined.scores.txt")
 

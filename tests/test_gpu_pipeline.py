@@ -67,6 +67,17 @@ def test_refine_matches_reference_files(golden_dir, tmp_path):
     cmp_scores_table(open(out + ".scores.txt").read(), gold["scores.txt"])
     cmp_scores_table(open(out + ".refined.scores.txt").read(), gold["refined.scores.txt"])
     assert open(out + ".matches.json").read() == gold["matches.json"]
+    if hasattr(gt, "result_fine"):
+        # filter_tophits restricts the second pass through a flag per DB row; the reference's interface (an index array through
+        # genotyper(filter_pos_ix=...), core/snpmatch.py:202-205) selects the same rows
+        top = np.flatnonzero(gt.result.lrts < snpmatch.lr_thres)
+        others = np.flatnonzero(gt.result.lrts >= snpmatch.lr_thres)
+        seg = gt.g.identify_segregating_snps(top)
+        assert np.array_equal(seg, np.flatnonzero(gt.g.segregating_mask(top)))
+        again = snpmatch.Genotyper(make_inputs(toy), make_g(toy), out + "_again", run_genotyper=False)
+        fine = again.genotyper(filter_pos_ix=seg, mask_acc_ix=others)
+        assert np.array_equal(fine.scores, gt.result_fine.scores) and np.array_equal(fine.ninfo, gt.result_fine.ninfo)
+        assert fine.num_snps == gt.result_fine.num_snps and np.array_equal(fine.accs, gt.result_fine.accs)
 
 
 def cmp_window_table(got_text, want_text, strict_scores=None):
