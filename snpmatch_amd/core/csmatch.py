@@ -141,7 +141,8 @@ class CrossIdentifier(object):
         summary_file = self.output_id + ".scores.txt.matches.json"
         totals = self.window_genotyper(self.output_id + '.windowscore.txt')
         totals.print_json_output(summary_file)
-        snpmatch.getHeterozygosity(self.inputs.gt[totals.matchedTarInd], summary_file)
+        codes = self.inputs.gt_codes_of(totals.matchedTarInd) if hasattr(self.inputs, "gt_codes_of") else None
+        snpmatch.getHeterozygosity(self.inputs.gt[totals.matchedTarInd] if codes is None else codes, summary_file, _codes=codes)
         with open(summary_file) as fh:
             self.cross_identfier_json = json.load(fh)                   # attribute name as in the reference
         self.result = self.match_insilico_f1s(totals, self.output_id + '.scores.txt')

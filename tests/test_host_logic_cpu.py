@@ -281,3 +281,34 @@ def test_packed_flat_panel_on_disk_reads_like_the_int8_matrix(tmp_path, golden_d
         snp_genotype.save_native(str(tmp_path / "odd.snpm"), odd, toy["accs"][:47], toy["positions"], toy["chrs"], toy["regions"], packed=True)
     assert cli.main(["makedb-native", "--packed", "-i", os.path.join(golden_dir, "h5", "toy_db.hdf5"), "-o", str(tmp_path / "q.snpm")]) == 0
     assert np.array_equal(np.asarray(snp_genotype.Genotype(str(tmp_path / "q.snpm"), None).g.snps), toy["snps"])
+
+
+def test_report_json_writer_equals_the_standard_library():
+    """_report._json_text writes what json.dumps(sort_keys=True, indent=4) writes (the reports' bytes are compared with the
+    reference's files) -- random nested structures incl. NaN / infinities, huge ints, numpy floats, escapes, a default hook"""
+    import json
+    import random
+    from snpmatch_amd.core import _report
+    from snpmatch_amd.core.csmatch import convert_int64
+    rnd = random.Random(5)
+
+    def rand(depth=0):
+        r = rnd.random()
+        if depth > 4 or r < 0.35:
+            return rnd.choice([None, True, False, 0, -17, 2 ** 70, 1.5, -0.0, 1e-300, 1e22, 123456789.123456789, float("nan"),
+                               float("inf"), -float("inf"), "", "abc", "tab\t\"q\"\\", "ünï cödé", np.float64(0.1) + 0.2, "\x00\x1f"])
+        if r < 0.65:
+            return [rand(depth + 1) for _ in range(rnd.randrange(0, 5))]
+        if r < 0.75:
+            return tuple(rand(depth + 1) for _ in range(rnd.randrange(0, 4)))
+        return {rnd.choice(["a", "B", "zz", "é", "k%d" % rnd.randrange(50), ""]): rand(depth + 1) for _ in range(rnd.randrange(0, 6))}
+
+    for _ in range(2000):
+        o = rand()
+        assert _report._json_text(o) == json.dumps(o, sort_keys=True, indent=4), o
+    o = {"a": np.int64(5), "b": [np.int64(7), 1.0], "c": object()}
+    assert _report._json_text(o, convert_int64) == json.dumps(o, sort_keys=True, indent=4, default=convert_int64)
+    with pytest.raises(_report._NotPlain):
+        _report._json_text({1: 2})                     # anything the fast writer is not sure about goes to json.dumps
+    with pytest.raises(_report._NotPlain):
+        _report._json_text({"x": {3, 4}})
