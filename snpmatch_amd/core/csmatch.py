@@ -20,7 +20,7 @@ import logging
 import os
 
 import numpy as np
-import pandas as pd
+from ._report import pd          # pandas, imported at first use
 
 from . import _report
 from . import genomes
@@ -249,7 +249,7 @@ class CrossIdentifier(object):
             snpmatch_result.ninfo = np.append(snpmatch_result.ninfo, extra_n)
             snpmatch_result.accs = np.append(snpmatch_result.accs, extra_a)
         if out_file is not None:
-            snpmatch_result.print_out_table(out_file)
+            snpmatch_result.print_out_table(out_file, _frame=False)
         return snpmatch_result
 
     def cross_interpreter(self, out_file):

@@ -19,7 +19,7 @@ import re
 import sys
 
 import numpy as np
-import pandas as pd
+from ._report import pd          # pandas, imported at first use
 
 from . import _report
 from . import _vcf

@@ -126,12 +126,16 @@ class GenotyperOutput(object):
         self.get_likelihoods()
         self.get_probabilities()
 
-    def print_out_table(self, outFile):
+    def print_out_table(self, outFile, _frame=True):
+        """``*.scores.txt`` + the table as a DataFrame (:122-138).  ``_frame=False`` (the package's own callers, which drop the
+        return value): no DataFrame is built -- an `inbred` run then never imports pandas."""
         self._refresh()
         dp_mean = _report.mean_depth(self.dp)        # once: a pass over the sample's depth column
         if outFile:
             _report.write_scores_table(outFile, self.accs, self.scores, self.ninfo, self.probabilies, self.likelis, self.lrts,
                                        self.num_snps, dp_mean)
+        if not _frame:
+            return None
         return _report.scores_frame(self.accs, self.scores, self.ninfo, self.probabilies, self.likelis, self.lrts,
                                     self.num_snps, dp_mean)
 
@@ -219,7 +223,7 @@ class Genotyper(object):
 
     def write_genotyper_output(self, result):
         log.info("writing score file!")
-        result.print_out_table(self.outFile + '.scores.txt')
+        result.print_out_table(self.outFile + '.scores.txt', _frame=False)
         result.print_json_output(self.outFile + ".matches.json")
         codes = self.inputs.gt_codes_of(self.commonSNPs[1]) if hasattr(self.inputs, "gt_codes_of") else None
         getHeterozygosity(self.inputs.gt[self.commonSNPs[1]] if codes is None else codes, self.outFile + ".matches.json", _codes=codes)
@@ -245,7 +249,7 @@ class Genotyper(object):
         else:
             self.result_fine = self.genotyper(filter_pos_ix=self.g.identify_segregating_snps(top), mask_acc_ix=others)
         log.info("writing output: %s" % self.outFile + ".refined.scores.txt")
-        self.result_fine.print_out_table(self.outFile + ".refined.scores.txt")
+        self.result_fine.print_out_table(self.outFile + ".refined.scores.txt", _frame=False)
 
 
 def getHeterozygosity(snpGT, outFile='default', _codes=None):
@@ -281,7 +285,7 @@ def genotype_batch(inputs_list, g, out_files, skip_db_hets=False, chunk_size=100
         n_matched = len(common[b][0])
         out = GenotyperOutput(g.g.accessions, res["score"][b], res["ninfo"][b], get_fraction(n_matched, len(inputs.pos)),
                               n_matched, inputs.dp)
-        out.print_out_table(out_files[b] + '.scores.txt')
+        out.print_out_table(out_files[b] + '.scores.txt', _frame=False)
         out.print_json_output(out_files[b] + ".matches.json")
         codes = inputs.gt_codes_of(common[b][1]) if hasattr(inputs, "gt_codes_of") else None
         getHeterozygosity(inputs.gt[common[b][1]] if codes is None else codes, out_files[b] + ".matches.json", _codes=codes)

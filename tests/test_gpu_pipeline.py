@@ -324,6 +324,12 @@ def test_config1_sample_vcf_through_cli(golden_dir, tmp_path):
     assert js["interpretation"]["case"] == 0 and js["matches"][0][0] == accs[planted]
     assert js["overlap"] == [1.0, 7545] and js["percent_heterozygosity"] == 110 / 7545.0
     assert os.path.exists(vcf + ".snpmatch.npz") and os.path.exists(vcf + ".snpmatch.stats.json")
+    # such a run imports neither pandas nor torch (most of a second of a cold start), and it ran on the library
+    probe = ("import sys; from snpmatch_amd import cli; rc = cli.main(['inbred', '-i', %r, '-d', %r, '-o', %r]); "
+             "print('RC', rc, 'PANDAS', 'pandas' in sys.modules, 'TORCH', 'torch' in sys.modules)" % (vcf, db, out + "_again"))
+    r = subprocess.run([sys.executable, "-c", probe], env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=300)
+    assert "RC 0 PANDAS False TORCH False" in r.stdout, (r.stdout, r.stderr[-2000:])
+    assert open(out + "_again.scores.txt").read() == open(out + ".scores.txt").read()
 
 
 def test_inbred_on_packed_panel_matches_reference_files(golden_dir, tmp_path, monkeypatch):
