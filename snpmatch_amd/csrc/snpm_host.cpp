@@ -93,7 +93,12 @@ int snpm_intersect_sorted_search(const int64_t *a, int64_t na, const int64_t *b,
         const int64_t lo = (j0 < j1) ? (int64_t)(std::lower_bound(a, a + na, b[j0]) - a) : 0;
         cnt[(size_t)t] = gallop_range(a, na, b, j0, j1, lo, ia, ib);
     };
-    pool.run(n_thr, work);
+    {
+        // the pool runs one job at a time, and ctypes calls arrive without the GIL: callers on several Python threads take turns
+        static std::mutex one_job;
+        std::lock_guard<std::mutex> turn(one_job);
+        pool.run(n_thr, work);
+    }
     int64_t k = cnt[0];
     for (int t = 1; t < n_thr; ++t) {
         const int64_t j0 = start[(size_t)t];

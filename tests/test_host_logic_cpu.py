@@ -312,3 +312,27 @@ def test_report_json_writer_equals_the_standard_library():
         _report._json_text({1: 2})                     # anything the fast writer is not sure about goes to json.dumps
     with pytest.raises(_report._NotPlain):
         _report._json_text({"x": {3, 4}})
+
+
+def test_native_intersection_from_several_python_threads():
+    """ctypes calls run without the GIL: eight threads intersect at once (the library's shared host pool runs one job at a time,
+    the callers take turns) and each gets the single-threaded answer"""
+    import threading
+    from snpmatch_amd import _lib
+    rng = np.random.default_rng(1)
+    a = np.sort(rng.choice(5_000_000, size=800_000, replace=False)).astype(np.int64)
+    bs = [np.sort(rng.choice(a, size=30_000 + 1000 * k, replace=False)) for k in range(8)]
+    want = [_lib.intersect_sorted(a, b, a_verified=True) for b in bs]
+    got = [None] * 8
+
+    def run(k):
+        for _ in range(10):
+            got[k] = _lib.intersect_sorted(a, bs[k], a_verified=True)
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for g, w in zip(got, want):
+        assert np.array_equal(g[0], w[0]) and np.array_equal(g[1], w[1])
