@@ -265,3 +265,37 @@ def test_native_vcf_reader_inflates_bgzf_members_side_by_side(golden_dir, tmp_pa
     assert _lib.vcf_parse(bg, 0) is None
     open(bg, "wb").write(bytes(raw) + b"garbage-that-is-no-member")
     assert _lib.vcf_parse(bg, 0) is None
+
+
+def test_parse_cache_is_read_through_one_memory_map(tmp_path):
+    """the .npz parse cache (np.savez: stored members) is opened as views of one memory map instead of through zipfile; the arrays
+    equal np.load's, and anything else (compressed members, object arrays) is left to np.load"""
+    rng = np.random.default_rng(3)
+    n = 5000
+    pl = rng.integers(0, 200, size=(n, 3)).astype(float)
+    wei = np.exp(pl / -10)
+    p = parsers.ParseInputs("")
+    p.load_snp_info(np.array(["Chr%d" % (1 + i * 5 // n) for i in range(n)]), np.arange(n) * 7 + 1,
+                    rng.choice(np.array(["0/0", "1/1", "0/1", "./."]), size=n), wei, rng.integers(1, 40, n))
+    p._adopt_codes(parsers._weight_codes(pl, np.zeros(n, bool), wei))
+    path = str(tmp_path / "s.vcf.snpmatch")
+    p.save_snp_info(path)
+    fast, slow = parsers._StoredNpz.open(path + ".npz"), np.load(path + ".npz")
+    assert fast is not None and sorted(fast.files) == sorted(slow.files)
+    for k in slow.files:
+        assert fast[k].dtype == slow[k].dtype and fast[k].shape == slow[k].shape and np.array_equal(fast[k], slow[k]), k
+    q = parsers.ParseInputs("")
+    q._load_npz(path + ".npz")
+    for k in ("chrs", "pos", "gt", "wei", "dp"):
+        assert np.array_equal(getattr(q, k), getattr(p, k)), k
+    assert q.weight_codes() is not None and np.array_equal(q.weight_codes()[0], p.weight_codes()[0])
+    # BED-style cache: dp is the string "NA" (a 0-d member), no codes stored
+    np.savez(str(tmp_path / "bed.npz"), chr=p.chrs, pos=p.pos, gt=p.gt, wei=np.eye(3)[rng.integers(0, 3, n)], dp="NA")
+    b = parsers.ParseInputs("")
+    b._load_npz(str(tmp_path / "bed.npz"))
+    assert str(b.dp) == "NA" and b.weight_codes() is not None and b.weight_codes()[1].tolist() == [0.0, 1.0]
+    np.savez_compressed(str(tmp_path / "c.npz"), a=np.arange(5))
+    assert parsers._StoredNpz.open(str(tmp_path / "c.npz")) is None
+    np.savez(str(tmp_path / "o.npz"), a=np.array([{"x": 1}], dtype=object))
+    assert parsers._StoredNpz.open(str(tmp_path / "o.npz")) is None
+    assert parsers._StoredNpz.open(str(tmp_path / "missing.npz")) is None
