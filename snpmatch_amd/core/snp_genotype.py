@@ -132,7 +132,7 @@ def _load_any(path):
         g.npy_path = os.path.join(path, "snps.npy")      # lets Genotype.panel() stream the file natively
         return g
     if path.endswith(".npz"):
-        d = np.load(path)
+        d = parsers._StoredNpz.open(path) or np.load(path)       # stored members: views of one memory map (no pass through zipfile)
         return MemGenotype(d["snps"], d["accessions"], d["positions"], np.asarray(d["chrs"]).astype("U"), d["chr_regions"])
     # The reference's HDF5 DB (pygwas/genotype.py:310-326, :534-673): read by the library's own reader (csrc/snpm_h5.cpp) -- no
     # h5py / libhdf5 needed, and the chunks go from the file through the loader's threads into the staging slabs.  Files in a
