@@ -72,7 +72,7 @@ struct snpm_ctx {
     Buf ws_once_state;                  // {ticket, bad-input bits} of k_once_prep / k_once_finish: zero between calls
     bool once_state_clean = false;
     int once_fused = 1;                 // SNPM_ONCE_FUSED=0: snpm_genotype_once keeps the unfused kernels and copies of its first version
-    int once_zero_copy = -1;            // SNPM_ONCE_ZEROCOPY: 1 the fused form reads the pinned slab in place, 0 it goes through the copy engine; unset: coded samples (10 B per SNP) in place, fp64 samples (32 B) through the copy engine behind the fill
+    int once_zero_copy = 1;             // SNPM_ONCE_ZEROCOPY=0: the fused form sends the slab through the copy engine (two pieces behind the fill) instead of reading it in place
     Buf ws_seg_desc, ws_eseg, ws_pairs, ws_pair_sums, ws_bscore, ws_bninfo, ws_blut, ws_brows, ws_brows32, ws_bw, ws_bcodes;   // segmented / batched scoring
     int64_t *h_desc = nullptr;          // pinned host image of ws_seg_desc
     size_t h_desc_cap = 0;

@@ -168,22 +168,46 @@ k_once_prep(const void *src_rows, const void *src_wei, const double *__restrict_
         for (int64_t t0 = r0; t0 < r1; t0 += ONCE_SUB) {
             const int64_t t1 = (t0 + ONCE_SUB < r1) ? t0 + ONCE_SUB : r1;
             __syncthreads();                              // the previous sub-tile has been consumed
+            // every load of the sub-tile is issued before the first one is waited for: over the bus a load takes ~2 us, and
+            // one at a time (row index, then staged word after staged word) they made the kernel latency-bound
+            constexpr int RPT = ONCE_SUB / 256;           // rows per thread and sub-tile
+            int64_t prow_in[RPT];
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int64_t r = t0 + tid + 256 * j;
+                prow_in[j] = r < t1 ? (CODED ? (int64_t)reinterpret_cast<const int32_t *>(src_rows)[r] : reinterpret_cast<const int64_t *>(src_rows)[r]) : 0;
+            }
             int shift = 0;                                // CODED: first code of the sub-tile inside its first staged dword (0 or 1)
             if constexpr (CODED) {
                 const int64_t b0 = 6 * t0, b1 = 6 * t1, a0 = b0 & ~(int64_t)3;
                 const int n_dw = (int)((b1 - a0 + 3) / 4);
                 const uint32_t *src = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(src_wei) + a0);
                 uint32_t *dst = reinterpret_cast<uint32_t *>(s_w);
-                for (int e = tid; e < n_dw; e += 256) dst[e] = src[e];
+                constexpr int WPT = (ONCE_SUB * 6 / 4 + 1 + 255) / 256;        // staged dwords per thread
+                uint32_t v[WPT];
+#pragma unroll
+                for (int j = 0; j < WPT; ++j) v[j] = (tid + 256 * j < n_dw) ? src[tid + 256 * j] : 0u;
+#pragma unroll
+                for (int j = 0; j < WPT; ++j)
+                    if (tid + 256 * j < n_dw) dst[tid + 256 * j] = v[j];
                 shift = (int)((b0 - a0) / 2);
             } else {
                 const double *src = reinterpret_cast<const double *>(src_wei) + 3 * t0;
                 const int n_el = (int)(3 * (t1 - t0));
-                for (int e = tid; e < n_el; e += 256) s_w[e] = src[e];
+                constexpr int WPT = ONCE_SUB * 3 / 256;
+                double v[WPT];
+#pragma unroll
+                for (int j = 0; j < WPT; ++j) v[j] = (tid + 256 * j < n_el) ? src[tid + 256 * j] : 0.0;
+#pragma unroll
+                for (int j = 0; j < WPT; ++j)
+                    if (tid + 256 * j < n_el) s_w[tid + 256 * j] = v[j];
             }
             __syncthreads();
-            for (int64_t r = t0 + tid; r < t1; r += 256) {
-                int64_t prow = CODED ? (int64_t)reinterpret_cast<const int32_t *>(src_rows)[r] : reinterpret_cast<const int64_t *>(src_rows)[r];
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int64_t r = t0 + tid + 256 * j;
+                if (r >= t1) break;
+                int64_t prow = prow_in[j];
                 if (prow < 0 || prow >= n_snp) { prow = 0; bad |= 1; }
                 double w0, w1, w2;
                 const int l = (int)(r - t0);

@@ -210,9 +210,9 @@ def _ctx_with(**env):
 
 
 def test_fused_and_unfused_forms_of_the_call_agree():
-    """the short form of snpm_genotype_once (k_once_prep + k_once_finish; by default coded samples are read in place from the pinned
-    slab and fp64 samples go through the copy engine behind the fill), both transports forced for both kinds of sample, and the
-    first version's kernels and copies return the same bits -- plain and coded,
+    """the short form of snpm_genotype_once (k_once_prep + k_once_finish; by default the sample is read in place from the pinned
+    slab), the same with the sample sent through the copy engine behind the fill, and the first version's kernels and copies
+    return the same bits -- plain and coded,
     with forced sparse-tier and dense-tier re-evaluations, and with a chunk above the fused form's limit"""
     from snpmatch_amd.core import parsers
     rng = np.random.default_rng(2024)
