@@ -86,7 +86,7 @@ def _window_segments_sorted(genome, db, sample, bin_len):
         hit = _lib.intersect_sorted(p1, p2, a_verified=True)
         if hit is None:                                    # sample positions not strictly increasing
             return None
-        win = (p1[hit[0]] - 1) // bin_len
+        win = (p2[hit[1]] - 1) // bin_len                  # (matched positions are equal: the sample side is the short, contiguous one)
         inside = win < n_win
         per_db.append(row0 + hit[0][inside])
         per_sample.append(int(mine[0]) + hit[1][inside])
