@@ -46,7 +46,7 @@ for n_acc in (1, 2, 3, 7):
             for skip in (False, True):
                 rs, rn = ref_sm.matchGTsAccs(wei, db.copy(), skip)
                 ps, pn = orc.match_gts_accs(wei, db, skip)
-                cs, cn = c_oracle.match_gts_accs(wei, db, skip)
+                cs, cn = c_oracle.match(wei, db, skip)
                 tot += 1
                 same = np.array_equal(bits(rs), bits(ps)) and np.array_equal(bits(rs), bits(cs)) and np.array_equal(rn, pn) and np.array_equal(rn, cn)
                 if not same:
