@@ -299,3 +299,24 @@ def test_parse_cache_is_read_through_one_memory_map(tmp_path):
     np.savez(str(tmp_path / "o.npz"), a=np.array([{"x": 1}], dtype=object))
     assert parsers._StoredNpz.open(str(tmp_path / "o.npz")) is None
     assert parsers._StoredNpz.open(str(tmp_path / "missing.npz")) is None
+
+
+def test_gt_codes_of_equals_parse_gt_of_the_gathered_strings():
+    """ParseInputs.gt_codes_of(rows) == parseGT(gt[rows]) -- including parseGT's habit of taking the separator from the FIRST entry
+    it is given (a mixed '/' and '|' column parses differently depending on which row leads); cached per separator and per array"""
+    gt = np.array(["0/0", "0/1", "1|1", "./.", "1/0", "0|1", ".|.", "1/1"] * 7)
+    p = parsers.ParseInputs("")
+    p.load_snp_info(["1"] * len(gt), np.arange(len(gt)), gt, np.zeros((len(gt), 3)), 3)
+    rng = np.random.default_rng(2)
+    for _ in range(30):
+        rows = rng.choice(len(gt), size=int(rng.integers(1, 40)), replace=False)
+        assert np.array_equal(p.gt_codes_of(rows), parsers.parseGT(p.gt[rows])), rows
+    assert len(p.gt_codes_of(np.zeros(0, dtype=int))) == 0
+    cached = p._gt_code_cache["/"][1]
+    p.gt_codes_of(np.array([0, 1]))
+    assert p._gt_code_cache["/"][1] is cached                     # the column is parsed once per separator
+    p.gt = np.array(["1/1"] * len(gt))                            # a new column: parsed again
+    assert p.gt_codes_of(np.array([3, 4])).tolist() == [1, 1]
+    q = parsers.ParseInputs("")
+    q.load_snp_info(["1", "1"], [1, 2], np.array(["0", "1"]), np.zeros((2, 3)), 3)      # numeric codes: no separator, the caller parses
+    assert q.gt_codes_of(np.array([0, 1])) is None
