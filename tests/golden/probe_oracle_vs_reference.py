@@ -5,7 +5,7 @@ shapes the committed goldens do not hold -- 1 ... 7 accessions, n from 1 to 50 0
 hard-call and PL weights, both skip_hets settings -- fp64 bit patterns and counts.  Round 3's verdict found the one-accession
 divergence with a probe like this one; it is kept so that the next shape question takes a minute.
 
-    python tests/golden/probe_oracle_vs_reference.py          # prints "cases N diffs 0"
+    python tests/golden/probe_oracle_vs_reference.py [seed]   # prints "cases N diffs 0" (matchGTsAccs shapes, then likelihood / LRT / identity on random counts)
 """
 import os
 import sys
@@ -52,5 +52,23 @@ for n_acc in (1, 2, 3, 7):
                 if not same:
                     bad += 1
                     print("DIFF n_acc %d n %d frac_pl %.1f skip %s" % (n_acc, n, frac_pl, skip))
+# likelihood / ratio (core/snpmatch.py:40-55, :106-117) and the identity test (:57-72) on random counts, integer and float scores
+for _ in range(200):
+    m = int(rng.integers(1, 400))
+    ninfo = rng.integers(0, 5000, size=m)
+    scores = np.minimum(ninfo, rng.integers(0, 5000, size=m)).astype(float)
+    if rng.integers(0, 2):
+        scores = scores * rng.random(m)                       # window scores are floats
+    if rng.integers(0, 3) == 0:
+        scores[rng.integers(0, m)] = ninfo[rng.integers(0, m)] = 0
+    scores = np.minimum(scores, ninfo)
+    rl, rr = ref_sm.GenotyperOutput.calculate_likelihoods(scores, ninfo)
+    ol, orr = orc.calculate_likelihoods(scores, ninfo)
+    ri = ref_sm.np_test_identity(scores, ninfo, 0.02)
+    oi = orc.test_identity(scores, ninfo, 0.02)
+    tot += 1
+    if not (np.array_equal(bits(rl), bits(ol)) and np.array_equal(bits(rr), bits(orr)) and np.array_equal(np.asarray(ri).astype(int), np.asarray(oi).astype(int))):
+        bad += 1
+        print("DIFF likelihood / identity, m %d" % m)
 print("cases %d diffs %d" % (tot, bad))
 sys.exit(1 if bad else 0)
