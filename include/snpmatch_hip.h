@@ -241,7 +241,8 @@ int snpm_genotype_once_coded(snpm_panel *panel, const int64_t *row_idx, const ui
    return in one copy.  Outputs (host, may be NULL; lik and lrt both or neither): score / ninfo / lik / lrt [B, n_acc].
    mode as snpm_query_run: EXACT = int(score) and ninfo bit-exact per sample.
    info (may be NULL) int64 [4]: [0] (sample, accession) pairs re-scored in reference order, [1] 1 = every sample went
-   through the strict pass (more uncertain pairs than the sparse tier takes). */
+   through the strict pass (more uncertain pairs than the sparse tier takes), [2] 1 = scored by the shared-row pass
+   (snpm_batch_configure below), [3] its union rows. */
 int snpm_score_batch(snpm_panel *panel, int64_t n_samples, const int64_t *sample_off, const void *row_idx, const void *wei,
                      int device_inputs, int64_t chunk, int skip_hets, int mode, double *score, int64_t *ninfo,
                      double *lik, double *lrt, int64_t *info);
@@ -254,6 +255,28 @@ int snpm_score_batch(snpm_panel *panel, int64_t n_samples, const int64_t *sample
 int snpm_score_batch_coded(snpm_panel *panel, int64_t n_samples, const int64_t *sample_off, const int64_t *row_idx,
                            const uint16_t *codes, const double *table, int64_t table_len, int64_t chunk, int skip_hets,
                            int mode, double *score, int64_t *ninfo, double *lik, double *lrt, int64_t *info);
+
+/* Batches whose samples SHARE DB rows (many samples genotyped on largely the same markers, the production use of the reference:
+   one `snpmatch inbred` process per sample over the same panel, core/snpmatch.py:218-225 per sample): instead of one gathered pass
+   per sample, the union of the batch's matched rows is formed on the device, every DB row is read ONCE and scored against all
+   samples as an int8 MFMA contraction -- the weights as fixed-point numbers of `digits` base-256 digits (w in [0, 1] ->
+   floor(w 2^F), F = 8 (digits - 1) + 6), the panel rows as one-hot class bytes, products added exactly in int32.  The pass has
+   no rounding error, only the one-sided quantisation n_inexact 2^-F per sample; the certificate of SNPM_MODE_EXACT covers it and
+   the unproven (sample, accession) pairs are re-scored in reference order as before: int(score) and ninfo stay bit-exact.
+   Taken when every sample's row list is strictly increasing, all weights lie in [0, 1] and the panel holds no call code > 2;
+   otherwise (and in SNPM_MODE_STRICT) the per-sample pass runs.
+     shared_rows  -1 (default; SNPM_BATCH_SHARED) automatic: batches whose inputs are already on the device (device_inputs != 0),
+                  of at least 8 samples, with at least min_density calls per (sample, union row) slot;  0 never;
+                  1 whenever the batch allows it (host batches are uploaded whole first)
+     digits       3..7 (default 7: 2^-54 per matched SNP; SNPM_SHARED_DIGITS); 0 keeps the current value
+     min_density  threshold of the automatic choice (default 0.25; SNPM_SHARED_MIN_DENSITY); negative keeps the current value
+   snpm_score_batch[_coded] report in info[2] whether the shared-row pass scored the batch and in info[3] its union rows. */
+int snpm_batch_configure(snpm_ctx *ctx, int shared_rows, int digits, double min_density);
+/* stats int64 [8] of the context's last snpm_score_batch[_coded] call: [0] 1 = shared-row pass taken, [1] else why not (1 policy,
+   2 too few samples or rows, 3 a row list not strictly increasing, 4 a weight outside [0, 1], 5 call codes > 2 in the panel,
+   6 overlap below min_density, 7 sizes beyond 32-bit indices), [2] union rows, [3] density * 1e6, [4] row tiles, [5] groups of
+   128 matrix rows, [6] passes over groups, [7] digits */
+int snpm_batch_last_stats(snpm_ctx *ctx, int64_t *stats);
 
 /* pinned host memory (hipHostMalloc): batch inputs built in it go to the device at full PCIe speed without the
    staging copy (snpm_score_batch recognises pinned pointers) */

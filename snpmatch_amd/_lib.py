@@ -40,7 +40,7 @@ SYMBOLS = [
     "snpm_vcf_parse", "snpm_vcf_dims", "snpm_vcf_fill", "snpm_vcf_fill_u32", "snpm_vcf_sample_name", "snpm_vcf_free",
     "snpm_debug_stream_read", "snpm_profile_enable", "snpm_profile_reset", "snpm_profile_read",
     "snpm_panel_fill_synthetic_rows", "snpm_sample_synthetic", "snpm_query_create_device", "snpm_query_last_reeval",
-    "snpm_query_last_kernel", "snpm_carry_create", "snpm_carry_reset", "snpm_carry_free", "snpm_carry_set_columns", "snpm_carry_bind_outputs", "snpm_panel_segregating_first", "snpm_query_gather_columns", "snpm_query_run_windows_fast", "snpm_score_batch", "snpm_score_batch_coded", "snpm_genotype_once", "snpm_genotype_once_coded", "snpm_host_alloc", "snpm_host_free",
+    "snpm_query_last_kernel", "snpm_carry_create", "snpm_carry_reset", "snpm_carry_free", "snpm_carry_set_columns", "snpm_carry_bind_outputs", "snpm_panel_segregating_first", "snpm_query_gather_columns", "snpm_query_run_windows_fast", "snpm_score_batch", "snpm_score_batch_coded", "snpm_batch_configure", "snpm_batch_last_stats", "snpm_genotype_once", "snpm_genotype_once_coded", "snpm_host_alloc", "snpm_host_free",
     "snpm_query_run_carry", "snpm_carry_finish", "snpm_carry_patch", "snpm_carry_device_ptrs", "snpm_carry_error_bound",
     "snpm_group_unique_id", "snpm_group_create_rank", "snpm_group_create_local", "snpm_group_free", "snpm_group_last_error",
     "snpm_group_info", "snpm_group_ctx", "snpm_group_shard", "snpm_group_gather_scores", "snpm_group_gathered_ptrs",
@@ -211,6 +211,8 @@ def load():
     lib.snpm_host_alloc.argtypes = [p, i64, pp]
     lib.snpm_host_free.argtypes = [p, p]
     lib.snpm_score_batch.argtypes = [p, i64, p, p, p, ci, i64, ci, ci, p, p, p, p, p]
+    lib.snpm_batch_configure.argtypes = [p, ci, ci, dbl]
+    lib.snpm_batch_last_stats.argtypes = [p, p]
     lib.snpm_score_dense_host.argtypes = [p, p, i64, i64, i64, p, ci, p, p]
     lib.snpm_likelihood.argtypes = [p, p, p, i64, i64, ci, dbl, p, p]
     lib.snpm_likelihood_device.argtypes = [p, p, p, i64, i64, ci, dbl, p, p, C.POINTER(ci)]

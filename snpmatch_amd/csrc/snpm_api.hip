@@ -74,6 +74,15 @@ struct snpm_ctx {
     int once_fused = 1;                 // SNPM_ONCE_FUSED=0: snpm_genotype_once keeps the unfused kernels and copies of its first version
     int once_zero_copy = 1;             // SNPM_ONCE_ZEROCOPY=0: the fused form sends the slab through the copy engine (two pieces behind the fill) instead of reading it in place
     Buf ws_seg_desc, ws_eseg, ws_pairs, ws_pair_sums, ws_bscore, ws_bninfo, ws_blut, ws_brows, ws_brows32, ws_bw, ws_bcodes;   // segmented / batched scoring
+    // shared-row scan of a batch (snpm_api_shared.hpp): union of the samples' rows, the int8 digit matrix, partial digit sums
+    Buf ws_sh_bitmap, ws_sh_wordbase, ws_sh_blocks, ws_sh_urows, ws_sh_meta, ws_sh_A, ws_sh_pos, ws_sh_partial;
+    int batch_shared = -1;              // SNPM_BATCH_SHARED / snpm_batch_configure: -1 auto (batches whose inputs are on the device), 0 never, 1 whenever the batch allows it
+    int shared_digits = 7;              // base-256 digits of the fixed-point weights (3..7): 2^-(8 (digits - 1) + 6) per matched SNP of quantisation
+    int shared_min_samples = 8;         // auto: smaller batches keep the per-sample pass
+    double shared_min_density = 0.25;   // auto: calls per (sample, union row) slot below which the per-sample pass reads fewer bytes than the contraction computes
+    size_t shared_ws_bytes = size_t(2) << 30;   // SNPM_SHARED_WS_MB: digit matrix per pass over groups of samples
+    int shared_force_tiles = 0;         // SNPM_SHARED_TILES: row tiles of k_sh_mfma (tests, experiments)
+    int64_t shared_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // snpm_batch_last_stats
     int64_t *h_desc = nullptr;          // pinned host image of ws_seg_desc
     size_t h_desc_cap = 0;
     int stage_which = 0;                // next staging slab of stage_bytes
@@ -386,6 +395,8 @@ int wait_upload(snpm_panel *p)
 #include "snpm_api_strict.hpp"
 
 #include "snpm_api_seg.hpp"
+
+#include "snpm_api_shared.hpp"
 }  // namespace
 
 #include "snpm_loader.hpp"
@@ -467,6 +478,11 @@ try {
     if (const char *s = getenv("SNPM_ONCE_FUSED")) ctx->once_fused = atoi(s) != 0;
     if (const char *s = getenv("SNPM_ONCE_ZEROCOPY")) ctx->once_zero_copy = atoi(s) != 0;
     if (const char *s = getenv("SNPM_DEBUG_MAX_PARTS")) ctx->debug_max_parts = atoi(s);
+    if (const char *s = getenv("SNPM_BATCH_SHARED")) ctx->batch_shared = atoi(s) < 0 ? -1 : (atoi(s) ? 1 : 0);
+    if (const char *s = getenv("SNPM_SHARED_DIGITS")) ctx->shared_digits = std::min(7, std::max(3, atoi(s)));
+    if (const char *s = getenv("SNPM_SHARED_MIN_DENSITY")) ctx->shared_min_density = atof(s);
+    if (const char *s = getenv("SNPM_SHARED_WS_MB")) ctx->shared_ws_bytes = (size_t)std::max(1, atoi(s)) << 20;
+    if (const char *s = getenv("SNPM_SHARED_TILES")) ctx->shared_force_tiles = std::max(0, atoi(s));
     ctx->stage_threads = default_stage_threads();
     if (const char *s = getenv("SNPM_STAGE_THREADS")) ctx->stage_threads = std::max(1, atoi(s));
     if (const char *s = getenv("SNPM_STAGE_MB")) ctx->ld_want = (size_t)std::max(1, atoi(s)) << 20;
@@ -544,7 +560,9 @@ int snpm_destroy(snpm_ctx *ctx)
                        &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
                        &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r, &ctx->ws_wprops, &ctx->ws_epart,
                        &ctx->ws_seg_desc, &ctx->ws_eseg, &ctx->ws_pairs, &ctx->ws_pair_sums, &ctx->ws_bscore, &ctx->ws_bninfo,
-                       &ctx->ws_blut, &ctx->ws_brows, &ctx->ws_brows32, &ctx->ws_bw, &ctx->ws_bcodes};
+                       &ctx->ws_blut, &ctx->ws_brows, &ctx->ws_brows32, &ctx->ws_bw, &ctx->ws_bcodes,
+                       &ctx->ws_sh_bitmap, &ctx->ws_sh_wordbase, &ctx->ws_sh_blocks, &ctx->ws_sh_urows, &ctx->ws_sh_meta, &ctx->ws_sh_A,
+                       &ctx->ws_sh_pos, &ctx->ws_sh_partial};
         for (Buf *b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);

@@ -585,9 +585,28 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
         if (rc) return rc;
     }
     const double t_planned = now();
+    // Shared-row scan (snpm_api_shared.hpp): when the samples were genotyped on largely the same markers, every DB row is read
+    // once and scored against all of them (int8 MFMA contraction of fixed-point weight digits), same certificate, same
+    // reference-order re-evaluation of the unproven pairs.  It needs the whole batch on the device first: batches from host
+    // memory keep the per-sample pass and its upload overlap unless the policy says "whenever possible".
+    const int policy = ctx->batch_shared;
+    const bool try_shared = !strict_all && policy != 0 && (policy > 0 || device_inputs);
+    SharedStats shst;
+    shst.reason = 1;
+    auto shared_or_segments = [&]() -> int {        // every input is on the device (or ordered before what is enqueued here)
+        const SegJob keep = j;
+        int r = shared_rows_try(ctx, j, policy > 0, shst);
+        if (r) return r;
+        if (!shst.taken) {
+            j = keep;
+            r = seg_launch(ctx, j, pl, 0, n_samples);
+        }
+        return r;
+    };
     if (device_inputs) {
         rc = prepare_rows(0, N, nullptr);
-        if (!rc && !strict_all) rc = seg_launch(ctx, j, pl, 0, n_samples);
+        if (!rc && try_shared) rc = shared_or_segments();
+        else if (!rc && !strict_all) rc = seg_launch(ctx, j, pl, 0, n_samples);
         if (rc) return rc;
     } else {
         // Host inputs: the batch is cut into runs of samples of about one staging slab; while run k is scored, run
@@ -637,12 +656,16 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
                 HIPCHK(ctx, hipGetLastError());
             }
             rc = prepare_rows(r0, r1, rows32);
-            if (!rc && !strict_all) rc = seg_launch(ctx, j, pl, s0, s1);
+            if (!rc && !strict_all && !try_shared) rc = seg_launch(ctx, j, pl, s0, s1);
             if (rc) return rc;
             t_launch += now() - ts1;
             s0 = s1;
         }
+        if (try_shared && (rc = shared_or_segments())) return rc;
     }
+    ctx->shared_last[0] = shst.taken; ctx->shared_last[1] = shst.reason; ctx->shared_last[2] = shst.union_rows;
+    ctx->shared_last[3] = (int64_t)(shst.density * 1e6); ctx->shared_last[4] = shst.tiles; ctx->shared_last[5] = shst.groups;
+    ctx->shared_last[6] = shst.passes; ctx->shared_last[7] = shst.digits;
     const double t_enqueued = now();
     int n_pairs = 0;
     if (strict_all) {
@@ -686,7 +709,26 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
                 t_planned - t_begin, t_enqueued - t_planned, t_stage, t_launch, now() - t_enqueued);
     if (*h_bad & 4) return set_err(ctx, SNPM_ERR_BADARG, "SNP weights must be finite (a NaN or infinite weight was given)");
     if (*h_bad) return set_err(ctx, SNPM_ERR_BADARG, "a row index lies outside the panel (n_snp %lld)", (long long)p->n_snp);
-    if (info) { info[0] = n_pairs; info[1] = (strict_all && mode != SNPM_MODE_STRICT) ? 1 : 0; }
+    if (info) { info[0] = n_pairs; info[1] = (strict_all && mode != SNPM_MODE_STRICT) ? 1 : 0; info[2] = shst.taken; info[3] = shst.union_rows; }
+    return SNPM_OK;
+}
+
+int snpm_batch_configure(snpm_ctx *ctx, int shared_rows, int digits, double min_density)
+{
+    if (!ctx) return set_err(nullptr, SNPM_ERR_BADARG, "ctx is NULL");
+    CHECK_ARG(ctx, shared_rows >= -1 && shared_rows <= 1, "shared_rows: -1 auto, 0 never, 1 whenever the batch allows it");
+    CHECK_ARG(ctx, digits == 0 || (digits >= 3 && digits <= 7), "digits: 3..7 (0 keeps the current value)");
+    ctx->batch_shared = shared_rows;
+    if (digits) ctx->shared_digits = digits;
+    if (min_density >= 0.0) ctx->shared_min_density = min_density;
+    return SNPM_OK;
+}
+
+int snpm_batch_last_stats(snpm_ctx *ctx, int64_t *stats)
+{
+    if (!ctx) return set_err(nullptr, SNPM_ERR_BADARG, "ctx is NULL");
+    CHECK_ARG(ctx, stats != nullptr, "stats is NULL");
+    for (int i = 0; i < 8; ++i) stats[i] = ctx->shared_last[i];
     return SNPM_OK;
 }
 

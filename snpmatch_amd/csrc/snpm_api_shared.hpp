@@ -1,0 +1,193 @@
+// snpm_api_shared.hpp -- host side of the shared-row scan of a batch (kernels and the idea: snpm_k_shared.hpp).
+// Part of the one translation unit of libsnpmatch_hip.so: included by snpm_api.hip at this place (anonymous namespace), not on its own.
+//
+// shared_rows_try() takes a SegJob whose inputs are on the device (concatenated row lists + weights, sample = segment) and either
+// scores EVERY sample into j.d_score / j.d_ninfo with the certificate's list of unproven (sample, accession) pairs left for
+// seg_finish -- the same state seg_launch leaves -- or declines (rows not strictly increasing per sample, weights outside [0, 1],
+// call codes > 2 in the panel, too little overlap between the samples) and touches nothing the per-sample pass needs.
+struct SharedStats {
+    int64_t union_rows = 0;         // distinct panel rows of the batch
+    double density = 0.0;           // N / (union_rows * n_samples): share of (sample, union row) slots that hold a call
+    int taken = 0;
+    int reason = 0;                 // why not: 1 policy off, 2 too few samples / rows, 3 unsorted rows, 4 weights outside [0, 1], 5 codes > 2 in the panel,
+                                    //          6 overlap below the threshold, 7 panel / batch too large for 32-bit indices
+    int tiles = 0, groups = 0, accgroups = 0, passes = 0, digits = 0;
+};
+
+static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &st)
+{
+    snpm_panel *p = j.p;
+    st = SharedStats();
+    const int64_t n_seg = j.n_seg, N = j.n_total;
+    const int digits = ctx->shared_digits;
+    st.digits = digits;
+    if (n_seg < (forced ? 1 : ctx->shared_min_samples) || N < 1) { st.reason = 2; return SNPM_OK; }
+    if (p->n_snp > 0x7fffffffLL || N > 0xfffffff0LL || !j.d_row_idx) { st.reason = 7; return SNPM_OK; }
+    int rc;
+    const int rps = digits + 1, slots = SH_GROUP_ROWS / rps;
+    const int frac_bits = sh_frac_bits(digits);
+    int64_t maxlen = 0, kmax = 1;
+    for (int64_t s = 0; s < n_seg; ++s) {
+        const int64_t len = j.seg_off[s + 1] - j.seg_off[s];
+        maxlen = std::max(maxlen, len);
+        kmax = std::max<int64_t>(kmax, (len + j.chunk - 1) / j.chunk);
+    }
+    // ---- union of the samples' rows: bitmap of panel rows -> ranks -> row list
+    const int64_t n_words = (p->n_snp + 31) / 32;
+    const int64_t n_blocks = (n_words + SH_WORDS_PER_BLOCK - 1) / SH_WORDS_PER_BLOCK;
+    const int64_t u_max = std::min<int64_t>(N, p->n_snp);
+    const size_t urow_entries = (size_t)u_max + (size_t)(SH_PAD_STEPS + SH_DEPTH + 1) * SH_STEP_ROWS;   // zero rows behind the union: the steps that pad it to a multiple of SH_DEPTH and the kernel's read-ahead
+    if ((rc = ensure(ctx, ctx->ws_sh_bitmap, (size_t)n_words * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_sh_wordbase, (size_t)n_words * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_sh_blocks, (size_t)n_blocks * 8 + 256))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_sh_urows, urow_entries * 4))) return rc;
+    const size_t meta_bytes = 64 + ((size_t)n_seg + 1) * 8 + (size_t)n_seg * 4;     // meta | seg_off | n_inexact
+    if ((rc = ensure(ctx, ctx->ws_sh_meta, meta_bytes))) return rc;
+    long long *d_meta = (long long *)ctx->ws_sh_meta.p;
+    int64_t *d_seg_off = (int64_t *)((char *)ctx->ws_sh_meta.p + 64);
+    int *d_inexact = (int *)((char *)ctx->ws_sh_meta.p + 64 + ((size_t)n_seg + 1) * 8);
+    uint32_t *d_bitmap = (uint32_t *)ctx->ws_sh_bitmap.p;
+    uint32_t *d_wordbase = (uint32_t *)ctx->ws_sh_wordbase.p;
+    uint32_t *d_blocksum = (uint32_t *)ctx->ws_sh_blocks.p, *d_blockbase = d_blocksum + n_blocks;
+    int32_t *d_urows = (int32_t *)ctx->ws_sh_urows.p;
+    HIPCHK(ctx, hipMemsetAsync(ctx->ws_sh_meta.p, 0, meta_bytes, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_seg_off, j.seg_off, ((size_t)n_seg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_bitmap, 0, (size_t)n_words * 4, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(d_urows, 0, urow_entries * 4, ctx->stream));
+    const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((maxlen + 255) / 256, 64));
+    {
+        ProfScope ps(ctx, PK_LUT);
+        hipLaunchKernelGGL(k_sh_mark, dim3(gx, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, j.d_w, (const int64_t *)d_seg_off,
+                           frac_bits, j.skip, d_bitmap, d_inexact, d_meta);
+        hipLaunchKernelGGL(k_sh_count, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, n_words, d_blocksum);
+        hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)d_blocksum, n_blocks, d_blockbase, d_meta);
+        hipLaunchKernelGGL(k_sh_fill, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, n_words,
+                           (const uint32_t *)d_blockbase, d_wordbase, d_urows);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    if ((rc = ensure_pinned(ctx, 64))) return rc;
+    long long *h_meta = (long long *)ctx->h_pinned;
+    h_meta[2] = 0;
+    HIPCHK(ctx, hipMemcpyAsync(h_meta, d_meta, 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (!p->packed && p->d_other) HIPCHK(ctx, hipMemcpyAsync(h_meta + 2, p->d_other, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t U = h_meta[0];
+    const int bad = (int)h_meta[1];
+    const int other = (int)(h_meta[2] & 0xffffffffLL);
+    st.union_rows = U;
+    st.density = U > 0 ? (double)N / ((double)U * (double)n_seg) : 0.0;
+    if (bad & 1) { st.reason = 3; return SNPM_OK; }
+    if (bad & 2) { st.reason = 4; return SNPM_OK; }
+    if (other) { st.reason = 5; return SNPM_OK; }
+    if (U < 1) { st.reason = 2; return SNPM_OK; }
+    if (!forced && st.density < ctx->shared_min_density) { st.reason = 6; return SNPM_OK; }
+
+    // ---- geometry
+    // K steps of 8 union rows, padded to a multiple of SH_DEPTH with rows no sample has a call at (zero digits): the kernel's body is unconditional
+    const int64_t n_steps = ((U + SH_STEP_ROWS - 1) / SH_STEP_ROWS + SH_DEPTH - 1) / SH_DEPTH * SH_DEPTH;
+    const int64_t steps_ld = n_steps + 2 * SH_DEPTH;
+    const int64_t ld_pos = n_steps * SH_STEP_ROWS;
+    const int n_accgroups = (int)((p->n_acc + SH_WAVE_ACCS - 1) / SH_WAVE_ACCS);
+    const int64_t ldn = (int64_t)n_accgroups * SH_WAVE_ACCS;
+    const int64_t groups_total = (n_seg + slots - 1) / slots;
+    const size_t bytes_per_group = (size_t)steps_ld * 4096;
+    const size_t budget = ctx->shared_ws_bytes;
+    int64_t groups_per_pass = std::max<int64_t>(1, std::min<int64_t>(groups_total, (int64_t)(budget / std::max<size_t>(bytes_per_group, 1))));
+    // row tiles: blocks of one tile run on one XCD (n_cu / 8 CUs, one block each at a time); among T = 8 m tiles take the m with the
+    // shortest schedule (rounds x steps per tile) whose partial sums stay small
+    auto plan_tiles = [&](int64_t groups, int &n_tiles, int64_t &steps_per_tile, int &blocks_per_tile) {
+        blocks_per_tile = (int)((groups * n_accgroups + 3) / 4);
+        const int cu_per_xcd = std::max(1, ctx->n_cu / 8);
+        double best = 1e300;
+        int best_m = 1;
+        for (int m = 1; m <= 16; ++m) {
+            const int64_t T = 8 * m;
+            if (T * 16 > n_steps && m > 1) break;                                   // at least 16 steps per tile
+            const size_t part_bytes = (size_t)T * groups * SH_GROUP_ROWS * ldn * 4;
+            if (part_bytes > (size_t(192) << 20) && m > 1) break;
+            const int64_t rounds = ((int64_t)m * blocks_per_tile + cu_per_xcd - 1) / cu_per_xcd;
+            const double cost = (double)rounds * (double)((n_steps + T - 1) / T);
+            if (cost < best * 0.97) { best = cost; best_m = m; }
+        }
+        int64_t T = 8 * best_m;
+        if (T * 16 > n_steps) T = std::max<int64_t>(1, n_steps / 16);
+        steps_per_tile = ((n_steps + T - 1) / T + SH_DEPTH - 1) / SH_DEPTH * SH_DEPTH;
+        n_tiles = (int)((n_steps + steps_per_tile - 1) / steps_per_tile);
+    };
+    int n_tiles = 1, blocks_per_tile = 1;
+    int64_t steps_per_tile = n_steps;
+    plan_tiles(groups_per_pass, n_tiles, steps_per_tile, blocks_per_tile);
+    // the int32 accumulators of a tile hold sums of digits (|d| <= 128) over its rows
+    if (steps_per_tile * SH_STEP_ROWS > (int64_t(1) << 23) && ctx->shared_force_tiles <= 0) { st.reason = 7; return SNPM_OK; }
+    if (ctx->shared_force_tiles > 0) {
+        n_tiles = (int)std::min<int64_t>(ctx->shared_force_tiles, n_steps);
+        steps_per_tile = ((n_steps + n_tiles - 1) / n_tiles + SH_DEPTH - 1) / SH_DEPTH * SH_DEPTH;
+        n_tiles = (int)((n_steps + steps_per_tile - 1) / steps_per_tile);
+    }
+    const int64_t samples_per_pass = groups_per_pass * slots;
+    if ((rc = ensure(ctx, ctx->ws_sh_A, ((size_t)groups_per_pass * steps_ld + SH_PAD_STEPS) * 4096))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_sh_pos, (size_t)std::min<int64_t>(samples_per_pass, n_seg) * ld_pos * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_sh_partial, (size_t)n_tiles * groups_per_pass * SH_GROUP_ROWS * ldn * 4))) return rc;
+    // ---- certificate: per-sample reference-order bound (k_eseg_*), pair list
+    j.d_seg_off = d_seg_off;
+    j.kmax = kmax;
+    j.cap = (int)std::max<int64_t>(64, std::min<int64_t>(SEG_PAIR_CAP, (int64_t(8) << 20) / kmax));
+    if ((rc = ensure(ctx, ctx->ws_pairs, 16 + (size_t)SEG_PAIR_CAP * 2 * sizeof(int32_t)))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(seg_pair_count(ctx), 0, sizeof(int), ctx->stream));
+    if (j.certify) {
+        if ((rc = ensure(ctx, ctx->ws_eseg, (size_t)n_seg * sizeof(double)))) return rc;
+        if ((rc = ensure(ctx, ctx->ws_pair_sums, (size_t)j.cap * (size_t)kmax * sizeof(double)))) return rc;
+        const int npart = (int)((kmax + 3) / 4);
+        if ((rc = ensure(ctx, ctx->ws_epart, (size_t)n_seg * (size_t)npart * 3 * sizeof(double)))) return rc;
+        hipLaunchKernelGGL(k_eseg_part, dim3((unsigned)npart, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_w, (const int64_t *)d_seg_off,
+                           j.chunk, (int64_t)0, npart, (double *)ctx->ws_epart.p);
+        // fast_adds = 4: the integer pass adds nothing; the term covers the two conversions and the addition of k_sh_finish
+        hipLaunchKernelGGL(k_eseg_finish, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, (const double *)ctx->ws_epart.p,
+                           (const int64_t *)d_seg_off, j.chunk, (int64_t)4, (int64_t)0, npart, (double *)ctx->ws_eseg.p);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    // ---- passes over groups of samples
+    st.tiles = n_tiles; st.accgroups = n_accgroups; st.groups = (int)groups_total;
+    for (int64_t s_base = 0; s_base < n_seg; s_base += samples_per_pass) {
+        const int64_t s_pass = std::min<int64_t>(samples_per_pass, n_seg - s_base);
+        const int64_t groups = (s_pass + slots - 1) / slots;
+        int tiles = n_tiles, bpt = blocks_per_tile;
+        int64_t spt = steps_per_tile;
+        if (groups != groups_per_pass) {
+            bpt = (int)((groups * n_accgroups + 3) / 4);
+        }
+        HIPCHK(ctx, hipMemsetAsync(ctx->ws_sh_pos.p, 0, (size_t)s_pass * ld_pos * 4, ctx->stream));
+        hipLaunchKernelGGL(k_sh_pos, dim3(gx, (unsigned)s_pass), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, s_base,
+                           (const uint32_t *)d_bitmap, (const uint32_t *)d_wordbase, (uint32_t *)ctx->ws_sh_pos.p, ld_pos);
+        {
+            ProfScope ps(ctx, PK_LUT);
+            const int64_t threads = groups * n_steps * slots * 2;
+            hipLaunchKernelGGL(k_sh_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
+                               (const uint32_t *)ctx->ws_sh_pos.p, ld_pos, j.d_w, s_pass, digits, j.skip, n_steps, steps_ld,
+                               (sh_v4i *)ctx->ws_sh_A.p);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        {
+            ProfScope ps(ctx, PK_FAST);
+            const unsigned nblk = (unsigned)(8 * ((tiles + 7) / 8) * bpt);
+#define LAUNCH_SH(PK)                                                                                                          \
+    hipLaunchKernelGGL((k_sh_mfma<PK>), dim3(nblk), dim3(256), 0, ctx->stream, p->d, p->kpitch, p->desc, (const int32_t *)d_urows,     \
+                       (const sh_v4i *)ctx->ws_sh_A.p, n_steps, steps_ld, spt, tiles, (int)groups, n_accgroups, bpt,                    \
+                       (int *)ctx->ws_sh_partial.p, ldn)
+            if (p->packed) LAUNCH_SH(true); else LAUNCH_SH(false);
+#undef LAUNCH_SH
+            HIPCHK(ctx, hipGetLastError());
+        }
+        {
+            ProfScope ps(ctx, PK_REDUCE);
+            hipLaunchKernelGGL(k_sh_finish, dim3((unsigned)p->n_acc, (unsigned)((s_pass + 63) / 64)), dim3(64), 0, ctx->stream,
+                               (const int *)ctx->ws_sh_partial.p, tiles, (int)groups, ldn, digits, (const int64_t *)d_seg_off, s_base,
+                               s_pass, p->n_acc, (const int *)d_inexact, j.certify ? (const double *)ctx->ws_eseg.p : (const double *)nullptr,
+                               ctx->debug_reeval, j.d_score, j.d_ninfo, j.ldo, seg_pairs(ctx), seg_pair_count(ctx), j.cap);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        ++st.passes;
+    }
+    st.taken = 1;
+    return SNPM_OK;
+}

@@ -1,0 +1,472 @@
+// snpm_k_shared.hpp -- the SHARED-ROW scan of a batch of samples ("batching many samples per launch turns the scan
+// into a small-N contraction; only then would MFMA be worth revisiting").
+// One of the kernel-family headers behind snpm_kernels.hpp (include that one: the families share constants and helpers in this order).
+//
+// snpm_score_batch scores sample b as its own segment: every sample gathers and reads its own DB rows (B x 233 MB for 64
+// samples of 200k SNPs on 1135 accessions).  When the samples of a batch are genotyped on largely the same markers -- the
+// production use, many samples against one panel -- each DB row can be read ONCE and scored against every sample:
+//
+//     score[s, a] = sum_r sum_c W[s, r, c] * [db[r, a] == c]                       (core/snpmatch.py:84-88, per sample)
+//
+// is a contraction over k = (row, class) of a weight matrix [samples, k] with the one-hot expansion of the panel [k, accessions].
+// fp64 arithmetic cannot use it (gfx950 runs v_mfma_f64 at the fp64 VALU rate, 3-4 x the flops of the LUT form), but the
+// EXACT mode only needs a fast pass with a rigorous error bound (DESIGN.md "Exactness contract"), so the weights are taken as
+// FIXED-POINT numbers: w in [0, 1] -> Q = floor(w * 2^F), written as L balanced base-256 digits d_0 .. d_{L-1} in [-128, 127],
+// w ~ sum_j d_j 256^(L-1-j) 2^-F, F = 8 (L - 1) + 6.  Digit j of every sample is one ROW of an int8 matrix A; the one-hot panel
+// expansion B is int8 {0, 1}; v_mfma_i32_32x32x32_i8 adds the products EXACTLY in int32.  One further row per sample holds
+// ones in the "missing" class: its product counts the sample's uninformative sites (ninfo).  The error of the pass is the
+// quantisation alone, one-sided: fixed <= exact <= fixed + n_inexact 2^-F (weights 0 / 1 / exp(-PL/10) of small PL: exact
+// ones cost nothing), and the certificate flags the few (sample, accession) pairs whose int() is not proven, as the fp64
+// fast pass does; those are re-scored in reference order by k_strict_pairs.
+//
+// Geometry of the contraction (k_sh_mfma):
+//   K step     = 8 union rows x 4 classes = the K = 32 of one MFMA; lane (c = lane & 31, h = lane >> 5) holds rows 4h .. 4h+3 of
+//                the step, one dword per row whose byte `class` belongs to k = (row, class)  [A and B use the same slots, so
+//                the hardware's k order inside a lane does not matter]
+//   A fragment = 32 matrix rows (sample digits) x one K step, 16 B per lane, stored in fragment order by k_sh_expand:
+//                A[group][step][tile t < 4][lane][16 B], group = 128 matrix rows
+//   B fragment = 32 accessions x one K step, built in registers: four row dwords (4 accessions each) are transposed with
+//                v_perm_b32 and every call code c becomes the dword 1 << 8 (c & 3): ref -> byte 0, alt -> 1, het -> 2, missing -> 3
+//   wave tile  = 128 matrix rows x 128 accessions = 4 x 4 MFMA tiles, 256 accumulator registers, one wave per SIMD;
+//                a wave reads its A fragments and panel dwords straight into registers (no LDS, no barrier), three steps in flight
+//   grid       = row tiles x (groups x accession groups / 4); blocks of one row tile are dealt to ONE XCD so that the L2 of that
+//                XCD serves the re-reads (A by every accession group, panel rows by every matrix-row group)
+#pragma once
+
+namespace snpm {
+
+constexpr int SH_GROUP_ROWS = 128;      // matrix rows (sample digits) per wave tile
+constexpr int SH_WAVE_ACCS = 128;       // accessions per wave tile
+constexpr int SH_STEP_ROWS = 8;         // union rows per K step
+constexpr int SH_DEPTH = 3;             // K steps in flight per wave
+constexpr int SH_PAD_STEPS = 3 * SH_DEPTH;   // steps a wave may read (never score) past the last one: row list 3 x DEPTH - 2, A fragments 2 x DEPTH - 1
+constexpr int SH_MAX_RPS = 8;           // matrix rows per sample: digits + the missing-count row
+
+typedef int sh_v4i __attribute__((ext_vector_type(4)));
+typedef int sh_v16i __attribute__((ext_vector_type(16)));
+
+__host__ __device__ __forceinline__ int sh_frac_bits(int digits) { return 8 * (digits - 1) + 6; }
+
+// meta block of a shared-row pass (device, int64 [8]): [0] union rows U, [1] bad-input bits (1 a sample's rows are not strictly
+// increasing, 2 a weight lies outside [0, 1] or is not finite), [2..] spare
+// ---------------------------------------------------------------------------------------------------------------
+// k_sh_mark: blockIdx.y = sample.  Marks the sample's rows in the bitmap of panel rows, checks that its row list is strictly
+// increasing (the union needs every (sample, row) at most once) and its weights lie in [0, 1], counts the rows with a weight that
+// 2^-F does not divide (the quantisation bound of the sample).
+__global__ void __launch_bounds__(256)
+k_sh_mark(const int64_t *__restrict__ rows, const double *__restrict__ w, const int64_t *__restrict__ seg_off, int frac_bits,
+          int skip_hets, uint32_t *__restrict__ bitmap, int *__restrict__ n_inexact, long long *__restrict__ meta)
+{
+    const int64_t s = blockIdx.y;
+    const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
+    const double scale = __builtin_ldexp(1.0, frac_bits);
+    int inexact = 0, bad = 0;
+    for (int64_t i = r0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < r1; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = rows[i];
+        if (i > r0 && rows[i - 1] >= r) bad |= 1;
+        atomicOr(&bitmap[r >> 5], 1u << (r & 31));
+        const double a = w[3 * i], b = skip_hets ? 0.0 : w[3 * i + 1], c = w[3 * i + 2];
+        if (!(a >= 0.0 && a <= 1.0 && b >= 0.0 && b <= 1.0 && c >= 0.0 && c <= 1.0)) bad |= 2;
+        const double xa = a * scale, xb = b * scale, xc = c * scale;
+        if (!(xa == floor(xa) && xb == floor(xb) && xc == floor(xc))) ++inexact;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        inexact += __shfl_xor(inexact, o);
+        bad |= __shfl_xor(bad, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (inexact) atomicAdd(&n_inexact[s], inexact);
+        if (bad) atomicOr((unsigned long long *)&meta[1], (unsigned long long)bad);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// rank of the marked rows: a block owns 4096 bitmap words (16 consecutive words per thread).
+//   k_sh_count   popcount of a block's words -> block_sum[b]
+//   k_sh_scan    ONE block: exclusive prefix of block_sum -> block_base, total -> meta[0]
+//   k_sh_fill    word_base[w] = marked rows before word w; union_rows[rank] = row for every marked row
+constexpr int SH_WORDS_PER_THREAD = 16;
+constexpr int SH_WORDS_PER_BLOCK = 256 * SH_WORDS_PER_THREAD;
+
+__global__ void __launch_bounds__(256)
+k_sh_count(const uint32_t *__restrict__ bitmap, int64_t n_words, uint32_t *__restrict__ block_sum)
+{
+    __shared__ uint32_t sm[4];
+    const int64_t w0 = (int64_t)blockIdx.x * SH_WORDS_PER_BLOCK + (int64_t)threadIdx.x * SH_WORDS_PER_THREAD;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < SH_WORDS_PER_THREAD; ++i)
+        if (w0 + i < n_words) c += __popc(bitmap[w0 + i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ void __launch_bounds__(1024)
+k_sh_scan(const uint32_t *__restrict__ block_sum, int64_t n_blocks, uint32_t *__restrict__ block_base, long long *__restrict__ meta)
+{
+    __shared__ uint32_t sm[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t b0 = 0; b0 < n_blocks; b0 += 1024) {
+        const int64_t b = b0 + threadIdx.x;
+        const uint32_t v = b < n_blocks ? block_sum[b] : 0;
+        uint32_t x = v;                                  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) sm[wave] = x;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int i = 0; i < wave; ++i) before += sm[i];
+        if (b < n_blocks) block_base[b] = before + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) meta[0] = (long long)carry;
+}
+
+__global__ void __launch_bounds__(256)
+k_sh_fill(const uint32_t *__restrict__ bitmap, int64_t n_words, const uint32_t *__restrict__ block_base,
+          uint32_t *__restrict__ word_base, int32_t *__restrict__ union_rows)
+{
+    __shared__ uint32_t sm[4];
+    const int64_t w0 = (int64_t)blockIdx.x * SH_WORDS_PER_BLOCK + (int64_t)threadIdx.x * SH_WORDS_PER_THREAD;
+    uint32_t word[SH_WORDS_PER_THREAD];
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < SH_WORDS_PER_THREAD; ++i) {
+        word[i] = (w0 + i < n_words) ? bitmap[w0 + i] : 0;
+        c += __popc(word[i]);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t x = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) sm[wave] = x;
+    __syncthreads();
+    uint32_t base = block_base[blockIdx.x] + x - c;
+    for (int i = 0; i < wave; ++i) base += sm[i];
+#pragma unroll
+    for (int i = 0; i < SH_WORDS_PER_THREAD; ++i) {
+        if (w0 + i >= n_words) break;
+        word_base[w0 + i] = base;
+        uint32_t m = word[i];
+        while (m) {
+            const int b = __ffs(m) - 1;
+            m &= m - 1;
+            union_rows[base++] = (int32_t)((w0 + i) * 32 + b);
+        }
+    }
+}
+
+// position of every (sample, row) entry in the union: pos[s_local, u] = entry index + 1 (0 = the sample has no call at union
+// row u).  blockIdx.y = sample of this pass (s_base + blockIdx.y).
+__global__ void __launch_bounds__(256)
+k_sh_pos(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off, int64_t s_base, const uint32_t *__restrict__ bitmap,
+         const uint32_t *__restrict__ word_base, uint32_t *__restrict__ pos, int64_t ld_pos)
+{
+    const int64_t s = s_base + blockIdx.y;
+    const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
+    for (int64_t i = r0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < r1; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = rows[i];
+        const uint32_t u = word_base[r >> 5] + __popc(bitmap[r >> 5] & ((1u << (r & 31)) - 1u));
+        pos[(int64_t)blockIdx.y * ld_pos + u] = (uint32_t)(i + 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_sh_expand: the A matrix in fragment order.  Thread = (group g, K step k, sample slot, lane half h): converts the sample's
+// weights at union rows 8k + 4h .. + 3 to fixed point, splits them into balanced digits and stores the 16 B of every digit row
+// (and of the missing-count row) where lane (m, h) of tile t will load them.
+//   matrix row of (sample slot sl, digit j) inside its group: sl * RPS + j;  RPS = digits + 1;  slots per group = 128 / RPS
+//   byte order of a row dword: class 0 (ref) = W[:, 0], class 1 (alt) = W[:, 2], class 2 (het) = W[:, 1] (0 when skip_hets),
+//   class 3 (missing) = 0 in digit rows; the missing-count row holds 1 in class 3 (and in class 2 when skip_hets).
+__global__ void __launch_bounds__(256)
+k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__restrict__ w, int64_t n_samples_pass, int digits,
+            int skip_hets, int64_t n_steps, int64_t steps_ld, sh_v4i *__restrict__ A)
+{
+    const int rps = digits + 1;
+    const int slots = SH_GROUP_ROWS / rps;
+    const int64_t per_step = (int64_t)slots * 2;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n_groups = (n_samples_pass + slots - 1) / slots;
+    if (idx >= n_groups * n_steps * per_step) return;
+    const int q = (int)(idx % per_step);
+    const int64_t k = (idx / per_step) % n_steps;
+    const int64_t g = idx / (per_step * n_steps);
+    const int sl = q >> 1, h = q & 1;
+    const int64_t s = g * slots + sl;
+    const int frac_bits = sh_frac_bits(digits);
+    const double scale = __builtin_ldexp(1.0, frac_bits);
+    uint32_t dw[SH_MAX_RPS][4];
+#pragma unroll
+    for (int j = 0; j < SH_MAX_RPS; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dw[j][i] = 0;
+    if (s < n_samples_pass) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t u = k * SH_STEP_ROWS + 4 * h + i;
+            const uint32_t e = pos[s * ld_pos + u];
+            if (!e) continue;
+            const double *wr = w + 3 * (int64_t)(e - 1);
+            double wc[3] = {wr[0], wr[2], skip_hets ? 0.0 : wr[1]};      // class order: ref, alt, het
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double x = wc[c];
+                x = (x >= 0.0 && x <= 1.0) ? x : 0.0;                    // refused by k_sh_mark; keep the conversion defined
+                long long Q = (long long)floor(x * scale);
+                for (int j = digits - 1; j >= 1; --j) {
+                    const int d = (int)((Q + 128) & 255) - 128;
+                    Q = (Q - d) >> 8;
+                    dw[j][i] |= (uint32_t)(d & 255) << (8 * c);
+                }
+                dw[0][i] |= (uint32_t)((int)Q & 255) << (8 * c);
+            }
+            dw[digits][i] = skip_hets ? 0x01010000u : 0x01000000u;
+        }
+    }
+    for (int j = 0; j < rps; ++j) {
+        const int M = sl * rps + j;
+        const int t = M >> 5, m = M & 31;
+        sh_v4i v;
+        v.x = (int)dw[j][0]; v.y = (int)dw[j][1]; v.z = (int)dw[j][2]; v.w = (int)dw[j][3];
+        A[((g * steps_ld + k) * 4 + t) * 64 + h * 32 + m] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// one-hot B fragments of 4 accessions x 4 rows.  int8 panel: x[i] = the dword of row i (4 accessions as bytes): transpose, then
+// byte -> 1 << 8 (code & 3).  Packed panel: x[i] = one byte of row i (4 accessions as 2-bit fields).
+template <bool PACKED>
+__device__ __forceinline__ void sh_onehot(const uint32_t (&x)[4], sh_v4i (&b)[4])
+{
+    if (PACKED) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b[j].x = (int)(1u << (((x[0] >> (2 * j)) & 3u) << 3));
+            b[j].y = (int)(1u << (((x[1] >> (2 * j)) & 3u) << 3));
+            b[j].z = (int)(1u << (((x[2] >> (2 * j)) & 3u) << 3));
+            b[j].w = (int)(1u << (((x[3] >> (2 * j)) & 3u) << 3));
+        }
+    } else {
+        const uint32_t p0 = __builtin_amdgcn_perm(x[1], x[0], 0x05010400u);   // (x0.b0, x1.b0, x0.b1, x1.b1)
+        const uint32_t p1 = __builtin_amdgcn_perm(x[1], x[0], 0x07030602u);   // (x0.b2, x1.b2, x0.b3, x1.b3)
+        const uint32_t p2 = __builtin_amdgcn_perm(x[3], x[2], 0x05010400u);
+        const uint32_t p3 = __builtin_amdgcn_perm(x[3], x[2], 0x07030602u);
+        uint32_t t[4];
+        t[0] = __builtin_amdgcn_perm(p2, p0, 0x05040100u);                    // accession 0: rows 0..3
+        t[1] = __builtin_amdgcn_perm(p2, p0, 0x07060302u);
+        t[2] = __builtin_amdgcn_perm(p3, p1, 0x05040100u);
+        t[3] = __builtin_amdgcn_perm(p3, p1, 0x07060302u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t s = (t[j] & 0x03030303u) << 3;
+            b[j].x = (int)(1u << (s & 0xffu));
+            b[j].y = (int)(1u << ((s >> 8) & 0xffu));
+            b[j].z = (int)(1u << ((s >> 16) & 0xffu));
+            b[j].w = (int)(1u << (s >> 24));
+        }
+    }
+}
+
+// k_sh_mfma: see the head of this file.  partial [n_tiles, ldn, n_groups * 128] int32 (accession-major), ldn = n_accgroups * 128: every
+// element is written by exactly one wave.  steps_per_tile K steps per row tile; union_rows carries SH_PAD_STEPS * 8 valid entries past the
+// last step and A SH_PAD_STEPS steps past the last group.
+template <bool PACKED>
+__global__ void __launch_bounds__(256, 1)
+k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int32_t *__restrict__ union_rows,
+          const sh_v4i *__restrict__ A, int64_t n_steps, int64_t steps_ld, int64_t steps_per_tile, int n_tiles, int n_groups,
+          int n_accgroups, int blocks_per_tile, int *__restrict__ partial, int64_t ldn)
+{
+    // blocks of one row tile on ONE XCD: workgroups are dealt round-robin over the 8 XCDs in launch order
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = bid >> 3;
+    const int tile = (q / blocks_per_tile) * 8 + xcd;
+    const int wb = q % blocks_per_tile;
+    if (tile >= n_tiles) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wt = wb * 4 + wave;
+    if (wt >= n_groups * n_accgroups) return;
+    const int g = wt / n_accgroups, ng = wt % n_accgroups;
+    const int lane = threadIdx.x & 63;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t k0 = (int64_t)tile * steps_per_tile;
+    int64_t k1 = k0 + steps_per_tile;
+    if (k1 > n_steps) k1 = n_steps;
+
+    // byte offset of this lane's accessions inside a row (and the matrix it lies in, for split packed panels)
+    int64_t col_off, row_stride, mat_off = 0;
+    if (PACKED) {
+        const int64_t b = (int64_t)ng * 32 + c;
+        const int64_t tp = pk_tail_pitch(desc);
+        if (tp && b >= pitch) {                 // the ragged tail of a split panel: its own matrix and pitch
+            int64_t bb = b - pitch;
+            if (bb > tp - 1) bb = tp - 1;       // lanes past the tail re-read its last byte (accessions >= n_acc: never reported)
+            col_off = bb; row_stride = tp; mat_off = pk_tail_off(desc);
+        } else {
+            col_off = (!tp && b > pitch - 1) ? pitch - 1 : b;
+            row_stride = pitch;
+        }
+    } else {
+        col_off = (int64_t)ng * 128 + 4 * c;
+        if (col_off > pitch - 4) col_off = pitch - 4;
+        row_stride = pitch;
+    }
+    const int8_t *base = db + mat_off + col_off;
+    const sh_v4i *Ag = A + (int64_t)g * steps_ld * 256 + lane;
+
+    sh_v16i acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0;
+
+    sh_v4i a[SH_DEPTH][4];
+    uint32_t x[SH_DEPTH][4];
+    int32_t rows_next[SH_DEPTH][4];          // union rows of the step this stage loads NEXT (one round ahead of the panel loads)
+
+#define SH_LOAD_ROWS(D, KS)                                                                   \
+    do {                                                                                      \
+        const sh_v4i rr = *reinterpret_cast<const sh_v4i *>(union_rows + (KS) * SH_STEP_ROWS + 4 * h); \
+        rows_next[D][0] = rr.x; rows_next[D][1] = rr.y; rows_next[D][2] = rr.z; rows_next[D][3] = rr.w; \
+    } while (0)
+#define SH_LOAD_STAGE(D, KS)                                                                  \
+    do {                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+            const int8_t *p = base + (int64_t)rows_next[D][i] * row_stride;                   \
+            x[D][i] = PACKED ? (uint32_t) * reinterpret_cast<const uint8_t *>(p) : *reinterpret_cast<const uint32_t *>(p); \
+        }                                                                                     \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) a[D][t] = Ag[((KS) * 4 + t) * 64];      \
+    } while (0)
+
+    // prologue: rows of the first 2 * DEPTH steps, panel dwords and A fragments of the first DEPTH steps
+#pragma unroll
+    for (int d = 0; d < SH_DEPTH; ++d) SH_LOAD_ROWS(d, k0 + d);
+#pragma unroll
+    for (int d = 0; d < SH_DEPTH; ++d) {
+        SH_LOAD_STAGE(d, k0 + d);
+        SH_LOAD_ROWS(d, k0 + d + SH_DEPTH);
+    }
+    // the prologue's loads are drained here: the wait the compiler places at the loop head is the merge of "entered from the
+    // prologue" (its panel loads are the youngest in flight: vmcnt(0)) and "came round the loop" (vmcnt(18)), i.e. a full drain
+    // in EVERY iteration unless the first path arrives with nothing pending
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) expcnt(7) lgkmcnt(15)
+    // [k0, k1) holds a multiple of SH_DEPTH steps (the host pads the union with rows no sample has a call at: zero digits), so the
+    // body is straight-line code: the compiler counts the loads in flight exactly (s_waitcnt vmcnt(n) with n > 0)
+    int64_t ks = k0;
+    do {                                    // a tile is never empty
+#pragma unroll
+        for (int d = 0; d < SH_DEPTH; ++d) {
+            sh_v4i b[4];
+            sh_onehot<PACKED>(x[d], b);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[t][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d][t], b[j], acc[t][j], 0, 0, 0);
+            // the next round's step of this stage (unconditional: the pads make it readable).  The scheduler must not move these
+            // loads (it sinks them to their uses a round later and waits with vmcnt(0)): fences on both sides
+            __builtin_amdgcn_sched_barrier(0);
+            SH_LOAD_STAGE(d, ks + d + SH_DEPTH);
+            SH_LOAD_ROWS(d, ks + d + 2 * SH_DEPTH);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ks += SH_DEPTH;
+    } while (ks < k1);
+#undef SH_LOAD_ROWS
+#undef SH_LOAD_STAGE
+
+    // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): registers 4 q .. 4 q + 3 of a
+    // tile are four adjacent matrix rows of one accession.  The partial sums are kept accession-major ([.., accession, matrix
+    // row]) so that those four registers leave as ONE 16-B store straight from the accumulators (no repacking, no copies).
+    // Column c of accession tile j is accession ng * 128 + 4 c + j.
+    const int64_t ldm = (int64_t)n_groups * SH_GROUP_ROWS;
+    int *out = partial + ((int64_t)tile * ldn + (int64_t)ng * SH_WAVE_ACCS + 4 * c) * ldm + (int64_t)g * SH_GROUP_ROWS + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                sh_v4i v;
+                v.x = acc[t][j][4 * q4]; v.y = acc[t][j][4 * q4 + 1]; v.z = acc[t][j][4 * q4 + 2]; v.w = acc[t][j][4 * q4 + 3];
+                *reinterpret_cast<sh_v4i *>(out + (int64_t)j * ldm + 32 * t + 8 * q4) = v;
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_sh_finish: block = accession a, thread = sample of the pass (the digit sums of one sample are adjacent in the accession-major
+// partial array, samples follow each other).  Adds the row tiles' partial digit sums (int64), puts the digits together,
+// converts to fp64 (hi / lo parts: each conversion is exact or rounds once far below the bound), ninfo = calls of the
+// sample - missing count, and runs the certificate: the reference's score lies in [v - E, v + E + Eq], E = eseg[s] (reference-order
+// bound + the conversion), Eq = n_inexact[s] 2^-F (the quantisation, one-sided).
+__global__ void __launch_bounds__(64)
+k_sh_finish(const int *__restrict__ partial, int n_tiles, int n_groups, int64_t ldn, int digits, const int64_t *__restrict__ seg_off,
+            int64_t s_base, int64_t n_samples_pass, int64_t n_acc, const int *__restrict__ n_inexact, const double *__restrict__ eseg,
+            int force_first, double *__restrict__ score, int64_t *__restrict__ ninfo, int64_t ldo, int32_t *__restrict__ pairs,
+            int *__restrict__ count, int cap)
+{
+    const int64_t a = blockIdx.x;
+    const int64_t sp = (int64_t)blockIdx.y * 64 + threadIdx.x;
+    if (sp >= n_samples_pass) return;
+    const int64_t sg = s_base + sp;
+    const int rps = digits + 1, slots = SH_GROUP_ROWS / rps;
+    const int64_t g = sp / slots, sl = sp % slots;
+    const int64_t ldm = (int64_t)n_groups * SH_GROUP_ROWS;
+    long long dsum[SH_MAX_RPS];
+#pragma unroll
+    for (int j = 0; j < SH_MAX_RPS; ++j) dsum[j] = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+        const int *p = partial + ((int64_t)t * ldn + a) * ldm + g * SH_GROUP_ROWS + sl * rps;
+#pragma unroll
+        for (int j = 0; j < SH_MAX_RPS; ++j)
+            if (j < rps) dsum[j] += p[j];
+    }
+    // digits 0 .. 2 form the high part (units of 256^(digits-3) 2^-F), the others the low part (units of 2^-F)
+    long long hi = 0, lo = 0;
+#pragma unroll
+    for (int j = 0; j < SH_MAX_RPS - 1; ++j) {
+        if (j >= digits) break;
+        if (j < 3) hi = hi * 256 + dsum[j];
+        else lo = lo * 256 + dsum[j];
+    }
+    const int frac_bits = sh_frac_bits(digits);
+    const int n_hi = digits < 3 ? digits : 3;
+    const double v = __builtin_ldexp((double)hi, 8 * (digits - n_hi) - frac_bits) + __builtin_ldexp((double)lo, -frac_bits);
+    const int64_t len = seg_off[sg + 1] - seg_off[sg];
+    long long missing = 0;
+#pragma unroll
+    for (int j = 0; j < SH_MAX_RPS; ++j)
+        if (j == digits) missing = dsum[j];
+    score[sg * ldo + a] = v;
+    ninfo[sg * ldo + a] = len - missing;
+    if (eseg) {
+        const double E = eseg[sg] + 8.0 * 1.1102230246251565e-16 * (fabs(v) + 1.0);
+        const double Eq = __builtin_ldexp((double)n_inexact[sg], -frac_bits) * 1.0000001;
+        const double lo_v = v - E, hi_v = (v + Eq) + E;
+        if (!(lo_v >= 0.0) || floor(lo_v) != floor(hi_v) || a < force_first) {
+            const int k = atomicAdd(count, 1);
+            if (k < cap) {
+                pairs[2 * k] = (int32_t)sg;
+                pairs[2 * k + 1] = (int32_t)a;
+            }
+        }
+    }
+}
+
+}  // namespace snpm

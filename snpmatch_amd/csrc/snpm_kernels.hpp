@@ -45,6 +45,7 @@
 #include "snpm_k_packed.hpp"      // k_fast_packed_q4, k_fast_bits
 #include "snpm_k_reduce.hpp"      // k_reduce*, k_carry_*, k_eseg_*, k_reduce_seg, k_strict_pairs, k_scan_pairs, k_tot_seg, helpers
 #include "snpm_k_strict.hpp"      // k_strict, k_strict4, k_strict_sparse(_T), k_pack_transpose*, k_scan, k_scan_few, k_seg_pack, k_patch
+#include "snpm_k_shared.hpp"      // k_sh_*: the shared-row scan of a batch (int8 MFMA contraction of fixed-point weight digits with the one-hot panel)
 #include "snpm_k_post.hpp"        // k_likelihood, k_binom_identity, k_segregating, k_f1_*, k_once_pack
 #include "snpm_k_io.hpp"          // k_pack_rows, k_repitch_canon, k_unpack_rows, k_synth*, k_calib_read
 #include "snpm_kernels_single.hpp"   // k_strict_single (panels of one accession: numpy's pairwise order)

@@ -710,7 +710,27 @@ def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, li
                                        ptr(out["score"]), ptr(out["ninfo"]), ptr(out.get("lik")), ptr(out.get("lrt")), ptr(info)),
               ctx.h)
     out["pairs_reeval"], out["strict_fallback"] = int(info[0]), bool(info[1])
+    out["shared_rows"], out["union_rows"] = bool(info[2]), int(info[3])
     return out
+
+
+SHARED_WHY_NOT = {0: "", 1: "policy", 2: "too few samples or rows", 3: "a row list is not strictly increasing", 4: "a weight outside [0, 1]",
+                  5: "call codes > 2 in the panel", 6: "overlap below the threshold", 7: "sizes beyond 32-bit indices"}
+
+
+def batch_configure(ctx, shared_rows=-1, digits=0, min_density=-1.0):
+    """Policy of score_batch for batches whose samples share DB rows (snpm_batch_configure): shared_rows -1 automatic (device
+    inputs, >= 8 samples, enough overlap), 0 never, 1 whenever the batch allows it; digits 3..7 base-256 digits of the fixed-point
+    weights (0: keep); min_density: threshold of the automatic choice (negative: keep)."""
+    check(ctx.lib.snpm_batch_configure(ctx.h, int(shared_rows), int(digits), float(min_density)), ctx.h)
+
+
+def batch_last_stats(ctx):
+    """What the context's last score_batch call did about shared rows (snpm_batch_last_stats)."""
+    st = np.zeros(8, dtype=np.int64)
+    check(ctx.lib.snpm_batch_last_stats(ctx.h, ptr(st)), ctx.h)
+    return {"taken": bool(st[0]), "why_not": SHARED_WHY_NOT.get(int(st[1]), str(int(st[1]))), "union_rows": int(st[2]),
+            "density": float(st[3]) / 1e6, "row_tiles": int(st[4]), "groups": int(st[5]), "passes": int(st[6]), "digits": int(st[7])}
 
 
 class Carry(object):

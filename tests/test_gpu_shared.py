@@ -1,0 +1,251 @@
+"""
+Shared-row scan of a batch of samples (-m gpu): every DB row read once and scored against all samples as an int8 MFMA
+contraction of fixed-point weight digits with the one-hot panel (snpmatch_amd/csrc/snpm_k_shared.hpp), same certificate and
+reference-order re-evaluation as the per-sample pass.  Reference: one `Genotyper.genotyper` run per sample over the same
+panel (core/snpmatch.py:207-233, the chunk loop :218-225); counts and informative sites must be bit-equal to the C oracle
+and to the per-sample pass, for overlapping and disjoint marker sets, int8 and packed panels.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import snpmatch_oracle as orc
+from snpmatch_amd import engine, synth
+
+pytestmark = pytest.mark.gpu
+LIK_RTOL = 1e-12
+
+
+def rand_db(rng, n, n_acc):
+    return rng.choice(np.array([-1, 0, 1, 2], dtype=np.int8), size=(n, n_acc), p=[0.05, 0.60, 0.33, 0.02])
+
+
+def make_ctx(**env):
+    for k, v in env.items():
+        os.environ[k] = str(v)
+    try:
+        return engine.Context(0)
+    finally:
+        for k in env:
+            del os.environ[k]
+
+
+def sample_on(rng, db, rows, kind):
+    """weights of a sample planted on a random accession at the given rows: kind 0 PL + 3 % wrong calls, 1 hard 0/1 calls,
+    2 perfect PL match (an exact-integer score for the planted accession)"""
+    n_acc = db.shape[1]
+    acc = int(rng.integers(0, n_acc))
+    codes = db[rows, acc].copy()
+    codes[codes < 0] = 0
+    codes[codes > 2] = 0
+    if kind == 1:
+        return orc.weights_from_gt_codes(codes)
+    if kind == 2:
+        return synth.sample_weights(rng, codes, frac_pl=1.0)
+    flip = rng.random(len(rows)) < 0.03
+    codes[flip] = rng.integers(0, 3, size=int(flip.sum()))
+    return synth.sample_weights(rng, codes, frac_pl=0.8)
+
+
+def chip_samples(rng, db, count, n_markers, drop=0.05, extra=0.02):
+    """samples genotyped on one marker set: each lacks a few markers and has a few of its own"""
+    n_snp = db.shape[0]
+    base = np.sort(rng.choice(n_snp, size=n_markers, replace=False))
+    out = []
+    for b in range(count):
+        keep = base[rng.random(n_markers) >= drop]
+        own = rng.choice(n_snp, size=int(extra * n_markers), replace=False)
+        rows = np.unique(np.concatenate([keep, own])).astype(np.int64)
+        out.append((rows, sample_on(rng, db, rows, b % 3)))
+    return out
+
+
+def check_against_oracle(db, samples, got, skip, lik=True):
+    for b, (rows, wei) in enumerate(samples):
+        want_s, want_n = c_oracle.genotyper(db, rows, wei, 1000, skip)
+        assert np.array_equal(got["ninfo"][b], want_n), b
+        assert np.array_equal(np.array(got["score"][b], dtype=np.int64), np.array(want_s, dtype=np.int64)), b
+        assert np.max(np.abs(got["score"][b] - want_s), initial=0) < 1e-6, b
+        if lik:
+            wl, wr = orc.calculate_likelihoods(np.array(want_s, dtype=np.int64), want_n)
+            np.testing.assert_allclose(got["lik"][b], wl, rtol=LIK_RTOL, equal_nan=True)
+            np.testing.assert_allclose(got["lrt"][b], wr, rtol=LIK_RTOL, equal_nan=True)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("skip", [False, True])
+def test_shared_rows_equal_oracle_and_per_sample_pass(packed, skip):
+    ctx = make_ctx()
+    rng = np.random.default_rng(77 + packed + 2 * skip)
+    n_snp, n_acc = 50_000, 1135
+    db = rand_db(rng, n_snp, n_acc)
+    db[:, 2] = -1
+    panel = engine.Panel.from_host(ctx, db, packed=packed)
+    samples = chip_samples(rng, db, 37, 6000)
+    samples[5] = (np.zeros(0, dtype=np.int64), np.zeros((0, 3)))           # an empty sample
+    samples[6] = (samples[6][0][:1], samples[6][1][:1])                     # one SNP
+    engine.batch_configure(ctx, shared_rows=1)
+    got = engine.score_batch(panel, samples, 1000, skip, engine.MODE_EXACT)
+    st = engine.batch_last_stats(ctx)
+    assert got["shared_rows"] and st["taken"] and st["digits"] == 7, st
+    union = np.unique(np.concatenate([r for r, _ in samples]))
+    assert got["union_rows"] == len(union) == st["union_rows"]
+    assert got["pairs_reeval"] >= 1 and not got["strict_fallback"]          # the perfect PL matches
+    check_against_oracle(db, samples, got, skip)
+    engine.batch_configure(ctx, shared_rows=0)
+    seg = engine.score_batch(panel, samples, 1000, skip, engine.MODE_EXACT)
+    assert not seg["shared_rows"] and engine.batch_last_stats(ctx)["why_not"] == "policy"
+    assert np.array_equal(seg["ninfo"], got["ninfo"])
+    assert np.array_equal(seg["score"].astype(np.int64), got["score"].astype(np.int64))
+    np.testing.assert_allclose(seg["lik"], got["lik"], rtol=LIK_RTOL, equal_nan=True)
+    # the fast pass alone (no certificate): the quantisation is far below what MODE_FAST promises
+    engine.batch_configure(ctx, shared_rows=1)
+    fast = engine.score_batch(panel, samples, 1000, skip, engine.MODE_FAST, likelihoods=False)
+    assert fast["shared_rows"] and np.array_equal(fast["ninfo"], got["ninfo"])
+    assert np.max(np.abs(fast["score"] - seg["score"])) < 1e-7
+    ctx.close()
+
+
+@pytest.mark.parametrize("digits", [3, 5, 6, 7])
+def test_fewer_digits_flag_more_pairs_and_stay_exact(digits):
+    """the certificate carries the quantisation: with coarse fixed-point weights more (sample, accession) pairs go through
+    the reference-order re-evaluation, the counts do not change"""
+    ctx = make_ctx(SNPM_SHARED_TILES=5)                                     # several row tiles on a small job
+    rng = np.random.default_rng(100 + digits)
+    n_snp, n_acc = 30_000, 700
+    db = rand_db(rng, n_snp, n_acc)
+    panel = engine.Panel.from_host(ctx, db)
+    samples = chip_samples(rng, db, 24, 3000)
+    engine.batch_configure(ctx, shared_rows=1, digits=digits)
+    got = engine.score_batch(panel, samples, 1000, False, engine.MODE_EXACT)
+    st = engine.batch_last_stats(ctx)
+    assert st["taken"] and st["digits"] == digits and st["row_tiles"] >= 2, st
+    check_against_oracle(db, samples, got, False)
+    if digits == 3:
+        assert got["pairs_reeval"] > 100 or got["strict_fallback"]          # 2^-22 per SNP: hundreds of unproven pairs
+    ctx.close()
+
+
+@pytest.mark.parametrize("packed", [False, True])
+@pytest.mark.parametrize("n_acc", [1, 5, 130, 257, 1135, 2100])
+def test_widths_and_disjoint_marker_sets(packed, n_acc):
+    """panel widths around the 128-accession wave tiles (split packed layouts included); samples that share no row at all"""
+    ctx = make_ctx()
+    rng = np.random.default_rng(n_acc * 2 + packed)
+    n_snp = 20_000
+    db = rand_db(rng, n_snp, n_acc)
+    panel = engine.Panel.from_host(ctx, db, packed=packed)
+    perm = rng.permutation(n_snp)
+    samples = []
+    for b in range(9):                                                      # disjoint: sample b owns its own slice of the rows
+        rows = np.sort(perm[b * 2000:b * 2000 + int(rng.integers(1, 2000))]).astype(np.int64)
+        samples.append((rows, sample_on(rng, db, rows, b % 3)))
+    engine.batch_configure(ctx, shared_rows=1)
+    got = engine.score_batch(panel, samples, 1000, False, engine.MODE_EXACT)
+    assert got["shared_rows"] and got["union_rows"] == sum(len(r) for r, _ in samples)
+    check_against_oracle(db, samples, got, False)
+    samples = chip_samples(rng, db, 11, 2500, drop=0.3, extra=0.3)
+    got = engine.score_batch(panel, samples, 777, True, engine.MODE_EXACT)   # another chunk length, het calls skipped
+    assert got["shared_rows"]
+    for b, (rows, wei) in enumerate(samples):
+        want_s, want_n = c_oracle.genotyper(db, rows, wei, 777, True)
+        assert np.array_equal(got["ninfo"][b], want_n) and np.array_equal(got["score"][b].astype(np.int64), want_s.astype(np.int64)), b
+    ctx.close()
+
+
+def test_batches_the_contraction_cannot_take_fall_back():
+    ctx = make_ctx()
+    rng = np.random.default_rng(9)
+    n_snp, n_acc = 20_000, 300
+    db = rand_db(rng, n_snp, n_acc)
+    panel = engine.Panel.from_host(ctx, db)
+    engine.batch_configure(ctx, shared_rows=1)
+    samples = chip_samples(rng, db, 10, 2000)
+    # (a) a row list that is not increasing
+    rows, wei = samples[3]
+    order = rng.permutation(len(rows))
+    shuffled = list(samples)
+    shuffled[3] = (rows[order], wei[order])
+    got = engine.score_batch(panel, shuffled, 1000, False, engine.MODE_EXACT)
+    assert not got["shared_rows"] and engine.batch_last_stats(ctx)["why_not"] == "a row list is not strictly increasing"
+    check_against_oracle(db, shuffled, got, False)
+    # (b) weights outside [0, 1]
+    heavy = list(samples)
+    heavy[7] = (samples[7][0], samples[7][1] * 3.0)
+    got = engine.score_batch(panel, heavy, 1000, False, engine.MODE_EXACT)
+    assert not got["shared_rows"] and engine.batch_last_stats(ctx)["why_not"] == "a weight outside [0, 1]"
+    check_against_oracle(db, heavy, got, False)
+    # (c) a panel with call codes > 2 (informative, matching nothing): the one-hot expansion has no class for them
+    db2 = db.copy()
+    db2[::7, 11] = 3
+    panel2 = engine.Panel.from_host(ctx, db2)
+    got = engine.score_batch(panel2, samples, 1000, False, engine.MODE_EXACT)
+    assert not got["shared_rows"] and engine.batch_last_stats(ctx)["why_not"] == "call codes > 2 in the panel"
+    check_against_oracle(db2, samples, got, False)
+    # (d) strict mode never takes it; (e) the automatic policy keeps host batches and sparse overlaps on the per-sample pass
+    got = engine.score_batch(panel, samples, 1000, False, engine.MODE_STRICT, likelihoods=False)
+    assert not got["shared_rows"]
+    engine.batch_configure(ctx, shared_rows=-1)
+    got = engine.score_batch(panel, samples, 1000, False, engine.MODE_EXACT)
+    assert not got["shared_rows"] and engine.batch_last_stats(ctx)["why_not"] == "policy"
+    ctx.close()
+
+
+def test_automatic_policy_on_device_inputs_and_passes_over_groups():
+    import torch
+    ctx = make_ctx(SNPM_SHARED_WS_MB=1)                                     # a tiny digit-matrix budget: several passes over groups of samples
+    rng = np.random.default_rng(31)
+    n_snp, n_acc = 40_000, 513
+    db = rand_db(rng, n_snp, n_acc)
+    panel = engine.Panel.from_host(ctx, db, packed=True)
+    samples = chip_samples(rng, db, 70, 1500)
+    off = np.concatenate([[0], np.cumsum([len(r) for r, _ in samples])]).astype(np.int64)
+    d_rows = torch.as_tensor(np.concatenate([r for r, _ in samples]), device="cuda:0")
+    d_wei = torch.as_tensor(np.concatenate([w for _, w in samples]), device="cuda:0")
+    got = engine.score_batch(panel, None, 1000, False, engine.MODE_EXACT, device=(d_rows.data_ptr(), d_wei.data_ptr(), off))
+    st = engine.batch_last_stats(ctx)
+    assert got["shared_rows"] and st["passes"] >= 2 and st["density"] > 0.5, st
+    check_against_oracle(db, samples, got, False)
+    # sparse overlap: random markers out of the whole panel -> the automatic choice declines, the forced one still agrees
+    sparse = []
+    for b in range(16):
+        rows = np.sort(rng.choice(n_snp, size=1200, replace=False)).astype(np.int64)
+        sparse.append((rows, sample_on(rng, db, rows, 0)))
+    off = np.concatenate([[0], np.cumsum([len(r) for r, _ in sparse])]).astype(np.int64)
+    d_rows = torch.as_tensor(np.concatenate([r for r, _ in sparse]), device="cuda:0")
+    d_wei = torch.as_tensor(np.concatenate([w for _, w in sparse]), device="cuda:0")
+    got = engine.score_batch(panel, None, 1000, False, engine.MODE_EXACT, device=(d_rows.data_ptr(), d_wei.data_ptr(), off))
+    assert not got["shared_rows"] and engine.batch_last_stats(ctx)["why_not"] == "overlap below the threshold"
+    engine.batch_configure(ctx, shared_rows=1)
+    forced = engine.score_batch(panel, None, 1000, False, engine.MODE_EXACT, device=(d_rows.data_ptr(), d_wei.data_ptr(), off))
+    assert forced["shared_rows"]
+    assert np.array_equal(forced["ninfo"], got["ninfo"]) and np.array_equal(forced["score"].astype(np.int64), got["score"].astype(np.int64))
+    check_against_oracle(db, sparse, forced, False)
+    ctx.close()
+
+
+def test_coded_batch_through_the_shared_rows():
+    """dictionary-coded weights (exp(-PL/10) tables, snpm_score_batch_coded): the digits come from the table's fp64 values"""
+    ctx = make_ctx()
+    rng = np.random.default_rng(4)
+    n_snp, n_acc = 30_000, 1135
+    db = rand_db(rng, n_snp, n_acc)
+    panel = engine.Panel.from_host(ctx, db, packed=True)
+    table = engine.pl_table(7460)
+    base = np.sort(rng.choice(n_snp, size=4000, replace=False)).astype(np.int64)
+    samples, plain = [], []
+    for b in range(20):
+        rows = base[rng.random(len(base)) > 0.1]
+        pl = rng.integers(0, 256, size=(len(rows), 3)).astype(np.uint16)
+        pl[np.arange(len(rows)), rng.integers(0, 3, size=len(rows))] = 0
+        hard = rng.random(len(rows)) < 0.2
+        pl[hard] = np.where(pl[hard] == 0, 0, 7459).astype(np.uint16)     # hard calls: weights 1 / 0 (exp underflows to 0.0)
+        samples.append((rows, pl))
+        plain.append((rows, table[pl]))
+    engine.batch_configure(ctx, shared_rows=1)
+    got = engine.score_batch(panel, samples, 1000, False, engine.MODE_EXACT, table=table)
+    assert got["shared_rows"]
+    check_against_oracle(db, plain, got, False)
+    ctx.close()

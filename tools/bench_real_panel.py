@@ -107,6 +107,18 @@ def main():
         acc = PLANTED if b == 0 else (b * 7) % N_ACC
         col = synth.panel_rows(SEED, rows, acc // 4 * 4, 4)[:, acc % 4]
         samples.append((rows, synth.planted_sample(rng, col, 0.02)[1], acc))
+    # the same number of samples on ONE marker set of n_match rows, each lacking 3 % of it (a SNP chip / a fixed capture panel)
+    base = np.sort(rng.choice(n_snp, size=n_match, replace=False)).astype(np.int64)
+    c_rows, c_wei, c_accs = [], [], []
+    for b in range(B):
+        rows = base[rng.random(n_match) >= 0.03]
+        acc = PLANTED if b == 0 else (b * 11) % N_ACC
+        col = synth.panel_rows(SEED, rows, acc // 4 * 4, 4)[:, acc % 4]
+        c_rows.append(rows)
+        c_wei.append(synth.planted_sample(rng, col, 0.02)[1])
+        c_accs.append(acc)
+    chip_batches = [{"rows": np.concatenate(c_rows), "wei": np.concatenate(c_wei), "accs": c_accs,
+                     "off": np.concatenate([[0], np.cumsum([len(r) for r in c_rows])]).astype(np.int64)}]
     rows0, wei0, _ = samples[0]
     win_off = window_offsets(g0, bounds, positions, rows0)
     off = np.concatenate([[0], np.cumsum([len(r) for r, _, _ in samples])]).astype(np.int64)
@@ -198,7 +210,64 @@ def main():
         leg["samples_per_s"] = B / (leg["wall_ms_per_call"] * 1e-3)
         assert [int(np.nanargmin(res[0]["lik"][b])) for b in range(B)] == [s[2] for s in samples]
         legs.append(leg)
+        # (5) the same number of samples genotyped on ONE marker set (each lacks 3 % of it): the per-sample pass reads every sample's
+        # rows again (B x 200k gathered rows); the shared-row scan reads each DB row once and scores it against all samples as an int8
+        # MFMA contraction (snpm_k_shared.hpp).  Then the shared-row scan forced onto the random-marker batch of (4): almost no
+        # (sample, union row) slot holds a call there, the contraction computes zeros -- the automatic policy keeps the per-sample pass.
+        chip = chip_batches[0]
+        d_rows_c = torch.as_tensor(chip["rows"], device="cuda:0")
+        d_wei_c = torch.as_tensor(chip["wei"], device="cuda:0")
+        torch.cuda.synchronize()
+        dev_c = (d_rows_c.data_ptr(), d_wei_c.data_ptr(), chip["off"])
+
+        def shared_leg(name, device, n_entries, accs, policy, reps):
+            engine.batch_configure(ctx, shared_rows=policy)
+
+            def run():
+                res[0] = engine.score_batch(panel, None, device=device)
+
+            leg = kernel_leg(ctx, name, run, n_entries, row_bytes, reps)
+            st = engine.batch_last_stats(ctx)
+            engine.batch_configure(ctx, shared_rows=-1)
+            assert [int(np.nanargmin(res[0]["lik"][b])) for b in range(B)] == accs
+            leg["samples_per_s"] = B / (leg["wall_ms_per_call"] * 1e-3)
+            leg["pairs_reeval"] = res[0]["pairs_reeval"]
+            leg["shared_rows"] = st
+            if st["taken"]:
+                leg["kernel"] = "k_sh_mfma<%s>" % ("packed" if packed else "int8")
+                u, rps = st["union_rows"], st["digits"] + 1
+                steps = -(-(-(-u // 8)) // 3) * 3
+                m_rows = st["groups"] * 128
+                n_cols = -(-N_ACC // 128) * 128
+                macs = float(m_rows) * n_cols * steps * 32
+                # bytes that must come from HBM once: the union's panel rows, the samples' rows + weights, the digit matrix written and read
+                hbm = u * (row_bytes + 4.0) + n_entries * 32.0 + 2.0 * steps * 4096.0 * st["groups"]
+                leg["algorithmic_bytes_per_call"] = hbm
+                leg["hbm_bytes_per_sample"] = hbm / B
+                leg["achieved_GBs"] = hbm / (leg["kernel_ms_per_call"] * 1e-3) / 1e9
+                leg["frac_of_hbm_peak"] = leg["achieved_GBs"] / HBM_PEAK_GBS
+                leg["int8_macs_per_call"] = macs
+                peak_macs = 256 * 4 * 1024 * 2.4e9          # 32x32x32 int8 MFMA: 32768 MACs per 32 cycles per SIMD
+                leg["mfma_TMACs"] = macs / (leg["kernel_ms_per_call"] * 1e-3) / 1e12
+                leg["frac_of_int8_mfma_peak"] = macs / (leg["kernel_ms_per_call"] * 1e-3) / peak_macs
+                leg["ceilings"] = {"hbm_ms": hbm / (HBM_PEAK_GBS * 1e9) * 1e3, "int8_mfma_ms": macs / peak_macs * 1e3,
+                                   "fp64_valu_ms_if_lut_form": float(n_entries) * N_ACC / (256 * 4 * 16 * 2.4e9) * 1e3,
+                                   "note": "fp64 VALU: one v_add_f64 per (sample, row, accession) at 16 lanes per clock and SIMD -- what a shared-row LUT "
+                                           "form (or v_mfma_f64 at the same rate and 3x the flops) would be bound by"}
+                leg["comparisons_per_s"] = float(n_entries) * N_ACC / (leg["wall_ms_per_call"] * 1e-3)
+            else:
+                leg["kernel"] = "k_fast_packed_q4<GATHER, SEG>" if packed else "k_fast<GATHER, SEG>"
+                leg["hbm_bytes_per_sample"] = leg["algorithmic_bytes_per_call"] / B
+            return leg
+
+        reps_b = max(2, args.reps // 2)
+        legs.append(shared_leg("batch_%d_per_sample_pass_same_markers" % B, dev_c, int(chip["off"][-1]), chip["accs"], 0, reps_b))
+        legs.append(shared_leg("batch_%d_shared_rows_same_markers" % B, dev_c, int(chip["off"][-1]), chip["accs"], 1, reps_b))
+        legs.append(shared_leg("batch_%d_shared_rows_random_markers" % B, dev, B * n_match, [s[2] for s in samples], 1, 2))
+        del d_rows_c, d_wei_c
         for leg in legs:
+            if leg.get("kernel", "").startswith("k_sh_mfma"):
+                continue
             if packed:
                 leg["bytes_counted"] = "packed bytes (n_acc / 4 per row): the bytes the kernel moves"
                 leg["int8_equivalent_GBs"] = leg["achieved_GBs"] * (N_ACC + 32.0) / (row_bytes + 32.0)
