@@ -390,7 +390,8 @@ int snpm_binom_sf_host(const double *k, const double *n, int64_t len, double p, 
    strictly increasing (the caller then takes its generic path). */
 int snpm_intersect_sorted(const int64_t *a, int64_t na, const int64_t *b, int64_t nb, int64_t *ia, int64_t *ib,
                           int64_t *n_out);
-/* Same result for a short list b against a long list a: galloping search, O(nb log(na / nb)).  a must be
+/* Same result for a short list b against a long list a: galloping search, O(nb log(na / nb)); from 4096 values of b on the search
+   runs in ranges of b on a pool of host threads.  Capacity of ia / ib: min(na, nb), as above.  a must be
    strictly increasing and is NOT checked here (DB positions are verified once, when the DB is opened);
    b is checked (SNPM_ERR_STATE). */
 int snpm_intersect_sorted_search(const int64_t *a, int64_t na, const int64_t *b, int64_t nb, int64_t *ia, int64_t *ib,

@@ -82,7 +82,9 @@ int snpm_intersect_sorted_search(const int64_t *a, int64_t na, const int64_t *b,
     // per-range hit lists are closed up afterwards: the same pairs in the same order as the single walk.
     HostPool &pool = shared_pool();
     const int n_thr = (int)std::max<int64_t>(1, std::min<int64_t>(4 * (int64_t)(pool.size() + 1), nb / 2048));   // ranges, handed out dynamically
-    if (n_thr <= 1) {
+    // The ranges write their hits at slot j0 of ia / ib, i.e. they need room for nb entries; the contract promises the caller
+    // min(na, nb).  With na < nb (a list shorter than the one searched for) the single walk runs: it fills ia / ib from slot 0.
+    if (n_thr <= 1 || na < nb) {
         *n_out = gallop_range(a, na, b, 0, nb, 0, ia, ib);
         return SNPM_OK;
     }

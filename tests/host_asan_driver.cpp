@@ -146,6 +146,28 @@ int main(int argc, char **argv)
         if (!ok) { printf("intersect mismatch in round %d\n", round); return 1; }
         ++checked;
     }
+    // the pooled form of the galloping search (nb >= 4096: ranges of b on the pool's threads), buffers of EXACTLY min(na, nb)
+    // entries -- the documented capacity -- including a DB list shorter than the list searched for
+    long long pooled = 0;
+    const int shapes[][2] = {{10, 20000}, {300000, 20000}, {20000, 20000}, {19999, 20000}, {20001, 20000}, {5000, 9000}, {0, 8192}, {70000, 4096}};
+    for (const auto &sh : shapes) {
+        const int na = sh[0], nb = sh[1];
+        std::vector<int64_t> a, b;
+        int64_t x = 0;
+        for (int i = 0; i < na; ++i) { x += 1 + (int64_t)(rng() % 3); a.push_back(x); }
+        x = 0;
+        for (int i = 0; i < nb; ++i) { x += 1 + (int64_t)(rng() % (na > 10 * nb ? 30 : 3)); b.push_back(x); }
+        const size_t cap = (size_t)std::min(na, nb);
+        std::vector<int64_t> ia(cap), ib(cap), ja(cap), jb(cap);
+        int64_t k1 = -1, k2 = -1;
+        const int r1 = snpm_intersect_sorted(a.data(), na, b.data(), nb, ia.data(), ib.data(), &k1);
+        const int r2 = snpm_intersect_sorted_search(a.data(), na, b.data(), nb, ja.data(), jb.data(), &k2);
+        bool ok = r1 == SNPM_OK && r2 == SNPM_OK && k1 == k2 && k1 <= (int64_t)cap;
+        for (int64_t t = 0; ok && t < k1; ++t) ok = ia[(size_t)t] == ja[(size_t)t] && ib[(size_t)t] == jb[(size_t)t];
+        if (!ok) { printf("pooled intersect mismatch na=%d nb=%d (%d %d, %lld %lld)\n", na, nb, r1, r2, (long long)k1, (long long)k2); return 1; }
+        ++pooled;
+    }
+    printf("intersect_pooled shapes=%lld\n", pooled);
     const int64_t dup[] = {1, 2, 2, 3}, inc[] = {1, 2, 3};
     int64_t o1[4], o2[4], k = 0;
     printf("intersect rounds=%lld not_increasing rc=%d %d %d empty rc=%d\n", checked,

@@ -30,6 +30,7 @@ def test_host_sources_under_asan_and_ubsan(tmp_path, golden_dir):
     assert r.stdout.strip().endswith("done")
     assert lines["sample_vcf"] == "rc=0 records=10000"               # /root/reference/sample_files: 10 000 records
     assert lines["intersect"].startswith("rounds=400 not_increasing rc=-4 -4 -4 empty rc=0")
+    assert lines["intersect_pooled"] == "shapes=8"          # the threaded search with buffers of exactly min(na, nb) entries
     # 150 000 records, ~9 MB of text: lines straddle the reader's 4 MiB blocks; sums of POS / DP / PL pin the content
     n = 150000
     want = "rc=0 records=%d" % n
@@ -49,6 +50,21 @@ def test_host_sources_under_asan_and_ubsan(tmp_path, golden_dir):
     assert "rc=0 records=1" in out["no_newline_at_end"]
     for declined in ("crlf", "bad_pos", "bad_dp", "bad_pl", "huge_gt", "huge_chrom", "long_number"):
         assert "rc=-4" in out[declined], out[declined]
+
+
+def test_pooled_intersection_under_tsan(tmp_path):
+    """the threaded galloping search (snpm_intersect_sorted_search from 4096 searched values on: ranges of the list on the
+    persistent pool's threads, hit lists closed up afterwards) under ThreadSanitizer"""
+    exe = str(tmp_path / "intersect_tsan_driver")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-pthread", "-fsanitize=thread",
+                           "-I", os.path.join(ROOT, "include"), "-I", CSRC, os.path.join(ROOT, "tests", "intersect_tsan_driver.cpp"),
+                           os.path.join(CSRC, "snpm_host.cpp"), "-o", exe])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-4000:]
+    assert r.stdout.strip().endswith("done") and "fails=0" in r.stdout
 
 
 def test_hdf5_reader_under_asan_and_ubsan(tmp_path, golden_dir):
