@@ -77,7 +77,7 @@ struct snpm_ctx {
     // shared-row scan of a batch (snpm_api_shared.hpp): union of the samples' rows, the int8 digit matrix, partial digit sums
     Buf ws_sh_bitmap, ws_sh_wordbase, ws_sh_blocks, ws_sh_urows, ws_sh_meta, ws_sh_A, ws_sh_pos, ws_sh_partial;
     int batch_shared = -1;              // SNPM_BATCH_SHARED / snpm_batch_configure: -1 auto (batches whose inputs are on the device), 0 never, 1 whenever the batch allows it
-    int shared_digits = 7;              // base-256 digits of the fixed-point weights (3..7): 2^-(8 (digits - 1) + 6) per matched SNP of quantisation
+    int shared_digits = 0;              // base-256 digits of the fixed-point weights (3..7: 2^-(8 (digits - 1) + 6) per matched SNP of quantisation); 0 = by the longest sample
     int shared_min_samples = 8;         // auto: smaller batches keep the per-sample pass
     double shared_min_density = 0.25;   // auto: calls per (sample, union row) slot below which the per-sample pass reads fewer bytes than the contraction computes
     size_t shared_ws_bytes = size_t(2) << 30;   // SNPM_SHARED_WS_MB: digit matrix per pass over groups of samples
@@ -479,7 +479,7 @@ try {
     if (const char *s = getenv("SNPM_ONCE_ZEROCOPY")) ctx->once_zero_copy = atoi(s) != 0;
     if (const char *s = getenv("SNPM_DEBUG_MAX_PARTS")) ctx->debug_max_parts = atoi(s);
     if (const char *s = getenv("SNPM_BATCH_SHARED")) ctx->batch_shared = atoi(s) < 0 ? -1 : (atoi(s) ? 1 : 0);
-    if (const char *s = getenv("SNPM_SHARED_DIGITS")) ctx->shared_digits = std::min(7, std::max(3, atoi(s)));
+    if (const char *s = getenv("SNPM_SHARED_DIGITS")) ctx->shared_digits = atoi(s) <= 0 ? 0 : std::min(7, std::max(3, atoi(s)));
     if (const char *s = getenv("SNPM_SHARED_MIN_DENSITY")) ctx->shared_min_density = atof(s);
     if (const char *s = getenv("SNPM_SHARED_WS_MB")) ctx->shared_ws_bytes = (size_t)std::max(1, atoi(s)) << 20;
     if (const char *s = getenv("SNPM_SHARED_TILES")) ctx->shared_force_tiles = std::max(0, atoi(s));

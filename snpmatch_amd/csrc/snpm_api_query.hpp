@@ -513,7 +513,6 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     int64_t *d_rows = (int64_t *)ctx->ws_brows.p;
     const double *d_w = nullptr;
     if (device_inputs) {
-        HIPCHK(ctx, hipMemcpyAsync(d_rows, row_idx, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
         d_w = (const double *)wei;
     } else {
         if ((rc = ensure(ctx, ctx->ws_bw, NN * 3 * sizeof(double)))) return rc;
@@ -529,8 +528,6 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     }
     // the scoring kernel prefetches (never scores) a few row-list entries past a part: every entry it can reach must be
     // a row of THIS panel before the first launch -- also the ones whose upload is still on its way
-    if (device_inputs) HIPCHK(ctx, hipMemsetAsync(d_rows + N, 0, PREFETCH_PAD_ROWS * sizeof(int64_t), ctx->stream));
-    else HIPCHK(ctx, hipMemsetAsync(d_rows, 0, ((size_t)N + PREFETCH_PAD_ROWS) * sizeof(int64_t), ctx->stream));
     SegJob j;
     j.p = p;
     j.d_row_idx = d_rows;
@@ -547,23 +544,33 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     j.ldo = p->n_acc;
     // rows [r0, r1) of the concatenated inputs are on the device (or on their way, ordered before what follows):
     // sanitise the row list, build the LUT rows
-    auto prepare_rows = [&](int64_t r0, int64_t r1, const int32_t *rows32) -> int {
+    auto check_rows = [&](int64_t r0, int64_t r1, const int32_t *rows32) -> int {
         if (r1 <= r0) return SNPM_OK;
         const int64_t n = r1 - r0;
         hipLaunchKernelGGL(k_check_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_rows + r0, rows32, n,
                            p->n_snp, (int *)ctx->ws_flags2.p);
+        HIPCHK(ctx, hipGetLastError());
+        return SNPM_OK;
+    };
+    auto build_lut = [&](int64_t r0, int64_t r1) -> int {
+        if (r1 <= r0) return SNPM_OK;
+        const int64_t n = r1 - r0;
         ProfScope ps(ctx, PK_LUT);
         hipLaunchKernelGGL(k_build_lut, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_w + 3 * r0,
                            (double *)ctx->ws_blut.p + 4 * r0, n, skip, (int *)ctx->ws_flags2.p);
         HIPCHK(ctx, hipGetLastError());
         return SNPM_OK;
     };
+    auto prepare_rows = [&](int64_t r0, int64_t r1, const int32_t *rows32) -> int {
+        int r = check_rows(r0, r1, rows32);
+        return r ? r : build_lut(r0, r1);
+    };
     // every sample through the reference-order chain (requested, or more uncertain pairs than the sparse tier takes)
     auto strict_every_sample = [&]() -> int {
         for (int64_t b = 0; b < n_samples; ++b) {
             snpm_query *q = nullptr;
             const int64_t o = sample_off[b], nb = sample_off[b + 1] - o;
-            int r = snpm_query_create_device(p, d_rows + o, 0, nb, d_w + 3 * o, &q);
+            int r = snpm_query_create_device(p, j.d_row_idx + o, 0, nb, d_w + 3 * o, &q);
             if (r) return r;
             r = run_strict_chain(q, skip, chunk, nullptr, nullptr, nullptr, (double *)ctx->ws_bscore.p + b * na,
                                  (int64_t *)ctx->ws_bninfo.p + b * na);
@@ -579,12 +586,6 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_begin = now();
     double t_stage = 0, t_launch = 0;
-    SegPlan pl;
-    if (!strict_all) {
-        rc = seg_plan(ctx, j, pl);
-        if (rc) return rc;
-    }
-    const double t_planned = now();
     // Shared-row scan (snpm_api_shared.hpp): when the samples were genotyped on largely the same markers, every DB row is read
     // once and scored against all of them (int8 MFMA contraction of fixed-point weight digits), same certificate, same
     // reference-order re-evaluation of the unproven pairs.  It needs the whole batch on the device first: batches from host
@@ -593,20 +594,49 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     const bool try_shared = !strict_all && policy != 0 && (policy > 0 || device_inputs);
     SharedStats shst;
     shst.reason = 1;
-    auto shared_or_segments = [&]() -> int {        // every input is on the device (or ordered before what is enqueued here)
+    bool shared_done = false;
+    if (device_inputs && try_shared) {
+        // inputs already in HBM: the pass reads the caller's row list and weights in place (its first kernel vets every index
+        // and weight); only a batch it declines pays for the sanitised copy and the LUT rows of the per-sample pass
+        SegJob js = j;
+        js.d_row_idx = (const int64_t *)row_idx;
+        rc = shared_rows_try(ctx, js, policy > 0, shst);
+        if (rc) return rc;
+        if (shst.taken) {
+            j = js;
+            shared_done = true;
+        }
+    }
+    if (device_inputs && !shared_done) {
+        HIPCHK(ctx, hipMemcpyAsync(d_rows, row_idx, (size_t)N * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(d_rows + N, 0, PREFETCH_PAD_ROWS * sizeof(int64_t), ctx->stream));
+    } else if (!device_inputs) {
+        HIPCHK(ctx, hipMemsetAsync(d_rows, 0, ((size_t)N + PREFETCH_PAD_ROWS) * sizeof(int64_t), ctx->stream));
+    }
+    SegPlan pl;
+    if (!strict_all && !shared_done) {
+        rc = seg_plan(ctx, j, pl);
+        if (rc) return rc;
+    }
+    const double t_planned = now();
+    auto shared_or_segments = [&]() -> int {        // host batch, whole on the device now (ordered before what is enqueued here)
         const SegJob keep = j;
         int r = shared_rows_try(ctx, j, policy > 0, shst);
         if (r) return r;
-        if (!shst.taken) {
+        if (shst.taken) {
+            shared_done = true;
+        } else {
             j = keep;
-            r = seg_launch(ctx, j, pl, 0, n_samples);
+            r = build_lut(0, N);
+            if (!r) r = seg_launch(ctx, j, pl, 0, n_samples);
         }
         return r;
     };
-    if (device_inputs) {
+    if (shared_done) {
+        // scored above
+    } else if (device_inputs) {
         rc = prepare_rows(0, N, nullptr);
-        if (!rc && try_shared) rc = shared_or_segments();
-        else if (!rc && !strict_all) rc = seg_launch(ctx, j, pl, 0, n_samples);
+        if (!rc && !strict_all) rc = seg_launch(ctx, j, pl, 0, n_samples);
         if (rc) return rc;
     } else {
         // Host inputs: the batch is cut into runs of samples of about one staging slab; while run k is scored, run
@@ -655,7 +685,7 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
                                    (double *)ctx->ws_bw.p + 3 * r0);
                 HIPCHK(ctx, hipGetLastError());
             }
-            rc = prepare_rows(r0, r1, rows32);
+            rc = try_shared ? check_rows(r0, r1, rows32) : prepare_rows(r0, r1, rows32);
             if (!rc && !strict_all && !try_shared) rc = seg_launch(ctx, j, pl, s0, s1);
             if (rc) return rc;
             t_launch += now() - ts1;
@@ -717,9 +747,9 @@ int snpm_batch_configure(snpm_ctx *ctx, int shared_rows, int digits, double min_
 {
     if (!ctx) return set_err(nullptr, SNPM_ERR_BADARG, "ctx is NULL");
     CHECK_ARG(ctx, shared_rows >= -1 && shared_rows <= 1, "shared_rows: -1 auto, 0 never, 1 whenever the batch allows it");
-    CHECK_ARG(ctx, digits == 0 || (digits >= 3 && digits <= 7), "digits: 3..7 (0 keeps the current value)");
+    CHECK_ARG(ctx, digits == -1 || digits == 0 || (digits >= 3 && digits <= 7), "digits: 3..7, -1 chosen by the longest sample, 0 keeps the current value");
     ctx->batch_shared = shared_rows;
-    if (digits) ctx->shared_digits = digits;
+    if (digits) ctx->shared_digits = digits < 0 ? 0 : digits;
     if (min_density >= 0.0) ctx->shared_min_density = min_density;
     return SNPM_OK;
 }

@@ -212,7 +212,7 @@ static int seg_finish(snpm_ctx *ctx, const SegJob &j)
         if (rc) return rc;
     } else {
         ProfScope ps(ctx, PK_STRICT);
-        dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(j.kmax, 1), 256), (unsigned)std::min(j.cap, 512));   // a wave per (pair, chunk); both axes walk
+        dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(j.kmax, 1), 256), (unsigned)std::min(j.cap, 128));   // a wave per (pair, chunk); both axes walk (the usual launch finds no pair: 128 rows of blocks leave in 8 us, 512 took 23)
 #define LAUNCH_PAIRS(S, G)                                                                                        \
     hipLaunchKernelGGL((k_strict_pairs<S, G>), grid, dim3(WAVE), 0, ctx->stream, p->d, p->kpitch, p->desc, j.d_row_idx,     \
                        j.row0, j.d_w, j.d_seg_off, j.chunk, (const int32_t *)seg_pairs(ctx), (const int *)seg_pair_count(ctx), \

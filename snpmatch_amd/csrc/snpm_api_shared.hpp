@@ -10,7 +10,7 @@ struct SharedStats {
     double density = 0.0;           // N / (union_rows * n_samples): share of (sample, union row) slots that hold a call
     int taken = 0;
     int reason = 0;                 // why not: 1 policy off, 2 too few samples / rows, 3 unsorted rows, 4 weights outside [0, 1], 5 codes > 2 in the panel,
-                                    //          6 overlap below the threshold, 7 panel / batch too large for 32-bit indices
+                                    //          6 overlap below the threshold, 7 panel / batch too large for 32-bit indices, 8 a row index outside the panel
     int tiles = 0, groups = 0, accgroups = 0, passes = 0, digits = 0;
 };
 
@@ -19,19 +19,22 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     snpm_panel *p = j.p;
     st = SharedStats();
     const int64_t n_seg = j.n_seg, N = j.n_total;
-    const int digits = ctx->shared_digits;
-    st.digits = digits;
     if (n_seg < (forced ? 1 : ctx->shared_min_samples) || N < 1) { st.reason = 2; return SNPM_OK; }
     if (p->n_snp > 0x7fffffffLL || N > 0xfffffff0LL || !j.d_row_idx) { st.reason = 7; return SNPM_OK; }
     int rc;
-    const int rps = digits + 1, slots = SH_GROUP_ROWS / rps;
-    const int frac_bits = sh_frac_bits(digits);
     int64_t maxlen = 0, kmax = 1;
     for (int64_t s = 0; s < n_seg; ++s) {
         const int64_t len = j.seg_off[s + 1] - j.seg_off[s];
         maxlen = std::max(maxlen, len);
         kmax = std::max<int64_t>(kmax, (len + j.chunk - 1) / j.chunk);
     }
+    // digits of the fixed-point weights: the fewest that keep a sample's quantisation (2^-F per matched SNP) below 2^-20 -- the
+    // certificate then flags about one (sample, accession) pair in a million for it -- unless the caller fixed the number
+    int digits = ctx->shared_digits;
+    if (digits == 0) digits = maxlen <= (int64_t(1) << 18) ? 5 : (maxlen <= (int64_t(1) << 26) ? 6 : 7);
+    st.digits = digits;
+    const int rps = digits + 1;
+    const int frac_bits = sh_frac_bits(digits);
     // ---- union of the samples' rows: bitmap of panel rows -> ranks -> row list
     const int64_t n_words = (p->n_snp + 31) / 32;
     const int64_t n_blocks = (n_words + SH_WORDS_PER_BLOCK - 1) / SH_WORDS_PER_BLOCK;
@@ -55,10 +58,23 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     HIPCHK(ctx, hipMemsetAsync(d_bitmap, 0, (size_t)n_words * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(d_urows, 0, urow_entries * 4, ctx->stream));
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((maxlen + 255) / 256, 64));
+    // one pass over the entries: marks, input checks, quantisation counts and (chunks of ordinary length) the partial sums of the
+    // reference-order error bound, which k_eseg_finish turns into the per-sample bound
+    const int npart = (int)((kmax + 3) / 4);
+    const bool fused_bound = j.certify && j.chunk <= 8192;
+    if (j.certify) {
+        if ((rc = ensure(ctx, ctx->ws_eseg, (size_t)n_seg * sizeof(double)))) return rc;
+        if ((rc = ensure(ctx, ctx->ws_epart, (size_t)n_seg * (size_t)npart * 3 * sizeof(double)))) return rc;
+    }
     {
         ProfScope ps(ctx, PK_LUT);
-        hipLaunchKernelGGL(k_sh_mark, dim3(gx, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, j.d_w, (const int64_t *)d_seg_off,
-                           frac_bits, j.skip, d_bitmap, d_inexact, d_meta);
+        if (fused_bound)
+            hipLaunchKernelGGL(k_sh_mark_chunks, dim3((unsigned)npart, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, j.d_w,
+                               (const int64_t *)d_seg_off, j.chunk, npart, frac_bits, j.skip, p->n_snp, d_bitmap, d_inexact, d_meta,
+                               (double *)ctx->ws_epart.p);
+        else
+            hipLaunchKernelGGL(k_sh_mark, dim3(gx, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, j.d_w, (const int64_t *)d_seg_off,
+                               frac_bits, j.skip, p->n_snp, d_bitmap, d_inexact, d_meta);
         hipLaunchKernelGGL(k_sh_count, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, n_words, d_blocksum);
         hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)d_blocksum, n_blocks, d_blockbase, d_meta);
         hipLaunchKernelGGL(k_sh_fill, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, n_words,
@@ -76,6 +92,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     const int other = (int)(h_meta[2] & 0xffffffffLL);
     st.union_rows = U;
     st.density = U > 0 ? (double)N / ((double)U * (double)n_seg) : 0.0;
+    if (bad & 4) { st.reason = 8; return SNPM_OK; }
     if (bad & 1) { st.reason = 3; return SNPM_OK; }
     if (bad & 2) { st.reason = 4; return SNPM_OK; }
     if (other) { st.reason = 5; return SNPM_OK; }
@@ -89,7 +106,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     const int64_t ld_pos = n_steps * SH_STEP_ROWS;
     const int n_accgroups = (int)((p->n_acc + SH_WAVE_ACCS - 1) / SH_WAVE_ACCS);
     const int64_t ldn = (int64_t)n_accgroups * SH_WAVE_ACCS;
-    const int64_t groups_total = (n_seg + slots - 1) / slots;
+    const int64_t groups_total = (n_seg * rps + SH_GROUP_ROWS - 1) / SH_GROUP_ROWS;   // sample s owns matrix rows s * rps .. + rps - 1
     const size_t bytes_per_group = (size_t)steps_ld * 4096;
     const size_t budget = ctx->shared_ws_bytes;
     int64_t groups_per_pass = std::max<int64_t>(1, std::min<int64_t>(groups_total, (int64_t)(budget / std::max<size_t>(bytes_per_group, 1))));
@@ -124,7 +141,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
         steps_per_tile = ((n_steps + n_tiles - 1) / n_tiles + SH_DEPTH - 1) / SH_DEPTH * SH_DEPTH;
         n_tiles = (int)((n_steps + steps_per_tile - 1) / steps_per_tile);
     }
-    const int64_t samples_per_pass = groups_per_pass * slots;
+    const int64_t samples_per_pass = std::max<int64_t>(1, groups_per_pass * SH_GROUP_ROWS / rps);
     if ((rc = ensure(ctx, ctx->ws_sh_A, ((size_t)groups_per_pass * steps_ld + SH_PAD_STEPS) * 4096))) return rc;
     if ((rc = ensure(ctx, ctx->ws_sh_pos, (size_t)std::min<int64_t>(samples_per_pass, n_seg) * ld_pos * 4))) return rc;
     if ((rc = ensure(ctx, ctx->ws_sh_partial, (size_t)n_tiles * groups_per_pass * SH_GROUP_ROWS * ldn * 4))) return rc;
@@ -135,12 +152,10 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     if ((rc = ensure(ctx, ctx->ws_pairs, 16 + (size_t)SEG_PAIR_CAP * 2 * sizeof(int32_t)))) return rc;
     HIPCHK(ctx, hipMemsetAsync(seg_pair_count(ctx), 0, sizeof(int), ctx->stream));
     if (j.certify) {
-        if ((rc = ensure(ctx, ctx->ws_eseg, (size_t)n_seg * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->ws_pair_sums, (size_t)j.cap * (size_t)kmax * sizeof(double)))) return rc;
-        const int npart = (int)((kmax + 3) / 4);
-        if ((rc = ensure(ctx, ctx->ws_epart, (size_t)n_seg * (size_t)npart * 3 * sizeof(double)))) return rc;
-        hipLaunchKernelGGL(k_eseg_part, dim3((unsigned)npart, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_w, (const int64_t *)d_seg_off,
-                           j.chunk, (int64_t)0, npart, (double *)ctx->ws_epart.p);
+        if (!fused_bound)
+            hipLaunchKernelGGL(k_eseg_part, dim3((unsigned)npart, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_w, (const int64_t *)d_seg_off,
+                               j.chunk, (int64_t)0, npart, (double *)ctx->ws_epart.p);
         // fast_adds = 4: the integer pass adds nothing; the term covers the two conversions and the addition of k_sh_finish
         hipLaunchKernelGGL(k_eseg_finish, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, (const double *)ctx->ws_epart.p,
                            (const int64_t *)d_seg_off, j.chunk, (int64_t)4, (int64_t)0, npart, (double *)ctx->ws_eseg.p);
@@ -150,7 +165,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     st.tiles = n_tiles; st.accgroups = n_accgroups; st.groups = (int)groups_total;
     for (int64_t s_base = 0; s_base < n_seg; s_base += samples_per_pass) {
         const int64_t s_pass = std::min<int64_t>(samples_per_pass, n_seg - s_base);
-        const int64_t groups = (s_pass + slots - 1) / slots;
+        const int64_t groups = (s_pass * rps + SH_GROUP_ROWS - 1) / SH_GROUP_ROWS;
         int tiles = n_tiles, bpt = blocks_per_tile;
         int64_t spt = steps_per_tile;
         if (groups != groups_per_pass) {
@@ -161,10 +176,19 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
                            (const uint32_t *)d_bitmap, (const uint32_t *)d_wordbase, (uint32_t *)ctx->ws_sh_pos.p, ld_pos);
         {
             ProfScope ps(ctx, PK_LUT);
-            const int64_t threads = groups * n_steps * slots * 2;
-            hipLaunchKernelGGL(k_sh_expand, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream,
-                               (const uint32_t *)ctx->ws_sh_pos.p, ld_pos, j.d_w, s_pass, digits, j.skip, n_steps, steps_ld,
-                               (sh_v4i *)ctx->ws_sh_A.p);
+            const int64_t threads = n_steps * s_pass * 2;
+            const dim3 eg((unsigned)((threads + 255) / 256));
+#define LAUNCH_EXPAND(D)                                                                                                     \
+    hipLaunchKernelGGL((k_sh_expand<D>), eg, dim3(256), 0, ctx->stream, (const uint32_t *)ctx->ws_sh_pos.p, ld_pos, j.d_w, s_pass, j.skip,  \
+                       n_steps, steps_ld, (sh_v4i *)ctx->ws_sh_A.p)
+            switch (digits) {
+            case 3: LAUNCH_EXPAND(3); break;
+            case 4: LAUNCH_EXPAND(4); break;
+            case 5: LAUNCH_EXPAND(5); break;
+            case 6: LAUNCH_EXPAND(6); break;
+            default: LAUNCH_EXPAND(7); break;
+            }
+#undef LAUNCH_EXPAND
             HIPCHK(ctx, hipGetLastError());
         }
         {
@@ -180,7 +204,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
         }
         {
             ProfScope ps(ctx, PK_REDUCE);
-            hipLaunchKernelGGL(k_sh_finish, dim3((unsigned)p->n_acc, (unsigned)((s_pass + 63) / 64)), dim3(64), 0, ctx->stream,
+            hipLaunchKernelGGL(k_sh_finish, dim3((unsigned)p->n_acc, (unsigned)((s_pass + 63) / 64)), dim3(256), 0, ctx->stream,
                                (const int *)ctx->ws_sh_partial.p, tiles, (int)groups, ldn, digits, (const int64_t *)d_seg_off, s_base,
                                s_pass, p->n_acc, (const int *)d_inexact, j.certify ? (const double *)ctx->ws_eseg.p : (const double *)nullptr,
                                ctx->debug_reeval, j.d_score, j.d_ninfo, j.ldo, seg_pairs(ctx), seg_pair_count(ctx), j.cap);

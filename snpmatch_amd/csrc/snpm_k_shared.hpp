@@ -48,27 +48,99 @@ typedef int sh_v16i __attribute__((ext_vector_type(16)));
 __host__ __device__ __forceinline__ int sh_frac_bits(int digits) { return 8 * (digits - 1) + 6; }
 
 // meta block of a shared-row pass (device, int64 [8]): [0] union rows U, [1] bad-input bits (1 a sample's rows are not strictly
-// increasing, 2 a weight lies outside [0, 1] or is not finite), [2..] spare
+// increasing, 2 a weight lies outside [0, 1] or is not finite, 4 a row index outside the panel), [2..] spare
 // ---------------------------------------------------------------------------------------------------------------
-// k_sh_mark: blockIdx.y = sample.  Marks the sample's rows in the bitmap of panel rows, checks that its row list is strictly
-// increasing (the union needs every (sample, row) at most once) and its weights lie in [0, 1], counts the rows with a weight that
-// 2^-F does not divide (the quantisation bound of the sample).
+// One pass over the batch's entries (sample = segment of the concatenated row list and weights):
+//   - marks the rows in the bitmap of panel rows (the bit is read first: most rows of a batch on one marker set are marked already,
+//     and 64 samples would otherwise send 64 atomics to every word),
+//   - checks what the contraction needs: row indices inside the panel, strictly increasing per sample (the union holds every
+//     (sample, row) at most once), weights in [0, 1],
+//   - counts per sample the rows with a weight that 2^-F does not divide (the quantisation bound),
+//   - and leaves the partial sums of the reference-order error bound exactly as k_eseg_part does (same decomposition: block =
+//     four chunks of `chunk` rows, a wave per chunk; same order of additions), so that k_eseg_finish follows directly.
+__device__ __forceinline__ void sh_mark_entry(const int64_t *__restrict__ rows, const double *__restrict__ w, int64_t i, int64_t r0,
+                                              int64_t n_snp, double scale, int skip_hets, uint32_t *__restrict__ bitmap, int &inexact,
+                                              int &bad, double &wmax, int &nonint)
+{
+    const int64_t r = rows[i];
+    if (r < 0 || r >= n_snp) {
+        bad |= 4;
+    } else {
+        if (i > r0 && rows[i - 1] >= r) bad |= 1;
+        uint32_t *wp = &bitmap[r >> 5];
+        const uint32_t bit = 1u << (r & 31);
+        if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(wp, bit);
+    }
+    const double w0 = w[3 * i], w1 = w[3 * i + 1], w2 = w[3 * i + 2];
+    const double a = fabs(w0), b = fabs(w1), c = fabs(w2);
+    wmax = fmax(a, fmax(b, c));
+    if (!(a == floor(a) && b == floor(b) && c == floor(c)) || !(a < 1e300 && b < 1e300 && c < 1e300)) nonint = 1;
+    const double h = skip_hets ? 0.0 : w1;
+    if (!(w0 >= 0.0 && w0 <= 1.0 && h >= 0.0 && h <= 1.0 && w2 >= 0.0 && w2 <= 1.0)) bad |= 2;
+    const double xa = w0 * scale, xb = h * scale, xc = w2 * scale;
+    if (!(xa == floor(xa) && xb == floor(xb) && xc == floor(xc))) ++inexact;
+}
+
+__global__ void __launch_bounds__(256)
+k_sh_mark_chunks(const int64_t *__restrict__ rows, const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk,
+                 int npart, int frac_bits, int skip_hets, int64_t n_snp, uint32_t *__restrict__ bitmap, int *__restrict__ n_inexact,
+                 long long *__restrict__ meta, double *__restrict__ partial)
+{
+    __shared__ double sm[4][3];
+    const int64_t s = blockIdx.y;
+    const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
+    const int64_t len = r1 - r0;
+    const int64_t K = (len + chunk - 1) / chunk;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * 4 + wave;
+    const double scale = __builtin_ldexp(1.0, frac_bits);
+    double v = 0.0;
+    int nonint = 0, inexact = 0, bad = 0;
+    int64_t c0 = 0, c1 = 0;
+    if (k < K) {
+        c0 = r0 + k * chunk;
+        c1 = (c0 + chunk < r1) ? c0 + chunk : r1;
+        for (int64_t r = c0 + lane; r < c1; r += 64) {
+            double wmax;
+            sh_mark_entry(rows, w, r, r0, n_snp, scale, skip_hets, bitmap, inexact, bad, wmax, nonint);
+            v += wmax;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        v += __shfl_xor(v, o);
+        nonint |= __shfl_xor(nonint, o);
+        inexact += __shfl_xor(inexact, o);
+        bad |= __shfl_xor(bad, o);
+    }
+    if (lane == 0) {
+        sm[wave][0] = (k < K) ? v * (double)((c1 - c0) + 3 + (K - k)) : 0.0;
+        sm[wave][1] = v;
+        sm[wave][2] = (double)nonint;
+        if (inexact) atomicAdd(&n_inexact[s], inexact);
+        if (bad) atomicOr((unsigned long long *)&meta[1], (unsigned long long)bad);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int q = threadIdx.x;
+        const double t = (q == 2) ? fmax(fmax(sm[0][2], sm[1][2]), fmax(sm[2][2], sm[3][2]))
+                                  : ((sm[0][q] + sm[1][q]) + sm[2][q]) + sm[3][q];
+        partial[((int64_t)blockIdx.y * npart + blockIdx.x) * 3 + q] = t;
+    }
+}
+
+// the same marks and checks without the error-bound sums (very long chunks: k_eseg_part keeps its own launch), grid-stride
 __global__ void __launch_bounds__(256)
 k_sh_mark(const int64_t *__restrict__ rows, const double *__restrict__ w, const int64_t *__restrict__ seg_off, int frac_bits,
-          int skip_hets, uint32_t *__restrict__ bitmap, int *__restrict__ n_inexact, long long *__restrict__ meta)
+          int skip_hets, int64_t n_snp, uint32_t *__restrict__ bitmap, int *__restrict__ n_inexact, long long *__restrict__ meta)
 {
     const int64_t s = blockIdx.y;
     const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
     const double scale = __builtin_ldexp(1.0, frac_bits);
-    int inexact = 0, bad = 0;
+    int inexact = 0, bad = 0, nonint = 0;
     for (int64_t i = r0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < r1; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = rows[i];
-        if (i > r0 && rows[i - 1] >= r) bad |= 1;
-        atomicOr(&bitmap[r >> 5], 1u << (r & 31));
-        const double a = w[3 * i], b = skip_hets ? 0.0 : w[3 * i + 1], c = w[3 * i + 2];
-        if (!(a >= 0.0 && a <= 1.0 && b >= 0.0 && b <= 1.0 && c >= 0.0 && c <= 1.0)) bad |= 2;
-        const double xa = a * scale, xb = b * scale, xc = c * scale;
-        if (!(xa == floor(xa) && xb == floor(xb) && xc == floor(xc))) ++inexact;
+        double wmax;
+        sh_mark_entry(rows, w, i, r0, n_snp, scale, skip_hets, bitmap, inexact, bad, wmax, nonint);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -187,60 +259,67 @@ k_sh_pos(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_sh_expand: the A matrix in fragment order.  Thread = (group g, K step k, sample slot, lane half h): converts the sample's
+// k_sh_expand: the A matrix in fragment order.  Thread = (K step k, sample s of the pass, lane half h): converts the sample's
 // weights at union rows 8k + 4h .. + 3 to fixed point, splits them into balanced digits and stores the 16 B of every digit row
 // (and of the missing-count row) where lane (m, h) of tile t will load them.
-//   matrix row of (sample slot sl, digit j) inside its group: sl * RPS + j;  RPS = digits + 1;  slots per group = 128 / RPS
+//   matrix row of (sample s, digit j): M = s * RPS + j, RPS = DIGITS + 1 (samples follow each other without gaps: a sample may
+//   lie across two groups of 128 rows); group M >> 7, tile (M >> 5) & 3, lane row M & 31
+//   balanced digits: Q' = floor(w 2^F) + sum_{p < DIGITS-1} 128 * 256^p; digit at position p < DIGITS-1 = byte p of Q' - 128
+//   (stored byte = byte ^ 0x80), top digit = Q' >> 8 (DIGITS - 1) (0 .. 65)
 //   byte order of a row dword: class 0 (ref) = W[:, 0], class 1 (alt) = W[:, 2], class 2 (het) = W[:, 1] (0 when skip_hets),
 //   class 3 (missing) = 0 in digit rows; the missing-count row holds 1 in class 3 (and in class 2 when skip_hets).
+template <int DIGITS>
 __global__ void __launch_bounds__(256)
-k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__restrict__ w, int64_t n_samples_pass, int digits,
-            int skip_hets, int64_t n_steps, int64_t steps_ld, sh_v4i *__restrict__ A)
+k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__restrict__ w, int64_t n_samples_pass, int skip_hets,
+            int64_t n_steps, int64_t steps_ld, sh_v4i *__restrict__ A)
 {
-    const int rps = digits + 1;
-    const int slots = SH_GROUP_ROWS / rps;
-    const int64_t per_step = (int64_t)slots * 2;
+    constexpr int RPS = DIGITS + 1;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t n_groups = (n_samples_pass + slots - 1) / slots;
-    if (idx >= n_groups * n_steps * per_step) return;
-    const int q = (int)(idx % per_step);
-    const int64_t k = (idx / per_step) % n_steps;
-    const int64_t g = idx / (per_step * n_steps);
-    const int sl = q >> 1, h = q & 1;
-    const int64_t s = g * slots + sl;
-    const int frac_bits = sh_frac_bits(digits);
+    if (idx >= n_steps * n_samples_pass * 2) return;
+    const int h = (int)(idx & 1);
+    const int64_t s = (idx >> 1) % n_samples_pass;
+    const int64_t k = (idx >> 1) / n_samples_pass;
+    constexpr int frac_bits = 8 * (DIGITS - 1) + 6;
     const double scale = __builtin_ldexp(1.0, frac_bits);
-    uint32_t dw[SH_MAX_RPS][4];
+    unsigned long long bias = 0;
 #pragma unroll
-    for (int j = 0; j < SH_MAX_RPS; ++j)
+    for (int p = 0; p < DIGITS - 1; ++p) bias |= 128ull << (8 * p);
+    const sh_v4i e4 = *reinterpret_cast<const sh_v4i *>(pos + s * ld_pos + k * SH_STEP_ROWS + 4 * h);
+    const uint32_t e[4] = {(uint32_t)e4.x, (uint32_t)e4.y, (uint32_t)e4.z, (uint32_t)e4.w};
+    uint32_t dw[RPS][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dw[j][i] = 0;
-    if (s < n_samples_pass) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t u = k * SH_STEP_ROWS + 4 * h + i;
-            const uint32_t e = pos[s * ld_pos + u];
-            if (!e) continue;
-            const double *wr = w + 3 * (int64_t)(e - 1);
-            double wc[3] = {wr[0], wr[2], skip_hets ? 0.0 : wr[1]};      // class order: ref, alt, het
+    for (int i = 0; i < 4; ++i) {
+        uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        if (e[i]) {
+            const double *wr = w + 3 * (int64_t)(e[i] - 1);
+            const double wc[3] = {wr[0], wr[2], skip_hets ? 0.0 : wr[1]};      // class order: ref, alt, het
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 double x = wc[c];
-                x = (x >= 0.0 && x <= 1.0) ? x : 0.0;                    // refused by k_sh_mark; keep the conversion defined
-                long long Q = (long long)floor(x * scale);
-                for (int j = digits - 1; j >= 1; --j) {
-                    const int d = (int)((Q + 128) & 255) - 128;
-                    Q = (Q - d) >> 8;
-                    dw[j][i] |= (uint32_t)(d & 255) << (8 * c);
-                }
-                dw[0][i] |= (uint32_t)((int)Q & 255) << (8 * c);
+                x = (x >= 0.0 && x <= 1.0) ? x : 0.0;                          // refused by the mark pass; keep the conversion defined
+                const unsigned long long Q = (unsigned long long)floor(x * scale) + bias;
+                lo[c] = (uint32_t)Q;
+                hi[c] = (uint32_t)(Q >> 32);
             }
-            dw[digits][i] = skip_hets ? 0x01010000u : 0x01000000u;
         }
+#pragma unroll
+        for (int j = 0; j < DIGITS; ++j) {
+            const int p = DIGITS - 1 - j;                                      // byte position of digit j (j = 0: the top digit)
+            const uint32_t *src = (p < 4) ? lo : hi;
+            const uint32_t b = (uint32_t)(p & 3);
+            // (ref.b, alt.b, 0, 0) then (.., .., het.b, 0)
+            const uint32_t t = __builtin_amdgcn_perm(src[1], src[0], 0x0c0c0000u | ((4u + b) << 8) | b);
+            uint32_t d = __builtin_amdgcn_perm(src[2], t, 0x0c000100u | ((4u + b) << 16));
+            if (j > 0) d ^= 0x00808080u;
+            dw[j][i] = e[i] ? d : 0u;
+        }
+        dw[DIGITS][i] = e[i] ? (skip_hets ? 0x01010000u : 0x01000000u) : 0u;
     }
-    for (int j = 0; j < rps; ++j) {
-        const int M = sl * rps + j;
-        const int t = M >> 5, m = M & 31;
+#pragma unroll
+    for (int j = 0; j < RPS; ++j) {
+        const int64_t M = s * RPS + j;
+        const int64_t g = M >> 7;
+        const int t = (int)((M >> 5) & 3), m = (int)(M & 31);
         sh_v4i v;
         v.x = (int)dw[j][0]; v.y = (int)dw[j][1]; v.z = (int)dw[j][2]; v.w = (int)dw[j][3];
         A[((g * steps_ld + k) * 4 + t) * 64 + h * 32 + m] = v;
@@ -410,33 +489,44 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_sh_finish: block = accession a, thread = sample of the pass (the digit sums of one sample are adjacent in the accession-major
-// partial array, samples follow each other).  Adds the row tiles' partial digit sums (int64), puts the digits together,
-// converts to fp64 (hi / lo parts: each conversion is exact or rounds once far below the bound), ninfo = calls of the
-// sample - missing count, and runs the certificate: the reference's score lies in [v - E, v + E + Eq], E = eseg[s] (reference-order
-// bound + the conversion), Eq = n_inexact[s] 2^-F (the quantisation, one-sided).
-__global__ void __launch_bounds__(64)
+// k_sh_finish: block = accession a, four waves; lane = sample of the pass (the digit sums of one sample are adjacent in the
+// accession-major partial array, samples follow each other), wave w adds the row tiles w, w + 4, ... (int64), the waves' sums meet
+// in LDS.  Then the digits are put together and converted to fp64 (hi / lo parts: each conversion is exact or rounds once far
+// below the bound), ninfo = calls of the sample - missing count, and the certificate runs: the reference's score lies in
+// [v - E, v + E + Eq], E = eseg[s] (reference-order bound + the conversion), Eq = n_inexact[s] 2^-F (the quantisation, one-sided).
+__global__ void __launch_bounds__(256)
 k_sh_finish(const int *__restrict__ partial, int n_tiles, int n_groups, int64_t ldn, int digits, const int64_t *__restrict__ seg_off,
             int64_t s_base, int64_t n_samples_pass, int64_t n_acc, const int *__restrict__ n_inexact, const double *__restrict__ eseg,
             int force_first, double *__restrict__ score, int64_t *__restrict__ ninfo, int64_t ldo, int32_t *__restrict__ pairs,
             int *__restrict__ count, int cap)
 {
+    __shared__ long long sm[3][64][SH_MAX_RPS];
     const int64_t a = blockIdx.x;
-    const int64_t sp = (int64_t)blockIdx.y * 64 + threadIdx.x;
-    if (sp >= n_samples_pass) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t sp = (int64_t)blockIdx.y * 64 + lane;
+    const bool on = sp < n_samples_pass;
     const int64_t sg = s_base + sp;
-    const int rps = digits + 1, slots = SH_GROUP_ROWS / rps;
-    const int64_t g = sp / slots, sl = sp % slots;
+    const int rps = digits + 1;
     const int64_t ldm = (int64_t)n_groups * SH_GROUP_ROWS;
     long long dsum[SH_MAX_RPS];
 #pragma unroll
     for (int j = 0; j < SH_MAX_RPS; ++j) dsum[j] = 0;
-    for (int t = 0; t < n_tiles; ++t) {
-        const int *p = partial + ((int64_t)t * ldn + a) * ldm + g * SH_GROUP_ROWS + sl * rps;
+    if (on) {
+        for (int t = wave; t < n_tiles; t += 4) {
+            const int *p = partial + ((int64_t)t * ldn + a) * ldm + sp * rps;
 #pragma unroll
-        for (int j = 0; j < SH_MAX_RPS; ++j)
-            if (j < rps) dsum[j] += p[j];
+            for (int j = 0; j < SH_MAX_RPS; ++j)
+                if (j < rps) dsum[j] += p[j];
+        }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < SH_MAX_RPS; ++j) sm[wave - 1][lane][j] = dsum[j];
+    }
+    __syncthreads();
+    if (wave > 0 || !on) return;
+#pragma unroll
+    for (int j = 0; j < SH_MAX_RPS; ++j) dsum[j] += sm[0][lane][j] + sm[1][lane][j] + sm[2][lane][j];
     // digits 0 .. 2 form the high part (units of 256^(digits-3) 2^-F), the others the low part (units of 2^-F)
     long long hi = 0, lo = 0;
 #pragma unroll

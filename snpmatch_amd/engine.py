@@ -715,13 +715,13 @@ def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, li
 
 
 SHARED_WHY_NOT = {0: "", 1: "policy", 2: "too few samples or rows", 3: "a row list is not strictly increasing", 4: "a weight outside [0, 1]",
-                  5: "call codes > 2 in the panel", 6: "overlap below the threshold", 7: "sizes beyond 32-bit indices"}
+                  5: "call codes > 2 in the panel", 6: "overlap below the threshold", 7: "sizes beyond 32-bit indices", 8: "a row index outside the panel"}
 
 
 def batch_configure(ctx, shared_rows=-1, digits=0, min_density=-1.0):
     """Policy of score_batch for batches whose samples share DB rows (snpm_batch_configure): shared_rows -1 automatic (device
     inputs, >= 8 samples, enough overlap), 0 never, 1 whenever the batch allows it; digits 3..7 base-256 digits of the fixed-point
-    weights (0: keep); min_density: threshold of the automatic choice (negative: keep)."""
+    weights (-1: chosen by the longest sample, 0: keep); min_density: threshold of the automatic choice (negative: keep)."""
     check(ctx.lib.snpm_batch_configure(ctx.h, int(shared_rows), int(digits), float(min_density)), ctx.h)
 
 

@@ -62,7 +62,7 @@ def chip_samples(rng, db, count, n_markers, drop=0.05, extra=0.02):
     return out
 
 
-def check_against_oracle(db, samples, got, skip, lik=True, digits=7):
+def check_against_oracle(db, samples, got, skip, lik=True, digits=5):
     for b, (rows, wei) in enumerate(samples):
         want_s, want_n = c_oracle.genotyper(db, rows, wei, 1000, skip)
         assert np.array_equal(got["ninfo"][b], want_n), b
@@ -90,7 +90,7 @@ def test_shared_rows_equal_oracle_and_per_sample_pass(packed, skip):
     engine.batch_configure(ctx, shared_rows=1)
     got = engine.score_batch(panel, samples, 1000, skip, engine.MODE_EXACT)
     st = engine.batch_last_stats(ctx)
-    assert got["shared_rows"] and st["taken"] and st["digits"] == 7, st
+    assert got["shared_rows"] and st["taken"] and st["digits"] == 5, st       # chosen by the longest sample: 2^-38 per matched SNP
     union = np.unique(np.concatenate([r for r, _ in samples]))
     assert got["union_rows"] == len(union) == st["union_rows"]
     assert got["pairs_reeval"] >= 1 and not got["strict_fallback"]          # the perfect PL matches
@@ -105,7 +105,7 @@ def test_shared_rows_equal_oracle_and_per_sample_pass(packed, skip):
     engine.batch_configure(ctx, shared_rows=1)
     fast = engine.score_batch(panel, samples, 1000, skip, engine.MODE_FAST, likelihoods=False)
     assert fast["shared_rows"] and np.array_equal(fast["ninfo"], got["ninfo"])
-    assert np.max(np.abs(fast["score"] - seg["score"])) < 1e-7
+    assert np.max(np.abs(fast["score"] - seg["score"])) < 1e-7 + 6400 * 2.0 ** -38
     ctx.close()
 
 
