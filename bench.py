@@ -132,6 +132,7 @@ def main():
                     help="seconds the ranks may take to join the library's RCCL group before all of them fall back to torch.distributed")
     ap.add_argument("--degraded-reason", default="", help=argparse.SUPPRESS)      # set by a parent whose group join hung (see join_library_group)
     ap.add_argument("--no-real-panel", action="store_true", help="skip the configs[1] / configs[2] legs (tools/bench_real_panel.py) after the headline")
+    ap.add_argument("--no-staging", action="store_true", help="skip the DB staging legs (tools/bench_staging.py) after the headline")
     ap.add_argument("--collective", default="c-abi", choices=["c-abi", "torch"],
                     help="who runs the all-gather of the per-accession results at N>1: the library itself (snpm_group_*: RCCL "
                          "communicator inside libsnpmatch_hip.so, one packed all-gather) or torch.distributed")
@@ -594,13 +595,26 @@ def main():
                                        capture_output=True, text=True, timeout=300)
                 rp = json.loads(child.stdout.strip().splitlines()[-1])
                 keep = ("leg", "kernel", "wall_ms_per_call", "kernel_ms_per_call", "algorithmic_bytes_per_call", "achieved_GBs",
-                        "frac_of_hbm_peak", "bytes_counted", "int8_equivalent_GBs", "samples_per_s", "windows")
-                out["real_panel"] = {"workload": rp["workload"], "traffic": "profiles/r04_pmc_split_real_*.json (request-size split, separate --pmc passes)",
+                        "frac_of_hbm_peak", "bytes_counted", "int8_equivalent_GBs", "samples_per_s", "windows", "shared_rows", "hbm_bytes_per_sample",
+                        "frac_of_int8_mfma_peak", "mfma_TMACs", "ceilings", "pairs_reeval", "other_kernels_ms_per_call")
+                out["real_panel"] = {"workload": rp["workload"], "traffic": "profiles/r04_pmc_split_real_*.json (request-size split, separate --pmc passes; per-sample legs)",
                                      "formats": {f: {"row_pitch": v["row_pitch"], "panel_gb": v["panel_gb"],
                                                      "legs": [{k: leg[k] for k in keep if k in leg} for leg in v["legs"]]}
                                                  for f, v in rp["formats"].items()}}
             except Exception as e:          # noqa: BLE001
                 out["real_panel"] = {"error": str(e)[:200]}
+        # The DB staging path north_star names (pinned-host slabs + hipMemcpyAsync on a side stream, in place of the reference's
+        # h5py read, core/snpmatch.py:222): a 20 GB int8 host panel into int8 / packed panels from memory, from a flat file and
+        # from the reference's lzf HDF5 layout, against the hipMemcpyAsync ceiling of the same run, and an upload while a
+        # resident query is being scored.  A child process: tools/bench_staging.py.
+        if world == 1 and not args.no_staging and whole_job and not profiled and not args.packed:
+            try:
+                import subprocess
+                child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_staging.py")], capture_output=True, text=True,
+                                       timeout=420)
+                out["staging"] = json.loads(child.stdout.strip().splitlines()[-1])
+            except Exception as e:          # noqa: BLE001
+                out["staging"] = {"error": str(e)[:200]}
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
