@@ -1,11 +1,16 @@
 """
-One rank of a 2-rank job on ONE GPU over gloo (tests/test_gpu_dist.py starts two of these).  Not a test module.
+One rank of a 2-rank job on ONE GPU over gloo (tests/test_gpu_dist.py starts two of these) -- or, with SNPM_TEST_BACKEND=nccl
+and SNPM_TEST_DEVICE=<rank>, one rank of a job whose ranks own a GPU each and talk over RCCL (tests/test_gpu_multi.py, which
+switches itself on when the box has two GPUs).  Not a test module.
 
   device  the bench-shaped flow with the real kernels: a shard of a synthetic panel, results bound into torch
           tensors (bind_outputs), the library on torch's stream (set_stream), all_gather_into_tensor over padded,
           uneven shards, likelihood_device on the gathered vector; every mode, plus a slab-streamed carry.
   product the drop-in classes under an accession-sharded job: Genotyper (+ --refine) and CrossIdentifier on the toy
           DBs of the golden fixtures; rank 0 writes the files.
+  rank    the C ABI's own group of ranks (snpm_group_create_rank = ncclCommInitRank, no torch.distributed): the rank's context
+          on ITS device, the unique id through a file, uneven accession shards of a seeded DB, one snpm_group_gather_scores
+          with the likelihoods over the full vector, windows gathered as rows.
 """
 import json
 import os
@@ -23,17 +28,23 @@ def device_flow(out_dir):
     from snpmatch_amd import engine, synth
     from snpmatch_amd.dist import AccessionShards
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
-    dev = torch.device("cuda", 0)
+    backend = os.environ.get("SNPM_TEST_BACKEND", "gloo")
+    dev_index = int(os.environ.get("SNPM_TEST_DEVICE", "0"))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     os.environ["SNPM_DEBUG_REEVAL"] = "2"            # every certified run re-evaluates two accessions per shard
-    ctx = engine.Context(0)
+    ctx = engine.Context(dev_index)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     n_snp, n_acc, seed, planted = 60_000, 1135, 4242, 417
     sh = AccessionShards(n_acc, world, rank, dev)
-    assert sh.per == 568 and sh.n_local == (568 if rank == 0 else 567)          # uneven shards, padded to 568
+    if world == 2:
+        assert sh.per == 568 and sh.n_local == (568 if rank == 0 else 567)      # uneven shards, padded to 568
     panel = engine.Panel(ctx, n_snp, sh.n_local)
     panel.fill_synthetic(seed, 0, sh.a0)
     wei = synth.sample_weights_twin(seed, 0, n_snp, planted)
@@ -82,9 +93,9 @@ def product_flow(out_dir, golden):
     def make_g(toy):
         return snp_genotype.Genotype.from_arrays(toy["snps"], toy["accs"], toy["positions"], toy["chrs"], toy["regions"])
 
-    os.environ["SNPMATCH_DIST_BACKEND"] = "gloo"
+    os.environ.setdefault("SNPMATCH_DIST_BACKEND", "gloo")
     job = sdist.init_from_env()
-    assert job is not None and job.world == 2
+    assert job is not None and job.world == int(os.environ["WORLD_SIZE"])
     toy = np.load(os.path.join(golden, "toy_db.npz"))
     for skip in (False, True):
         gt = snpmatch.Genotyper(make_inputs(toy), make_g(toy), os.path.join(out_dir, "inbred%d" % skip), run_genotyper=True,
@@ -105,8 +116,54 @@ def product_flow(out_dir, golden):
     dist.destroy_process_group()
 
 
+def rank_flow(out_dir):
+    import time
+    from snpmatch_amd import engine, synth
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev_index = int(os.environ.get("SNPM_TEST_DEVICE", "0"))
+    ctx = engine.Context(dev_index)
+    id_path = os.path.join(out_dir, "group_id.bin")
+    if rank == 0:
+        uid = engine.Group.unique_id()
+        with open(id_path + ".tmp", "wb") as fh:
+            fh.write(bytes(uid))
+        os.replace(id_path + ".tmp", id_path)
+    else:
+        t0 = time.time()
+        while not os.path.exists(id_path):
+            assert time.time() - t0 < 120, "rank 0 never published the group id"
+            time.sleep(0.05)
+        uid = open(id_path, "rb").read()
+    group = engine.Group.from_rank(ctx, uid, world, rank)
+    assert (group.world, group.rank0, group.n_local) == (world, rank, 1) and "rccl" in group.transport.lower()
+    n_snp, n_acc, seed = 30_000, int(os.environ.get("SNPM_TEST_N_ACC", "1135")), 99
+    rng = np.random.default_rng(seed)
+    db = rng.choice(np.array([-1, 0, 1, 2], dtype=np.int8), size=(n_snp, n_acc), p=[0.05, 0.60, 0.33, 0.02])
+    codes = db[:, 5].copy()
+    codes[codes < 0] = 0
+    wei = synth.sample_weights(rng, codes, 0.8)
+    a0, a1 = group.shard(n_acc, rank)
+    res = {"bounds": np.array([a0, a1])}
+    if a1 > a0:
+        panel = engine.Panel.from_host(ctx, db, cols=(a0, a1))           # this rank's columns of the wider DB
+        q = engine.Query(panel, None, wei)
+    for name, mode in (("strict", engine.MODE_STRICT), ("exact", engine.MODE_EXACT)):
+        if a1 > a0:
+            d_s, d_n = q.run_device(1000, False, mode)
+        else:
+            d_s, d_n = 0, 0
+        out = group.gather([d_s], [d_n], n_acc, truncate=True, likelihoods=True)
+        for k in ("score", "ninfo", "lik", "lrt"):
+            res[name + "_" + k] = out[k]
+    np.savez(os.path.join(out_dir, "rank_flow_rank%d.npz" % rank), **res)
+    group.free()
+    ctx.close()
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "device":
         device_flow(sys.argv[2])
+    elif sys.argv[1] == "rank":
+        rank_flow(sys.argv[2])
     else:
         product_flow(sys.argv[2], sys.argv[3])

@@ -34,12 +34,16 @@ def free_port():
     return p
 
 
-def run_ranks(args, world=2, timeout=600):
+def run_ranks(args, world=2, timeout=600, per_rank_env=None):
+    """start `world` copies of tests/dist_worker.py; per_rank_env(rank) -> extra environment (tests/test_gpu_multi.py gives every
+    rank its own device and the nccl backend)"""
     port = free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if per_rank_env is not None:
+            env.update(per_rank_env(r))
         procs.append(subprocess.Popen([sys.executable, WORKER] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                                       text=True))
     outs = []
@@ -109,3 +113,20 @@ def test_two_ranks_product_path_writes_the_reference_files(tmp_path, golden_dir)
         cmp_scores_table(open(pre + ".scores.txt").read(), want[".scores.txt"])
         assert open(pre + ".scores.txt.matches.json").read() == want[".scores.txt.matches.json"]
         assert os.path.exists(pre + ".matches.json") == (".matches.json" in want)
+
+
+def test_rank_flow_worker_with_one_rank(tmp_path):
+    """the worker of tests/test_gpu_multi.py's process-per-GPU test (C ABI group of ranks, id through a file), rehearsed with the
+    one rank a one-GPU box can give it: the same code joins, shards, gathers and writes its results"""
+    from oracle import c_oracle
+    run_ranks(["rank", str(tmp_path)], world=1)
+    rng = np.random.default_rng(99)
+    db = rng.choice(np.array([-1, 0, 1, 2], dtype=np.int8), size=(30_000, 1135), p=[0.05, 0.60, 0.33, 0.02])
+    codes = db[:, 5].copy()
+    codes[codes < 0] = 0
+    wei = synth.sample_weights(rng, codes, 0.8)
+    want_s, want_n = c_oracle.genotyper(db, None, wei, 1000, False)
+    got = np.load(os.path.join(str(tmp_path), "rank_flow_rank0.npz"))
+    assert tuple(got["bounds"]) == (0, 1135)
+    assert np.array_equal(bits(got["strict_score"]), bits(want_s)) and np.array_equal(got["strict_ninfo"], want_n)
+    assert np.array_equal(got["exact_score"].astype(np.int64), want_s.astype(np.int64)) and int(np.nanargmin(got["exact_lik"])) == 5

@@ -95,14 +95,23 @@ def test_group_errors_are_reported():
 @pytest.mark.parametrize("n_members,n_acc", [(3, 1135), (2, 257), (4, 1000)])
 def test_loopback_group_equals_unsharded(n_members, n_acc):
     """members on device 0, uneven shards with padded tails (1135 / 3: 380 + 380 + 375; 257 / 2: 132 + 125)"""
+    group = engine.Group.local([0] * n_members, loopback=True)
+    assert group.transport == "loopback" and group.n_local == n_members
+    group_equals_unsharded(group, n_members, n_acc)
+
+
+def group_equals_unsharded(group, n_members, n_acc):
+    """every product of a GroupPanel over `group` (one process, n_members members) against the unsharded run on device 0, bit for
+    bit: reference-order and certified scores, windows, the --refine scan, in-silico crosses, batches.  Used with the loopback
+    transport here and with RCCL over real devices by tests/test_gpu_multi.py; frees the group."""
     db, wei = make_case(n_acc, 40_000, n_acc)
     ctx = engine.Context(0)
     whole = engine.Panel.from_host(ctx, db)
     q = engine.Query(whole, None, wei)
     ss, sn = q.run(1000, False, engine.MODE_STRICT)
     es, en = q.run(1000, True, engine.MODE_EXACT)
-    group = engine.Group.local([0] * n_members, loopback=True)
-    assert group.transport == "loopback" and group.n_local == n_members
+    want_s, want_n = c_oracle.genotyper(db, None, wei, 1000, False)
+    assert np.array_equal(bits(ss), bits(want_s)) and np.array_equal(sn, want_n)
     bounds = group.local_shards(n_acc)
     assert bounds[0][0] == 0 and bounds[-1][1] == n_acc and all(b[0] % 4 == 0 for b in bounds)
     assert all(bounds[i][1] == bounds[i + 1][0] for i in range(n_members - 1))
