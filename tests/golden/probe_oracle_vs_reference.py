@@ -6,6 +6,7 @@ hard-call and PL weights, both skip_hets settings -- fp64 bit patterns and count
 divergence with a probe like this one; it is kept so that the next shape question takes a minute.
 
     python tests/golden/probe_oracle_vs_reference.py [seed]   # prints "cases N diffs 0" (matchGTsAccs shapes, then likelihood / LRT / identity on random counts)
+                                                              # and the verdict of the same reference under the second interpreter (numpy 1.26)
 """
 import os
 import sys
@@ -71,4 +72,15 @@ for _ in range(200):
         bad += 1
         print("DIFF likelihood / identity, m %d" % m)
 print("cases %d diffs %d" % (tot, bad))
+# the same reference under the image's second interpreter (numpy 1.26 / scipy 1.7) on the committed G1 / G1b / G4 inputs: the
+# committed bit patterns must come out again (tests/golden/probe_reference_second_numpy.py)
+PY39 = "/opt/conda/bin/python3.9"
+if os.path.exists(PY39):
+    import subprocess
+    r = subprocess.run([PY39, os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_reference_second_numpy.py")],
+                       capture_output=True, text=True)
+    print("second interpreter: " + (r.stdout.strip().splitlines() or ["(no output)"])[-1])
+    bad += int(r.returncode != 0)
+else:
+    print("second interpreter: %s is not here" % PY39)
 sys.exit(1 if bad else 0)

@@ -1,7 +1,10 @@
 """
-The native HDF5 reader (csrc/snpm_h5.cpp, snpmatch_amd/h5.py) against files written by REAL h5py / libhdf5 1.10.6 with the
-reference's own writer layout (tests/golden/make_hdf5_fixtures.py, run under the image's /opt/conda/bin/python3.9;
-pygwas/genotype.py:310-326, core/makedb.py:64-81).  No GPU: reading is host code.
+The native HDF5 reader (csrc/snpm_h5.cpp, snpmatch_amd/h5.py) against files written by REAL h5py / libhdf5 1.10.6.
+toy_db.hdf5 / toy_db.acc.hdf5 come out of the REFERENCE'S OWN writers (Genotype.save_as_hdf5, pygwas/genotype.py:310-326;
+makedb.save_as_hdf5_acc, core/makedb.py:64-81), called by tests/golden/make_hdf5_fixtures_ref.py under the image's
+/opt/conda/bin/python3.9; toy_db_ref_read.npz holds what the reference's reader (HDF5Genotype, pygwas/genotype.py:534-673)
+returned for them.  The stress / latest-format files (tests/golden/make_hdf5_fixtures.py) exercise format features those
+writers never produce.  No GPU: reading is host code.
 """
 import os
 
@@ -41,6 +44,29 @@ def test_reference_layout_row_chunked_lzf(toy):
     assert sorted(pos.attrs.keys()) == ["chr_regions", "chrs"]
     assert f["accessions"][:].astype("U").tolist() == [str(a) for a in toy["accs"]]
     f.close()
+
+
+def test_native_reader_returns_what_the_reference_reader_returned(toy):
+    """both files, every member the path touches: rows g.g.snps[idx, :] (core/snpmatch.py:222), columns g_acc.snps[:, i]
+    (core/csmatch.py:116), positions, accessions, chrs / chr_regions -- against the values HDF5Genotype handed out"""
+    want = np.load(os.path.join(H5DIR, "toy_db_ref_read.npz"))
+    rows, cols = want["rows"], want["cols"]
+    for tag, name in (("row", "toy_db.hdf5"), ("acc", "toy_db.acc.hdf5")):
+        with h5.File(os.path.join(H5DIR, name)) as f:
+            snps = f["snps"]
+            assert np.array_equal(snps[rows, :], want[tag + "_snps_rows"]) and snps[rows, :].dtype == want[tag + "_snps_rows"].dtype
+            assert np.array_equal(np.stack([snps[:, int(c)] for c in cols], axis=1), want[tag + "_snps_cols"])
+            assert np.array_equal(f["positions"][:], want[tag + "_positions"])
+            assert np.array_equal(f["accessions"][:].astype("S"), want[tag + "_accessions"])
+            assert np.array_equal(f["positions"].attrs["chrs"].astype("S"), want[tag + "_chrs"])
+            assert np.array_equal(f["positions"].attrs["chr_regions"], want[tag + "_chr_regions"])
+            assert str(np.asarray(snps.attrs["data_format"]).astype("U")) == want[tag + "_data_format"].astype("U")[0]
+    # HDF5Genotype.chromosomes (pygwas/genotype.py:156-161): one chromosome name per SNP -- what core/snp_genotype rebuilds
+    # from chrs + chr_regions
+    from snpmatch_amd.core import snp_genotype
+    g = snp_genotype.Genotype(os.path.join(H5DIR, "toy_db.hdf5"), os.path.join(H5DIR, "toy_db.acc.hdf5"))
+    assert np.array_equal(np.asarray(g.g.chromosomes).astype("S"), want["row_chromosomes"])
+    assert np.array_equal(np.asarray(g.g.positions), want["row_positions"])
 
 
 def test_reference_layout_accession_chunked_gzip(toy):

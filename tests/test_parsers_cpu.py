@@ -320,3 +320,38 @@ def test_gt_codes_of_equals_parse_gt_of_the_gathered_strings():
     q = parsers.ParseInputs("")
     q.load_snp_info(["1", "1"], [1, 2], np.array(["0", "1"]), np.zeros((2, 3)), 3)      # numeric codes: no separator, the caller parses
     assert q.gt_codes_of(np.array([0, 1])) is None
+
+
+def test_read_vcf_semantics_on_hand_built_records(tmp_path, monkeypatch):
+    """ParseInputs.read_vcf as the reference states it (core/parsers.py:141-157; scikit-allel is in neither interpreter of this
+    image, so the rules are pinned on records written by hand): records whose GT is './.' or '.|.' are dropped (:144); PL goes
+    through exp(PL / -10) (:148-149); a record WITHOUT any PL (allel's fill value -1 in all three places, :147) takes the hard 0/1
+    weights of its genotype (:150, get_wei_from_GT :132-139: ref -> column 0, het -> column 1, alt -> column 2); depth is INFO/DP
+    (:155, import_vcf_file :203-206), fill value -1"""
+    head = ("##fileformat=VCFv4.2\n##INFO=<ID=DP,Number=1,Type=Integer,Description=\"depth\">\n"
+            "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"genotype\">\n##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"PL\">\n"
+            "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n")
+    body = [
+        "Chr1\t100\t.\tA\tT\t50\tPASS\tDP=7\tGT:PL\t0/0:0,30,255",
+        "Chr1\t200\t.\tA\tT\t50\tPASS\tDP=9\tGT:PL\t./.:.",                # no call: dropped
+        "Chr1\t300\t.\tA\tT\t50\tPASS\tDP=3\tGT\t1/1",                      # no PL: hard weights of the genotype
+        "Chr1\t400\t.\tA\tT\t50\tPASS\t.\tGT:PL\t0/1:20,0,40",             # no INFO/DP: -1
+        "Chr2\t500\t.\tA\tT\t50\tPASS\tDP=5\tGT:PL\t.|.:0,0,0",             # phased no call: dropped
+        "Chr2\t600\t.\tA\tT\t.\t.\tDP=2\tGT:DP:PL\t1/1:2:99,12,0",          # PL as the third FORMAT item
+        "Chr2\t700\t.\tA\tT\t.\t.\tDP=4\tGT\t0/0",                          # no PL again
+    ]
+    vcf = tmp_path / "hand.vcf"
+    vcf.write_text(head + "\n".join(body) + "\n")
+    for native in (True, False):
+        if not native:
+            monkeypatch.setattr(_vcf, "_read_calls_native", lambda path, sample: None)      # the generic Python reader
+        if os.path.exists(str(vcf) + ".snpmatch.npz"):
+            os.remove(str(vcf) + ".snpmatch.npz")
+        s = parsers.ParseInputs(inFile=str(vcf), logDebug=False)
+        s.wait_for_cache()
+        assert s.chrs.tolist() == ["Chr1", "Chr1", "Chr1", "Chr2", "Chr2"] and s.pos.tolist() == [100, 300, 400, 600, 700]
+        assert s.gt.tolist() == ["0/0", "1/1", "0/1", "1/1", "0/0"]
+        want = np.array([np.exp(np.array([0.0, 30.0, 255.0]) / (-10)), [0.0, 0.0, 1.0], np.exp(np.array([20.0, 0.0, 40.0]) / (-10)),
+                         np.exp(np.array([99.0, 12.0, 0.0]) / (-10)), [1.0, 0.0, 0.0]])
+        assert np.array_equal(s.wei.view(np.uint64), want.view(np.uint64)), native
+        assert np.asarray(s.dp).tolist() == [7, 3, -1, 2, 4]
