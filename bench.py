@@ -105,6 +105,40 @@ def cpu_baseline(db, wei, n_acc, seconds_target=20.0):
                                  "how": "C restatement (oracle/snpmatch_oracle.c), same sample, one thread per accession block"}},             (s, n, chunk * n_chunks)
 
 
+def _numpy_worker(args):
+    """one process of the all-cores numpy baseline: an accession block of a panel with the workload's value mix, the numpy
+    restatement of matchGTsAccs over 1000-row chunks (the reference's expression graph), again and again for `seconds`"""
+    block, n_rows, n_acc_block, seconds, seed = args
+    from oracle import snpmatch_oracle as orc
+    from snpmatch_amd import synth
+    rng = np.random.default_rng(seed + block)
+    db = rng.choice(np.array([-1, 0, 1, 2], dtype=np.int8), size=(n_rows, n_acc_block), p=[0.05, 0.60, 0.33, 0.02])
+    wei = synth.sample_weights_twin(seed, 0, n_rows, 417)
+    orc.genotyper_scores(wei[:1000], db[:1000], 1000, False, match=orc.match_gts_accs_graph)      # imports, first touch
+    done = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        orc.genotyper_scores(wei, db, 1000, False, match=orc.match_gts_accs_graph)
+        done += n_rows * n_acc_block
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline_numpy_all_cores(n_acc, seconds=10.0):
+    """the numpy path on ALL host cores (multiprocessing over accession blocks), taken BEFORE this process
+    touches the GPU -- a GPU-initialised process must not fork.  The reference itself has no threading: this is what a user
+    gets by running one reference process per accession block."""
+    import multiprocessing as mp
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    per = max(1, n_acc // cores)
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_numpy_worker, [(b, 20_000, per, seconds, 10050) for b in range(cores)])
+    total = sum(r[0] for r in res)
+    wall = max(r[1] for r in res)
+    return {"value": total / wall, "unit": "comparisons/s", "cores": cores,
+            "how": "numpy restatement of matchGTsAccs (oracle.match_gts_accs_graph, the reference's expression graph), %d processes, each "
+                   "an accession block of %d x 20000 SNPs with the workload's value mix, 1000-row chunks, %.1f s" % (cores, per, wall)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,6 +185,13 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (WORLD_SIZE=%d)" % (args.gpus, world))
         args.gpus = world
+
+    numpy_all_cores = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        try:
+            numpy_all_cores = cpu_baseline_numpy_all_cores(args.n_acc)       # before anything touches the GPU (fork)
+        except Exception as e:          # noqa: BLE001
+            numpy_all_cores = {"error": str(e)[:200]}
 
     import torch
     import torch.distributed as dist
@@ -487,6 +528,8 @@ def main():
         db = panel.download_rows(0, nrows)
         wei_host = wei_dev[:nrows].cpu().numpy()
         cpu, (cs, cn, nrows) = cpu_baseline(db, wei_host, n_loc)
+        if numpy_all_cores is not None:
+            cpu["numpy_all_cores"] = numpy_all_cores
         q2 = engine.Query(panel, None, wei_host[:nrows])
         gs, gn = q2.run(chunk, False, engine.MODE_EXACT)
         parity = bool(np.array_equal(gn, cn) and np.array_equal(np.array(gs, dtype=int), np.array(cs, dtype=int)))
