@@ -65,6 +65,9 @@ struct snpm_ctx {
     Buf ws_part_score, ws_part_miss, ws_seg_score, ws_seg_miss, ws_seg_off, ws_cols, ws_tmp_score, ws_tmp_ninfo, ws_flags;
     Buf ws_lik_y, ws_lik_n, ws_lik_l, ws_lik_r;
     Buf ws_wprops, ws_epart;            // partial sums of k_wprops / k_eref
+    Buf ws_tickets;                     // k_reduce_all: one ticket per column block, zero between launches
+    int fused_reduce = 1;               // SNPM_FUSED_REDUCE=0: k_reduce_groups + k_reduce as two launches (round 4's form)
+    int once_tail = 1;                  // SNPM_ONCE_TAIL=0: snpm_genotype_once ends with k_scan_few + k_once_finish instead of k_once_tail
     Buf ws_once, ws_once_table;         // packed results of snpm_genotype_once; the weight table of its coded form
     std::vector<double> once_table;     // host image of ws_once_table
     std::vector<uint8_t> once_code_flags;   // per code: bit 0 a fractional / huge entry, 1 neither 0 nor 1, 2 NaN / infinite, 3 past the table
@@ -478,6 +481,8 @@ try {
     if (const char *s = getenv("SNPM_ONCE_FUSED")) ctx->once_fused = atoi(s) != 0;
     if (const char *s = getenv("SNPM_ONCE_ZEROCOPY")) ctx->once_zero_copy = atoi(s) != 0;
     if (const char *s = getenv("SNPM_DEBUG_MAX_PARTS")) ctx->debug_max_parts = atoi(s);
+    if (const char *s = getenv("SNPM_FUSED_REDUCE")) ctx->fused_reduce = atoi(s) != 0;
+    if (const char *s = getenv("SNPM_ONCE_TAIL")) ctx->once_tail = atoi(s) != 0;
     if (const char *s = getenv("SNPM_BATCH_SHARED")) ctx->batch_shared = atoi(s) < 0 ? -1 : (atoi(s) ? 1 : 0);
     if (const char *s = getenv("SNPM_SHARED_DIGITS")) ctx->shared_digits = atoi(s) <= 0 ? 0 : std::min(7, std::max(3, atoi(s)));
     if (const char *s = getenv("SNPM_SHARED_MIN_DENSITY")) ctx->shared_min_density = atof(s);
@@ -562,7 +567,7 @@ int snpm_destroy(snpm_ctx *ctx)
                        &ctx->ws_seg_desc, &ctx->ws_eseg, &ctx->ws_pairs, &ctx->ws_pair_sums, &ctx->ws_bscore, &ctx->ws_bninfo,
                        &ctx->ws_blut, &ctx->ws_brows, &ctx->ws_brows32, &ctx->ws_bw, &ctx->ws_bcodes,
                        &ctx->ws_sh_bitmap, &ctx->ws_sh_wordbase, &ctx->ws_sh_blocks, &ctx->ws_sh_urows, &ctx->ws_sh_meta, &ctx->ws_sh_A,
-                       &ctx->ws_sh_pos, &ctx->ws_sh_partial};
+                       &ctx->ws_sh_pos, &ctx->ws_sh_partial, &ctx->ws_tickets};
         for (Buf *b : bufs)
             if (b->p) (void)hipFree(b->p);
         if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);

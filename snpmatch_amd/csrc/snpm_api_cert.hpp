@@ -150,18 +150,32 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
         const int thr = 64;       // one wave per block: narrow panels still spread over many CUs
         const unsigned cb = (unsigned)((p->n_acc + thr - 1) / thr);
         const int64_t n_groups = q->n > 0 ? g.n_groups : 0;
-        if (n_groups > 0) {
-            hipLaunchKernelGGL(k_reduce_groups, dim3(cb, (unsigned)n_groups), dim3(thr), 0, ctx->stream,
-                               (const double *)ctx->ws_part_score.p, (const uint32_t *)ctx->ws_part_miss.p, g.n_slots,
-                               p->ld, p->n_acc, (double *)ctx->ws_grp_score.p, (uint32_t *)ctx->ws_grp_miss.p);
+        const double *eref = (certify && cert.flag) ? (const double *)q->cert_eref() : (const double *)nullptr;
+        const double efast = certify ? efast_bound(q, g) : 0.0;
+        if (n_groups > 0 && n_groups <= 65535 && ctx->fused_reduce) {
+            // both steps in one launch (tickets per column block, zero between launches)
+            if (ctx->ws_tickets.cap < (size_t)cb * sizeof(unsigned)) {
+                rc = ensure(ctx, ctx->ws_tickets, std::max<size_t>((size_t)cb * sizeof(unsigned), 4096));
+                if (rc) return rc;
+                HIPCHK(ctx, hipMemsetAsync(ctx->ws_tickets.p, 0, ctx->ws_tickets.cap, ctx->stream));
+            }
+            hipLaunchKernelGGL(k_reduce_all, dim3(cb, (unsigned)n_groups), dim3(thr), 0, ctx->stream,
+                               (const double *)ctx->ws_part_score.p, (const uint32_t *)ctx->ws_part_miss.p, g.n_slots, p->ld, p->n_acc,
+                               q->n, (double *)ctx->ws_grp_score.p, (uint32_t *)ctx->ws_grp_miss.p, q->d_score, q->d_ninfo, eref, efast,
+                               ctx->debug_reeval, q->cert_cols(), q->cert_count(), REEVAL_CAP, (unsigned *)ctx->ws_tickets.p);
+            HIPCHK(ctx, hipGetLastError());
+        } else {
+            if (n_groups > 0) {
+                hipLaunchKernelGGL(k_reduce_groups, dim3(cb, (unsigned)n_groups), dim3(thr), 0, ctx->stream,
+                                   (const double *)ctx->ws_part_score.p, (const uint32_t *)ctx->ws_part_miss.p, g.n_slots,
+                                   p->ld, p->n_acc, (double *)ctx->ws_grp_score.p, (uint32_t *)ctx->ws_grp_miss.p);
+                HIPCHK(ctx, hipGetLastError());
+            }
+            hipLaunchKernelGGL(k_reduce, dim3(cb), dim3(thr), 0, ctx->stream, (const double *)ctx->ws_grp_score.p,
+                               (const uint32_t *)ctx->ws_grp_miss.p, n_groups, p->ld, p->n_acc, q->n, q->d_score,
+                               q->d_ninfo, eref, efast, ctx->debug_reeval, q->cert_cols(), q->cert_count(), REEVAL_CAP);
             HIPCHK(ctx, hipGetLastError());
         }
-        hipLaunchKernelGGL(k_reduce, dim3(cb), dim3(thr), 0, ctx->stream, (const double *)ctx->ws_grp_score.p,
-                           (const uint32_t *)ctx->ws_grp_miss.p, n_groups, p->ld, p->n_acc, q->n, q->d_score,
-                           q->d_ninfo, (certify && cert.flag) ? (const double *)q->cert_eref() : (const double *)nullptr,
-                           certify ? efast_bound(q, g) : 0.0, ctx->debug_reeval, q->cert_cols(), q->cert_count(),
-                           REEVAL_CAP);
-        HIPCHK(ctx, hipGetLastError());
     }
     return SNPM_OK;
 }

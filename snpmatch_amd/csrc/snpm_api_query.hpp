@@ -204,7 +204,7 @@ try {
 // reads the count back (once per panel).
 // dense_tier = false (snpm_genotype_once): the > REEVAL_CAP tier is left to the caller, who sees the count with its results and
 // runs run_strict_chain only then -- two launches that almost never have work stay out of a short sample's critical path.
-static int enqueue_reevaluation(snpm_query *q, int skip, int64_t chunk, bool dense_tier = true)
+static int enqueue_reevaluation(snpm_query *q, int skip, int64_t chunk, bool dense_tier = true, const OnceTail *tail = nullptr)
 {
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
@@ -215,7 +215,7 @@ static int enqueue_reevaluation(snpm_query *q, int skip, int64_t chunk, bool den
         if (rc) return rc;
         if (cnt >= 1 && cnt <= REEVAL_CAP) (void)ensure_acc_major(p);
     }
-    int rc = run_strict_sparse(q, skip, chunk, q->cert_cols(), q->cert_count(), nullptr, nullptr, 0, q->d_score);
+    int rc = run_strict_sparse(q, skip, chunk, q->cert_cols(), q->cert_count(), nullptr, nullptr, 0, q->d_score, tail);
     if (rc || !dense_tier) return rc;
     // more than REEVAL_CAP flagged (many exact-integer scores, e.g. clonal accessions): everything in reference order
     return run_strict_chain(q, skip, chunk, q->cert_count(), nullptr, nullptr, q->d_score, q->d_ninfo);

@@ -127,8 +127,19 @@ int run_strict_chain(snpm_query *q, int skip, int64_t chunk, const int *gate, co
 // the kernels do nothing for other counts) -> ws_seg_score [n_seg, REEVAL_CAP] -> chain of additions ->
 // ws_tmp_score [REEVAL_CAP].  carry (may be NULL): compact totals of earlier slabs, continued by the chain.
 // patch_score (may be NULL): the totals also replace patch_score[d_cols[i]] (k_patch inside the chain's kernel: one launch less).
+// the one-call path's last step rides on the chain kernel of the sparse tier (k_once_tail instead of k_scan_few + k_once_finish)
+struct OnceTail {
+    const int64_t *d_ninfo = nullptr;
+    int64_t n_acc = 0;
+    int want_lik = 0;
+    unsigned *state = nullptr;
+    double *lik_tmp = nullptr;
+    int64_t *out = nullptr;
+};
+
 int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_cols, const int *d_ncols, const double *carry,
-                      const int64_t *d_seg_off = nullptr, int64_t n_seg_explicit = 0, double *patch_score = nullptr)
+                      const int64_t *d_seg_off = nullptr, int64_t n_seg_explicit = 0, double *patch_score = nullptr,
+                      const OnceTail *tail = nullptr)
 {
     snpm_ctx *ctx = q->panel->ctx;
     snpm_panel *p = q->panel;
@@ -181,8 +192,13 @@ int run_strict_sparse(snpm_query *q, int skip, int64_t chunk, const int32_t *d_c
         HIPCHK(ctx, hipGetLastError());
     }
     ProfScope ps(ctx, PK_SCAN);
-    hipLaunchKernelGGL(k_scan_few, dim3(1), dim3(256), 0, ctx->stream, (const double *)ctx->ws_seg_score.p, n_seg, ld,
-                       d_ncols, REEVAL_CAP, (double *)ctx->ws_tmp_score.p, carry, d_cols, patch_score);
+    if (tail)
+        hipLaunchKernelGGL(k_once_tail, dim3(1), dim3(256), 0, ctx->stream, (const double *)ctx->ws_seg_score.p, n_seg, ld, d_ncols,
+                           REEVAL_CAP, (double *)ctx->ws_tmp_score.p, d_cols, patch_score, tail->d_ninfo, tail->n_acc, tail->want_lik,
+                           tail->state, tail->lik_tmp, tail->out);
+    else
+        hipLaunchKernelGGL(k_scan_few, dim3(1), dim3(256), 0, ctx->stream, (const double *)ctx->ws_seg_score.p, n_seg, ld,
+                           d_ncols, REEVAL_CAP, (double *)ctx->ws_tmp_score.p, carry, d_cols, patch_score);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }

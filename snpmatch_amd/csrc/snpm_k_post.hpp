@@ -420,13 +420,11 @@ __global__ void k_once_pack(const double *__restrict__ score, const int64_t *__r
 // 96, 106-117) and written straight into `out` -- which may be the pinned host slab: no copy engine, no fill of the flag word
 // (profiles/r04_once_timeline_*).  ONE block.  state[1] = bad-input bits of k_once_prep (read, reported in word 4 n_acc + 1 bits
 // 1-2, cleared for the next call); lik_tmp [n_acc] device scratch (the ratio pass re-reads the likelihoods: not from the host).
-__global__ void __launch_bounds__(1024)
-k_once_finish(const double *__restrict__ score, const int64_t *__restrict__ ninfo, int64_t n_acc, int want_lik,
-              const int *__restrict__ count, unsigned *__restrict__ state, double *__restrict__ lik_tmp, int64_t *__restrict__ out)
+__device__ __forceinline__ void once_finish_body(const double *__restrict__ score, const int64_t *__restrict__ ninfo, int64_t n_acc,
+                                                 int want_lik, const int *__restrict__ count, unsigned *__restrict__ state,
+                                                 double *__restrict__ lik_tmp, int64_t *__restrict__ out, double (&s_min)[16],
+                                                 double &s_top, int &s_bad)
 {
-    __shared__ double s_min[16];
-    __shared__ double s_top;
-    __shared__ int s_bad;
     if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
     double mn = __builtin_inf();
@@ -466,6 +464,34 @@ k_once_finish(const double *__restrict__ score, const int64_t *__restrict__ ninf
     const double top = s_top;
     for (int64_t i = threadIdx.x; i < n_acc; i += blockDim.x)
         out[3 * n_acc + i] = want_lik ? __double_as_longlong((top <= 0.0) ? __builtin_nan("") : lik_tmp[i] / top) : 0;
+}
+
+__global__ void __launch_bounds__(1024)
+k_once_finish(const double *__restrict__ score, const int64_t *__restrict__ ninfo, int64_t n_acc, int want_lik,
+              const int *__restrict__ count, unsigned *__restrict__ state, double *__restrict__ lik_tmp, int64_t *__restrict__ out)
+{
+    __shared__ double s_min[16];
+    __shared__ double s_top;
+    __shared__ int s_bad;
+    once_finish_body(score, ninfo, n_acc, want_lik, count, state, lik_tmp, out, s_min, s_top, s_bad);
+}
+
+// The tail of the one-call path in ONE launch (round 5; it was two: k_scan_few and k_once_finish, ~5 us of stream time each): the
+// chain of the flagged accessions' chunk sums with the patch of their scores (scan_few_body: nothing to do when no accession was
+// flagged), then the likelihood / ratio / status step on the patched scores.  One block of 256 threads.
+__global__ void __launch_bounds__(256)
+k_once_tail(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, const int *__restrict__ d_ncols, int cap,
+            double *__restrict__ tot_score, const int32_t *__restrict__ patch_cols, double *__restrict__ score,
+            const int64_t *__restrict__ ninfo, int64_t n_acc, int want_lik, unsigned *__restrict__ state, double *__restrict__ lik_tmp,
+            int64_t *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) double tile[2][SCAN_TILE_ELEMS + 2 * WAVE];
+    __shared__ double s_min[16];
+    __shared__ double s_top;
+    __shared__ int s_bad;
+    scan_few_body(tile, seg_score, n_seg, ld, d_ncols, cap, tot_score, nullptr, patch_cols, score);
+    __syncthreads();                // the patched scores are visible to every wave of the block
+    once_finish_body(score, ninfo, n_acc, want_lik, d_ncols, state, lik_tmp, out, s_min, s_top, s_bad);
 }
 
 }  // namespace snpm

@@ -89,6 +89,68 @@ __global__ void k_reduce(const double *__restrict__ part_score, const uint32_t *
     if (d_eref) flag_if_uncertain(s, a, d_eref, efast, force_first, cols, count, cap);
 }
 
+// k_reduce_groups and k_reduce in ONE launch (round 5: a launch costs ~5 us of stream time, the two reduce steps of a 200k-SNP
+// sample took 10 of its 130): grid (column blocks, groups) as k_reduce_groups; every block leaves its group's sums and takes a
+// ticket of its column block, the block that draws the last ticket adds the groups in order (the additions, and therefore the
+// bits, of the two-kernel form), runs the certificate and puts the ticket back to zero.  Hand-off: every thread's stores, then an
+// agent-scope fence, then the ticket (one wave per block: no barrier needed beyond the wave's own order); the last block reads
+// the group sums with agent-scope loads behind its own fence.
+__global__ void __launch_bounds__(64)
+k_reduce_all(const double *__restrict__ part_score, const uint32_t *__restrict__ part_miss, int64_t n_slots, int64_t ld,
+             int64_t n_acc, int64_t n_rows, double *__restrict__ grp_score, uint32_t *__restrict__ grp_miss,
+             double *__restrict__ score, int64_t *__restrict__ ninfo, const double *__restrict__ d_eref, double efast,
+             int force_first, int32_t *__restrict__ cols, int *__restrict__ count, int cap, unsigned *__restrict__ tickets)
+{
+    __shared__ int s_last;
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t g = blockIdx.y;
+    const int64_t n_groups = gridDim.y;
+    if (a < n_acc) {
+        const int64_t s0 = g * REDUCE_GROUP;
+        const int64_t s1 = (s0 + REDUCE_GROUP < n_slots) ? s0 + REDUCE_GROUP : n_slots;
+        double s = 0.0;
+        uint32_t m = 0;
+        int64_t k = s0;
+        for (; k + 8 <= s1; k += 8) {
+            double v[8];
+            uint32_t c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = part_score[(k + u) * ld + a];
+                c[u] = part_miss[(k + u) * ld + a];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                s = s + v[u];
+                m += c[u];
+            }
+        }
+        for (; k < s1; ++k) {
+            s = s + part_score[k * ld + a];
+            m += part_miss[k * ld + a];
+        }
+        grp_score[g * ld + a] = s;
+        grp_miss[g * ld + a] = m;
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (atomicAdd(&tickets[blockIdx.x], 1u) == (unsigned)(n_groups - 1)) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x == 0) tickets[blockIdx.x] = 0u;
+    if (a >= n_acc) return;
+    double s = 0.0;
+    int64_t m = 0;
+    for (int64_t p = 0; p < n_groups; ++p) {
+        s = s + __hip_atomic_load(&grp_score[p * ld + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        m += __hip_atomic_load(&grp_miss[p * ld + a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    score[a] = s;
+    ninfo[a] = n_rows - m;
+    if (d_eref) flag_if_uncertain(s, a, d_eref, efast, force_first, cols, count, cap);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Jobs scored SNP slab after SNP slab (panels larger than HBM): running totals.
 //   k_carry_add   totals += this slab's fast-pass results (one fp64 addition per slab and accession, in slab

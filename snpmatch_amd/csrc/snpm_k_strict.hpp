@@ -622,12 +622,13 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
         s = s + (S##6).x; s = s + (S##6).y; s = s + (S##7).x; s = s + (S##7).y;                                      \
     } while (0)
 
-__global__ void __launch_bounds__(256)
-k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, const int *__restrict__ d_ncols, int cap,
-           double *__restrict__ tot_score, const double *__restrict__ carry, const int32_t *__restrict__ patch_cols = nullptr,
-           double *__restrict__ patch_score = nullptr)
+// the body of k_scan_few (one block of 256 threads; `tile` is the kernel's LDS): also the first half of k_once_tail, which adds the
+// one-call path's likelihood / ratio / status step behind it in the same launch
+__device__ __forceinline__ void scan_few_body(double (&tile)[2][SCAN_TILE_ELEMS + 2 * WAVE], const double *__restrict__ seg_score,
+                                              int64_t n_seg, int64_t ld, const int *__restrict__ d_ncols, int cap,
+                                              double *__restrict__ tot_score, const double *__restrict__ carry,
+                                              const int32_t *__restrict__ patch_cols, double *__restrict__ patch_score)
 {
-    __shared__ __attribute__((aligned(16))) double tile[2][SCAN_TILE_ELEMS + 2 * WAVE];
     const int ncols = *d_ncols;
     if (ncols < 1 || ncols > cap) return;          // block-uniform
     const int ts = (SCAN_TILE_ELEMS / ncols) & ~31;  // segments per tile: a multiple of 32, >= 64
@@ -693,6 +694,15 @@ k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, cons
         tot_score[threadIdx.x] = s;
         if (patch_score) patch_score[patch_cols[threadIdx.x]] = s;        // k_patch fused in: the totals replace the fast-pass scores
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_few(const double *__restrict__ seg_score, int64_t n_seg, int64_t ld, const int *__restrict__ d_ncols, int cap,
+           double *__restrict__ tot_score, const double *__restrict__ carry, const int32_t *__restrict__ patch_cols = nullptr,
+           double *__restrict__ patch_score = nullptr)
+{
+    __shared__ __attribute__((aligned(16))) double tile[2][SCAN_TILE_ELEMS + 2 * WAVE];
+    scan_few_body(tile, seg_score, n_seg, ld, d_ncols, cap, tot_score, carry, patch_cols, patch_score);
 }
 #undef SCAN_READ8
 #undef SCAN_WAIT8

@@ -282,7 +282,6 @@ static int genotype_once_fused(snpm_panel *p, const int64_t *row_idx, const doub
         cert.chunk = chunk;
         if ((rc = run_fast(q, skip, nullptr, cert))) return rc;
         certified = cert.on && !q->all_integer;
-        if (certified && (rc = enqueue_reevaluation(q, skip, chunk, false))) return rc;
     }
     if ((rc = ensure(ctx, ctx->ws_lik_l, na * sizeof(double)))) return rc;
     int64_t *h_out = (int64_t *)h_slab;
@@ -295,6 +294,19 @@ static int genotype_once_fused(snpm_panel *p, const int64_t *row_idx, const doub
         if ((rc = ensure(ctx, ctx->ws_once, out_words * sizeof(int64_t)))) return rc;
         d_out = (int64_t *)ctx->ws_once.p;
     }
+    // the sparse tier behind the fast pass; its chain kernel also does the likelihood / ratio / status step (k_once_tail)
+    bool tail_done = false;
+    if (certified) {
+        OnceTail tail;
+        tail.d_ninfo = q->d_ninfo; tail.n_acc = (int64_t)na; tail.want_lik = lik ? 1 : 0;
+        tail.state = (unsigned *)ctx->ws_once_state.p; tail.lik_tmp = (double *)ctx->ws_lik_l.p; tail.out = d_out;
+        const bool fuse = ctx->once_tail && !single_accession(p);
+        if ((rc = enqueue_reevaluation(q, skip, chunk, false, fuse ? &tail : nullptr))) return rc;
+        if (fuse) {
+            if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(h_out, d_out, out_words * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+            tail_done = true;
+        }
+    }
     auto finish = [&]() -> int {
         hipLaunchKernelGGL(k_once_finish, dim3(1), dim3(1024), 0, ctx->stream, (const double *)q->d_score, (const int64_t *)q->d_ninfo, (int64_t)na,
                            lik ? 1 : 0, certified ? (const int *)q->cert_count() : (const int *)nullptr, (unsigned *)ctx->ws_once_state.p,
@@ -303,7 +315,7 @@ static int genotype_once_fused(snpm_panel *p, const int64_t *row_idx, const doub
         if (!zero_copy) HIPCHK(ctx, hipMemcpyAsync(h_out, d_out, out_words * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
         return SNPM_OK;
     };
-    if ((rc = finish())) return rc;
+    if (!tail_done && (rc = finish())) return rc;
     const double t_enqueued = trace ? now() : 0.0;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->once_state_clean = true;

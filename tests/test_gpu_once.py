@@ -231,7 +231,9 @@ def test_fused_and_unfused_forms_of_the_call_agree():
     for reeval in (0, 3, 100):                     # 100 > the sparse tier's 64: the deferred dense tier
         forms = {"fused": _ctx_with(SNPM_DEBUG_REEVAL=reeval), "copies": _ctx_with(SNPM_DEBUG_REEVAL=reeval, SNPM_ONCE_ZEROCOPY=0),
                  "in-place": _ctx_with(SNPM_DEBUG_REEVAL=reeval, SNPM_ONCE_ZEROCOPY=1),
-                 "unfused": _ctx_with(SNPM_DEBUG_REEVAL=reeval, SNPM_ONCE_FUSED=0)}
+                 "unfused": _ctx_with(SNPM_DEBUG_REEVAL=reeval, SNPM_ONCE_FUSED=0),
+                 # round 4's launch chain: two reduce launches, chain kernel and finish kernel apart (round 5 fused each pair)
+                 "seven-launches": _ctx_with(SNPM_DEBUG_REEVAL=reeval, SNPM_FUSED_REDUCE=0, SNPM_ONCE_TAIL=0)}
         res = {}
         for name, c in forms.items():
             for packed in (False, True):
