@@ -92,9 +92,9 @@ __global__ void k_reduce(const double *__restrict__ part_score, const uint32_t *
 // k_reduce_groups and k_reduce in ONE launch (round 5: a launch costs ~5 us of stream time, the two reduce steps of a 200k-SNP
 // sample took 10 of its 130): grid (column blocks, groups) as k_reduce_groups; every block leaves its group's sums and takes a
 // ticket of its column block, the block that draws the last ticket adds the groups in order (the additions, and therefore the
-// bits, of the two-kernel form), runs the certificate and puts the ticket back to zero.  Hand-off: every thread's stores, then an
-// agent-scope fence, then the ticket (one wave per block: no barrier needed beyond the wave's own order); the last block reads
-// the group sums with agent-scope loads behind its own fence.
+// bits, of the two-kernel form), runs the certificate and puts the ticket back to zero.  Hand-off without cache maintenance: the
+// group sums leave as write-through (sc1) stores, the wave waits for them (vmcnt(0)), one lane takes the ticket with an agent-scope
+// atomic; the block whose ticket came last reads the sums with sc1 loads (L2-served, never a stale L1 line).
 __global__ void __launch_bounds__(64)
 k_reduce_all(const double *__restrict__ part_score, const uint32_t *__restrict__ part_miss, int64_t n_slots, int64_t ld,
              int64_t n_acc, int64_t n_rows, double *__restrict__ grp_score, uint32_t *__restrict__ grp_miss,
@@ -129,16 +129,17 @@ k_reduce_all(const double *__restrict__ part_score, const uint32_t *__restrict__
             s = s + part_score[k * ld + a];
             m += part_miss[k * ld + a];
         }
-        grp_score[g * ld + a] = s;
-        grp_miss[g * ld + a] = m;
+        // write-through stores (sc1): the sums are in memory, not in this XCD's L2, once the wave's vmcnt is zero -- no
+        // cache write-back per block (a __threadfence() here made the fused kernel slower than the two launches it replaces)
+        __hip_atomic_store(&grp_score[g * ld + a], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&grp_miss[g * ld + a], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = (atomicAdd(&tickets[blockIdx.x], 1u) == (unsigned)(n_groups - 1)) ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // one wave per block: its own stores are all there is to wait for
+    if (threadIdx.x == 0)
+        s_last = (__hip_atomic_fetch_add(&tickets[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_groups - 1)) ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
-    if (threadIdx.x == 0) tickets[blockIdx.x] = 0u;
+    if (threadIdx.x == 0) __hip_atomic_store(&tickets[blockIdx.x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a >= n_acc) return;
     double s = 0.0;
     int64_t m = 0;
