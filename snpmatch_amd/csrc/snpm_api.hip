@@ -66,7 +66,7 @@ struct snpm_ctx {
     Buf ws_lik_y, ws_lik_n, ws_lik_l, ws_lik_r;
     Buf ws_wprops, ws_epart;            // partial sums of k_wprops / k_eref
     Buf ws_tickets;                     // k_reduce_all: one ticket per column block, zero between launches
-    int fused_reduce = 1;               // SNPM_FUSED_REDUCE=0: k_reduce_groups + k_reduce as two launches (round 4's form)
+    int fused_reduce = 0;               // SNPM_FUSED_REDUCE=1: k_reduce_groups + k_reduce as ONE launch with a ticket per column block (measured SLOWER: 12.8 us against 5.4 + 4.7 us on a 200k-SNP sample, profiles/r05_once_timeline.txt)
     int once_tail = 1;                  // SNPM_ONCE_TAIL=0: snpm_genotype_once ends with k_scan_few + k_once_finish instead of k_once_tail
     Buf ws_once, ws_once_table;         // packed results of snpm_genotype_once; the weight table of its coded form
     std::vector<double> once_table;     // host image of ws_once_table
@@ -82,9 +82,17 @@ struct snpm_ctx {
     int batch_shared = -1;              // SNPM_BATCH_SHARED / snpm_batch_configure: -1 auto (batches whose inputs are on the device), 0 never, 1 whenever the batch allows it
     int shared_digits = 0;              // base-256 digits of the fixed-point weights (3..7: 2^-(8 (digits - 1) + 6) per matched SNP of quantisation); 0 = by the longest sample
     int shared_min_samples = 8;         // auto: smaller batches keep the per-sample pass
-    double shared_min_density = 0.25;   // auto: calls per (sample, union row) slot below which the per-sample pass reads fewer bytes than the contraction computes
+    double shared_min_density = -1.0;   // auto threshold; negative: by panel format (shared_min_density_of)
     size_t shared_ws_bytes = size_t(2) << 30;   // SNPM_SHARED_WS_MB: digit matrix per pass over groups of samples
     int shared_force_tiles = 0;         // SNPM_SHARED_TILES: row tiles of k_sh_mfma (tests, experiments)
+    int shared_probe = 1;               // SNPM_SHARED_PROBE=0: the automatic policy decides after the full pass over the batch only
+    int shared_parts = 4;               // SNPM_SHARED_PARTS: parts of a pass whose digit layout (auxiliary stream) runs beside the previous part's contraction; 1 = one stream
+    hipStream_t aux_stream = nullptr;   // created with the context
+    hipEvent_t aux_ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // the automatic choice: calls per (sample, union row) slot from which the contraction is the cheaper pass -- measured on 64
+    // samples x 200k SNPs x 1135 accessions: the contraction costs ~2.8 ns per union row, the per-sample pass 0.27 ns (int8) /
+    // 0.16 ns (packed) per call
+    double shared_min_density_of(bool packed) const { return shared_min_density >= 0.0 ? shared_min_density : (packed ? 0.35 : 0.2); }
     int64_t shared_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // snpm_batch_last_stats
     int64_t *h_desc = nullptr;          // pinned host image of ws_seg_desc
     size_t h_desc_cap = 0;
@@ -457,6 +465,20 @@ try {
         return set_err(nullptr, SNPM_ERR_HIP, "hipStreamCreate failed");
     }
     ctx->stream = ctx->own_stream;
+    // auxiliary compute stream + its events (the shared-row scan lays out a part's digits beside the previous part's contraction);
+    // without them that pass simply runs on one stream
+    if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        ctx->aux_stream = nullptr;
+    } else {
+        for (auto &ev : ctx->aux_ev)
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipStreamDestroy(ctx->aux_stream);
+                ctx->aux_stream = nullptr;
+                break;
+            }
+    }
     if (const char *s = getenv("SNPM_FORCE_BPL")) ctx->force_bpl = atoi(s);
     if (const char *s = getenv("SNPM_PARTS_MULT")) ctx->parts_mult = std::max(1, atoi(s));
     if (const char *s = getenv("SNPM_FORCE_WPB")) ctx->force_wpb = atoi(s);
@@ -488,6 +510,8 @@ try {
     if (const char *s = getenv("SNPM_SHARED_MIN_DENSITY")) ctx->shared_min_density = atof(s);
     if (const char *s = getenv("SNPM_SHARED_WS_MB")) ctx->shared_ws_bytes = (size_t)std::max(1, atoi(s)) << 20;
     if (const char *s = getenv("SNPM_SHARED_TILES")) ctx->shared_force_tiles = std::max(0, atoi(s));
+    if (const char *s = getenv("SNPM_SHARED_PROBE")) ctx->shared_probe = atoi(s) != 0;
+    if (const char *s = getenv("SNPM_SHARED_PARTS")) ctx->shared_parts = std::max(1, std::min(8, atoi(s)));
     ctx->stage_threads = default_stage_threads();
     if (const char *s = getenv("SNPM_STAGE_THREADS")) ctx->stage_threads = std::max(1, atoi(s));
     if (const char *s = getenv("SNPM_STAGE_MB")) ctx->ld_want = (size_t)std::max(1, atoi(s)) << 20;
@@ -585,6 +609,9 @@ int snpm_destroy(snpm_ctx *ctx)
         if (ctx->compute_mark) (void)hipEventDestroy(ctx->compute_mark);
         if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        for (auto &ev : ctx->aux_ev)
+            if (ev) (void)hipEventDestroy(ev);
+        if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     }
     ctx->qcache.clear();
     host_pool_destroy(ctx);

@@ -58,6 +58,29 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     HIPCHK(ctx, hipMemsetAsync(d_bitmap, 0, (size_t)n_words * 4, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(d_urows, 0, urow_entries * 4, ctx->stream));
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((maxlen + 255) / 256, 64));
+    if ((rc = ensure_pinned(ctx, 64))) return rc;
+    long long *h_meta = (long long *)ctx->h_pinned;
+    if (!forced && p->n_snp >= 4096 && ctx->shared_probe) {
+        // automatic policy: look at 1/32 of the panel first (the batch's calls below row n_snp / 32); scattered marker sets are
+        // declined here, before the full pass over every row and weight of the batch
+        const int64_t row_limit = (p->n_snp / 32 + 31) / 32 * 32;
+        const int64_t words_probe = row_limit / 32;
+        const int64_t blocks_probe = (words_probe + SH_WORDS_PER_BLOCK - 1) / SH_WORDS_PER_BLOCK;
+        hipLaunchKernelGGL(k_sh_probe, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, row_limit,
+                           p->n_snp, d_bitmap, d_meta);
+        hipLaunchKernelGGL(k_sh_count, dim3((unsigned)blocks_probe), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, words_probe, d_blocksum);
+        hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)d_blocksum, blocks_probe, d_blockbase, d_meta);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(h_meta, d_meta, 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        const int64_t u_probe = h_meta[0], n_probe = h_meta[3];
+        if (u_probe > 0 && n_probe >= 1024) {
+            const double est = (double)n_probe / ((double)u_probe * (double)n_seg);
+            st.union_rows = u_probe * 32;                       // an estimate
+            st.density = est;
+            if (est < 0.8 * ctx->shared_min_density_of(p->packed != 0)) { st.reason = 6; return SNPM_OK; }
+        }
+    }
     // one pass over the entries: marks, input checks, quantisation counts and (chunks of ordinary length) the partial sums of the
     // reference-order error bound, which k_eseg_finish turns into the per-sample bound
     const int npart = (int)((kmax + 3) / 4);
@@ -81,8 +104,6 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
                            (const uint32_t *)d_blockbase, d_wordbase, d_urows);
         HIPCHK(ctx, hipGetLastError());
     }
-    if ((rc = ensure_pinned(ctx, 64))) return rc;
-    long long *h_meta = (long long *)ctx->h_pinned;
     h_meta[2] = 0;
     HIPCHK(ctx, hipMemcpyAsync(h_meta, d_meta, 16, hipMemcpyDeviceToHost, ctx->stream));
     if (!p->packed && p->d_other) HIPCHK(ctx, hipMemcpyAsync(h_meta + 2, p->d_other, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -97,7 +118,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     if (bad & 2) { st.reason = 4; return SNPM_OK; }
     if (other) { st.reason = 5; return SNPM_OK; }
     if (U < 1) { st.reason = 2; return SNPM_OK; }
-    if (!forced && st.density < ctx->shared_min_density) { st.reason = 6; return SNPM_OK; }
+    if (!forced && st.density < ctx->shared_min_density_of(p->packed != 0)) { st.reason = 6; return SNPM_OK; }
 
     // ---- geometry
     // K steps of 8 union rows, padded to a multiple of SH_DEPTH with rows no sample has a call at (zero digits): the kernel's body is unconditional
@@ -174,33 +195,53 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
         HIPCHK(ctx, hipMemsetAsync(ctx->ws_sh_pos.p, 0, (size_t)s_pass * ld_pos * 4, ctx->stream));
         hipLaunchKernelGGL(k_sh_pos, dim3(gx, (unsigned)s_pass), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, s_base,
                            (const uint32_t *)d_bitmap, (const uint32_t *)d_wordbase, (uint32_t *)ctx->ws_sh_pos.p, ld_pos);
-        {
-            ProfScope ps(ctx, PK_LUT);
-            const int64_t threads = n_steps * s_pass * 2;
-            const dim3 eg((unsigned)((threads + 255) / 256));
-#define LAUNCH_EXPAND(D)                                                                                                     \
-    hipLaunchKernelGGL((k_sh_expand<D>), eg, dim3(256), 0, ctx->stream, (const uint32_t *)ctx->ws_sh_pos.p, ld_pos, j.d_w, s_pass, j.skip,  \
-                       n_steps, steps_ld, (sh_v4i *)ctx->ws_sh_A.p)
-            switch (digits) {
-            case 3: LAUNCH_EXPAND(3); break;
-            case 4: LAUNCH_EXPAND(4); break;
-            case 5: LAUNCH_EXPAND(5); break;
-            case 6: LAUNCH_EXPAND(6); break;
-            default: LAUNCH_EXPAND(7); break;
-            }
-#undef LAUNCH_EXPAND
-            HIPCHK(ctx, hipGetLastError());
+        // The pass in parts of whole row tiles: the digits of part i + 1 are laid out (k_sh_expand, on the auxiliary stream: memory
+        // latency) while part i is contracted (k_sh_mfma, one wave per SIMD: the matrix cores); the expansion's waves fit beside
+        // the contraction's on every SIMD (368 + ~60 of 512 registers).  One part = everything on the main stream.
+        const int m_tiles = (tiles + 7) / 8;                                // tiles come in sets of 8 (one per XCD)
+        const int n_parts = (ctx->shared_parts > 0 && ctx->aux_stream) ? std::max(1, std::min(ctx->shared_parts, m_tiles)) : 1;
+        const bool overlap = n_parts > 1;
+        if (overlap) {
+            HIPCHK(ctx, hipEventRecord(ctx->aux_ev[0], ctx->stream));       // k_sh_pos (and the previous pass's readers of A) before the first expansion
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->aux_ev[0], 0));
         }
-        {
-            ProfScope ps(ctx, PK_FAST);
-            const unsigned nblk = (unsigned)(8 * ((tiles + 7) / 8) * bpt);
+        for (int part = 0; part < n_parts; ++part) {
+            const int t0 = 8 * (int)((int64_t)m_tiles * part / n_parts), t1 = std::min(tiles, 8 * (int)((int64_t)m_tiles * (part + 1) / n_parts));
+            if (t1 <= t0) continue;
+            const int64_t k0 = (int64_t)t0 * spt, k1 = std::min<int64_t>(n_steps, (int64_t)t1 * spt);
+            hipStream_t es = overlap ? ctx->aux_stream : ctx->stream;
+            {
+                ProfScope ps(ctx, PK_LUT);
+                const int64_t threads = (k1 - k0) * s_pass * 2;
+                const dim3 eg((unsigned)((threads + 255) / 256));
+#define LAUNCH_EXPAND(D)                                                                                                     \
+    hipLaunchKernelGGL((k_sh_expand<D>), eg, dim3(256), 0, es, (const uint32_t *)ctx->ws_sh_pos.p, ld_pos, j.d_w, s_pass, j.skip,  \
+                       k0, k1 - k0, steps_ld, (sh_v4i *)ctx->ws_sh_A.p)
+                switch (digits) {
+                case 3: LAUNCH_EXPAND(3); break;
+                case 4: LAUNCH_EXPAND(4); break;
+                case 5: LAUNCH_EXPAND(5); break;
+                case 6: LAUNCH_EXPAND(6); break;
+                default: LAUNCH_EXPAND(7); break;
+                }
+#undef LAUNCH_EXPAND
+                HIPCHK(ctx, hipGetLastError());
+            }
+            if (overlap) {
+                HIPCHK(ctx, hipEventRecord(ctx->aux_ev[1 + part], ctx->aux_stream));
+                HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->aux_ev[1 + part], 0));
+            }
+            {
+                ProfScope ps(ctx, PK_FAST);
+                const unsigned nblk = (unsigned)(8 * ((t1 - t0 + 7) / 8) * bpt);
 #define LAUNCH_SH(PK)                                                                                                          \
     hipLaunchKernelGGL((k_sh_mfma<PK>), dim3(nblk), dim3(256), 0, ctx->stream, p->d, p->kpitch, p->desc, (const int32_t *)d_urows,     \
-                       (const sh_v4i *)ctx->ws_sh_A.p, n_steps, steps_ld, spt, tiles, (int)groups, n_accgroups, bpt,                    \
+                       (const sh_v4i *)ctx->ws_sh_A.p, n_steps, steps_ld, spt, t0, t1, (int)groups, n_accgroups, bpt,                   \
                        (int *)ctx->ws_sh_partial.p, ldn)
-            if (p->packed) LAUNCH_SH(true); else LAUNCH_SH(false);
+                if (p->packed) LAUNCH_SH(true); else LAUNCH_SH(false);
 #undef LAUNCH_SH
-            HIPCHK(ctx, hipGetLastError());
+                HIPCHK(ctx, hipGetLastError());
+            }
         }
         {
             ProfScope ps(ctx, PK_REDUCE);

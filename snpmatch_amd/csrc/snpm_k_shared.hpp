@@ -154,6 +154,38 @@ k_sh_mark(const int64_t *__restrict__ rows, const double *__restrict__ w, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k_sh_probe: a cheap look at the batch before the full pass (automatic policy): block = sample; the entries whose rows lie below
+// `row_limit` (a prefix of a sorted row list: binary search) are marked and counted.  calls / (distinct rows x samples) of that
+// slice of the panel estimates the density of the whole batch; a batch on scattered marker sets is declined after ~40 us
+// instead of after the full pass over its rows and weights.  meta[3] += entries marked.
+__global__ void __launch_bounds__(256)
+k_sh_probe(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off, int64_t row_limit, int64_t n_snp,
+           uint32_t *__restrict__ bitmap, long long *__restrict__ meta)
+{
+    __shared__ long long s_len;
+    const int64_t s = blockIdx.x;
+    const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
+    if (threadIdx.x == 0) {
+        int64_t lo = r0, hi = r1;                   // first entry with row >= row_limit
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (rows[mid] < row_limit) lo = mid + 1; else hi = mid;
+        }
+        s_len = lo - r0;
+        if (lo > r0) atomicAdd((unsigned long long *)&meta[3], (unsigned long long)(lo - r0));
+    }
+    __syncthreads();
+    const int64_t len = s_len;
+    for (int64_t i = r0 + threadIdx.x; i < r0 + len; i += 256) {
+        const int64_t r = rows[i];
+        if (r < 0 || r >= n_snp || r >= row_limit) continue;      // an unsorted or invalid list: the full pass reports it
+        uint32_t *wp = &bitmap[r >> 5];
+        const uint32_t bit = 1u << (r & 31);
+        if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(wp, bit);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // rank of the marked rows: a block owns 4096 bitmap words (16 consecutive words per thread).
 //   k_sh_count   popcount of a block's words -> block_sum[b]
 //   k_sh_scan    ONE block: exclusive prefix of block_sum -> block_base, total -> meta[0]
@@ -271,14 +303,15 @@ k_sh_pos(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off, 
 template <int DIGITS>
 __global__ void __launch_bounds__(256)
 k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__restrict__ w, int64_t n_samples_pass, int skip_hets,
-            int64_t n_steps, int64_t steps_ld, sh_v4i *__restrict__ A)
+            int64_t step0, int64_t n_steps, int64_t steps_ld, sh_v4i *__restrict__ A)
 {
+    // K steps [step0, step0 + n_steps) of the pass (a launch per part: the contraction of a part starts when its digits are there)
     constexpr int RPS = DIGITS + 1;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_steps * n_samples_pass * 2) return;
     const int h = (int)(idx & 1);
     const int64_t s = (idx >> 1) % n_samples_pass;
-    const int64_t k = (idx >> 1) / n_samples_pass;
+    const int64_t k = step0 + (idx >> 1) / n_samples_pass;
     constexpr int frac_bits = 8 * (DIGITS - 1) + 6;
     const double scale = __builtin_ldexp(1.0, frac_bits);
     unsigned long long bias = 0;
@@ -367,13 +400,14 @@ __device__ __forceinline__ void sh_onehot(const uint32_t (&x)[4], sh_v4i (&b)[4]
 template <bool PACKED>
 __global__ void __launch_bounds__(256, 1)
 k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int32_t *__restrict__ union_rows,
-          const sh_v4i *__restrict__ A, int64_t n_steps, int64_t steps_ld, int64_t steps_per_tile, int n_tiles, int n_groups,
+          const sh_v4i *__restrict__ A, int64_t n_steps, int64_t steps_ld, int64_t steps_per_tile, int tile0, int n_tiles, int n_groups,
           int n_accgroups, int blocks_per_tile, int *__restrict__ partial, int64_t ldn)
 {
-    // blocks of one row tile on ONE XCD: workgroups are dealt round-robin over the 8 XCDs in launch order
+    // blocks of one row tile on ONE XCD: workgroups are dealt round-robin over the 8 XCDs in launch order.  This launch owns the
+    // row tiles [tile0, n_tiles) it can reach: a pass is cut into parts of whole tiles, one launch each.
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = bid >> 3;
-    const int tile = (q / blocks_per_tile) * 8 + xcd;
+    const int tile = tile0 + (q / blocks_per_tile) * 8 + xcd;
     const int wb = q % blocks_per_tile;
     if (tile >= n_tiles) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

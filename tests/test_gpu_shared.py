@@ -250,3 +250,49 @@ def test_coded_batch_through_the_shared_rows():
     assert got["shared_rows"]
     check_against_oracle(db, plain, got, False)
     ctx.close()
+
+
+def test_parts_on_two_streams_and_the_probe_agree_with_one_stream():
+    """the pass cut into parts (digit layout on the auxiliary stream beside the previous part's contraction) returns the bits of
+    the one-stream pass, over several passes over groups too; the automatic policy's probe declines scattered marker sets before
+    the full pass and lets a batch on one marker set through"""
+    import torch
+    rng = np.random.default_rng(12)
+    n_snp, n_acc = 60_000, 900
+    db = rand_db(rng, n_snp, n_acc)
+    samples = chip_samples(rng, db, 40, 9000)
+    off = np.concatenate([[0], np.cumsum([len(r) for r, _ in samples])]).astype(np.int64)
+    res = {}
+    for name, env in (("one stream", {"SNPM_SHARED_PARTS": 1, "SNPM_SHARED_TILES": 32}), ("four parts", {"SNPM_SHARED_PARTS": 4, "SNPM_SHARED_TILES": 32}),
+                      ("eight parts, three passes", {"SNPM_SHARED_PARTS": 8, "SNPM_SHARED_TILES": 64, "SNPM_SHARED_WS_MB": 4})):
+        ctx = make_ctx(**env)
+        panel = engine.Panel.from_host(ctx, db, packed=True)
+        d_rows = torch.as_tensor(np.concatenate([r for r, _ in samples]), device="cuda:0")
+        d_wei = torch.as_tensor(np.concatenate([w for _, w in samples]), device="cuda:0")
+        for rep in range(3):                                                 # back to back: a pass must not overwrite digits still being read
+            got = engine.score_batch(panel, None, 1000, False, engine.MODE_EXACT, device=(d_rows.data_ptr(), d_wei.data_ptr(), off))
+        st = engine.batch_last_stats(ctx)
+        assert got["shared_rows"] and st["taken"], (name, st)                # automatic policy: probe, then the full pass
+        if "three passes" in name:
+            assert st["passes"] >= 3, st
+        res[name] = got
+        ctx.close()
+    check_against_oracle(db, samples, res["one stream"], False)
+    for name, got in res.items():
+        for k in ("score", "ninfo", "lik", "lrt"):
+            assert np.array_equal(np.ascontiguousarray(got[k]).view(np.uint64), np.ascontiguousarray(res["one stream"][k]).view(np.uint64)), (name, k)
+    # scattered markers: declined by the probe (the estimate is reported), same results from the per-sample pass
+    ctx = make_ctx()
+    panel = engine.Panel.from_host(ctx, db, packed=True)
+    sparse = []
+    for b in range(16):
+        rows = np.sort(rng.choice(n_snp, size=3000, replace=False)).astype(np.int64)
+        sparse.append((rows, sample_on(rng, db, rows, 0)))
+    off = np.concatenate([[0], np.cumsum([len(r) for r, _ in sparse])]).astype(np.int64)
+    d_rows = torch.as_tensor(np.concatenate([r for r, _ in sparse]), device="cuda:0")
+    d_wei = torch.as_tensor(np.concatenate([w for _, w in sparse]), device="cuda:0")
+    got = engine.score_batch(panel, None, 1000, False, engine.MODE_EXACT, device=(d_rows.data_ptr(), d_wei.data_ptr(), off))
+    st = engine.batch_last_stats(ctx)
+    assert not got["shared_rows"] and st["why_not"] == "overlap below the threshold" and 0.0 < st["density"] < 0.2, st
+    check_against_oracle(db, sparse, got, False)
+    ctx.close()
