@@ -86,7 +86,9 @@ struct snpm_ctx {
     size_t shared_ws_bytes = size_t(2) << 30;   // SNPM_SHARED_WS_MB: digit matrix per pass over groups of samples
     int shared_force_tiles = 0;         // SNPM_SHARED_TILES: row tiles of k_sh_mfma (tests, experiments)
     int shared_probe = 1;               // SNPM_SHARED_PROBE=0: the automatic policy decides after the full pass over the batch only
-    int shared_parts = 4;               // SNPM_SHARED_PARTS: parts of a pass whose digit layout (auxiliary stream) runs beside the previous part's contraction; 1 = one stream
+    int shared_parts = 1;               // SNPM_SHARED_PARTS=n: the pass in n parts, the digit layout of a part (auxiliary stream) beside the previous part's contraction.
+                                        // Measured SLOWER (64 x 200k x 1135: 1.08 ms on one stream, 1.28 / 1.33 / 1.91 ms with 2 / 4 / 8 parts: the layout's waves take issue slots
+                                        // and L1 from the one-wave-per-SIMD contraction, and a part no longer fills the chip), kept for experiments
     hipStream_t aux_stream = nullptr;   // created with the context
     hipEvent_t aux_ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // the automatic choice: calls per (sample, union row) slot from which the contraction is the cheaper pass -- measured on 64

@@ -58,20 +58,18 @@ __host__ __device__ __forceinline__ int sh_frac_bits(int digits) { return 8 * (d
 //   - counts per sample the rows with a weight that 2^-F does not divide (the quantisation bound),
 //   - and leaves the partial sums of the reference-order error bound exactly as k_eseg_part does (same decomposition: block =
 //     four chunks of `chunk` rows, a wave per chunk; same order of additions), so that k_eseg_finish follows directly.
-__device__ __forceinline__ void sh_mark_entry(const int64_t *__restrict__ rows, const double *__restrict__ w, int64_t i, int64_t r0,
-                                              int64_t n_snp, double scale, int skip_hets, uint32_t *__restrict__ bitmap, int &inexact,
-                                              int &bad, double &wmax, int &nonint)
+__device__ __forceinline__ void sh_mark_values(int64_t r, int64_t r_prev, bool has_prev, double w0, double w1, double w2, int64_t n_snp,
+                                               double scale, int skip_hets, uint32_t *__restrict__ bitmap, int &inexact, int &bad,
+                                               double &wmax, int &nonint)
 {
-    const int64_t r = rows[i];
     if (r < 0 || r >= n_snp) {
         bad |= 4;
     } else {
-        if (i > r0 && rows[i - 1] >= r) bad |= 1;
+        if (has_prev && r_prev >= r) bad |= 1;
         uint32_t *wp = &bitmap[r >> 5];
         const uint32_t bit = 1u << (r & 31);
         if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(wp, bit);
     }
-    const double w0 = w[3 * i], w1 = w[3 * i + 1], w2 = w[3 * i + 2];
     const double a = fabs(w0), b = fabs(w1), c = fabs(w2);
     wmax = fmax(a, fmax(b, c));
     if (!(a == floor(a) && b == floor(b) && c == floor(c)) || !(a < 1e300 && b < 1e300 && c < 1e300)) nonint = 1;
@@ -79,6 +77,14 @@ __device__ __forceinline__ void sh_mark_entry(const int64_t *__restrict__ rows, 
     if (!(w0 >= 0.0 && w0 <= 1.0 && h >= 0.0 && h <= 1.0 && w2 >= 0.0 && w2 <= 1.0)) bad |= 2;
     const double xa = w0 * scale, xb = h * scale, xc = w2 * scale;
     if (!(xa == floor(xa) && xb == floor(xb) && xc == floor(xc))) ++inexact;
+}
+
+__device__ __forceinline__ void sh_mark_entry(const int64_t *__restrict__ rows, const double *__restrict__ w, int64_t i, int64_t r0,
+                                              int64_t n_snp, double scale, int skip_hets, uint32_t *__restrict__ bitmap, int &inexact,
+                                              int &bad, double &wmax, int &nonint)
+{
+    sh_mark_values(rows[i], i > r0 ? rows[i - 1] : -1, i > r0, w[3 * i], w[3 * i + 1], w[3 * i + 2], n_snp, scale, skip_hets, bitmap,
+                   inexact, bad, wmax, nonint);
 }
 
 __global__ void __launch_bounds__(256)
@@ -100,7 +106,27 @@ k_sh_mark_chunks(const int64_t *__restrict__ rows, const double *__restrict__ w,
     if (k < K) {
         c0 = r0 + k * chunk;
         c1 = (c0 + chunk < r1) ? c0 + chunk : r1;
-        for (int64_t r = c0 + lane; r < c1; r += 64) {
+        // four entries per lane at a time, every load issued before the first use (the order of the additions into v is the
+        // order of k_eseg_part: r, r + 64, r + 128, ...)
+        int64_t r = c0 + lane;
+        for (; r + 192 < c1; r += 256) {
+            int64_t rw[4], rp[4];
+            double ww[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = r + 64 * u;
+                rw[u] = rows[i];
+                rp[u] = i > r0 ? rows[i - 1] : -1;
+                ww[u][0] = w[3 * i]; ww[u][1] = w[3 * i + 1]; ww[u][2] = w[3 * i + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                double wmax;
+                sh_mark_values(rw[u], rp[u], r + 64 * u > r0, ww[u][0], ww[u][1], ww[u][2], n_snp, scale, skip_hets, bitmap, inexact, bad, wmax, nonint);
+                v += wmax;
+            }
+        }
+        for (; r < c1; r += 64) {
             double wmax;
             sh_mark_entry(rows, w, r, r0, n_snp, scale, skip_hets, bitmap, inexact, bad, wmax, nonint);
             v += wmax;
@@ -320,20 +346,24 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
     const sh_v4i e4 = *reinterpret_cast<const sh_v4i *>(pos + s * ld_pos + k * SH_STEP_ROWS + 4 * h);
     const uint32_t e[4] = {(uint32_t)e4.x, (uint32_t)e4.y, (uint32_t)e4.z, (uint32_t)e4.w};
     uint32_t dw[RPS][4];
+    // every weight of the four rows is requested before the first one is used (rows the sample has no call at re-read entry 0:
+    // harmless, their digits are cleared below) -- one memory round trip per thread instead of four
+    double wv[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        uint32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-        if (e[i]) {
-            const double *wr = w + 3 * (int64_t)(e[i] - 1);
-            const double wc[3] = {wr[0], wr[2], skip_hets ? 0.0 : wr[1]};      // class order: ref, alt, het
+        const double *wr = w + 3 * (int64_t)(e[i] ? e[i] - 1 : 0);
+        wv[i][0] = wr[0]; wv[i][1] = wr[2]; wv[i][2] = wr[1];                  // class order: ref, alt, het
+    }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double x = wc[c];
-                x = (x >= 0.0 && x <= 1.0) ? x : 0.0;                          // refused by the mark pass; keep the conversion defined
-                const unsigned long long Q = (unsigned long long)floor(x * scale) + bias;
-                lo[c] = (uint32_t)Q;
-                hi[c] = (uint32_t)(Q >> 32);
-            }
+    for (int i = 0; i < 4; ++i) {
+        uint32_t lo[3], hi[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double x = (c == 2 && skip_hets) ? 0.0 : wv[i][c];
+            x = (x >= 0.0 && x <= 1.0) ? x : 0.0;                              // refused by the mark pass; keep the conversion defined
+            const unsigned long long Q = (unsigned long long)floor(x * scale) + bias;
+            lo[c] = (uint32_t)Q;
+            hi[c] = (uint32_t)(Q >> 32);
         }
 #pragma unroll
         for (int j = 0; j < DIGITS; ++j) {
