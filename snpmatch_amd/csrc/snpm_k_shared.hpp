@@ -38,7 +38,7 @@ namespace snpm {
 constexpr int SH_GROUP_ROWS = 128;      // matrix rows (sample digits) per wave tile
 constexpr int SH_WAVE_ACCS = 128;       // accessions per wave tile
 constexpr int SH_STEP_ROWS = 8;         // union rows per K step
-constexpr int SH_DEPTH = 3;             // K steps in flight per wave
+constexpr int SH_DEPTH = 4;             // K steps in flight per wave (even: the one-hot fragments of step d + 1 are built beside the MFMAs of step d in two alternating register sets)
 constexpr int SH_PAD_STEPS = 3 * SH_DEPTH;   // steps a wave may read (never score) past the last one: row list 3 x DEPTH - 2, A fragments 2 x DEPTH - 1
 constexpr int SH_MAX_RPS = 8;           // matrix rows per sample: digits + the missing-count row
 
@@ -511,17 +511,26 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) expcnt(7) lgkmcnt(15)
     // [k0, k1) holds a multiple of SH_DEPTH steps (the host pads the union with rows no sample has a call at: zero digits), so the
     // body is straight-line code: the compiler counts the loads in flight exactly (s_waitcnt vmcnt(n) with n > 0)
+    // Software pipeline of the one-hot expansion: with one wave per SIMD nothing else feeds the matrix pipe while this wave runs
+    // its ~55 VALU instructions per step, so the fragments of step d + 1 are built BETWEEN the 16 MFMAs of step d (an MFMA holds
+    // the issue port for 8 of its 32 cycles; sched_group_barrier pins the pattern 1 MFMA : 4 VALU).
+    sh_v4i b[2][4];
+    sh_onehot<PACKED>(x[0], b[0]);
     int64_t ks = k0;
     do {                                    // a tile is never empty
 #pragma unroll
         for (int d = 0; d < SH_DEPTH; ++d) {
-            sh_v4i b[4];
-            sh_onehot<PACKED>(x[d], b);
+            sh_onehot<PACKED>(x[(d + 1) % SH_DEPTH], b[(d + 1) & 1]);       // stage 0 of the next round when d is the last stage
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[t][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d][t], b[j], acc[t][j], 0, 0, 0);
+                    acc[t][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d][t], b[d & 1][j], acc[t][j], 0, 0, 0);
+#pragma unroll
+            for (int g16 = 0; g16 < 16; ++g16) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);          // four VALU
+            }
             // the next round's step of this stage (unconditional: the pads make it readable).  The scheduler must not move these
             // loads (it sinks them to their uses a round later and waits with vmcnt(0)): fences on both sides
             __builtin_amdgcn_sched_barrier(0);
