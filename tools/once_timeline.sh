@@ -1,9 +1,9 @@
 #!/bin/bash
-# GPU timeline (kernels + copies) of the last snpm_genotype_once[_coded] calls of tools/debug/r04_once_trace.py
+# GPU timeline (kernels + copies) of the last snpm_genotype_once[_coded] calls of tools/once_trace.py
 set -uo pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-out=gpurun_out/r04t; mkdir -p $out
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out/trace -- python3 tools/debug/r04_once_trace.py ${ONCE_TIMELINE_FORM:-default} > $out/once_trace.txt 2>&1
+out=gpurun_out/once_timeline; mkdir -p $out
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $out/trace -- python3 tools/once_trace.py ${ONCE_TIMELINE_FORM:-default} > $out/once_trace.txt 2>&1
 python3 - "$out" <<'PY'
 import csv, glob, sys
 out = sys.argv[1]
