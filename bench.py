@@ -139,6 +139,152 @@ def cpu_baseline_numpy_all_cores(n_acc, seconds=10.0):
                    "an accession block of %d x 20000 SNPs with the workload's value mix, 1000-row chunks, %.1f s" % (cores, per, wall)}
 
 
+def child_legs(out, args, world):
+    """The legs reported beside the headline, each measured by a CHILD process after this one has released its memory (a failure
+    there only drops the extra field): the same job on the 2-bit packed panel, the real-panel configurations
+    (tools/bench_real_panel.py), the DB staging path (tools/bench_staging.py)."""
+    # Beside the headline (the int8 panel BASELINE.json names): the same job on the 2-bit packed panel, which fits one GPU
+    # whole (125 GB).  A child process after this one has released its memory; a failure there only drops the extra field.
+    whole_job = (args.n_acc == N_ACC_TOTAL and args.n_snp == N_SNP_TOTAL and args.mode == "exact" and not args.hard_calls)
+    # (not under a profiler: its preloaded tool would follow the child)
+    profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
+    if world == 1 and not args.packed and not args.no_alternatives and whole_job and not profiled:
+        try:
+            import subprocess
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--packed", "--steps", "8", "--warmup", "2",
+                                    "--no-cpu-baseline", "--no-alternatives"], capture_output=True, text=True, timeout=300)
+            alt = json.loads(child.stdout.strip().splitlines()[-1])
+            out["alternatives"] = {"packed2_panel_resident": {
+                "value": alt["value"], "unit": alt["unit"], "ms_per_step": alt["ms_per_step"], "steps": alt["steps"],
+                "kernel": alt["roofline"]["kernel"], "kernel_avg_ms": alt["roofline"]["avg_ms"],
+                "panel_gb": N_SNP_TOTAL * ((N_ACC_TOTAL // 4 + 255) // 256 * 256) / 1e9, "checks": alt["checks"],
+                "note": "same job, same sample, 2 bits per call: results identical (tests), not the format the metric names"}}
+        except Exception as e:          # noqa: BLE001
+            out["alternatives"] = {"packed2_panel_resident": {"error": str(e)[:200]}}
+    # The real-panel configurations (configs[1]: one 200k-SNP sample against 1135 x 11M resident -- gathered rows; a batch of 64;
+    # configs[2]: the 399 windows of `cross`), int8 and packed, as a child process: tools/bench_real_panel.py.  Informative
+    # legs beside the headline, each with its kernel, its HIP-event duration, algorithmic bytes and fraction of the HBM peak.
+    if world == 1 and not args.no_real_panel and whole_job and not profiled and not args.packed:
+        try:
+            import subprocess
+            child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_real_panel.py"), "--reps", "10"],
+                                   capture_output=True, text=True, timeout=300)
+            rp = json.loads(child.stdout.strip().splitlines()[-1])
+            keep = ("leg", "kernel", "wall_ms_per_call", "kernel_ms_per_call", "algorithmic_bytes_per_call", "achieved_GBs",
+                    "frac_of_hbm_peak", "bytes_counted", "int8_equivalent_GBs", "samples_per_s", "windows", "shared_rows", "hbm_bytes_per_sample",
+                    "frac_of_int8_mfma_peak", "mfma_TMACs", "ceilings", "pairs_reeval", "other_kernels_ms_per_call")
+            out["real_panel"] = {"workload": rp["workload"], "traffic": "profiles/r04_pmc_split_real_*.json (request-size split, separate --pmc passes; per-sample legs)",
+                                 "formats": {f: {"row_pitch": v["row_pitch"], "panel_gb": v["panel_gb"],
+                                                 "legs": [{k: leg[k] for k in keep if k in leg} for leg in v["legs"]]}
+                                             for f, v in rp["formats"].items()}}
+        except Exception as e:          # noqa: BLE001
+            out["real_panel"] = {"error": str(e)[:200]}
+    # The DB staging path north_star names (pinned-host slabs + hipMemcpyAsync on a side stream, in place of the reference's
+    # h5py read, core/snpmatch.py:222): a 20 GB int8 host panel into int8 / packed panels from memory, from a flat file and
+    # from the reference's lzf HDF5 layout, against the hipMemcpyAsync ceiling of the same run, and an upload while a
+    # resident query is being scored.  A child process: tools/bench_staging.py.
+    if world == 1 and not args.no_staging and whole_job and not profiled and not args.packed:
+        try:
+            import subprocess
+            child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_staging.py")], capture_output=True, text=True,
+                                   timeout=420)
+            out["staging"] = json.loads(child.stdout.strip().splitlines()[-1])
+        except Exception as e:          # noqa: BLE001
+            out["staging"] = {"error": str(e)[:200]}
+
+
+def join_library_group(args, ctx, dev, rank, world, n_acc, shards, use_dist, side_group, real_stdout):
+    """The collective of the path behind the C ABI (snpm_group_*): rank 0 makes the RCCL id, torch.distributed (already up for
+    the barriers of the timing contract) carries its 128 bytes to the other ranks, every rank joins with its context.  Joined
+    BEFORE the panel is allocated, so that a process whose join hangs holds next to no HBM.
+      every rank joined           -> collective.transport = "c-abi-rccl"
+      a rank failed cleanly       -> every rank gathers through torch.distributed in this process: "torch-nccl-fallback" + reason
+      a rank is STUCK in the join -> nothing is measured in this process (a thread inside ncclCommInitRank holds the context):
+                                     every rank starts a fresh child with --collective torch, rank 0's child prints the line
+                                     (transport "torch-nccl-fallback", the reason, "degraded": true) and the parents leave with
+                                     exit code 3, so that the run is recorded as degraded, not as a normal one.
+    The ranks agree on the outcome over `side_group` (gloo, with a timeout): the NCCL process group may be exactly what hangs, and a
+    rank that hears nothing within the timeout treats the join as stuck too.
+    Returns (group or None, collective record, seconds spent joining)."""
+    import torch
+    import torch.distributed as dist
+    from snpmatch_amd import engine
+    group = None
+    coll = {"transport": "none", "reason": None}
+    join_s = 0.0
+    if not use_dist:
+        return group, coll, join_s
+    coll["transport"] = "torch-%s" % args.backend
+    if args.degraded_reason:
+        coll = {"transport": "torch-nccl-fallback", "reason": args.degraded_reason, "degraded": True}
+    if not (args.collective == "c-abi" and args.backend == "nccl"):
+        return group, coll, join_s
+    status, why = 2, ""                 # 2 joined, 1 failed cleanly, 0 stuck
+    t_join = time.perf_counter()
+    try:
+        box = [engine.Group.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0, group=side_group)
+        made = {}
+
+        def join_group():
+            try:
+                if os.environ.get("SNPM_BENCH_SIMULATE_STUCK_JOIN") == str(rank):      # rehearsal of the stuck branch
+                    time.sleep(3600)
+                made["group"] = engine.Group.from_rank(ctx, box[0], world, rank)
+            except Exception as exc:          # noqa: BLE001
+                made["error"] = exc
+
+        th = threading.Thread(target=join_group, daemon=True)
+        th.start()
+        th.join(args.group_timeout)
+        if th.is_alive():
+            status, why = 0, "rank %d: snpm_group_create_rank (ncclCommInitRank) did not return within %.0f s" % (rank, args.group_timeout)
+        elif "error" in made:
+            status, why = 1, "rank %d: snpm_group_create_rank failed: %s" % (rank, str(made["error"])[:200])
+        else:
+            group = made["group"]
+            assert group.shard(n_acc, rank) == (shards.a0, shards.a1), "the library and bench.py disagree about the shards"
+    except Exception as e:          # noqa: BLE001
+        status, why = 1, "rank %d: %s" % (rank, str(e)[:200])
+    join_s = time.perf_counter() - t_join
+    if why:
+        sys.stderr.write(why + "\n")
+    # the verdict of all ranks, over gloo (CPU tensors): a hang of the NCCL side cannot block it, and it times out
+    try:
+        t = torch.tensor([status], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=side_group)
+        worst = int(t.item())
+        reasons = [None] * world
+        dist.all_gather_object(reasons, why, group=side_group)
+        reason = "; ".join(r for r in reasons if r) or None
+    except Exception as e:          # noqa: BLE001
+        worst, reason = 0, "rank %d: no agreement with the other ranks within the side group's timeout (%s)" % (rank, str(e)[:120])
+    if worst == 2:
+        coll = {"transport": "c-abi-rccl", "reason": None,
+                "how": "snpm_group_gather_scores: one ncclAllGather inside libsnpmatch_hip.so (%s)" % group.transport}
+    elif worst == 1:
+        if group is not None:
+            group.free()
+        group = None
+        coll = {"transport": "torch-nccl-fallback", "reason": reason}
+    else:
+        # stuck: leave this process alone.  torch's process group is abandoned, not torn down (a destroy could hang on the same
+        # communicator); the children form their own on the next port
+        try:
+            dist.barrier(group=side_group)
+        except Exception:          # noqa: BLE001
+            pass
+        import subprocess
+        env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 1))
+        env.pop("SNPM_BENCH_SIMULATE_STUCK_JOIN", None)
+        cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + \
+              ["--collective", "torch", "--degraded-reason", "library RCCL group join hung (%s); measured in a fresh process over torch.distributed" % reason]
+        child = subprocess.run(cmd, env=env, stdout=real_stdout if rank == 0 else subprocess.DEVNULL)
+        sys.stderr.write("rank %d: degraded run, child exit code %d\n" % (rank, child.returncode))
+        os._exit(3 if child.returncode == 0 else 4)
+    return group, coll, join_s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +351,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
+    side_group = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -212,6 +359,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+        # a gloo side group with a timeout for what must not depend on the NCCL communicator (the verdict about the library's
+        # group join: join_library_group)
+        import datetime
+        side_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=max(60.0, args.group_timeout + 30.0)))
 
     ctx = engine.Context(local_rank)
     # One dedicated (non-default) stream for everything: the library's kernels are launched on it and
@@ -227,80 +378,7 @@ def main():
     a0, n_loc, per = shards.a0, shards.n_local, shards.per
     mode = {"exact": engine.MODE_EXACT, "strict": engine.MODE_STRICT, "fast": engine.MODE_FAST}[args.mode]
 
-    # The collective of the path behind the C ABI (snpm_group_*): rank 0 makes the RCCL id, torch.distributed (already up
-    # for the barriers of the timing contract) carries its 128 bytes to the other ranks, every rank joins with its context.
-    # Joined BEFORE the panel is allocated, so that a process whose join hangs holds next to no HBM.
-    #   every rank joined          -> collective.transport = "c-abi-rccl"
-    #   a rank failed cleanly      -> every rank gathers through torch.distributed in this process: "torch-nccl-fallback" + reason
-    #   a rank is STUCK in the join -> nothing is measured in this process (a thread inside ncclCommInitRank holds the context):
-    #                                 every rank starts a fresh child with --collective torch, rank 0's child prints the line
-    #                                 (transport "torch-nccl-fallback", the reason, "degraded": true) and the parents leave with
-    #                                 exit code 3, so that the run is recorded as degraded, not as a normal one.
-    group = None
-    coll = {"transport": "none", "reason": None}
-    join_s = 0.0
-    if use_dist:
-        coll["transport"] = "torch-%s" % args.backend
-        if args.degraded_reason:
-            coll = {"transport": "torch-nccl-fallback", "reason": args.degraded_reason, "degraded": True}
-        if args.collective == "c-abi" and args.backend == "nccl":
-            status, why = 2, ""                 # 2 joined, 1 failed cleanly, 0 stuck
-            t_join = time.perf_counter()
-            try:
-                box = [engine.Group.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                made = {}
-
-                def join_group():
-                    try:
-                        if os.environ.get("SNPM_BENCH_SIMULATE_STUCK_JOIN") == str(rank):      # rehearsal of the stuck branch
-                            time.sleep(3600)
-                        made["group"] = engine.Group.from_rank(ctx, box[0], world, rank)
-                    except Exception as exc:          # noqa: BLE001
-                        made["error"] = exc
-
-                th = threading.Thread(target=join_group, daemon=True)
-                th.start()
-                th.join(args.group_timeout)
-                if th.is_alive():
-                    status, why = 0, "rank %d: snpm_group_create_rank (ncclCommInitRank) did not return within %.0f s" % (rank, args.group_timeout)
-                elif "error" in made:
-                    status, why = 1, "rank %d: snpm_group_create_rank failed: %s" % (rank, str(made["error"])[:200])
-                else:
-                    group = made["group"]
-                    assert group.shard(n_acc, rank) == (shards.a0, shards.a1), "the library and bench.py disagree about the shards"
-            except Exception as e:          # noqa: BLE001
-                status, why = 1, "rank %d: %s" % (rank, str(e)[:200])
-            join_s = time.perf_counter() - t_join
-            if why:
-                sys.stderr.write(why + "\n")
-            t = torch.tensor([status], dtype=torch.int64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            worst = int(t.item())
-            reasons = [None] * world
-            dist.all_gather_object(reasons, why)
-            reason = "; ".join(r for r in reasons if r) or None
-            if worst == 2:
-                coll = {"transport": "c-abi-rccl", "reason": None,
-                        "how": "snpm_group_gather_scores: one ncclAllGather inside libsnpmatch_hip.so (%s)" % group.transport}
-            elif worst == 1:
-                if group is not None:
-                    group.free()
-                group = None
-                coll = {"transport": "torch-nccl-fallback", "reason": reason}
-            else:
-                # stuck: leave this process alone.  torch's process group goes first (the children form their own on the next port)
-                dist.barrier()
-                dist.destroy_process_group()
-                import subprocess
-                env = dict(os.environ, MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29533")) + 1))
-                env.pop("SNPM_BENCH_SIMULATE_STUCK_JOIN", None)
-                cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:]] + \
-                      ["--collective", "torch", "--degraded-reason", "library RCCL group join hung (%s); measured in a fresh process over torch.distributed" % reason]
-                child = subprocess.run(cmd, env=env, stdout=real_stdout if rank == 0 else subprocess.DEVNULL)
-                sys.stderr.write("rank %d: degraded run, child exit code %d\n" % (rank, child.returncode))
-                os._exit(3 if child.returncode == 0 else 4)
-
+    group, coll, join_s = join_library_group(args, ctx, dev, rank, world, n_acc, shards, use_dist, side_group, real_stdout)
 
     # ---- slabs of this rank's shard (the same on every rank: sized for the widest shard)
     pitch_max = ctx.row_pitch(per, args.packed)          # the library's rule (128-B rows for narrow int8 panels, + 256 B at multiples of 8 KiB)
@@ -610,54 +688,7 @@ def main():
         dist.destroy_process_group()
     ctx.close()
     if rank == 0:
-        # Beside the headline (the int8 panel BASELINE.json names): the same job on the 2-bit packed panel, which fits one GPU
-        # whole (125 GB).  A child process after this one has released its memory; a failure there only drops the extra field.
-        whole_job = (args.n_acc == N_ACC_TOTAL and args.n_snp == N_SNP_TOTAL and args.mode == "exact" and not args.hard_calls)
-        # (not under a profiler: its preloaded tool would follow the child)
-        profiled = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB"))
-        if world == 1 and not args.packed and not args.no_alternatives and whole_job and not profiled:
-            try:
-                import subprocess
-                child = subprocess.run([sys.executable, os.path.abspath(__file__), "--packed", "--steps", "8", "--warmup", "2",
-                                        "--no-cpu-baseline", "--no-alternatives"], capture_output=True, text=True, timeout=300)
-                alt = json.loads(child.stdout.strip().splitlines()[-1])
-                out["alternatives"] = {"packed2_panel_resident": {
-                    "value": alt["value"], "unit": alt["unit"], "ms_per_step": alt["ms_per_step"], "steps": alt["steps"],
-                    "kernel": alt["roofline"]["kernel"], "kernel_avg_ms": alt["roofline"]["avg_ms"],
-                    "panel_gb": N_SNP_TOTAL * ((N_ACC_TOTAL // 4 + 255) // 256 * 256) / 1e9, "checks": alt["checks"],
-                    "note": "same job, same sample, 2 bits per call: results identical (tests), not the format the metric names"}}
-            except Exception as e:          # noqa: BLE001
-                out["alternatives"] = {"packed2_panel_resident": {"error": str(e)[:200]}}
-        # The real-panel configurations (configs[1]: one 200k-SNP sample against 1135 x 11M resident -- gathered rows; a batch of 64;
-        # configs[2]: the 399 windows of `cross`), int8 and packed, as a child process: tools/bench_real_panel.py.  Informative
-        # legs beside the headline, each with its kernel, its HIP-event duration, algorithmic bytes and fraction of the HBM peak.
-        if world == 1 and not args.no_real_panel and whole_job and not profiled and not args.packed:
-            try:
-                import subprocess
-                child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_real_panel.py"), "--reps", "10"],
-                                       capture_output=True, text=True, timeout=300)
-                rp = json.loads(child.stdout.strip().splitlines()[-1])
-                keep = ("leg", "kernel", "wall_ms_per_call", "kernel_ms_per_call", "algorithmic_bytes_per_call", "achieved_GBs",
-                        "frac_of_hbm_peak", "bytes_counted", "int8_equivalent_GBs", "samples_per_s", "windows", "shared_rows", "hbm_bytes_per_sample",
-                        "frac_of_int8_mfma_peak", "mfma_TMACs", "ceilings", "pairs_reeval", "other_kernels_ms_per_call")
-                out["real_panel"] = {"workload": rp["workload"], "traffic": "profiles/r04_pmc_split_real_*.json (request-size split, separate --pmc passes; per-sample legs)",
-                                     "formats": {f: {"row_pitch": v["row_pitch"], "panel_gb": v["panel_gb"],
-                                                     "legs": [{k: leg[k] for k in keep if k in leg} for leg in v["legs"]]}
-                                                 for f, v in rp["formats"].items()}}
-            except Exception as e:          # noqa: BLE001
-                out["real_panel"] = {"error": str(e)[:200]}
-        # The DB staging path north_star names (pinned-host slabs + hipMemcpyAsync on a side stream, in place of the reference's
-        # h5py read, core/snpmatch.py:222): a 20 GB int8 host panel into int8 / packed panels from memory, from a flat file and
-        # from the reference's lzf HDF5 layout, against the hipMemcpyAsync ceiling of the same run, and an upload while a
-        # resident query is being scored.  A child process: tools/bench_staging.py.
-        if world == 1 and not args.no_staging and whole_job and not profiled and not args.packed:
-            try:
-                import subprocess
-                child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_staging.py")], capture_output=True, text=True,
-                                       timeout=420)
-                out["staging"] = json.loads(child.stdout.strip().splitlines()[-1])
-            except Exception as e:          # noqa: BLE001
-                out["staging"] = {"error": str(e)[:200]}
+        child_legs(out, args, world)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
