@@ -204,7 +204,9 @@ class ParseInputs(object):
 
     def _load_npz(self, path):
         z = _StoredNpz.open(path) or np.load(path)
-        self.load_snp_info(z['chr'], z['pos'], z['gt'], z['wei'], z['dp'])
+        # the small members are copied out of the memory map (a cache file that another writer rewrites IN PLACE -- the reference's
+        # own writer does -- would change them under a running job); the wide ones (chr / gt text, weights) stay views: read-only
+        self.load_snp_info(z['chr'], np.array(z['pos']), z['gt'], z['wei'], np.array(z['dp']))
         if 'wei_codes' in z.files and 'wei_table' in z.files:       # written by this package's parser; verified, not trusted
             codes, table = z['wei_codes'], z['wei_table']
             if codes.shape == self.wei.shape and codes.dtype == np.uint16 and len(table) and int(codes.max(initial=0)) < len(table) and \
@@ -339,17 +341,18 @@ class ParseInputs(object):
         arrays = dict(chr=self.chrs, pos=self.pos, gt=self.gt, wei=self.wei, dp=self.dp)
         if self.weight_codes() is not None:             # extra keys: the reference's loader reads its five by name
             arrays.update(wei_codes=self._wei_codes, wei_table=self._wei_table)
-        if not background:
-            np.savez(outFile, **arrays)
-            return
-
         def write():
+            # always a new inode: a reader that mapped the previous cache (_StoredNpz hands out views of a read-only map) keeps
+            # its bytes -- a file rewritten in place would be truncated under the mapping (SIGBUS, or arrays that change)
             tmp = outFile + ".tmp%d" % os.getpid()
             try:
                 np.savez(tmp, **arrays)                 # numpy appends .npz
                 os.replace(tmp + ".npz", outFile + ".npz")      # readers never see a half-written cache
             except OSError as e:          # a read-only input directory costs the cache, not the run
                 log.warning("could not cache the parse: %s", e)
+        if not background:
+            write()
+            return
         import threading
         self._cache_writer = threading.Thread(target=write, name="snpmatch-parse-cache")
         self._cache_writer.start()

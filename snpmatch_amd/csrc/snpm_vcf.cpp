@@ -299,33 +299,37 @@ try {
                 queue.pop_front();
             }
             cv_room.notify_one();
-            std::unique_ptr<VcfChunk> c(new (std::nothrow) VcfChunk());
-            bool ok = c != nullptr;
-            if (ok && !failed.load()) {
-                try {
+            // nothing a worker does may leave it as an exception (a thread that throws ends the process): the chunk's own
+            // allocations and the store into v->chunks included
+            try {
+                std::unique_ptr<VcfChunk> c(new VcfChunk());
+                if (!failed.load()) {
                     parse_block(c.get(), job.text->data(), job.text->data() + job.text->size(), sample_index);
-                    ok = c->ok;
-                } catch (...) {
-                    ok = false;
+                    if (!c->ok) failed.store(true);
                 }
+                std::lock_guard<std::mutex> lk(m);
+                if (v->chunks.size() <= job.seq) v->chunks.resize(job.seq + 1);
+                v->chunks[job.seq] = std::move(c);
+            } catch (...) {
+                failed.store(true);
             }
-            if (!ok) failed.store(true);
-            std::lock_guard<std::mutex> lk(m);
-            if (v->chunks.size() <= job.seq) v->chunks.resize(job.seq + 1);
-            v->chunks[job.seq] = std::move(c);
         }
     };
+    // the guard exists BEFORE the first thread does: if a later thread cannot be created (or anything below throws) the ones
+    // already running are told to finish and joined -- a joinable std::thread that is destroyed ends the process
     std::vector<std::thread> team;
-    for (int t = 0; t < n_thr; ++t) team.emplace_back(worker);
     auto finish_team = [&]() {
         {
             std::lock_guard<std::mutex> lk(m);
             done = true;
         }
         cv_job.notify_all();
-        for (auto &t : team) t.join();
+        for (auto &t : team)
+            if (t.joinable()) t.join();
     };
     struct TeamGuard { std::function<void()> f; bool armed = true; ~TeamGuard() { if (armed) f(); } } guard{finish_team};
+    team.reserve((size_t)n_thr);
+    for (int t = 0; t < n_thr; ++t) team.emplace_back(worker);
     size_t seq = 0;
     auto submit = [&](std::unique_ptr<std::string> text) {
         std::unique_lock<std::mutex> lk(m);
@@ -359,11 +363,12 @@ try {
         else if (raw) { fclose(raw); raw = nullptr; }
     }
     // next batch: false on a malformed member (the whole file is then declined)
+    const size_t kMaxBatchText = size_t(192) << 20;      // inflated bytes per batch
     auto bgzf_refill = [&]() -> bool {
         text.clear();
         text_pos = 0;
         while (text.empty() && !(raw_eof && comp.empty())) {
-            if (!raw_eof) {
+            if (!raw_eof && comp.size() < kBatch) {
                 const size_t have = comp.size();
                 comp.resize(have + kBatch);
                 const size_t got = fread(&comp[have], 1, kBatch, raw);
@@ -388,6 +393,10 @@ try {
                 const uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
                 const size_t isize = (size_t)t[4] | ((size_t)t[5] << 8) | ((size_t)t[6] << 16) | ((size_t)t[7] << 24);
                 if (isize > 65536) return false;
+                // a batch is bounded by its INFLATED size too: ~100 B of compressed bytes can announce a 64-KiB member, so 16 MiB of a
+                // crafted (or merely very repetitive) file would otherwise expand to ~10 GB in one string.  The members left over
+                // stay in `comp` for the next refill.
+                if (total + isize > kMaxBatchText && !mem.empty()) break;
                 mem.push_back(BgzfMember{pos + data_off, msz - data_off - 8, total, isize, crc});
                 total += isize;
                 pos += msz;
@@ -403,10 +412,14 @@ try {
                 }
             };
             const int helpers = (int)std::min<size_t>((size_t)n_thr, mem.size() / 8);
-            std::vector<std::thread> inflaters;
-            for (int t = 1; t < helpers; ++t) inflaters.emplace_back(inflate_some);
-            inflate_some();
-            for (auto &t : inflaters) t.join();
+            {
+                // joined by the guard however this scope is left (a thread that cannot be created, an exception in inflate_some)
+                std::vector<std::thread> inflaters;
+                struct JoinAll { std::vector<std::thread> &v; ~JoinAll() { for (auto &t : v) if (t.joinable()) t.join(); } } join_all{inflaters};
+                inflaters.reserve((size_t)std::max(helpers, 1));
+                for (int t = 1; t < helpers; ++t) inflaters.emplace_back(inflate_some);
+                inflate_some();
+            }
             if (bad.load()) return false;
             comp.erase(0, pos);
         }
