@@ -316,6 +316,13 @@ static int run_windows_impl(snpm_query *q, const int64_t *win_off, int64_t n_win
     if (rc) return rc;
     const int thr = 256;
     const size_t na = (size_t)p->n_acc;
+    // results through the pinned slab (HostFetch) -- except for slab-streamed jobs, which do not wait here and hand in pinned
+    // buffers of their own
+    HostFetch fetch(ctx);
+    {
+        const size_t per_win = (size_t)n_win * na * 8, tot = na * 8;
+        if ((rc = fetch.reserve(carry ? 0 : ((score ? per_win + 64 : 0) + (ninfo ? per_win + 64 : 0) + (tot_score ? tot + 64 : 0) + (tot_ninfo ? tot + 64 : 0))))) return rc;
+    }
     if (carry) {
         // the windows of a DB scored slab after slab: the reference's totals run window after window over the whole genome
         // (core/csmatch.py:88-90), so the chain of additions continues from the carry, in place
@@ -334,10 +341,8 @@ static int run_windows_impl(snpm_query *q, const int64_t *win_off, int64_t n_win
                                (const double *)nullptr, (const int64_t *)nullptr, (const int *)nullptr, 0);
             HIPCHK(ctx, hipGetLastError());
         }
-        if (tot_score) HIPCHK(ctx, hipMemcpyAsync(tot_score, q->d_score, na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (tot_ninfo) {
-            HIPCHK(ctx, hipMemcpyAsync(tot_ninfo, q->d_ninfo, na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-        }
+        if ((rc = fetch.add(tot_score, q->d_score, na * sizeof(double)))) return rc;
+        if ((rc = fetch.add(tot_ninfo, q->d_ninfo, na * sizeof(int64_t)))) return rc;
     }
     if ((score || ninfo) && n_win > 0) {
         rc = ensure(ctx, ctx->ws_tmp_score, (size_t)n_win * na * sizeof(double));
@@ -354,14 +359,15 @@ static int run_windows_impl(snpm_query *q, const int64_t *win_off, int64_t n_win
                                (double *)ctx->ws_tmp_score.p + w0 * p->n_acc, (int64_t *)ctx->ws_tmp_ninfo.p + w0 * p->n_acc);
             HIPCHK(ctx, hipGetLastError());
         }
-        if (score)
-            HIPCHK(ctx, hipMemcpyAsync(score, ctx->ws_tmp_score.p, (size_t)n_win * na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        if (ninfo)
-            HIPCHK(ctx, hipMemcpyAsync(ninfo, ctx->ws_tmp_ninfo.p, (size_t)n_win * na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        if ((rc = fetch.add(score, ctx->ws_tmp_score.p, (size_t)n_win * na * sizeof(double)))) return rc;
+        if ((rc = fetch.add(ninfo, ctx->ws_tmp_ninfo.p, (size_t)n_win * na * sizeof(int64_t)))) return rc;
     }
     // slab-streamed jobs do not wait here: the next slab is loaded while this one is scored; the per-window rows arrive in the
     // caller's (pinned) buffers by the time snpm_carry_finish / snpm_synchronize returns
-    if (!carry) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!carry) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        fetch.finish();
+    }
     return SNPM_OK;
 }
 
@@ -458,17 +464,21 @@ try {
     HIPCHK(ctx, hipGetLastError());
     rc = run_strict_sparse(q, skip, maxlen, q->cert_cols(), q->cert_count(), nullptr, j.d_seg_off, n_win, q->d_score);
     if (rc) return rc;
-    rc = ensure_pinned(ctx, 64);
-    if (rc) return rc;
+    HostFetch fetch(ctx);
+    {
+        const size_t per_win = (size_t)n_win * na * 8, tot = na * 8;
+        if ((rc = fetch.reserve((score ? per_win + 64 : 0) + (ninfo ? per_win + 64 : 0) + (tot_score ? tot + 64 : 0) + (tot_ninfo ? tot + 64 : 0)))) return rc;
+    }
     int *h_cnt = (int *)ctx->h_pinned;
     HIPCHK(ctx, hipMemcpyAsync(h_cnt, seg_pair_count(ctx), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(h_cnt + 1, q->cert_count(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    if (score) HIPCHK(ctx, hipMemcpyAsync(score, ctx->ws_bscore.p, (size_t)n_win * na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (ninfo) HIPCHK(ctx, hipMemcpyAsync(ninfo, ctx->ws_bninfo.p, (size_t)n_win * na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    if (tot_score) HIPCHK(ctx, hipMemcpyAsync(tot_score, q->d_score, na * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (tot_ninfo) HIPCHK(ctx, hipMemcpyAsync(tot_ninfo, q->d_ninfo, na * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = fetch.add(score, ctx->ws_bscore.p, (size_t)n_win * na * sizeof(double)))) return rc;
+    if ((rc = fetch.add(ninfo, ctx->ws_bninfo.p, (size_t)n_win * na * sizeof(int64_t)))) return rc;
+    if ((rc = fetch.add(tot_score, q->d_score, na * sizeof(double)))) return rc;
+    if ((rc = fetch.add(tot_ninfo, q->d_ninfo, na * sizeof(int64_t)))) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const int n_pairs = h_cnt[0], n_tot = h_cnt[1];
+    if (!(n_pairs > j.cap || n_tot > REEVAL_CAP)) fetch.finish();      // (else: every window again in reference order, below)
     if (info) { info[0] = n_pairs; info[1] = n_tot; }
     if (n_pairs > j.cap || n_tot > REEVAL_CAP) {
         // more uncertain results than the sparse tiers take: every window in reference order
@@ -705,30 +715,16 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     // sparse tier takes -- rare -- is scored again in reference order and delivered a second time).
     const size_t out_elems = B * na;
     const size_t n_out = (score ? 1 : 0) + (ninfo ? 1 : 0) + (lik ? 2 : 0);
-    const bool via_slab = n_out > 0 && out_elems * 8 * n_out <= (size_t(256) << 20);
-    if ((rc = ensure_pinned(ctx, 256 + (via_slab ? out_elems * 8 * n_out : 0)))) return rc;
+    HostFetch fetch(ctx);
+    if ((rc = fetch.reserve(n_out * (out_elems * 8 + 64)))) return rc;
     int *h_small = (int *)ctx->h_pinned;            // [0] unproven pairs, [1] likelihood domain flag, [8] input flags
-    char *slab = (char *)ctx->h_pinned + 256;
     if (lik) {
         if ((rc = ensure(ctx, ctx->ws_lik_l, B * na * sizeof(double)))) return rc;
         if ((rc = ensure(ctx, ctx->ws_lik_r, B * na * sizeof(double)))) return rc;
     }
     auto deliver = [&]() -> int {
-        struct OutCopy { void *dst; const void *src; };
-        OutCopy outs[4];
-        int n_outs = 0;
-        size_t slab_used = 0;
-        auto fetch = [&](void *host_dst, const void *dev_src) -> int {
-            if (via_slab && !host_pointer_is_pinned(host_dst)) {
-                HIPCHK(ctx, hipMemcpyAsync(slab + slab_used, dev_src, out_elems * 8, hipMemcpyDeviceToHost, ctx->stream));
-                outs[n_outs++] = {host_dst, slab + slab_used};
-                slab_used += out_elems * 8;
-            } else {
-                HIPCHK(ctx, hipMemcpyAsync(host_dst, dev_src, out_elems * 8, hipMemcpyDeviceToHost, ctx->stream));
-            }
-            return SNPM_OK;
-        };
         int r;
+        fetch.finish();                             // (a second delivery starts from an empty list)
         h_small[0] = h_small[1] = 0;
         if (j.certify && !strict_all)
             HIPCHK(ctx, hipMemcpyAsync(h_small, seg_pair_count(ctx), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -737,15 +733,19 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
                                        ctx->ws_lik_l.p, ctx->ws_lik_r.p, nullptr);
             if (r) return r;
             HIPCHK(ctx, hipMemcpyAsync(h_small + 1, ctx->ws_flags.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            if ((r = fetch(lik, ctx->ws_lik_l.p))) return r;
-            if ((r = fetch(lrt, ctx->ws_lik_r.p))) return r;
+            if ((r = fetch.add(lik, ctx->ws_lik_l.p, out_elems * 8))) return r;
+            if ((r = fetch.add(lrt, ctx->ws_lik_r.p, out_elems * 8))) return r;
         }
-        if (score && (r = fetch(score, ctx->ws_bscore.p))) return r;
-        if (ninfo && (r = fetch(ninfo, ctx->ws_bninfo.p))) return r;
+        if ((r = fetch.add(score, ctx->ws_bscore.p, out_elems * 8))) return r;
+        if ((r = fetch.add(ninfo, ctx->ws_bninfo.p, out_elems * 8))) return r;
         HIPCHK(ctx, hipMemcpyAsync(h_small + 8, ctx->ws_flags2.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (j.certify && !strict_all && h_small[0] > j.cap) return SNPM_OK;          // the caller scores again in reference order
-        for (int i = 0; i < n_outs; ++i) parallel_copy(ctx, (int8_t *)outs[i].dst, (const int8_t *)outs[i].src, out_elems * 8);
+        if (j.certify && !strict_all && h_small[0] > j.cap) {          // the caller scores again in reference order
+            fetch.n_items = 0;
+            fetch.used = 0;
+            return SNPM_OK;
+        }
+        fetch.finish();
         return SNPM_OK;
     };
     if (strict_all) {

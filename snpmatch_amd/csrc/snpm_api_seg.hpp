@@ -325,6 +325,49 @@ static bool host_pointer_is_pinned(const void *ptr)
     return attr.type == hipMemoryTypeHost;
 }
 
+// Results -> the caller's host arrays through the context's pinned slab.  A device-to-host copy into pageable memory is staged by
+// the runtime piece by piece with the host waiting in between (2.3 MB of results of 64 samples: ~0.35 ms of a 1.4-ms call; the 7 MB
+// of 399 windows: 0.2 ms of a 0.38-ms call); a copy into pinned memory is one DMA, and the host threads then move the slab into
+// the caller's arrays.  Usage: add() every output (enqueues the copy on ctx->stream), synchronise the stream, finish().
+// Outputs the caller pinned itself, and sets too large for the slab, are copied directly.  The slab starts 256 bytes into
+// ctx->h_pinned (the first words hold the small read-backs of the calls).
+struct HostFetch {
+    snpm_ctx *ctx;
+    struct Item { void *dst; const void *src; size_t bytes; };
+    Item items[8];
+    int n_items = 0;
+    size_t used = 0, cap = 0;
+    explicit HostFetch(snpm_ctx *c) : ctx(c) {}
+    // total: bytes of every output that may come; call before the first add()
+    int reserve(size_t total)
+    {
+        cap = 0;
+        if (total == 0 || total > (size_t(256) << 20)) return ensure_pinned(ctx, 256);
+        int rc = ensure_pinned(ctx, 256 + total);
+        if (!rc) cap = total;
+        return rc;
+    }
+    int add(void *host_dst, const void *dev_src, size_t bytes)
+    {
+        if (!host_dst || bytes == 0) return SNPM_OK;
+        if (n_items < 8 && used + bytes <= cap && !host_pointer_is_pinned(host_dst)) {
+            char *slab = (char *)ctx->h_pinned + 256 + used;
+            HIPCHK(ctx, hipMemcpyAsync(slab, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+            items[n_items++] = Item{host_dst, slab, bytes};
+            used += (bytes + 63) & ~size_t(63);
+        } else {
+            HIPCHK(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        return SNPM_OK;
+    }
+    void finish()                   // after the stream has been synchronised
+    {
+        for (int i = 0; i < n_items; ++i) parallel_copy(ctx, (int8_t *)items[i].dst, (const int8_t *)items[i].src, items[i].bytes);
+        n_items = 0;
+        used = 0;
+    }
+};
+
 // number of accessions the last certified run flagged (synchronises the stream)
 int read_count(snpm_query *q, int64_t *out)
 {
