@@ -66,6 +66,7 @@ struct snpm_ctx {
     Buf ws_lik_y, ws_lik_n, ws_lik_l, ws_lik_r;
     Buf ws_wprops, ws_epart;            // partial sums of k_wprops / k_eref
     Buf ws_tickets;                     // k_reduce_all: one ticket per column block, zero between launches
+    int even_tiles = 1;                 // SNPM_EVEN_TILES=0: short int8 queries keep 128-row tiles (round 4) instead of tiles that divide evenly over the parts
     int fused_reduce = 0;               // SNPM_FUSED_REDUCE=1: k_reduce_groups + k_reduce as ONE launch with a ticket per column block (measured SLOWER: 12.8 us against 5.4 + 4.7 us on a 200k-SNP sample, profiles/r05_once_timeline.txt)
     int once_tail = 1;                  // SNPM_ONCE_TAIL=0: snpm_genotype_once ends with k_scan_few + k_once_finish instead of k_once_tail
     Buf ws_once, ws_once_table;         // packed results of snpm_genotype_once; the weight table of its coded form
@@ -506,6 +507,7 @@ try {
     if (const char *s = getenv("SNPM_ONCE_ZEROCOPY")) ctx->once_zero_copy = atoi(s) != 0;
     if (const char *s = getenv("SNPM_DEBUG_MAX_PARTS")) ctx->debug_max_parts = atoi(s);
     if (const char *s = getenv("SNPM_FUSED_REDUCE")) ctx->fused_reduce = atoi(s) != 0;
+    if (const char *s = getenv("SNPM_EVEN_TILES")) ctx->even_tiles = atoi(s) != 0;
     if (const char *s = getenv("SNPM_ONCE_TAIL")) ctx->once_tail = atoi(s) != 0;
     if (const char *s = getenv("SNPM_BATCH_SHARED")) ctx->batch_shared = atoi(s) < 0 ? -1 : (atoi(s) ? 1 : 0);
     if (const char *s = getenv("SNPM_SHARED_DIGITS")) ctx->shared_digits = atoi(s) <= 0 ? 0 : std::min(7, std::max(3, atoi(s)));

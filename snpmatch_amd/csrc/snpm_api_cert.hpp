@@ -113,6 +113,18 @@ int run_fast(snpm_query *q, int skip, FastGeom *geom_out, const Certify &cert)
     // 1-4 or 8 waves do not care (profiles/r04_gather_occupancy.txt)
     if (gather && !p16 && bpl == 4 && g0.wpb >= 5 && g0.wpb <= 7 && !ctx->full_occupancy) occ = std::min(occ, g0.wpb == 5 ? 4 : 3);
     FastGeom g = fast_geom(ctx, p->n_acc, q->n, occ, bpl, tile_rows, wpb_fixed, kmult);
+    // Short int8 queries (a sample's 200k gathered rows: one or two 128-row tiles per resident block): tiles of such a length that
+    // every part walks the same number of them -- 1563 tiles over 1024 parts make the launch as long as its two-tile parts (76 %
+    // of the blocks' time is work); with k = ceil(tiles / parts) tiles of ceil(n / (k parts)) rows (a multiple of 8) it is 94 %.
+    if (!p16 && bpl == 4 && tile_rows == TILE_ROWS && ctx->even_tiles && g.n_epochs == 1 && g.n_parts > 1) {
+        const int64_t n_tiles = (q->n + TILE_ROWS - 1) / TILE_ROWS;
+        const int64_t k = (n_tiles + g.n_parts - 1) / g.n_parts;
+        if (k <= 8 && n_tiles > g.n_parts) {
+            int64_t tr = ((q->n + k * g.n_parts - 1) / (k * g.n_parts) + 7) / 8 * 8;
+            tr = std::max<int64_t>(32, std::min<int64_t>(TILE_ROWS, tr));
+            if (tr < TILE_ROWS) g = fast_geom(ctx, p->n_acc, q->n, occ, bpl, (int)tr, wpb_fixed, kmult);
+        }
+    }
     if (geom_out) *geom_out = g;
     q->last_kernel = bits ? "k_fast_bits" : (p16 ? "k_fast_packed_q4" : "k_fast");
     rc = ensure(ctx, ctx->ws_part_score, (size_t)g.n_slots * p->ld * sizeof(double));

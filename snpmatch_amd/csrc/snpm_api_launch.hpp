@@ -117,7 +117,8 @@ int launch_fast_t(snpm_query *q, const FastGeom &g)
                            p->ld, (const int64_t *)nullptr);
     else
         hipLaunchKernelGGL((k_fast<BPL, SKIP, GATHER, NT>), grid, block, 0, ctx->stream, p->d, p->pitch, q->d_row_idx, q->row0,
-                           q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld);
+                           q->n, q->d_lut, (double *)ctx->ws_part_score.p, (uint32_t *)ctx->ws_part_miss.p, p->ld,
+                           (const int64_t *)nullptr, (BPL == 4 && g.tile_rows < TILE_ROWS) ? g.tile_rows : 0);
     HIPCHK(ctx, hipGetLastError());
     return SNPM_OK;
 }

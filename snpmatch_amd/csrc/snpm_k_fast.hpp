@@ -100,7 +100,7 @@ template <int BPL, bool SKIP, bool GATHER, bool NT, bool SEG = false, int TR = T
 __global__ void __launch_bounds__(WAVE *MAX_WAVES_PER_BLOCK, (BPL <= 4 ? SNPM_FAST_MIN_WAVES : 1))
 k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__ row_idx, int64_t row0, int64_t n,
        const double *__restrict__ lut, double *__restrict__ out_score, uint32_t *__restrict__ out_miss, int64_t ld,
-       const int64_t *__restrict__ part_desc = nullptr)
+       const int64_t *__restrict__ part_desc = nullptr, int tile_rows_rt = 0)
 {
     // BPL = bytes (= accessions = accumulators) per lane and row; packed panels have their own kernels below
     static_assert(BPL == 4 || BPL == 8 || BPL == 16, "int8 panels: 4, 8 or 16 bytes per lane");
@@ -109,6 +109,10 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     // rows per prefetch group: 4 (G*32 B = half a 256-B LUT block); 8-row groups spill at the 80-VGPR budget and measured no gain
     constexpr int G = GATHER ? SNPM_FAST_G_GATHER : SNPM_FAST_G;
     __shared__ __attribute__((aligned(256))) double s_lut[2][TR * 4];
+    // rows per tile at run time (a multiple of 8, <= TR; 0 = TR): short gathered queries choose it so that every part gets the same
+    // number of tiles -- a 200k-row sample on 1024 resident blocks is 1563 tiles of 128 rows, i.e. half of the blocks walk two tiles
+    // and half one (the launch takes the time of two: 76 % efficient); tiles of 104 rows give 1924 = 1.88 per block (94 %)
+    const int TRR = (tile_rows_rt > 0 && tile_rows_rt <= TR) ? tile_rows_rt : TR;
 
     const int tid = threadIdx.x;
     const int nthr = blockDim.x;
@@ -126,7 +130,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     const int64_t T0 = SEG ? 0 : p;
     const int64_t slot0 = SEG ? part_desc[3 * p + 2] : p;         // partial slot of epoch 0 (epoch e: slot0 + e * slot_stride)
     const int64_t slot_stride = SEG ? 1 : (int64_t)gridDim.y;
-    const int64_t n_tiles_total = (rend - rbase + TR - 1) / TR;
+    const int64_t n_tiles_total = (rend - rbase + TRR - 1) / TRR;
 
     double acc[EPL];
     uint32_t miss16[NDW * 2];               // packed 2 x u16 per register, flushed from packed u8 every tile
@@ -179,15 +183,15 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
     if (T0 < n_tiles_total) {
         // first LUT tile -> LDS; first group in flight
         {
-            const int64_t tr0 = rbase + T0 * TR;
-            const int rows2 = 2 * (int)((rend - tr0 < TR) ? (rend - tr0) : TR);
+            const int64_t tr0 = rbase + T0 * TRR;
+            const int rows2 = 2 * (int)((rend - tr0 < TRR) ? (rend - tr0) : TRR);
             const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * tr0);
             double2 *dst = reinterpret_cast<double2 *>(&s_lut[0][0]);
             for (int i = tid; i < rows2; i += nthr) dst[i] = src[i];
         }
         uint32_t xa[G][NDW], xb[G][NDW];
 #pragma unroll
-        for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rbase + T0 * TR + u), xa[u]);
+        for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rbase + T0 * TRR + u), xa[u]);
         __syncthreads();
 
         int buf = 0;
@@ -200,15 +204,15 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
                 tiles_in_epoch = 0;
             }
             ++tiles_in_epoch;
-            const int64_t tr0 = rbase + T * TR;
-            const int rows = (int)((rend - tr0 < TR) ? (rend - tr0) : TR);
+            const int64_t tr0 = rbase + T * TRR;
+            const int rows = (int)((rend - tr0 < TRR) ? (rend - tr0) : TRR);
             const bool more = (T + P < n_tiles_total);
-            const int64_t ntr0 = more ? rbase + (T + P) * TR : tr0;      // my next tile (or a harmless re-read)
+            const int64_t ntr0 = more ? rbase + (T + P) * TRR : tr0;      // my next tile (or a harmless re-read)
             // stage the next LUT tile (256 double2) in ONE register pair per thread when the block has
             // >= 256 threads; narrower blocks copy it synchronously at the end of the tile instead
             double2 pre0 = make_double2(0.0, 0.0);
-            const bool staged = more && nthr >= TR * 2;
-            const int nrows2 = more ? 2 * (int)((rend - ntr0 < TR) ? (rend - ntr0) : TR) : 0;
+            const bool staged = more && nthr >= TRR * 2;
+            const int nrows2 = more ? 2 * (int)((rend - ntr0 < TRR) ? (rend - ntr0) : TRR) : 0;
 #if !defined(SNPM_FAST_PATTERN_ONLY) || SNPM_FAST_PATTERN_ONLY != 2
             if (staged && tid < nrows2) pre0 = reinterpret_cast<const double2 *>(lut + 4 * ntr0)[tid];
 #endif
@@ -242,7 +246,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
             for (; g + 2 <= full_groups; g += 2) {
                 const int64_t rnext = tr0 + (int64_t)(g + 1) * G;
                 // the group after the pair: inside this tile, or the first group of my next tile
-                const int64_t rafter = (g + 2 < TR / G) ? rnext + G : ntr0;
+                const int64_t rafter = (g + 2 < TRR / G) ? rnext + G : ntr0;
                 // ---- group g (data in xa); request group g+1 into xb
 #pragma unroll
                 for (int u = 0; u < G; ++u) load_row<BPL, NT>(row_ptr(rnext + u), xb[u]);
@@ -274,7 +278,7 @@ k_fast(const int8_t *__restrict__ db, int64_t pitch, const int64_t *__restrict__
             if (more) {
                 double2 *dst = reinterpret_cast<double2 *>(&s_lut[buf ^ 1][0]);
                 if (staged) {
-                    if (tid < TR * 2) dst[tid] = pre0;
+                    if (tid < TRR * 2) dst[tid] = pre0;
                 } else {
                     const double2 *src = reinterpret_cast<const double2 *>(lut + 4 * ntr0);
                     for (int i = tid; i < nrows2; i += nthr) dst[i] = src[i];
