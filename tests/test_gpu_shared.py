@@ -296,3 +296,38 @@ def test_parts_on_two_streams_and_the_probe_agree_with_one_stream():
     assert not got["shared_rows"] and st["why_not"] == "overlap below the threshold" and 0.0 < st["density"] < 0.2, st
     check_against_oracle(db, sparse, got, False)
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_configurations_against_the_oracle(seed):
+    """random widths (around the 128-accession wave tiles and the split packed layouts), batch sizes, sample lengths, overlaps,
+    digit counts, row-tile counts, digit-matrix budgets, chunk lengths; both formats, both skip_hets settings"""
+    rng = np.random.default_rng(9000 + seed)
+    for case in range(6):
+        n_acc = int(rng.choice([1, 3, 64, 127, 128, 129, 255, 300, 511, 513, 1023, 1135, 1500, 2049, 2600]))
+        n_snp = int(rng.integers(2_000, 40_000))
+        packed = bool(rng.integers(0, 2))
+        skip = bool(rng.integers(0, 2))
+        digits = int(rng.choice([-1, 3, 4, 5, 6, 7]))
+        env = {"SNPM_SHARED_TILES": int(rng.choice([1, 2, 3, 7, 16])), "SNPM_SHARED_WS_MB": int(rng.choice([1, 2, 64]))}
+        ctx = make_ctx(**env)
+        db = rand_db(rng, n_snp, n_acc)
+        panel = engine.Panel.from_host(ctx, db, packed=packed)
+        n_markers = int(rng.integers(8, max(9, n_snp // 2)))
+        B = int(rng.integers(1, 45))
+        samples = chip_samples(rng, db, B, n_markers, drop=float(rng.choice([0.0, 0.05, 0.5])), extra=float(rng.choice([0.0, 0.02, 0.3])))
+        samples = [(r, w) for r, w in samples]
+        if B > 2 and rng.integers(0, 2):
+            samples[1] = (np.zeros(0, dtype=np.int64), np.zeros((0, 3)))
+        chunk = int(rng.choice([1, 7, 100, 1000, 9000, 20000]))
+        engine.batch_configure(ctx, shared_rows=1, digits=digits)
+        got = engine.score_batch(panel, samples, chunk, skip, engine.MODE_EXACT)
+        st = engine.batch_last_stats(ctx)
+        assert got["shared_rows"] and st["taken"], (case, st)
+        for b, (rows, wei) in enumerate(samples):
+            want_s, want_n = c_oracle.genotyper(db, rows, wei, chunk, skip)
+            assert np.array_equal(got["ninfo"][b], want_n), (seed, case, b, n_acc, packed, skip, st)
+            assert np.array_equal(got["score"][b].astype(np.int64), want_s.astype(np.int64)), (seed, case, b, n_acc, packed, skip, st)
+            wl, wr = orc.calculate_likelihoods(np.array(want_s, dtype=np.int64), want_n)
+            np.testing.assert_allclose(got["lik"][b], wl, rtol=LIK_RTOL, equal_nan=True)
+        ctx.close()
