@@ -100,7 +100,10 @@ static int seg_plan(snpm_ctx *ctx, SegJob &j, SegPlan &pl)
     // (int8 panels: 32 parts per CU and column block, gathered batches of 64 samples 3.07 -> 2.72 ms with them; packed panels
     // measure the same from 8 to 64 and keep 8 -- profiles/r03j_ab_seg_blocks.txt)
     const int per_cu = ctx->seg_blocks_per_cu > 0 ? ctx->seg_blocks_per_cu : (q4 ? 8 : 32);
-    const int64_t want_blocks = std::max<int64_t>(1, (int64_t)ctx->n_cu * per_cu / std::max<int64_t>(1, pl.g0.n_colblocks));
+    // ... but k_reduce_seg adds a segment's slots one after the other: a batch of 8 samples cut into 8192 parts spent 0.21 of its
+    // 0.76 ms there (1024 dependent additions per accession); at most 256 slots per segment
+    const int64_t want_blocks = std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->n_cu * per_cu / std::max<int64_t>(1, pl.g0.n_colblocks),
+                                                                       std::max<int64_t>((int64_t)ctx->n_cu, 256 * n_seg)));
     pl.tiles_per_part = std::max<int64_t>(2, std::min<int64_t>(EPOCH_TILES, (total_tiles + want_blocks - 1) / want_blocks));
     // [seg_off | slot0 | part_desc], built in pinned memory (the copy below is asynchronous)
     const int64_t max_parts = total_tiles / pl.tiles_per_part + n_seg + 1;
