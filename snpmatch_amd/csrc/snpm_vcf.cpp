@@ -363,12 +363,14 @@ try {
         else if (raw) { fclose(raw); raw = nullptr; }
     }
     // next batch: false on a malformed member (the whole file is then declined)
-    const size_t kMaxBatchText = size_t(192) << 20;      // inflated bytes per batch
+    size_t kMaxBatchText = size_t(192) << 20;            // inflated bytes per batch
+    if (const char *e = getenv("SNPM_VCF_BGZF_TEXT_KB")) kMaxBatchText = (size_t)std::max(1, atoi(e)) << 10;   // tests: the cap at work on a small file
     auto bgzf_refill = [&]() -> bool {
         text.clear();
         text_pos = 0;
+        bool starved = false;       // the bytes at hand hold no whole member (a member larger than the batch): read on regardless
         while (text.empty() && !(raw_eof && comp.empty())) {
-            if (!raw_eof && comp.size() < kBatch) {
+            if (!raw_eof && (comp.size() < kBatch || starved)) {
                 const size_t have = comp.size();
                 comp.resize(have + kBatch);
                 const size_t got = fread(&comp[have], 1, kBatch, raw);
@@ -402,6 +404,7 @@ try {
                 pos += msz;
             }
             if (mem.empty() && pos == 0 && raw_eof && !comp.empty()) return false;     // trailing bytes that are no member
+            starved = mem.empty();
             text.resize(total);
             std::atomic<size_t> next{0};
             std::atomic<bool> bad{false};

@@ -253,6 +253,15 @@ def test_native_vcf_reader_inflates_bgzf_members_side_by_side(golden_dir, tmp_pa
         monkeypatch.delenv("SNPM_VCF_BGZF")
     for k in ("SNPM_VCF_BGZF_BATCH_KB", "SNPM_VCF_THREADS", "SNPM_VCF_BLOCK_KB"):
         monkeypatch.delenv(k)
+    # a batch is bounded by its INFLATED size as well (192 MiB; here 40 / 300 KiB): the members that do not fit wait for the next
+    # refill -- also when a single member is larger than the compressed batch, and when the cap is smaller than one member
+    for member, batch_kb, text_kb in ((65280, "16384", "300"), (65280, "16", "40"), (2000, "64", "40"), (30000, "1", "1")):
+        _write_bgzf(bg, data, member)
+        monkeypatch.setenv("SNPM_VCF_BGZF_BATCH_KB", batch_kb)
+        monkeypatch.setenv("SNPM_VCF_BGZF_TEXT_KB", text_kb)
+        _same_calls(_vcf.read_calls(bg, (0,), native=True), want)
+    monkeypatch.delenv("SNPM_VCF_BGZF_BATCH_KB")
+    monkeypatch.delenv("SNPM_VCF_BGZF_TEXT_KB")
     _write_bgzf(bg, data, 65280, eof=False)                          # no end-of-file member: still every record
     _same_calls(_vcf.read_calls(bg, (0,), native=True), want)
     # damage: a flipped byte inside a member's data (CRC / inflate error), a truncated file, trailing bytes that are no member
