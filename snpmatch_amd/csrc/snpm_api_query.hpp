@@ -494,7 +494,7 @@ try {
 // re-evaluation of the flagged pairs, one likelihood launch with a row per sample, one copy back.
 static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sample_off, const void *row_idx, const void *wei,
                             const uint16_t *codes, const double *table, int64_t table_len, int device_inputs, int64_t chunk, int skip_hets,
-                            int mode, double *score, int64_t *ninfo, double *lik, double *lrt, int64_t *info)
+                            int mode, double *score, int64_t *ninfo, double *lik, double *lrt, int64_t *info, bool allow_shared = true)
 {
     CHECK_PANEL(p);
     snpm_ctx *ctx = p->ctx;
@@ -601,7 +601,7 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     // reference-order re-evaluation of the unproven pairs.  It needs the whole batch on the device first: batches from host
     // memory keep the per-sample pass and its upload overlap unless the policy says "whenever possible".
     const int policy = ctx->batch_shared;
-    const bool try_shared = !strict_all && policy != 0 && (policy > 0 || device_inputs);
+    const bool try_shared = allow_shared && !strict_all && policy != 0 && (policy > 0 || device_inputs);
     SharedStats shst;
     shst.reason = 1;
     bool shared_done = false;
@@ -739,7 +739,14 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
         if ((r = fetch.add(score, ctx->ws_bscore.p, out_elems * 8))) return r;
         if ((r = fetch.add(ninfo, ctx->ws_bninfo.p, out_elems * 8))) return r;
         HIPCHK(ctx, hipMemcpyAsync(h_small + 8, ctx->ws_flags2.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        *(long long *)(h_small + 12) = 0;
+        if (shared_done) HIPCHK(ctx, hipMemcpyAsync(h_small + 12, shst.d_meta + 1, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (shared_done && (*(long long *)(h_small + 12) & 2)) {          // a weight outside [0, 1]: not a batch for the contraction
+            fetch.n_items = 0;
+            fetch.used = 0;
+            return SNPM_OK;
+        }
         if (j.certify && !strict_all && h_small[0] > j.cap) {          // the caller scores again in reference order
             fetch.n_items = 0;
             fetch.used = 0;
@@ -756,6 +763,16 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
         if (rc) return rc;
     }
     if ((rc = deliver())) return rc;
+    if (shared_done && (*(long long *)(h_small + 12) & 2)) {
+        // the expansion met a weight outside [0, 1] (it vets the weights while it converts them: the decision to take the shared-row
+        // pass is made before): the whole batch once more through the per-sample pass, which takes any finite weight
+        int r = score_batch_impl(p, n_samples, sample_off, row_idx, wei, codes, table, table_len, device_inputs, chunk, skip_hets, mode, score,
+                                 ninfo, lik, lrt, info, false);
+        ctx->shared_last[0] = 0;
+        ctx->shared_last[1] = 4;
+        if (info && !r) { info[2] = 0; }
+        return r;
+    }
     if (j.certify && !strict_all) {
         n_pairs = h_small[0];
         if (n_pairs > j.cap) {

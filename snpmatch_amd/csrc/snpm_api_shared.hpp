@@ -12,6 +12,7 @@ struct SharedStats {
     int reason = 0;                 // why not: 1 policy off, 2 too few samples / rows, 3 unsorted rows, 4 weights outside [0, 1], 5 codes > 2 in the panel,
                                     //          6 overlap below the threshold, 7 panel / batch too large for 32-bit indices, 8 a row index outside the panel
     int tiles = 0, groups = 0, accgroups = 0, passes = 0, digits = 0;
+    const long long *d_meta = nullptr;  // taken: meta[1] bit 1 is raised by the expansion when a weight lies outside [0, 1] (read with the results)
 };
 
 static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &st)
@@ -34,7 +35,6 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     if (digits == 0) digits = maxlen <= (int64_t(1) << 18) ? 5 : (maxlen <= (int64_t(1) << 26) ? 6 : 7);
     st.digits = digits;
     const int rps = digits + 1;
-    const int frac_bits = sh_frac_bits(digits);
     // ---- union of the samples' rows: bitmap of panel rows -> ranks -> row list
     const int64_t n_words = (p->n_snp + 31) / 32;
     const int64_t n_blocks = (n_words + SH_WORDS_PER_BLOCK - 1) / SH_WORDS_PER_BLOCK;
@@ -44,11 +44,11 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     if ((rc = ensure(ctx, ctx->ws_sh_wordbase, (size_t)n_words * 4))) return rc;
     if ((rc = ensure(ctx, ctx->ws_sh_blocks, (size_t)n_blocks * 8 + 256))) return rc;
     if ((rc = ensure(ctx, ctx->ws_sh_urows, urow_entries * 4))) return rc;
-    const size_t meta_bytes = 64 + ((size_t)n_seg + 1) * 8 + (size_t)n_seg * 4;     // meta | seg_off | n_inexact
+    const size_t meta_bytes = 64 + ((size_t)n_seg + 1) * 8 + (size_t)n_seg * 4;     // meta | seg_off | per-sample flag "a weight is not an integer"
     if ((rc = ensure(ctx, ctx->ws_sh_meta, meta_bytes))) return rc;
     long long *d_meta = (long long *)ctx->ws_sh_meta.p;
     int64_t *d_seg_off = (int64_t *)((char *)ctx->ws_sh_meta.p + 64);
-    int *d_inexact = (int *)((char *)ctx->ws_sh_meta.p + 64 + ((size_t)n_seg + 1) * 8);
+    int *d_nonint = (int *)((char *)ctx->ws_sh_meta.p + 64 + ((size_t)n_seg + 1) * 8);
     uint32_t *d_bitmap = (uint32_t *)ctx->ws_sh_bitmap.p;
     uint32_t *d_wordbase = (uint32_t *)ctx->ws_sh_wordbase.p;
     uint32_t *d_blocksum = (uint32_t *)ctx->ws_sh_blocks.p, *d_blockbase = d_blocksum + n_blocks;
@@ -81,23 +81,12 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
             if (est < 0.8 * ctx->shared_min_density_of(p->packed != 0)) { st.reason = 6; return SNPM_OK; }
         }
     }
-    // one pass over the entries: marks, input checks, quantisation counts and (chunks of ordinary length) the partial sums of the
-    // reference-order error bound, which k_eseg_finish turns into the per-sample bound
-    const int npart = (int)((kmax + 3) / 4);
-    const bool fused_bound = j.certify && j.chunk <= 8192;
-    if (j.certify) {
-        if ((rc = ensure(ctx, ctx->ws_eseg, (size_t)n_seg * sizeof(double)))) return rc;
-        if ((rc = ensure(ctx, ctx->ws_epart, (size_t)n_seg * (size_t)npart * 3 * sizeof(double)))) return rc;
-    }
+    // one pass over the row lists: marks and index checks (the weights are vetted by k_sh_expand while it converts them)
+    if (j.certify && (rc = ensure(ctx, ctx->ws_eseg, (size_t)n_seg * sizeof(double)))) return rc;
     {
         ProfScope ps(ctx, PK_LUT);
-        if (fused_bound)
-            hipLaunchKernelGGL(k_sh_mark_chunks, dim3((unsigned)npart, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, j.d_w,
-                               (const int64_t *)d_seg_off, j.chunk, npart, frac_bits, j.skip, p->n_snp, d_bitmap, d_inexact, d_meta,
-                               (double *)ctx->ws_epart.p);
-        else
-            hipLaunchKernelGGL(k_sh_mark, dim3(gx, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, j.d_w, (const int64_t *)d_seg_off,
-                               frac_bits, j.skip, p->n_snp, d_bitmap, d_inexact, d_meta);
+        hipLaunchKernelGGL(k_sh_mark, dim3(gx, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, p->n_snp,
+                           d_bitmap, d_meta);
         hipLaunchKernelGGL(k_sh_count, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, n_words, d_blocksum);
         hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)d_blocksum, n_blocks, d_blockbase, d_meta);
         hipLaunchKernelGGL(k_sh_fill, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, n_words,
@@ -115,7 +104,6 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     st.density = U > 0 ? (double)N / ((double)U * (double)n_seg) : 0.0;
     if (bad & 4) { st.reason = 8; return SNPM_OK; }
     if (bad & 1) { st.reason = 3; return SNPM_OK; }
-    if (bad & 2) { st.reason = 4; return SNPM_OK; }
     if (other) { st.reason = 5; return SNPM_OK; }
     if (U < 1) { st.reason = 2; return SNPM_OK; }
     if (!forced && st.density < ctx->shared_min_density_of(p->packed != 0)) { st.reason = 6; return SNPM_OK; }
@@ -172,16 +160,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     j.cap = (int)std::max<int64_t>(64, std::min<int64_t>(SEG_PAIR_CAP, (int64_t(8) << 20) / kmax));
     if ((rc = ensure(ctx, ctx->ws_pairs, 16 + (size_t)SEG_PAIR_CAP * 2 * sizeof(int32_t)))) return rc;
     HIPCHK(ctx, hipMemsetAsync(seg_pair_count(ctx), 0, sizeof(int), ctx->stream));
-    if (j.certify) {
-        if ((rc = ensure(ctx, ctx->ws_pair_sums, (size_t)j.cap * (size_t)kmax * sizeof(double)))) return rc;
-        if (!fused_bound)
-            hipLaunchKernelGGL(k_eseg_part, dim3((unsigned)npart, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_w, (const int64_t *)d_seg_off,
-                               j.chunk, (int64_t)0, npart, (double *)ctx->ws_epart.p);
-        // fast_adds = 4: the integer pass adds nothing; the term covers the two conversions and the addition of k_sh_finish
-        hipLaunchKernelGGL(k_eseg_finish, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, (const double *)ctx->ws_epart.p,
-                           (const int64_t *)d_seg_off, j.chunk, (int64_t)4, (int64_t)0, npart, (double *)ctx->ws_eseg.p);
-        HIPCHK(ctx, hipGetLastError());
-    }
+    if (j.certify && (rc = ensure(ctx, ctx->ws_pair_sums, (size_t)j.cap * (size_t)kmax * sizeof(double)))) return rc;
     // ---- passes over groups of samples
     st.tiles = n_tiles; st.accgroups = n_accgroups; st.groups = (int)groups_total;
     for (int64_t s_base = 0; s_base < n_seg; s_base += samples_per_pass) {
@@ -216,7 +195,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
                 const dim3 eg((unsigned)((threads + 255) / 256));
 #define LAUNCH_EXPAND(D)                                                                                                     \
     hipLaunchKernelGGL((k_sh_expand<D>), eg, dim3(256), 0, es, (const uint32_t *)ctx->ws_sh_pos.p, ld_pos, j.d_w, s_pass, j.skip,  \
-                       k0, k1 - k0, steps_ld, (sh_v4i *)ctx->ws_sh_A.p)
+                       k0, k1 - k0, steps_ld, (sh_v4i *)ctx->ws_sh_A.p, d_nonint + s_base, d_meta)
                 switch (digits) {
                 case 3: LAUNCH_EXPAND(3); break;
                 case 4: LAUNCH_EXPAND(4); break;
@@ -243,16 +222,24 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
                 HIPCHK(ctx, hipGetLastError());
             }
         }
+        if (j.certify) {
+            // the bound of this pass's samples: their "not an integer" flags are complete once every expansion of the pass has run
+            // (same stream, or waited for through the parts' events)
+            hipLaunchKernelGGL(k_sh_eseg, dim3((unsigned)((s_pass + 255) / 256)), dim3(256), 0, ctx->stream, (const int64_t *)d_seg_off + s_base,
+                               s_pass, j.chunk, (const int *)d_nonint + s_base, (double *)ctx->ws_eseg.p + s_base);
+            HIPCHK(ctx, hipGetLastError());
+        }
         {
             ProfScope ps(ctx, PK_REDUCE);
             hipLaunchKernelGGL(k_sh_finish, dim3((unsigned)p->n_acc, (unsigned)((s_pass + 63) / 64)), dim3(256), 0, ctx->stream,
                                (const int *)ctx->ws_sh_partial.p, tiles, (int)groups, ldn, digits, (const int64_t *)d_seg_off, s_base,
-                               s_pass, p->n_acc, (const int *)d_inexact, j.certify ? (const double *)ctx->ws_eseg.p : (const double *)nullptr,
+                               s_pass, p->n_acc, j.certify ? (const double *)ctx->ws_eseg.p : (const double *)nullptr,
                                ctx->debug_reeval, j.d_score, j.d_ninfo, j.ldo, seg_pairs(ctx), seg_pair_count(ctx), j.cap);
             HIPCHK(ctx, hipGetLastError());
         }
         ++st.passes;
     }
     st.taken = 1;
+    st.d_meta = d_meta;
     return SNPM_OK;
 }

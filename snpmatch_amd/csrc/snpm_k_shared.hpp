@@ -15,8 +15,7 @@
 // w ~ sum_j d_j 256^(L-1-j) 2^-F, F = 8 (L - 1) + 6.  Digit j of every sample is one ROW of an int8 matrix A; the one-hot panel
 // expansion B is int8 {0, 1}; v_mfma_i32_32x32x32_i8 adds the products EXACTLY in int32.  One further row per sample holds
 // ones in the "missing" class: its product counts the sample's uninformative sites (ninfo).  The error of the pass is the
-// quantisation alone, one-sided: fixed <= exact <= fixed + n_inexact 2^-F (weights 0 / 1 / exp(-PL/10) of small PL: exact
-// ones cost nothing), and the certificate flags the few (sample, accession) pairs whose int() is not proven, as the fp64
+// quantisation alone, one-sided: fixed <= exact <= fixed + n 2^-F over a sample's n matched SNPs, and the certificate flags the few (sample, accession) pairs whose int() is not proven, as the fp64
 // fast pass does; those are re-scored in reference order by k_strict_pairs.
 //
 // Geometry of the contraction (k_sh_mfma):
@@ -48,135 +47,75 @@ typedef int sh_v16i __attribute__((ext_vector_type(16)));
 __host__ __device__ __forceinline__ int sh_frac_bits(int digits) { return 8 * (digits - 1) + 6; }
 
 // meta block of a shared-row pass (device, int64 [8]): [0] union rows U, [1] bad-input bits (1 a sample's rows are not strictly
-// increasing, 2 a weight lies outside [0, 1] or is not finite, 4 a row index outside the panel), [2..] spare
+// increasing, 2 a weight lies outside [0, 1] or is not finite -- found by k_sh_expand, i.e. AFTER the pass was taken: the caller
+// then scores the batch again through the per-sample pass --, 4 a row index outside the panel), [3] entries the probe marked
 // ---------------------------------------------------------------------------------------------------------------
-// One pass over the batch's entries (sample = segment of the concatenated row list and weights):
-//   - marks the rows in the bitmap of panel rows (the bit is read first: most rows of a batch on one marker set are marked already,
-//     and 64 samples would otherwise send 64 atomics to every word),
-//   - checks what the contraction needs: row indices inside the panel, strictly increasing per sample (the union holds every
-//     (sample, row) at most once), weights in [0, 1],
-//   - counts per sample the rows with a weight that 2^-F does not divide (the quantisation bound),
-//   - and leaves the partial sums of the reference-order error bound exactly as k_eseg_part does (same decomposition: block =
-//     four chunks of `chunk` rows, a wave per chunk; same order of additions), so that k_eseg_finish follows directly.
-__device__ __forceinline__ void sh_mark_values(int64_t r, int64_t r_prev, bool has_prev, double w0, double w1, double w2, int64_t n_snp,
-                                               double scale, int skip_hets, uint32_t *__restrict__ bitmap, int &inexact, int &bad,
-                                               double &wmax, int &nonint)
+// k_sh_mark: one pass over the batch's ROW LISTS (blockIdx.y = sample; the weights are not read here: k_sh_expand vets them while
+// it converts them): marks the rows in the bitmap of panel rows (the bit is read first: most rows of a batch on one marker set are
+// marked already, and 64 samples would otherwise send 64 atomics to every word), checks that every index lies inside the panel and
+// that every sample's list is strictly increasing (the union holds every (sample, row) at most once).  Four entries per lane in
+// flight.
+__device__ __forceinline__ void sh_mark_row(int64_t r, int64_t r_prev, bool has_prev, int64_t n_snp, uint32_t *__restrict__ bitmap, int &bad)
 {
     if (r < 0 || r >= n_snp) {
         bad |= 4;
-    } else {
-        if (has_prev && r_prev >= r) bad |= 1;
-        uint32_t *wp = &bitmap[r >> 5];
-        const uint32_t bit = 1u << (r & 31);
-        if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(wp, bit);
+        return;
     }
-    const double a = fabs(w0), b = fabs(w1), c = fabs(w2);
-    wmax = fmax(a, fmax(b, c));
-    if (!(a == floor(a) && b == floor(b) && c == floor(c)) || !(a < 1e300 && b < 1e300 && c < 1e300)) nonint = 1;
-    const double h = skip_hets ? 0.0 : w1;
-    if (!(w0 >= 0.0 && w0 <= 1.0 && h >= 0.0 && h <= 1.0 && w2 >= 0.0 && w2 <= 1.0)) bad |= 2;
-    const double xa = w0 * scale, xb = h * scale, xc = w2 * scale;
-    if (!(xa == floor(xa) && xb == floor(xb) && xc == floor(xc))) ++inexact;
-}
-
-__device__ __forceinline__ void sh_mark_entry(const int64_t *__restrict__ rows, const double *__restrict__ w, int64_t i, int64_t r0,
-                                              int64_t n_snp, double scale, int skip_hets, uint32_t *__restrict__ bitmap, int &inexact,
-                                              int &bad, double &wmax, int &nonint)
-{
-    sh_mark_values(rows[i], i > r0 ? rows[i - 1] : -1, i > r0, w[3 * i], w[3 * i + 1], w[3 * i + 2], n_snp, scale, skip_hets, bitmap,
-                   inexact, bad, wmax, nonint);
+    if (has_prev && r_prev >= r) bad |= 1;
+    uint32_t *wp = &bitmap[r >> 5];
+    const uint32_t bit = 1u << (r & 31);
+    if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(wp, bit);
 }
 
 __global__ void __launch_bounds__(256)
-k_sh_mark_chunks(const int64_t *__restrict__ rows, const double *__restrict__ w, const int64_t *__restrict__ seg_off, int64_t chunk,
-                 int npart, int frac_bits, int skip_hets, int64_t n_snp, uint32_t *__restrict__ bitmap, int *__restrict__ n_inexact,
-                 long long *__restrict__ meta, double *__restrict__ partial)
+k_sh_mark(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off, int64_t n_snp, uint32_t *__restrict__ bitmap,
+          long long *__restrict__ meta)
 {
-    __shared__ double sm[4][3];
     const int64_t s = blockIdx.y;
     const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
-    const int64_t len = r1 - r0;
+    int bad = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = r0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < r1; i += 4 * stride) {
+        int64_t rw[4], rp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            rw[u] = rows[i + u * stride];
+            rp[u] = (i + u * stride > r0) ? rows[i + u * stride - 1] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) sh_mark_row(rw[u], rp[u], i + u * stride > r0, n_snp, bitmap, bad);
+    }
+    for (; i < r1; i += stride) sh_mark_row(rows[i], i > r0 ? rows[i - 1] : -1, i > r0, n_snp, bitmap, bad);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bad |= __shfl_xor(bad, o);
+    if ((threadIdx.x & 63) == 0 && bad) atomicOr((unsigned long long *)&meta[1], (unsigned long long)bad);
+}
+
+// k_sh_eseg: the reference-order error bound of every sample in closed form.  The contraction takes weights in [0, 1] only, so
+// wmax_r <= 1 (and = 1 on every row whose genotype likelihoods are normalised: min PL = 0) and the sum k_eseg_part forms from the
+// weights is at most  sum_k len_k (len_k + 3 + K - k)  (chunk k of K, len_k rows) -- no pass over the weights.  A sample whose
+// weights are all integers (`nonint` unset by k_sh_expand) has bound 0: any summation order is exact.  + the conversions of k_sh_finish.
+__global__ void k_sh_eseg(const int64_t *__restrict__ seg_off, int64_t n_seg, int64_t chunk, const int *__restrict__ nonint,
+                          double *__restrict__ eseg)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    const int64_t len = seg_off[s + 1] - seg_off[s];
+    if (!nonint[s] || len == 0) {
+        eseg[s] = 0.0;
+        return;
+    }
     const int64_t K = (len + chunk - 1) / chunk;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t k = (int64_t)blockIdx.x * 4 + wave;
-    const double scale = __builtin_ldexp(1.0, frac_bits);
-    double v = 0.0;
-    int nonint = 0, inexact = 0, bad = 0;
-    int64_t c0 = 0, c1 = 0;
-    if (k < K) {
-        c0 = r0 + k * chunk;
-        c1 = (c0 + chunk < r1) ? c0 + chunk : r1;
-        // four entries per lane at a time, every load issued before the first use (the order of the additions into v is the
-        // order of k_eseg_part: r, r + 64, r + 128, ...)
-        int64_t r = c0 + lane;
-        for (; r + 192 < c1; r += 256) {
-            int64_t rw[4], rp[4];
-            double ww[4][3];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t i = r + 64 * u;
-                rw[u] = rows[i];
-                rp[u] = i > r0 ? rows[i - 1] : -1;
-                ww[u][0] = w[3 * i]; ww[u][1] = w[3 * i + 1]; ww[u][2] = w[3 * i + 2];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                double wmax;
-                sh_mark_values(rw[u], rp[u], r + 64 * u > r0, ww[u][0], ww[u][1], ww[u][2], n_snp, scale, skip_hets, bitmap, inexact, bad, wmax, nonint);
-                v += wmax;
-            }
-        }
-        for (; r < c1; r += 64) {
-            double wmax;
-            sh_mark_entry(rows, w, r, r0, n_snp, scale, skip_hets, bitmap, inexact, bad, wmax, nonint);
-            v += wmax;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        v += __shfl_xor(v, o);
-        nonint |= __shfl_xor(nonint, o);
-        inexact += __shfl_xor(inexact, o);
-        bad |= __shfl_xor(bad, o);
-    }
-    if (lane == 0) {
-        sm[wave][0] = (k < K) ? v * (double)((c1 - c0) + 3 + (K - k)) : 0.0;
-        sm[wave][1] = v;
-        sm[wave][2] = (double)nonint;
-        if (inexact) atomicAdd(&n_inexact[s], inexact);
-        if (bad) atomicOr((unsigned long long *)&meta[1], (unsigned long long)bad);
-    }
-    __syncthreads();
-    if (threadIdx.x < 3) {
-        const int q = threadIdx.x;
-        const double t = (q == 2) ? fmax(fmax(sm[0][2], sm[1][2]), fmax(sm[2][2], sm[3][2]))
-                                  : ((sm[0][q] + sm[1][q]) + sm[2][q]) + sm[3][q];
-        partial[((int64_t)blockIdx.y * npart + blockIdx.x) * 3 + q] = t;
-    }
-}
-
-// the same marks and checks without the error-bound sums (very long chunks: k_eseg_part keeps its own launch), grid-stride
-__global__ void __launch_bounds__(256)
-k_sh_mark(const int64_t *__restrict__ rows, const double *__restrict__ w, const int64_t *__restrict__ seg_off, int frac_bits,
-          int skip_hets, int64_t n_snp, uint32_t *__restrict__ bitmap, int *__restrict__ n_inexact, long long *__restrict__ meta)
-{
-    const int64_t s = blockIdx.y;
-    const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
-    const double scale = __builtin_ldexp(1.0, frac_bits);
-    int inexact = 0, bad = 0, nonint = 0;
-    for (int64_t i = r0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < r1; i += (int64_t)gridDim.x * 256) {
-        double wmax;
-        sh_mark_entry(rows, w, i, r0, n_snp, scale, skip_hets, bitmap, inexact, bad, wmax, nonint);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        inexact += __shfl_xor(inexact, o);
-        bad |= __shfl_xor(bad, o);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (inexact) atomicAdd(&n_inexact[s], inexact);
-        if (bad) atomicOr((unsigned long long *)&meta[1], (unsigned long long)bad);
-    }
+    const int64_t last = len - (K - 1) * chunk;                  // rows of the last chunk
+    // sum over the K - 1 full chunks k = 0 .. K-2 of chunk (chunk + 3 + K - k), + the last one
+    const double kf = (double)(K - 1);
+    const double full = (double)chunk * (kf * (double)(chunk + 3) + (kf * (double)K - kf * (kf - 1.0) * 0.5));
+    const double acc = full + (double)last * (double)(last + 3 + 1);
+    const double u = 1.1102230246251565e-16;
+    const double mmax = (double)((chunk < len ? chunk : len) + 3 + K);
+    const double mf = 4.0;
+    eseg[s] = (acc * u / (1.0 - mmax * u) + (double)len * (mf * u / (1.0 - mf * u))) * 1.0000001;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -329,7 +268,8 @@ k_sh_pos(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off, 
 template <int DIGITS>
 __global__ void __launch_bounds__(256)
 k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__restrict__ w, int64_t n_samples_pass, int skip_hets,
-            int64_t step0, int64_t n_steps, int64_t steps_ld, sh_v4i *__restrict__ A)
+            int64_t step0, int64_t n_steps, int64_t steps_ld, sh_v4i *__restrict__ A, int *__restrict__ nonint /* of the pass's samples */,
+            long long *__restrict__ meta)
 {
     // K steps [step0, step0 + n_steps) of the pass (a launch per part: the contraction of a part starts when its digits are there)
     constexpr int RPS = DIGITS + 1;
@@ -354,13 +294,21 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
         const double *wr = w + 3 * (int64_t)(e[i] ? e[i] - 1 : 0);
         wv[i][0] = wr[0]; wv[i][1] = wr[2]; wv[i][2] = wr[1];                  // class order: ref, alt, het
     }
+    // the weights are vetted where they are read: outside [0, 1] (or not finite) -> the whole batch goes back to the per-sample
+    // pass (meta[1] bit 1, read by the host with the results); a weight that is not an integer -> the sample's reference-order
+    // bound is not zero (flag tested before it is set: after the first few threads of a sample every other one only reads it)
+    bool out_of_range = false, fractional = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint32_t lo[3], hi[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             double x = (c == 2 && skip_hets) ? 0.0 : wv[i][c];
-            x = (x >= 0.0 && x <= 1.0) ? x : 0.0;                              // refused by the mark pass; keep the conversion defined
+            if (e[i]) {
+                if (!(x >= 0.0 && x <= 1.0)) out_of_range = true;
+                else if (x != 0.0 && x != 1.0) fractional = true;
+            }
+            x = (x >= 0.0 && x <= 1.0) ? x : 0.0;                              // keep the conversion defined
             const unsigned long long Q = (unsigned long long)floor(x * scale) + bias;
             lo[c] = (uint32_t)Q;
             hi[c] = (uint32_t)(Q >> 32);
@@ -378,6 +326,8 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
         }
         dw[DIGITS][i] = e[i] ? (skip_hets ? 0x01010000u : 0x01000000u) : 0u;
     }
+    if (out_of_range) atomicOr((unsigned long long *)&meta[1], 2ull);
+    if (fractional && !__hip_atomic_load(&nonint[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&nonint[s], 1);
 #pragma unroll
     for (int j = 0; j < RPS; ++j) {
         const int64_t M = s * RPS + j;
@@ -566,10 +516,10 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
 // accession-major partial array, samples follow each other), wave w adds the row tiles w, w + 4, ... (int64), the waves' sums meet
 // in LDS.  Then the digits are put together and converted to fp64 (hi / lo parts: each conversion is exact or rounds once far
 // below the bound), ninfo = calls of the sample - missing count, and the certificate runs: the reference's score lies in
-// [v - E, v + E + Eq], E = eseg[s] (reference-order bound + the conversion), Eq = n_inexact[s] 2^-F (the quantisation, one-sided).
+// [v - E, v + E + Eq], E = eseg[s] (reference-order bound + the conversion), Eq = len[s] 2^-F (the quantisation, one-sided).
 __global__ void __launch_bounds__(256)
 k_sh_finish(const int *__restrict__ partial, int n_tiles, int n_groups, int64_t ldn, int digits, const int64_t *__restrict__ seg_off,
-            int64_t s_base, int64_t n_samples_pass, int64_t n_acc, const int *__restrict__ n_inexact, const double *__restrict__ eseg,
+            int64_t s_base, int64_t n_samples_pass, int64_t n_acc, const double *__restrict__ eseg,
             int force_first, double *__restrict__ score, int64_t *__restrict__ ninfo, int64_t ldo, int32_t *__restrict__ pairs,
             int *__restrict__ count, int cap)
 {
@@ -620,7 +570,9 @@ k_sh_finish(const int *__restrict__ partial, int n_tiles, int n_groups, int64_t 
     ninfo[sg * ldo + a] = len - missing;
     if (eseg) {
         const double E = eseg[sg] + 8.0 * 1.1102230246251565e-16 * (fabs(v) + 1.0);
-        const double Eq = __builtin_ldexp((double)n_inexact[sg], -frac_bits) * 1.0000001;
+        // quantisation, one-sided: every matched SNP may lose up to 2^-F (counted for all of them: an upward-only slack cannot
+        // flag an exact-integer score, floor(v) = floor(v + Eq) as long as Eq < 1)
+        const double Eq = __builtin_ldexp((double)len, -frac_bits) * 1.0000001;
         const double lo_v = v - E, hi_v = (v + Eq) + E;
         if (!(lo_v >= 0.0) || floor(lo_v) != floor(hi_v) || a < force_first) {
             const int k = atomicAdd(count, 1);
