@@ -191,8 +191,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
             hipStream_t es = overlap ? ctx->aux_stream : ctx->stream;
             {
                 ProfScope ps(ctx, PK_LUT);
-                const int64_t threads = (k1 - k0) * s_pass * 2;
-                const dim3 eg((unsigned)((threads + 255) / 256));
+                const dim3 eg((unsigned)s_pass, (unsigned)std::min<int64_t>(65535, (k1 - k0 + 127) / 128));
 #define LAUNCH_EXPAND(D)                                                                                                     \
     hipLaunchKernelGGL((k_sh_expand<D>), eg, dim3(256), 0, es, (const uint32_t *)ctx->ws_sh_pos.p, ld_pos, j.d_w, s_pass, j.skip,  \
                        k0, k1 - k0, steps_ld, (sh_v4i *)ctx->ws_sh_A.p, d_nonint + s_base, d_meta)

@@ -271,13 +271,18 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
             int64_t step0, int64_t n_steps, int64_t steps_ld, sh_v4i *__restrict__ A, int *__restrict__ nonint /* of the pass's samples */,
             long long *__restrict__ meta)
 {
-    // K steps [step0, step0 + n_steps) of the pass (a launch per part: the contraction of a part starts when its digits are there)
+    // K steps [step0, step0 + n_steps) of the pass (a launch per part: the contraction of a part starts when its digits are there).
+    // blockIdx.x = sample, blockIdx.y walks runs of 128 K steps: the lanes of a wave read CONSECUTIVE entries of one sample (positions
+    // 16 B and weights 96 B per lane, both contiguous across the wave); the 96-B digit rows a lane writes share their cache lines
+    // with the other samples of the group, whose blocks are dispatched next to this one (sample is the fast grid index).
     constexpr int RPS = DIGITS + 1;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_steps * n_samples_pass * 2) return;
-    const int h = (int)(idx & 1);
-    const int64_t s = (idx >> 1) % n_samples_pass;
-    const int64_t k = step0 + (idx >> 1) / n_samples_pass;
+    const int64_t s = blockIdx.x;
+    const int h = (int)(threadIdx.x & 1);
+    bool out_of_range = false, fractional = false;
+    for (int64_t kb = blockIdx.y; kb * 128 < n_steps; kb += gridDim.y) {
+    const int64_t kk = kb * 128 + (threadIdx.x >> 1);
+    if (kk < n_steps) {
+    const int64_t k = step0 + kk;
     constexpr int frac_bits = 8 * (DIGITS - 1) + 6;
     const double scale = __builtin_ldexp(1.0, frac_bits);
     unsigned long long bias = 0;
@@ -297,7 +302,6 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
     // the weights are vetted where they are read: outside [0, 1] (or not finite) -> the whole batch goes back to the per-sample
     // pass (meta[1] bit 1, read by the host with the results); a weight that is not an integer -> the sample's reference-order
     // bound is not zero (flag tested before it is set: after the first few threads of a sample every other one only reads it)
-    bool out_of_range = false, fractional = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         uint32_t lo[3], hi[3];
@@ -326,8 +330,6 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
         }
         dw[DIGITS][i] = e[i] ? (skip_hets ? 0x01010000u : 0x01000000u) : 0u;
     }
-    if (out_of_range) atomicOr((unsigned long long *)&meta[1], 2ull);
-    if (fractional && !__hip_atomic_load(&nonint[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&nonint[s], 1);
 #pragma unroll
     for (int j = 0; j < RPS; ++j) {
         const int64_t M = s * RPS + j;
@@ -336,6 +338,15 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
         sh_v4i v;
         v.x = (int)dw[j][0]; v.y = (int)dw[j][1]; v.z = (int)dw[j][2]; v.w = (int)dw[j][3];
         A[((g * steps_ld + k) * 4 + t) * 64 + h * 32 + m] = v;
+    }
+    }
+    }
+    // one flag update per block (the sample is block-uniform)
+    const int any_bad = __syncthreads_or(out_of_range ? 1 : 0);
+    const int any_frac = __syncthreads_or(fractional ? 1 : 0);
+    if (threadIdx.x == 0) {
+        if (any_bad) atomicOr((unsigned long long *)&meta[1], 2ull);
+        if (any_frac && !__hip_atomic_load(&nonint[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicOr(&nonint[s], 1);
     }
 }
 
