@@ -120,7 +120,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     const size_t budget = ctx->shared_ws_bytes;
     int64_t groups_per_pass = std::max<int64_t>(1, std::min<int64_t>(groups_total, (int64_t)(budget / std::max<size_t>(bytes_per_group, 1))));
     // row tiles: blocks of one tile run on one XCD (n_cu / 8 CUs, one block each at a time); among T = 8 m tiles take the m with the
-    // shortest schedule (rounds x steps per tile) whose partial sums stay small
+    // shortest schedule (rounds x (steps per tile + a round's fixed cost) + the finish over T tiles) whose partial sums stay small
     auto plan_tiles = [&](int64_t groups, int &n_tiles, int64_t &steps_per_tile, int &blocks_per_tile) {
         blocks_per_tile = (int)((groups * n_accgroups + 3) / 4);
         const int cu_per_xcd = std::max(1, ctx->n_cu / 8);
@@ -132,7 +132,10 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
             const size_t part_bytes = (size_t)T * groups * SH_GROUP_ROWS * ldn * 4;
             if (part_bytes > (size_t(192) << 20) && m > 1) break;
             const int64_t rounds = ((int64_t)m * blocks_per_tile + cu_per_xcd - 1) / cu_per_xcd;
-            const double cost = (double)rounds * (double)((n_steps + T - 1) / T);
+            // in units of one K step of one wave (~0.3 us): a round also pays for the waves' start and for their 64 KB of sums each,
+            // written in one burst when they all finish (~42k cycles, measured: profiles/r05_shared_tiles.txt), and k_sh_finish reads
+            // every tile's sums back
+            const double cost = (double)rounds * ((double)((n_steps + T - 1) / T) + 100.0) + 1.1 * (double)part_bytes / 1048576.0;
             if (cost < best * 0.97) { best = cost; best_m = m; }
         }
         int64_t T = 8 * best_m;

@@ -354,34 +354,29 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
 // one-hot B fragments of 4 accessions x 4 rows.  int8 panel: x[i] = the dword of row i (4 accessions as bytes): transpose, then
 // byte -> 1 << 8 (code & 3).  Packed panel: x[i] = one byte of row i (4 accessions as 2-bit fields).
 template <bool PACKED>
-__device__ __forceinline__ void sh_onehot(const uint32_t (&x)[4], sh_v4i (&b)[4])
+__device__ __forceinline__ void sh_onehot(const uint32_t (&x)[4], uint32_t one, sh_v4i (&b)[4])
 {
-    if (PACKED) {
+    // every byte of y[i] = 8 * class of one accession of row i; the fragment dword of (accession j, row i) is then ONE shift whose
+    // amount is byte j of y[i]: `one` is the constant 1 in a register the optimiser cannot see through and the amount keeps its
+    // `& 0xff`, so that the SDWA peephole folds the byte extraction into the shift (v_lshlrev_b32_sdwa ... src0_sel:BYTE_j).  24 (int8)
+    // and 32 (packed) VALU instructions a step; the first version transposed the rows with v_perm and took 52.
+    uint32_t y[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            b[j].x = (int)(1u << (((x[0] >> (2 * j)) & 3u) << 3));
-            b[j].y = (int)(1u << (((x[1] >> (2 * j)) & 3u) << 3));
-            b[j].z = (int)(1u << (((x[2] >> (2 * j)) & 3u) << 3));
-            b[j].w = (int)(1u << (((x[3] >> (2 * j)) & 3u) << 3));
+    for (int i = 0; i < 4; ++i) {
+        if (PACKED) {
+            const uint32_t t = (x[i] << 3) | (x[i] << 9);        // field 0 at bits 3-4, field 1 at bits 11-12 (and junk)
+            y[i] = (t | (t << 12)) & 0x18181818u;                // fields 2 and 3 at bits 19-20 and 27-28
+        } else {
+            y[i] = (x[i] << 3) & 0x18181818u;                    // -1 (0xff) -> class 3
         }
-    } else {
-        const uint32_t p0 = __builtin_amdgcn_perm(x[1], x[0], 0x05010400u);   // (x0.b0, x1.b0, x0.b1, x1.b1)
-        const uint32_t p1 = __builtin_amdgcn_perm(x[1], x[0], 0x07030602u);   // (x0.b2, x1.b2, x0.b3, x1.b3)
-        const uint32_t p2 = __builtin_amdgcn_perm(x[3], x[2], 0x05010400u);
-        const uint32_t p3 = __builtin_amdgcn_perm(x[3], x[2], 0x07030602u);
-        uint32_t t[4];
-        t[0] = __builtin_amdgcn_perm(p2, p0, 0x05040100u);                    // accession 0: rows 0..3
-        t[1] = __builtin_amdgcn_perm(p2, p0, 0x07060302u);
-        t[2] = __builtin_amdgcn_perm(p3, p1, 0x05040100u);
-        t[3] = __builtin_amdgcn_perm(p3, p1, 0x07060302u);
+        asm("" : "+v"(y[i]));
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t s = (t[j] & 0x03030303u) << 3;
-            b[j].x = (int)(1u << (s & 0xffu));
-            b[j].y = (int)(1u << ((s >> 8) & 0xffu));
-            b[j].z = (int)(1u << ((s >> 16) & 0xffu));
-            b[j].w = (int)(1u << (s >> 24));
-        }
+    for (int j = 0; j < 4; ++j) {
+        b[j].x = (int)(one << ((y[0] >> (8 * j)) & 0xffu));
+        b[j].y = (int)(one << ((y[1] >> (8 * j)) & 0xffu));
+        b[j].z = (int)(one << ((y[2] >> (8 * j)) & 0xffu));
+        b[j].w = (int)(one << ((y[3] >> (8 * j)) & 0xffu));
     }
 }
 
@@ -449,13 +444,26 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
         const sh_v4i rr = *reinterpret_cast<const sh_v4i *>(union_rows + (KS) * SH_STEP_ROWS + 4 * h); \
         rows_next[D][0] = rr.x; rows_next[D][1] = rr.y; rows_next[D][2] = rr.z; rows_next[D][3] = rr.w; \
     } while (0)
+    // row address = base + row * stride: rows are non-negative 32-bit numbers and a row stride is below 4 GiB, so ONE v_mad_u64_u32
+    // per row (the general 64 x 64-bit product took five instructions per row, 20 per step -- outside the MFMAs' shadow, where
+    // every VALU cycle is a cycle the matrix pipe idles)
+    const uint32_t stride32 = (uint32_t)row_stride;
+#define SH_ROW_PTRS(D, P)                                                                     \
+    do {                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
+            (P)[i] = base + (uint64_t)(uint32_t)rows_next[D][i] * (uint64_t)stride32;         \
+    } while (0)
+#define SH_LOAD_STAGE_AT(D, KS, P)                                                            \
+    do {                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
+            x[D][i] = PACKED ? (uint32_t) * reinterpret_cast<const uint8_t *>((P)[i]) : *reinterpret_cast<const uint32_t *>((P)[i]); \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) a[D][t] = Ag[((KS) * 4 + t) * 64];      \
+    } while (0)
 #define SH_LOAD_STAGE(D, KS)                                                                  \
     do {                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-            const int8_t *p = base + (int64_t)rows_next[D][i] * row_stride;                   \
-            x[D][i] = PACKED ? (uint32_t) * reinterpret_cast<const uint8_t *>(p) : *reinterpret_cast<const uint32_t *>(p); \
-        }                                                                                     \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) a[D][t] = Ag[((KS) * 4 + t) * 64];      \
+        const int8_t *p_[4];                                                                  \
+        SH_ROW_PTRS(D, p_);                                                                   \
+        SH_LOAD_STAGE_AT(D, KS, p_);                                                          \
     } while (0)
 
     // prologue: rows of the first 2 * DEPTH steps, panel dwords and A fragments of the first DEPTH steps
@@ -476,33 +484,41 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
     // its ~55 VALU instructions per step, so the fragments of step d + 1 are built BETWEEN the 16 MFMAs of step d (an MFMA holds
     // the issue port for 8 of its 32 cycles; sched_group_barrier pins the pattern 1 MFMA : 4 VALU).
     sh_v4i b[2][4];
-    sh_onehot<PACKED>(x[0], b[0]);
+    uint32_t one = 1u;
+    asm("" : "+v"(one));
+    sh_onehot<PACKED>(x[0], one, b[0]);
     int64_t ks = k0;
     do {                                    // a tile is never empty
 #pragma unroll
         for (int d = 0; d < SH_DEPTH; ++d) {
-            sh_onehot<PACKED>(x[(d + 1) % SH_DEPTH], b[(d + 1) & 1]);       // stage 0 of the next round when d is the last stage
+            sh_onehot<PACKED>(x[(d + 1) % SH_DEPTH], one, b[(d + 1) & 1]);       // stage 0 of the next round when d is the last stage
+            const int8_t *pn[4];
+            SH_ROW_PTRS(d, pn);                                             // the addresses of this stage's next loads: VALU work for the MFMAs' shadow too
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[t][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d][t], b[d & 1][j], acc[t][j], 0, 0, 0);
+            // the next round's step of this stage (unconditional: the pads make it readable), issued BETWEEN the MFMAs as well: nine
+            // loads behind a fence cost ~150 cycles a step in which the matrix pipe idled (SQ counters: MFMA busy 72 % of the
+            // wave's cycles).  The fence at the end of the stage stays: without it the scheduler sinks the loads to their uses a
+            // round later and waits with vmcnt(0).
+            SH_LOAD_STAGE_AT(d, ks + d + SH_DEPTH, pn);
+            SH_LOAD_ROWS(d, ks + d + 2 * SH_DEPTH);
 #pragma unroll
             for (int g16 = 0; g16 < 16; ++g16) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
                 __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);          // four VALU
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // one load (nine per stage: the last groups find none)
             }
-            // the next round's step of this stage (unconditional: the pads make it readable).  The scheduler must not move these
-            // loads (it sinks them to their uses a round later and waits with vmcnt(0)): fences on both sides
-            __builtin_amdgcn_sched_barrier(0);
-            SH_LOAD_STAGE(d, ks + d + SH_DEPTH);
-            SH_LOAD_ROWS(d, ks + d + 2 * SH_DEPTH);
             __builtin_amdgcn_sched_barrier(0);
         }
         ks += SH_DEPTH;
     } while (ks < k1);
 #undef SH_LOAD_ROWS
 #undef SH_LOAD_STAGE
+#undef SH_LOAD_STAGE_AT
+#undef SH_ROW_PTRS
 
     // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): registers 4 q .. 4 q + 3 of a
     // tile are four adjacent matrix rows of one accession.  The partial sums are kept accession-major ([.., accession, matrix
