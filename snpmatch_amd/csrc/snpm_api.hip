@@ -77,7 +77,7 @@ struct snpm_ctx {
     bool once_state_clean = false;
     int once_fused = 1;                 // SNPM_ONCE_FUSED=0: snpm_genotype_once keeps the unfused kernels and copies of its first version
     int once_zero_copy = 1;             // SNPM_ONCE_ZEROCOPY=0: the fused form sends the slab through the copy engine (two pieces behind the fill) instead of reading it in place
-    Buf ws_seg_desc, ws_eseg, ws_pairs, ws_pair_sums, ws_bscore, ws_bninfo, ws_blut, ws_brows, ws_brows32, ws_bw, ws_bcodes;   // segmented / batched scoring
+    Buf ws_seg_desc, ws_eseg, ws_pairs, ws_pair_sums, ws_bscore, ws_bninfo, ws_bout, ws_blut, ws_brows, ws_brows32, ws_bw, ws_bcodes;   // segmented / batched scoring
     // shared-row scan of a batch (snpm_api_shared.hpp): union of the samples' rows, the int8 digit matrix, partial digit sums
     Buf ws_sh_bitmap, ws_sh_wordbase, ws_sh_blocks, ws_sh_urows, ws_sh_meta, ws_sh_A, ws_sh_pos, ws_sh_partial;
     int batch_shared = -1;              // SNPM_BATCH_SHARED / snpm_batch_configure: -1 auto (batches whose inputs are on the device), 0 never, 1 whenever the batch allows it
@@ -592,7 +592,7 @@ int snpm_destroy(snpm_ctx *ctx)
         Buf *bufs[] = {&ctx->ws_stage_dev, &ctx->ws_flags2, &ctx->ws_grp_score, &ctx->ws_grp_miss, &ctx->ws_part_score, &ctx->ws_part_miss, &ctx->ws_seg_score, &ctx->ws_seg_miss, &ctx->ws_seg_off,
                        &ctx->ws_cols, &ctx->ws_tmp_score, &ctx->ws_tmp_ninfo, &ctx->ws_flags, &ctx->ws_lik_y,
                        &ctx->ws_lik_n, &ctx->ws_lik_l, &ctx->ws_lik_r, &ctx->ws_wprops, &ctx->ws_epart,
-                       &ctx->ws_seg_desc, &ctx->ws_eseg, &ctx->ws_pairs, &ctx->ws_pair_sums, &ctx->ws_bscore, &ctx->ws_bninfo,
+                       &ctx->ws_seg_desc, &ctx->ws_eseg, &ctx->ws_pairs, &ctx->ws_pair_sums, &ctx->ws_bscore, &ctx->ws_bninfo, &ctx->ws_bout,
                        &ctx->ws_blut, &ctx->ws_brows, &ctx->ws_brows32, &ctx->ws_bw, &ctx->ws_bcodes,
                        &ctx->ws_sh_bitmap, &ctx->ws_sh_wordbase, &ctx->ws_sh_blocks, &ctx->ws_sh_urows, &ctx->ws_sh_meta, &ctx->ws_sh_A,
                        &ctx->ws_sh_pos, &ctx->ws_sh_partial, &ctx->ws_tickets};

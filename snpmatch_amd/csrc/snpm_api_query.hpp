@@ -516,8 +516,15 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     const size_t na = (size_t)p->n_acc, B = (size_t)n_samples;
     if ((rc = ensure(ctx, ctx->ws_brows, (NN + PREFETCH_PAD_ROWS) * sizeof(int64_t)))) return rc;
     if ((rc = ensure(ctx, ctx->ws_blut, NN * 4 * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->ws_bscore, B * na * sizeof(double)))) return rc;
-    if ((rc = ensure(ctx, ctx->ws_bninfo, B * na * sizeof(int64_t)))) return rc;
+    // the results of the batch in ONE device block, [status line | score | ninfo | likelihood | ratio]: they return to the host
+    // in one copy (five copies of 0.6 MB and four of a flag each were ~0.16 ms of GPU timeline behind a 0.6-ms batch)
+    const size_t out_slot = (B * na * sizeof(double) + 255) & ~size_t(255);
+    if ((rc = ensure(ctx, ctx->ws_bout, 256 + 4 * out_slot))) return rc;
+    int *const d_status = (int *)ctx->ws_bout.p;
+    double *const d_bscore = (double *)((char *)ctx->ws_bout.p + 256);
+    int64_t *const d_bninfo = (int64_t *)((char *)ctx->ws_bout.p + 256 + out_slot);
+    double *const d_blik = (double *)((char *)ctx->ws_bout.p + 256 + 2 * out_slot);
+    double *const d_blrt = (double *)((char *)ctx->ws_bout.p + 256 + 3 * out_slot);
     if ((rc = ensure(ctx, ctx->ws_flags2, sizeof(int)))) return rc;
     HIPCHK(ctx, hipMemsetAsync(ctx->ws_flags2.p, 0, sizeof(int), ctx->stream));
     int64_t *d_rows = (int64_t *)ctx->ws_brows.p;
@@ -549,8 +556,8 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     j.chunk = chunk;
     j.skip = skip;
     j.certify = (mode == SNPM_MODE_EXACT);
-    j.d_score = (double *)ctx->ws_bscore.p;
-    j.d_ninfo = (int64_t *)ctx->ws_bninfo.p;
+    j.d_score = d_bscore;
+    j.d_ninfo = d_bninfo;
     j.ldo = p->n_acc;
     // rows [r0, r1) of the concatenated inputs are on the device (or on their way, ordered before what follows):
     // sanitise the row list, build the LUT rows
@@ -582,8 +589,7 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
             const int64_t o = sample_off[b], nb = sample_off[b + 1] - o;
             int r = snpm_query_create_device(p, j.d_row_idx + o, 0, nb, d_w + 3 * o, &q);
             if (r) return r;
-            r = run_strict_chain(q, skip, chunk, nullptr, nullptr, nullptr, (double *)ctx->ws_bscore.p + b * na,
-                                 (int64_t *)ctx->ws_bninfo.p + b * na);
+            r = run_strict_chain(q, skip, chunk, nullptr, nullptr, nullptr, d_bscore + b * na, d_bninfo + b * na);
             const std::string keep = ctx->err;
             (void)hipStreamSynchronize(ctx->stream);
             snpm_query_free(q);
@@ -714,40 +720,43 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
     // the likelihoods' domain flag and the input flags come back with the results (a batch with more unproven pairs than the
     // sparse tier takes -- rare -- is scored again in reference order and delivered a second time).
     const size_t out_elems = B * na;
-    const size_t n_out = (score ? 1 : 0) + (ninfo ? 1 : 0) + (lik ? 2 : 0);
     HostFetch fetch(ctx);
-    if ((rc = fetch.reserve(n_out * (out_elems * 8 + 64)))) return rc;
-    int *h_small = (int *)ctx->h_pinned;            // [0] unproven pairs, [1] likelihood domain flag, [8] input flags
-    if (lik) {
-        if ((rc = ensure(ctx, ctx->ws_lik_l, B * na * sizeof(double)))) return rc;
-        if ((rc = ensure(ctx, ctx->ws_lik_r, B * na * sizeof(double)))) return rc;
-    }
+    if ((rc = fetch.reserve(256 + 4 * out_slot))) return rc;
+    const int *h_status = (const int *)ctx->h_pinned;     // [0] unproven pairs, [1] likelihood domain flag, [2] input flags, [4..5] the contraction's flags
     auto deliver = [&]() -> int {
         int r;
         fetch.finish();                             // (a second delivery starts from an empty list)
-        h_small[0] = h_small[1] = 0;
-        if (j.certify && !strict_all)
-            HIPCHK(ctx, hipMemcpyAsync(h_small, seg_pair_count(ctx), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         if (lik) {
-            r = snpm_likelihood_device(ctx, ctx->ws_bscore.p, ctx->ws_bninfo.p, n_samples, p->n_acc, 1, __builtin_nan(""),
-                                       ctx->ws_lik_l.p, ctx->ws_lik_r.p, nullptr);
+            r = snpm_likelihood_device(ctx, d_bscore, d_bninfo, n_samples, p->n_acc, 1, __builtin_nan(""), d_blik, d_blrt, nullptr);
             if (r) return r;
-            HIPCHK(ctx, hipMemcpyAsync(h_small + 1, ctx->ws_flags.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            if ((r = fetch.add(lik, ctx->ws_lik_l.p, out_elems * 8))) return r;
-            if ((r = fetch.add(lrt, ctx->ws_lik_r.p, out_elems * 8))) return r;
         }
-        if ((r = fetch.add(score, ctx->ws_bscore.p, out_elems * 8))) return r;
-        if ((r = fetch.add(ninfo, ctx->ws_bninfo.p, out_elems * 8))) return r;
-        HIPCHK(ctx, hipMemcpyAsync(h_small + 8, ctx->ws_flags2.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        *(long long *)(h_small + 12) = 0;
-        if (shared_done) HIPCHK(ctx, hipMemcpyAsync(h_small + 12, shst.d_meta + 1, sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+        hipLaunchKernelGGL(k_batch_status, dim3(1), dim3(64), 0, ctx->stream, (j.certify && !strict_all) ? (const int *)seg_pair_count(ctx) : nullptr,
+                           lik ? (const int *)ctx->ws_flags.p : nullptr, (const int *)ctx->ws_flags2.p,
+                           shared_done ? (const unsigned long long *)(shst.d_meta + 1) : nullptr, d_status);
+        HIPCHK(ctx, hipGetLastError());
+        void *dsts[4] = {score, ninfo, lik, lrt};
+        const void *srcs[4] = {d_bscore, d_bninfo, d_blik, d_blrt};
+        int last = -1;
+        bool pinned_dst = false;
+        for (int i = 0; i < 4; ++i)
+            if (dsts[i]) { last = i; pinned_dst = pinned_dst || host_pointer_is_pinned(dsts[i]); }
+        const size_t span = 256 + (last < 0 ? 0 : (size_t)last * out_slot + out_elems * 8);
+        if (out_elems * 8 <= (size_t(1) << 20) && !pinned_dst && span <= fetch.cap) {
+            // one copy: the status line and every array up to the last one asked for (an array not asked for in between rides along)
+            char *slab = (char *)ctx->h_pinned + 256;
+            HIPCHK(ctx, hipMemcpyAsync(slab, ctx->ws_bout.p, span, hipMemcpyDeviceToHost, ctx->stream));
+            h_status = (const int *)slab;
+            for (int i = 0; i < 4; ++i)
+                if (dsts[i]) fetch.items[fetch.n_items++] = HostFetch::Item{dsts[i], slab + 256 + (size_t)i * out_slot, out_elems * 8};
+        } else {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, d_status, 64, hipMemcpyDeviceToHost, ctx->stream));
+            h_status = (const int *)ctx->h_pinned;
+            for (int i = 0; i < 4; ++i)
+                if ((r = fetch.add(dsts[i], srcs[i], out_elems * 8))) return r;
+        }
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (shared_done && (*(long long *)(h_small + 12) & 2)) {          // a weight outside [0, 1]: not a batch for the contraction
-            fetch.n_items = 0;
-            fetch.used = 0;
-            return SNPM_OK;
-        }
-        if (j.certify && !strict_all && h_small[0] > j.cap) {          // the caller scores again in reference order
+        if ((shared_done && (*(const long long *)(h_status + 4) & 2))               // a weight outside [0, 1]: not a batch for the contraction
+            || (j.certify && !strict_all && h_status[0] > j.cap)) {                  // the caller scores again in reference order
             fetch.n_items = 0;
             fetch.used = 0;
             return SNPM_OK;
@@ -763,7 +772,7 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
         if (rc) return rc;
     }
     if ((rc = deliver())) return rc;
-    if (shared_done && (*(long long *)(h_small + 12) & 2)) {
+    if (shared_done && (*(const long long *)(h_status + 4) & 2)) {
         // the expansion met a weight outside [0, 1] (it vets the weights while it converts them: the decision to take the shared-row
         // pass is made before): the whole batch once more through the per-sample pass, which takes any finite weight
         int r = score_batch_impl(p, n_samples, sample_off, row_idx, wei, codes, table, table_len, device_inputs, chunk, skip_hets, mode, score,
@@ -774,15 +783,15 @@ static int score_batch_impl(snpm_panel *p, int64_t n_samples, const int64_t *sam
         return r;
     }
     if (j.certify && !strict_all) {
-        n_pairs = h_small[0];
+        n_pairs = h_status[0];
         if (n_pairs > j.cap) {
             strict_all = true;
             if ((rc = strict_every_sample())) return rc;
             if ((rc = deliver())) return rc;
         }
     }
-    const int *h_bad = h_small + 8;
-    if (lik && !(*h_bad) && (h_small[1] & 1)) return set_err(ctx, SNPM_ERR_DOMAIN, "provided y is greater than n");
+    const int *h_bad = h_status + 2;
+    if (lik && !(*h_bad) && (h_status[1] & 1)) return set_err(ctx, SNPM_ERR_DOMAIN, "provided y is greater than n");
     if (trace)
         fprintf(stderr, "[snpm batch] plan %.3f ms, enqueue %.3f ms (staging %.3f, launches %.3f), finish+likelihood+copy back %.3f ms\n",
                 t_planned - t_begin, t_enqueued - t_planned, t_stage, t_launch, now() - t_enqueued);

@@ -40,23 +40,22 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     const int64_t n_blocks = (n_words + SH_WORDS_PER_BLOCK - 1) / SH_WORDS_PER_BLOCK;
     const int64_t u_max = std::min<int64_t>(N, p->n_snp);
     const size_t urow_entries = (size_t)u_max + (size_t)(SH_PAD_STEPS + SH_DEPTH + 1) * SH_STEP_ROWS;   // zero rows behind the union: the steps that pad it to a multiple of SH_DEPTH and the kernel's read-ahead
-    if ((rc = ensure(ctx, ctx->ws_sh_bitmap, (size_t)n_words * 4))) return rc;
+    // [meta | seg_off | per-sample flag "a weight is not an integer"] and the bitmap behind it: ONE memset clears both
+    const size_t meta_bytes = (64 + ((size_t)n_seg + 1) * 8 + (size_t)n_seg * 4 + 255) & ~size_t(255);
+    if ((rc = ensure(ctx, ctx->ws_sh_bitmap, meta_bytes + (size_t)n_words * 4))) return rc;
     if ((rc = ensure(ctx, ctx->ws_sh_wordbase, (size_t)n_words * 4))) return rc;
     if ((rc = ensure(ctx, ctx->ws_sh_blocks, (size_t)n_blocks * 8 + 256))) return rc;
     if ((rc = ensure(ctx, ctx->ws_sh_urows, urow_entries * 4))) return rc;
-    const size_t meta_bytes = 64 + ((size_t)n_seg + 1) * 8 + (size_t)n_seg * 4;     // meta | seg_off | per-sample flag "a weight is not an integer"
-    if ((rc = ensure(ctx, ctx->ws_sh_meta, meta_bytes))) return rc;
-    long long *d_meta = (long long *)ctx->ws_sh_meta.p;
-    int64_t *d_seg_off = (int64_t *)((char *)ctx->ws_sh_meta.p + 64);
-    int *d_nonint = (int *)((char *)ctx->ws_sh_meta.p + 64 + ((size_t)n_seg + 1) * 8);
-    uint32_t *d_bitmap = (uint32_t *)ctx->ws_sh_bitmap.p;
+    long long *d_meta = (long long *)ctx->ws_sh_bitmap.p;
+    int64_t *d_seg_off = (int64_t *)((char *)ctx->ws_sh_bitmap.p + 64);
+    int *d_nonint = (int *)((char *)ctx->ws_sh_bitmap.p + 64 + ((size_t)n_seg + 1) * 8);
+    uint32_t *d_bitmap = (uint32_t *)((char *)ctx->ws_sh_bitmap.p + meta_bytes);
     uint32_t *d_wordbase = (uint32_t *)ctx->ws_sh_wordbase.p;
     uint32_t *d_blocksum = (uint32_t *)ctx->ws_sh_blocks.p, *d_blockbase = d_blocksum + n_blocks;
     int32_t *d_urows = (int32_t *)ctx->ws_sh_urows.p;
-    HIPCHK(ctx, hipMemsetAsync(ctx->ws_sh_meta.p, 0, meta_bytes, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->ws_sh_bitmap.p, 0, meta_bytes + (size_t)n_words * 4, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_seg_off, j.seg_off, ((size_t)n_seg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_bitmap, 0, (size_t)n_words * 4, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(d_urows, 0, urow_entries * 4, ctx->stream));
+    const int urow_pad = (int)(urow_entries - (size_t)u_max);            // zero rows behind the union: written by k_sh_scan, which knows where it ends
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((maxlen + 255) / 256, 64));
     if ((rc = ensure_pinned(ctx, 64))) return rc;
     long long *h_meta = (long long *)ctx->h_pinned;
@@ -69,7 +68,8 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
         hipLaunchKernelGGL(k_sh_probe, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, row_limit,
                            p->n_snp, d_bitmap, d_meta);
         hipLaunchKernelGGL(k_sh_count, dim3((unsigned)blocks_probe), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, words_probe, d_blocksum);
-        hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)d_blocksum, blocks_probe, d_blockbase, d_meta);
+        hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)d_blocksum, blocks_probe, d_blockbase, d_meta,
+                           (int32_t *)nullptr, 0, (const int *)nullptr);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(h_meta, d_meta, 32, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -81,6 +81,9 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
             if (est < 0.8 * ctx->shared_min_density_of(p->packed != 0)) { st.reason = 6; return SNPM_OK; }
         }
     }
+    // (the pair counter is cleared here, ahead of the host's wait for the union, so that nothing but launches follows that wait)
+    if ((rc = ensure(ctx, ctx->ws_pairs, 16 + (size_t)SEG_PAIR_CAP * 2 * sizeof(int32_t)))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(seg_pair_count(ctx), 0, sizeof(int), ctx->stream));
     // one pass over the row lists: marks and index checks (the weights are vetted by k_sh_expand while it converts them)
     if (j.certify && (rc = ensure(ctx, ctx->ws_eseg, (size_t)n_seg * sizeof(double)))) return rc;
     {
@@ -88,14 +91,13 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
         hipLaunchKernelGGL(k_sh_mark, dim3(gx, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, p->n_snp,
                            d_bitmap, d_meta);
         hipLaunchKernelGGL(k_sh_count, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, n_words, d_blocksum);
-        hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)d_blocksum, n_blocks, d_blockbase, d_meta);
+        hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)d_blocksum, n_blocks, d_blockbase, d_meta, d_urows,
+                           urow_pad, (!p->packed && p->d_other) ? (const int *)p->d_other : (const int *)nullptr);
         hipLaunchKernelGGL(k_sh_fill, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, n_words,
                            (const uint32_t *)d_blockbase, d_wordbase, d_urows);
         HIPCHK(ctx, hipGetLastError());
     }
-    h_meta[2] = 0;
-    HIPCHK(ctx, hipMemcpyAsync(h_meta, d_meta, 16, hipMemcpyDeviceToHost, ctx->stream));
-    if (!p->packed && p->d_other) HIPCHK(ctx, hipMemcpyAsync(h_meta + 2, p->d_other, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_meta, d_meta, 24, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const int64_t U = h_meta[0];
     const int bad = (int)h_meta[1];
@@ -161,8 +163,6 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     j.d_seg_off = d_seg_off;
     j.kmax = kmax;
     j.cap = (int)std::max<int64_t>(64, std::min<int64_t>(SEG_PAIR_CAP, (int64_t(8) << 20) / kmax));
-    if ((rc = ensure(ctx, ctx->ws_pairs, 16 + (size_t)SEG_PAIR_CAP * 2 * sizeof(int32_t)))) return rc;
-    HIPCHK(ctx, hipMemsetAsync(seg_pair_count(ctx), 0, sizeof(int), ctx->stream));
     if (j.certify && (rc = ensure(ctx, ctx->ws_pair_sums, (size_t)j.cap * (size_t)kmax * sizeof(double)))) return rc;
     // ---- passes over groups of samples
     st.tiles = n_tiles; st.accgroups = n_accgroups; st.groups = (int)groups_total;
@@ -174,7 +174,6 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
         if (groups != groups_per_pass) {
             bpt = (int)((groups * n_accgroups + 3) / 4);
         }
-        HIPCHK(ctx, hipMemsetAsync(ctx->ws_sh_pos.p, 0, (size_t)s_pass * ld_pos * 4, ctx->stream));
         hipLaunchKernelGGL(k_sh_pos, dim3(gx, (unsigned)s_pass), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, s_base,
                            (const uint32_t *)d_bitmap, (const uint32_t *)d_wordbase, (uint32_t *)ctx->ws_sh_pos.p, ld_pos);
         // The pass in parts of whole row tiles: the digits of part i + 1 are laid out (k_sh_expand, on the auxiliary stream: memory

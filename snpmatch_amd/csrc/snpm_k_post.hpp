@@ -398,6 +398,22 @@ k_f1_finish(const double *__restrict__ chunk_sum, const uint32_t *__restrict__ m
     }
 }
 
+// the flags a batch call reads at its end -- the count of unproven pairs, the likelihoods' domain flag, the row / weight flags of
+// the inputs, the contraction's flags -- gathered into the status line in front of the results, so that they ride in the one copy
+// that brings the results back (a null source reads as 0)
+__global__ void k_batch_status(const int *__restrict__ pair_count, const int *__restrict__ lik_flag, const int *__restrict__ in_flags,
+                               const unsigned long long *__restrict__ contraction_flags, int *__restrict__ status)
+{
+    const int t = threadIdx.x;
+    if (t >= 16) return;
+    int v = 0;
+    if (t == 0 && pair_count) v = *pair_count;
+    if (t == 1 && lik_flag) v = *lik_flag;
+    if (t == 2 && in_flags) v = *in_flags;
+    if ((t == 4 || t == 5) && contraction_flags) v = (int)(*contraction_flags >> (32 * (t - 4)));
+    status[t] = v;
+}
+
 // snpm_genotype_once: (score, ninfo, likelihood, lrt) of one sample and the two status words (re-evaluated accessions, y > n
 // flag of k_likelihood) in ONE buffer of 8-byte words [4 * n_acc + 2], copied back in one piece
 __global__ void k_once_pack(const double *__restrict__ score, const int64_t *__restrict__ ninfo, const double *__restrict__ lik,

@@ -153,7 +153,7 @@ k_sh_probe(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off
 // ---------------------------------------------------------------------------------------------------------------
 // rank of the marked rows: a block owns 4096 bitmap words (16 consecutive words per thread).
 //   k_sh_count   popcount of a block's words -> block_sum[b]
-//   k_sh_scan    ONE block: exclusive prefix of block_sum -> block_base, total -> meta[0]
+//   k_sh_scan    ONE block: exclusive prefix of block_sum -> block_base, total -> meta[0]; zero rows behind the union
 //   k_sh_fill    word_base[w] = marked rows before word w; union_rows[rank] = row for every marked row
 constexpr int SH_WORDS_PER_THREAD = 16;
 constexpr int SH_WORDS_PER_BLOCK = 256 * SH_WORDS_PER_THREAD;
@@ -175,7 +175,8 @@ k_sh_count(const uint32_t *__restrict__ bitmap, int64_t n_words, uint32_t *__res
 }
 
 __global__ void __launch_bounds__(1024)
-k_sh_scan(const uint32_t *__restrict__ block_sum, int64_t n_blocks, uint32_t *__restrict__ block_base, long long *__restrict__ meta)
+k_sh_scan(const uint32_t *__restrict__ block_sum, int64_t n_blocks, uint32_t *__restrict__ block_base, long long *__restrict__ meta,
+          int32_t *__restrict__ union_rows /* or null */, int pad_entries, const int *__restrict__ other_codes /* or null */)
 {
     __shared__ uint32_t sm[16];
     __shared__ uint32_t carry;
@@ -200,7 +201,13 @@ k_sh_scan(const uint32_t *__restrict__ block_sum, int64_t n_blocks, uint32_t *__
         if (threadIdx.x == 1023) carry = before + x;
         __syncthreads();
     }
-    if (threadIdx.x == 0) meta[0] = (long long)carry;
+    if (threadIdx.x == 0) {
+        meta[0] = (long long)carry;
+        meta[2] = other_codes ? (long long)*other_codes : 0;        // "the int8 panel holds codes besides -1, 0, 1, 2": read with the total
+    }
+    // row 0 in the entries behind the union (k_sh_fill writes [0, total)): the steps that pad it and the contraction's read-ahead
+    if (union_rows)
+        for (int i = threadIdx.x; i < pad_entries; i += 1024) union_rows[(int64_t)carry + i] = 0;
 }
 
 __global__ void __launch_bounds__(256)
@@ -241,24 +248,51 @@ k_sh_fill(const uint32_t *__restrict__ bitmap, int64_t n_words, const uint32_t *
 }
 
 // position of every (sample, row) entry in the union: pos[s_local, u] = entry index + 1 (0 = the sample has no call at union
-// row u).  blockIdx.y = sample of this pass (s_base + blockIdx.y).
+// row u).  blockIdx.y = sample of this pass (s_base + blockIdx.y).  Every element of the row [0, ld_pos) is written here, none by
+// a memset (51 MB for 64 samples): a sample's rows ascend, so the 256 entries of a chunk own the stretch of the row from the
+// chunk's first rank to the next chunk's first rank (the first chunk from 0, the last to ld_pos) -- zeroed by the block, then
+// the entries stored on top.
 __global__ void __launch_bounds__(256)
 k_sh_pos(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off, int64_t s_base, const uint32_t *__restrict__ bitmap,
          const uint32_t *__restrict__ word_base, uint32_t *__restrict__ pos, int64_t ld_pos)
 {
+    __shared__ int64_t range[2];
     const int64_t s = s_base + blockIdx.y;
     const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
-    for (int64_t i = r0 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < r1; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = rows[i];
-        const uint32_t u = word_base[r >> 5] + __popc(bitmap[r >> 5] & ((1u << (r & 31)) - 1u));
-        pos[(int64_t)blockIdx.y * ld_pos + u] = (uint32_t)(i + 1);
+    uint32_t *row = pos + (int64_t)blockIdx.y * ld_pos;
+    if (r1 <= r0) {                                 // a sample without calls: all zeros
+        for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < ld_pos; u += (int64_t)gridDim.x * 256) row[u] = 0;
+        return;
+    }
+    for (int64_t c0 = r0 + (int64_t)blockIdx.x * 256; c0 < r1; c0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = c0 + threadIdx.x;
+        int64_t u = -1;
+        if (i < r1) {
+            const int64_t r = rows[i];
+            u = word_base[r >> 5] + __popc(bitmap[r >> 5] & ((1u << (r & 31)) - 1u));
+        }
+        if (threadIdx.x == 0) range[0] = c0 == r0 ? 0 : u;
+        if (threadIdx.x == 1) {
+            const int64_t nx = c0 + 256;
+            if (nx < r1) {
+                const int64_t r = rows[nx];
+                range[1] = word_base[r >> 5] + __popc(bitmap[r >> 5] & ((1u << (r & 31)) - 1u));
+            } else {
+                range[1] = ld_pos;
+            }
+        }
+        __syncthreads();
+        const int64_t u0 = range[0], u1 = range[1];
+        for (int64_t v = u0 + threadIdx.x; v < u1; v += 256) row[v] = 0;
+        __syncthreads();                            // (also: range[] is rewritten in the next round)
+        if (i < r1) row[u] = (uint32_t)(i + 1);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// k_sh_expand: the A matrix in fragment order.  Thread = (K step k, sample s of the pass, lane half h): converts the sample's
-// weights at union rows 8k + 4h .. + 3 to fixed point, splits them into balanced digits and stores the 16 B of every digit row
-// (and of the missing-count row) where lane (m, h) of tile t will load them.
+// k_sh_expand: the A matrix in fragment order.  Block = (sample s of the pass, run of 128 K steps); a thread converts the sample's
+// weights at ONE union row at a time to fixed point and splits them into balanced digits; four rows make the 16 B of a digit row
+// (and of the missing-count row) that lane (m, h) of tile t will load, assembled in LDS and stored in the order they lie in A.
 //   matrix row of (sample s, digit j): M = s * RPS + j, RPS = DIGITS + 1 (samples follow each other without gaps: a sample may
 //   lie across two groups of 128 rows); group M >> 7, tile (M >> 5) & 3, lane row M & 31
 //   balanced digits: Q' = floor(w 2^F) + sum_{p < DIGITS-1} 128 * 256^p; digit at position p < DIGITS-1 = byte p of Q' - 128
@@ -272,74 +306,87 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
             long long *__restrict__ meta)
 {
     // K steps [step0, step0 + n_steps) of the pass (a launch per part: the contraction of a part starts when its digits are there).
-    // blockIdx.x = sample, blockIdx.y walks runs of 128 K steps: the lanes of a wave read CONSECUTIVE entries of one sample (positions
-    // 16 B and weights 96 B per lane, both contiguous across the wave); the 96-B digit rows a lane writes share their cache lines
-    // with the other samples of the group, whose blocks are dispatched next to this one (sample is the fast grid index).
+    // blockIdx.x = sample, blockIdx.y walks runs of 128 K steps = 1024 union rows.  A thread converts ONE union row at a time
+    // (consecutive lanes = consecutive rows: positions 4 B and weights 24 B per lane, a wave's loads cover 12 cache lines each) and
+    // leaves its six dwords in LDS, where four rows make the 16-B piece of a (step, lane half, digit row); the pieces then leave in
+    // the order they lie in A: the six digit rows of a sample are 96 contiguous bytes, so a wave's store covers ~16 cache lines.
+    // (The first version gave a thread the four rows of a piece: every load and store instruction of a wave touched 48 - 64 lines,
+    // ~970 line visits per 256 rows against ~250 here, and the address path, not HBM, set its 0.22 ms.)
     constexpr int RPS = DIGITS + 1;
+    constexpr int PIECES = 128 * 2 * RPS;                                      // of one run
+    __shared__ uint32_t stage[PIECES * 4];
     const int64_t s = blockIdx.x;
-    const int h = (int)(threadIdx.x & 1);
     bool out_of_range = false, fractional = false;
-    for (int64_t kb = blockIdx.y; kb * 128 < n_steps; kb += gridDim.y) {
-    const int64_t kk = kb * 128 + (threadIdx.x >> 1);
-    if (kk < n_steps) {
-    const int64_t k = step0 + kk;
     constexpr int frac_bits = 8 * (DIGITS - 1) + 6;
     const double scale = __builtin_ldexp(1.0, frac_bits);
     unsigned long long bias = 0;
 #pragma unroll
     for (int p = 0; p < DIGITS - 1; ++p) bias |= 128ull << (8 * p);
-    const sh_v4i e4 = *reinterpret_cast<const sh_v4i *>(pos + s * ld_pos + k * SH_STEP_ROWS + 4 * h);
-    const uint32_t e[4] = {(uint32_t)e4.x, (uint32_t)e4.y, (uint32_t)e4.z, (uint32_t)e4.w};
-    uint32_t dw[RPS][4];
-    // every weight of the four rows is requested before the first one is used (rows the sample has no call at re-read entry 0:
-    // harmless, their digits are cleared below) -- one memory round trip per thread instead of four
-    double wv[4][3];
+    for (int64_t kb = blockIdx.y; kb * 128 < n_steps; kb += gridDim.y) {
+        const int64_t steps_here = (n_steps - kb * 128 < 128) ? n_steps - kb * 128 : 128;
+        // every position and weight of the thread's four rows is requested before the first one is used (rows the sample has no
+        // call at re-read entry 0: harmless, their digits are cleared below)
+        uint32_t e[4];
+        double wv[4][3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double *wr = w + 3 * (int64_t)(e[i] ? e[i] - 1 : 0);
-        wv[i][0] = wr[0]; wv[i][1] = wr[2]; wv[i][2] = wr[1];                  // class order: ref, alt, het
-    }
-    // the weights are vetted where they are read: outside [0, 1] (or not finite) -> the whole batch goes back to the per-sample
-    // pass (meta[1] bit 1, read by the host with the results); a weight that is not an integer -> the sample's reference-order
-    // bound is not zero (flag tested before it is set: after the first few threads of a sample every other one only reads it)
+        for (int i = 0; i < 4; ++i) {
+            const int ul = i * 256 + (int)threadIdx.x;                         // union row of the run
+            e[i] = (ul >> 3) < steps_here ? pos[s * ld_pos + (step0 + kb * 128) * SH_STEP_ROWS + ul] : 0u;
+        }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        uint32_t lo[3], hi[3];
+        for (int i = 0; i < 4; ++i) {
+            const double *wr = w + 3 * (int64_t)(e[i] ? e[i] - 1 : 0);
+            wv[i][0] = wr[0]; wv[i][1] = wr[2]; wv[i][2] = wr[1];              // class order: ref, alt, het
+        }
+        // the weights are vetted where they are read: outside [0, 1] (or not finite) -> the whole batch goes back to the per-sample
+        // pass (meta[1] bit 1, read by the host with the results); a weight that is not an integer -> the sample's reference-order
+        // bound is not zero
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            double x = (c == 2 && skip_hets) ? 0.0 : wv[i][c];
-            if (e[i]) {
-                if (!(x >= 0.0 && x <= 1.0)) out_of_range = true;
-                else if (x != 0.0 && x != 1.0) fractional = true;
+        for (int i = 0; i < 4; ++i) {
+            const int ul = i * 256 + (int)threadIdx.x;
+            uint32_t lo[3], hi[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double x = (c == 2 && skip_hets) ? 0.0 : wv[i][c];
+                if (e[i]) {
+                    if (!(x >= 0.0 && x <= 1.0)) out_of_range = true;
+                    else if (x != 0.0 && x != 1.0) fractional = true;
+                }
+                x = (x >= 0.0 && x <= 1.0) ? x : 0.0;                          // keep the conversion defined
+                const unsigned long long Q = (unsigned long long)floor(x * scale) + bias;
+                lo[c] = (uint32_t)Q;
+                hi[c] = (uint32_t)(Q >> 32);
             }
-            x = (x >= 0.0 && x <= 1.0) ? x : 0.0;                              // keep the conversion defined
-            const unsigned long long Q = (unsigned long long)floor(x * scale) + bias;
-            lo[c] = (uint32_t)Q;
-            hi[c] = (uint32_t)(Q >> 32);
-        }
+            // piece (step, half) of the row and its place in it: dword index = (piece * RPS + j) * 4 + row-in-piece
+            uint32_t *dst = stage + (ul >> 2) * (RPS * 4) + (ul & 3);
 #pragma unroll
-        for (int j = 0; j < DIGITS; ++j) {
-            const int p = DIGITS - 1 - j;                                      // byte position of digit j (j = 0: the top digit)
-            const uint32_t *src = (p < 4) ? lo : hi;
-            const uint32_t b = (uint32_t)(p & 3);
-            // (ref.b, alt.b, 0, 0) then (.., .., het.b, 0)
-            const uint32_t t = __builtin_amdgcn_perm(src[1], src[0], 0x0c0c0000u | ((4u + b) << 8) | b);
-            uint32_t d = __builtin_amdgcn_perm(src[2], t, 0x0c000100u | ((4u + b) << 16));
-            if (j > 0) d ^= 0x00808080u;
-            dw[j][i] = e[i] ? d : 0u;
+            for (int j = 0; j < DIGITS; ++j) {
+                const int p = DIGITS - 1 - j;                                  // byte position of digit j (j = 0: the top digit)
+                const uint32_t *src = (p < 4) ? lo : hi;
+                const uint32_t b = (uint32_t)(p & 3);
+                // (ref.b, alt.b, 0, 0) then (.., .., het.b, 0)
+                const uint32_t t = __builtin_amdgcn_perm(src[1], src[0], 0x0c0c0000u | ((4u + b) << 8) | b);
+                uint32_t d = __builtin_amdgcn_perm(src[2], t, 0x0c000100u | ((4u + b) << 16));
+                if (j > 0) d ^= 0x00808080u;
+                dst[j * 4] = e[i] ? d : 0u;
+            }
+            dst[DIGITS * 4] = e[i] ? (skip_hets ? 0x01010000u : 0x01000000u) : 0u;
         }
-        dw[DIGITS][i] = e[i] ? (skip_hets ? 0x01010000u : 0x01000000u) : 0u;
-    }
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RPS; ++j) {
-        const int64_t M = s * RPS + j;
-        const int64_t g = M >> 7;
-        const int t = (int)((M >> 5) & 3), m = (int)(M & 31);
-        sh_v4i v;
-        v.x = (int)dw[j][0]; v.y = (int)dw[j][1]; v.z = (int)dw[j][2]; v.w = (int)dw[j][3];
-        A[((g * steps_ld + k) * 4 + t) * 64 + h * 32 + m] = v;
-    }
-    }
+        for (int r = 0; r < (PIECES + 255) / 256; ++r) {
+            const int pc = r * 256 + (int)threadIdx.x;                         // piece = ((step * 2 + half) * RPS + digit row)
+            const int j = pc % RPS, kh = pc / RPS;
+            const int kk = kh >> 1, h = kh & 1;
+            if (pc < PIECES && kk < steps_here) {
+                const int64_t M = s * RPS + j;
+                const int64_t g = M >> 7;
+                const int t = (int)((M >> 5) & 3), m = (int)(M & 31);
+                const sh_v4i v = *reinterpret_cast<const sh_v4i *>(stage + pc * 4);
+                A[((g * steps_ld + step0 + kb * 128 + kk) * 4 + t) * 64 + h * 32 + m] = v;
+            }
+        }
+        __syncthreads();                                                       // the next run refills the stage
     }
     // one flag update per block (the sample is block-uniform)
     const int any_bad = __syncthreads_or(out_of_range ? 1 : 0);
