@@ -357,3 +357,46 @@ def test_forced_pairs_and_the_reference_order_fallback_behind_the_contraction():
             k = n_acc if reeval == 700 else reeval                     # these went through the reference-order kernels: its bits
             assert np.array_equal(got["score"][b][:k].view(np.uint64), want_s[:k].view(np.uint64)), b
         ctx.close()
+
+
+def test_samples_on_stretches_of_the_union_and_results_above_the_slab_limit():
+    """k_sh_pos writes every element of a sample's position row itself (zeros included): samples that cover only the head, the
+    middle or the tail of the union leave long zero stretches, a sample of 70k calls takes more than one round of the kernel's 64
+    blocks; 150 samples x 1135 accessions are 1.3 MB per result array: above the limit of the one-copy return, each array
+    travels by itself."""
+    ctx = make_ctx()
+    rng = np.random.default_rng(4711)
+    n_snp, n_acc = 160_000, 1135
+    db = rand_db(rng, n_snp, n_acc)
+    panel = engine.Panel.from_host(ctx, db)
+    base = np.sort(rng.choice(n_snp, size=70_000, replace=False)).astype(np.int64)
+    stretches = [(0, 70_000), (0, 9_000), (30_000, 41_000), (61_000, 70_000), (69_999, 70_000), (0, 1), (255, 257), (16_383, 16_390)]
+    samples = []
+    for b in range(150):
+        lo, hi = stretches[b % len(stretches)]
+        rows = base[lo:hi]
+        if b % 5 == 4:
+            rows = rows[rng.random(len(rows)) >= 0.4]
+        if b == 17:
+            rows = rows[:0]
+        samples.append((rows, sample_on(rng, db, rows, b % 3)))
+    engine.batch_configure(ctx, shared_rows=1)
+    got = engine.score_batch(panel, samples, 1000, False, engine.MODE_EXACT)
+    st = engine.batch_last_stats(ctx)
+    assert got["shared_rows"] and st["taken"] and got["union_rows"] == 70_000, st
+    assert got["score"].nbytes > (1 << 20)
+    check_against_oracle(db, samples, got, False)
+    # 64 of them: every array below the limit, one copy behind the status line
+    got64 = engine.score_batch(panel, samples[:64], 1000, False, engine.MODE_EXACT)
+    assert got64["shared_rows"] and got64["score"].nbytes < (1 << 20)
+    for k in ("score", "ninfo", "lik", "lrt"):
+        assert np.array_equal(got64[k], got[k][:64], equal_nan=True), k
+    # the same return path behind the per-sample pass
+    engine.batch_configure(ctx, shared_rows=0)
+    seg = engine.score_batch(panel, samples[:64], 1000, False, engine.MODE_EXACT)
+    assert not seg["shared_rows"]
+    assert np.array_equal(seg["ninfo"], got64["ninfo"]) and np.array_equal(seg["score"].astype(np.int64), got64["score"].astype(np.int64))
+    np.testing.assert_allclose(seg["lik"], got64["lik"], rtol=LIK_RTOL, equal_nan=True)
+    only_scores = engine.score_batch(panel, samples[:64], 1000, False, engine.MODE_EXACT, likelihoods=False)
+    assert np.array_equal(only_scores["score"], seg["score"]) and np.array_equal(only_scores["ninfo"], seg["ninfo"])
+    ctx.close()
