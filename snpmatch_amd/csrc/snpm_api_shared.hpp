@@ -85,10 +85,10 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     if ((rc = ensure(ctx, ctx->ws_pairs, 16 + (size_t)SEG_PAIR_CAP * 2 * sizeof(int32_t)))) return rc;
     HIPCHK(ctx, hipMemsetAsync(seg_pair_count(ctx), 0, sizeof(int), ctx->stream));
     // one pass over the row lists: marks and index checks (the weights are vetted by k_sh_expand while it converts them)
-    if (j.certify && (rc = ensure(ctx, ctx->ws_eseg, (size_t)n_seg * sizeof(double)))) return rc;
     {
         ProfScope ps(ctx, PK_LUT);
-        hipLaunchKernelGGL(k_sh_mark, dim3(gx, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, p->n_snp,
+        const unsigned mgx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((maxlen + 1023) / 1024, 16384));        // four entries per lane
+        hipLaunchKernelGGL(k_sh_mark, dim3(mgx, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, p->n_snp,
                            d_bitmap, d_meta);
         hipLaunchKernelGGL(k_sh_count, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, n_words, d_blocksum);
         hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)d_blocksum, n_blocks, d_blockbase, d_meta, d_urows,
@@ -159,7 +159,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     if ((rc = ensure(ctx, ctx->ws_sh_A, ((size_t)groups_per_pass * steps_ld + SH_PAD_STEPS) * 4096))) return rc;
     if ((rc = ensure(ctx, ctx->ws_sh_pos, (size_t)std::min<int64_t>(samples_per_pass, n_seg) * ld_pos * 4))) return rc;
     if ((rc = ensure(ctx, ctx->ws_sh_partial, (size_t)n_tiles * groups_per_pass * SH_GROUP_ROWS * ldn * 4))) return rc;
-    // ---- certificate: per-sample reference-order bound (k_eseg_*), pair list
+    // ---- certificate: pair list (the per-sample reference-order bound is a closed form here: sh_eseg_of)
     j.d_seg_off = d_seg_off;
     j.kmax = kmax;
     j.cap = (int)std::max<int64_t>(64, std::min<int64_t>(SEG_PAIR_CAP, (int64_t(8) << 20) / kmax));
@@ -174,6 +174,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
         if (groups != groups_per_pass) {
             bpt = (int)((groups * n_accgroups + 3) / 4);
         }
+        // (32 .. 512 blocks per sample: the same 38 us, it moves 250 MB)
         hipLaunchKernelGGL(k_sh_pos, dim3(gx, (unsigned)s_pass), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, s_base,
                            (const uint32_t *)d_bitmap, (const uint32_t *)d_wordbase, (uint32_t *)ctx->ws_sh_pos.p, ld_pos);
         // The pass in parts of whole row tiles: the digits of part i + 1 are laid out (k_sh_expand, on the auxiliary stream: memory
@@ -223,18 +224,13 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
                 HIPCHK(ctx, hipGetLastError());
             }
         }
-        if (j.certify) {
-            // the bound of this pass's samples: their "not an integer" flags are complete once every expansion of the pass has run
-            // (same stream, or waited for through the parts' events)
-            hipLaunchKernelGGL(k_sh_eseg, dim3((unsigned)((s_pass + 255) / 256)), dim3(256), 0, ctx->stream, (const int64_t *)d_seg_off + s_base,
-                               s_pass, j.chunk, (const int *)d_nonint + s_base, (double *)ctx->ws_eseg.p + s_base);
-            HIPCHK(ctx, hipGetLastError());
-        }
+        // (the reference-order bound of a sample is a closed form of its length and its "not an integer" flag, complete once every
+        // expansion of the pass has run: k_sh_finish evaluates it where it needs it)
         {
             ProfScope ps(ctx, PK_REDUCE);
             hipLaunchKernelGGL(k_sh_finish, dim3((unsigned)p->n_acc, (unsigned)((s_pass + 63) / 64)), dim3(256), 0, ctx->stream,
                                (const int *)ctx->ws_sh_partial.p, tiles, (int)groups, ldn, digits, (const int64_t *)d_seg_off, s_base,
-                               s_pass, p->n_acc, j.certify ? (const double *)ctx->ws_eseg.p : (const double *)nullptr,
+                               s_pass, p->n_acc, j.chunk, j.certify ? (const int *)d_nonint : (const int *)nullptr,
                                ctx->debug_reeval, j.d_score, j.d_ninfo, j.ldo, seg_pairs(ctx), seg_pair_count(ctx), j.cap);
             HIPCHK(ctx, hipGetLastError());
         }

@@ -54,7 +54,8 @@ __host__ __device__ __forceinline__ int sh_frac_bits(int digits) { return 8 * (d
 // it converts them): marks the rows in the bitmap of panel rows (the bit is read first: most rows of a batch on one marker set are
 // marked already, and 64 samples would otherwise send 64 atomics to every word), checks that every index lies inside the panel and
 // that every sample's list is strictly increasing (the union holds every (sample, row) at most once).  Four entries per lane in
-// flight.
+// flight, and the grid is sized so that those four are ALL a lane has (ceil(longest sample / 1024) blocks per sample: 41 us for
+// 64 x 194k entries; three rounds of four on a quarter of the blocks took 70).
 __device__ __forceinline__ void sh_mark_row(int64_t r, int64_t r_prev, bool has_prev, int64_t n_snp, uint32_t *__restrict__ bitmap, int &bad)
 {
     if (r < 0 || r >= n_snp) {
@@ -64,7 +65,7 @@ __device__ __forceinline__ void sh_mark_row(int64_t r, int64_t r_prev, bool has_
     if (has_prev && r_prev >= r) bad |= 1;
     uint32_t *wp = &bitmap[r >> 5];
     const uint32_t bit = 1u << (r & 31);
-    if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(wp, bit);
+    if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(wp, bit);      // (a plain test load: same time)
 }
 
 __global__ void __launch_bounds__(256)
@@ -92,20 +93,14 @@ k_sh_mark(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off,
     if ((threadIdx.x & 63) == 0 && bad) atomicOr((unsigned long long *)&meta[1], (unsigned long long)bad);
 }
 
-// k_sh_eseg: the reference-order error bound of every sample in closed form.  The contraction takes weights in [0, 1] only, so
+// sh_eseg_of: the reference-order error bound of a sample in closed form.  The contraction takes weights in [0, 1] only, so
 // wmax_r <= 1 (and = 1 on every row whose genotype likelihoods are normalised: min PL = 0) and the sum k_eseg_part forms from the
 // weights is at most  sum_k len_k (len_k + 3 + K - k)  (chunk k of K, len_k rows) -- no pass over the weights.  A sample whose
-// weights are all integers (`nonint` unset by k_sh_expand) has bound 0: any summation order is exact.  + the conversions of k_sh_finish.
-__global__ void k_sh_eseg(const int64_t *__restrict__ seg_off, int64_t n_seg, int64_t chunk, const int *__restrict__ nonint,
-                          double *__restrict__ eseg)
+// weights are all integers (`nonint` unset by k_sh_expand) has bound 0: any summation order is exact.  + the conversions of
+// k_sh_finish, which evaluates this per (sample, accession) -- some thirty flops -- instead of reading it from a kernel of its own.
+__device__ __forceinline__ double sh_eseg_of(int64_t len, int64_t chunk, int nonint)
 {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seg) return;
-    const int64_t len = seg_off[s + 1] - seg_off[s];
-    if (!nonint[s] || len == 0) {
-        eseg[s] = 0.0;
-        return;
-    }
+    if (!nonint || len == 0) return 0.0;
     const int64_t K = (len + chunk - 1) / chunk;
     const int64_t last = len - (K - 1) * chunk;                  // rows of the last chunk
     // sum over the K - 1 full chunks k = 0 .. K-2 of chunk (chunk + 3 + K - k), + the last one
@@ -115,7 +110,7 @@ __global__ void k_sh_eseg(const int64_t *__restrict__ seg_off, int64_t n_seg, in
     const double u = 1.1102230246251565e-16;
     const double mmax = (double)((chunk < len ? chunk : len) + 3 + K);
     const double mf = 4.0;
-    eseg[s] = (acc * u / (1.0 - mmax * u) + (double)len * (mf * u / (1.0 - mf * u))) * 1.0000001;
+    return (acc * u / (1.0 - mmax * u) + (double)len * (mf * u / (1.0 - mf * u))) * 1.0000001;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -593,7 +588,7 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
 // [v - E, v + E + Eq], E = eseg[s] (reference-order bound + the conversion), Eq = len[s] 2^-F (the quantisation, one-sided).
 __global__ void __launch_bounds__(256)
 k_sh_finish(const int *__restrict__ partial, int n_tiles, int n_groups, int64_t ldn, int digits, const int64_t *__restrict__ seg_off,
-            int64_t s_base, int64_t n_samples_pass, int64_t n_acc, const double *__restrict__ eseg,
+            int64_t s_base, int64_t n_samples_pass, int64_t n_acc, int64_t chunk, const int *__restrict__ nonint /* of the batch's samples; null: no certificate */,
             int force_first, double *__restrict__ score, int64_t *__restrict__ ninfo, int64_t ldo, int32_t *__restrict__ pairs,
             int *__restrict__ count, int cap)
 {
@@ -642,8 +637,8 @@ k_sh_finish(const int *__restrict__ partial, int n_tiles, int n_groups, int64_t 
         if (j == digits) missing = dsum[j];
     score[sg * ldo + a] = v;
     ninfo[sg * ldo + a] = len - missing;
-    if (eseg) {
-        const double E = eseg[sg] + 8.0 * 1.1102230246251565e-16 * (fabs(v) + 1.0);
+    if (nonint) {
+        const double E = sh_eseg_of(len, chunk, nonint[sg]) + 8.0 * 1.1102230246251565e-16 * (fabs(v) + 1.0);
         // quantisation, one-sided: every matched SNP may lose up to 2^-F (counted for all of them: an upward-only slack cannot
         // flag an exact-integer score, floor(v) = floor(v + Eq) as long as Eq < 1)
         const double Eq = __builtin_ldexp((double)len, -frac_bits) * 1.0000001;
