@@ -54,22 +54,24 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     uint32_t *d_blocksum = (uint32_t *)ctx->ws_sh_blocks.p, *d_blockbase = d_blocksum + n_blocks;
     int32_t *d_urows = (int32_t *)ctx->ws_sh_urows.p;
     HIPCHK(ctx, hipMemsetAsync(ctx->ws_sh_bitmap.p, 0, meta_bytes + (size_t)n_words * 4, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(d_seg_off, j.seg_off, ((size_t)n_seg + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     const int urow_pad = (int)(urow_entries - (size_t)u_max);            // zero rows behind the union: written by k_sh_scan, which knows where it ends
     const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((maxlen + 255) / 256, 64));
-    if ((rc = ensure_pinned(ctx, 64))) return rc;
+    // the sample offsets: left in pinned memory, read there by the first kernels (k_sh_probe, k_sh_mark; the latter stores the device copy)
+    if ((rc = ensure_pinned(ctx, 64 + ((size_t)n_seg + 1) * 8))) return rc;
     long long *h_meta = (long long *)ctx->h_pinned;
+    const int64_t *h_seg_off = (const int64_t *)((char *)ctx->h_pinned + 64);
+    memcpy((char *)ctx->h_pinned + 64, j.seg_off, ((size_t)n_seg + 1) * 8);
     if (!forced && p->n_snp >= 4096 && ctx->shared_probe) {
         // automatic policy: look at 1/32 of the panel first (the batch's calls below row n_snp / 32); scattered marker sets are
         // declined here, before the full pass over every row and weight of the batch
         const int64_t row_limit = (p->n_snp / 32 + 31) / 32 * 32;
         const int64_t words_probe = row_limit / 32;
         const int64_t blocks_probe = (words_probe + SH_WORDS_PER_BLOCK - 1) / SH_WORDS_PER_BLOCK;
-        hipLaunchKernelGGL(k_sh_probe, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, row_limit,
+        hipLaunchKernelGGL(k_sh_probe, dim3((unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, h_seg_off, row_limit,
                            p->n_snp, d_bitmap, d_meta);
         hipLaunchKernelGGL(k_sh_count, dim3((unsigned)blocks_probe), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, words_probe, d_blocksum);
         hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)d_blocksum, blocks_probe, d_blockbase, d_meta,
-                           (int32_t *)nullptr, 0, (const int *)nullptr);
+                           (int32_t *)nullptr, 0, (const int *)nullptr, (int *)nullptr);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(h_meta, d_meta, 32, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -81,18 +83,17 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
             if (est < 0.8 * ctx->shared_min_density_of(p->packed != 0)) { st.reason = 6; return SNPM_OK; }
         }
     }
-    // (the pair counter is cleared here, ahead of the host's wait for the union, so that nothing but launches follows that wait)
+    // (the pair counter is cleared by k_sh_scan: no memset of its own, and nothing but launches follows the host's wait for the union)
     if ((rc = ensure(ctx, ctx->ws_pairs, 16 + (size_t)SEG_PAIR_CAP * 2 * sizeof(int32_t)))) return rc;
-    HIPCHK(ctx, hipMemsetAsync(seg_pair_count(ctx), 0, sizeof(int), ctx->stream));
     // one pass over the row lists: marks and index checks (the weights are vetted by k_sh_expand while it converts them)
     {
         ProfScope ps(ctx, PK_LUT);
         const unsigned mgx = (unsigned)std::max<int64_t>(1, std::min<int64_t>((maxlen + 1023) / 1024, 16384));        // four entries per lane
-        hipLaunchKernelGGL(k_sh_mark, dim3(mgx, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, p->n_snp,
+        hipLaunchKernelGGL(k_sh_mark, dim3(mgx, (unsigned)n_seg), dim3(256), 0, ctx->stream, j.d_row_idx, h_seg_off, d_seg_off, p->n_snp,
                            d_bitmap, d_meta);
         hipLaunchKernelGGL(k_sh_count, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, n_words, d_blocksum);
         hipLaunchKernelGGL(k_sh_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)d_blocksum, n_blocks, d_blockbase, d_meta, d_urows,
-                           urow_pad, (!p->packed && p->d_other) ? (const int *)p->d_other : (const int *)nullptr);
+                           urow_pad, (!p->packed && p->d_other) ? (const int *)p->d_other : (const int *)nullptr, seg_pair_count(ctx));
         hipLaunchKernelGGL(k_sh_fill, dim3((unsigned)n_blocks), dim3(256), 0, ctx->stream, (const uint32_t *)d_bitmap, n_words,
                            (const uint32_t *)d_blockbase, d_wordbase, d_urows);
         HIPCHK(ctx, hipGetLastError());

@@ -69,11 +69,17 @@ __device__ __forceinline__ void sh_mark_row(int64_t r, int64_t r_prev, bool has_
 }
 
 __global__ void __launch_bounds__(256)
-k_sh_mark(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off, int64_t n_snp, uint32_t *__restrict__ bitmap,
-          long long *__restrict__ meta)
+k_sh_mark(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off /* pinned host memory */, int64_t *__restrict__ seg_off_dev,
+          int64_t n_snp, uint32_t *__restrict__ bitmap, long long *__restrict__ meta)
 {
+    // the sample offsets are read where the host left them (two 8-byte reads over the bus per block) and stored for the kernels that
+    // follow: an upload of their own was one more operation in front of the first kernel of the call
     const int64_t s = blockIdx.y;
     const int64_t r0 = seg_off[s], r1 = seg_off[s + 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        seg_off_dev[s] = r0;
+        if (s + 1 == (int64_t)gridDim.y) seg_off_dev[s + 1] = r1;
+    }
     int bad = 0;
     const int64_t stride = (int64_t)gridDim.x * 256;
     int64_t i = r0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -171,8 +177,10 @@ k_sh_count(const uint32_t *__restrict__ bitmap, int64_t n_words, uint32_t *__res
 
 __global__ void __launch_bounds__(1024)
 k_sh_scan(const uint32_t *__restrict__ block_sum, int64_t n_blocks, uint32_t *__restrict__ block_base, long long *__restrict__ meta,
-          int32_t *__restrict__ union_rows /* or null */, int pad_entries, const int *__restrict__ other_codes /* or null */)
+          int32_t *__restrict__ union_rows /* or null */, int pad_entries, const int *__restrict__ other_codes /* or null */,
+          int *__restrict__ pair_count /* cleared here, or null */)
 {
+    if (threadIdx.x == 0 && pair_count) *pair_count = 0;
     __shared__ uint32_t sm[16];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
