@@ -21,7 +21,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     st = SharedStats();
     const int64_t n_seg = j.n_seg, N = j.n_total;
     if (n_seg < (forced ? 1 : ctx->shared_min_samples) || N < 1) { st.reason = 2; return SNPM_OK; }
-    if (p->n_snp > 0x7fffffffLL || N > 0xfffffff0LL || !j.d_row_idx) { st.reason = 7; return SNPM_OK; }
+    if (p->n_snp > 0x7fffffffLL || N > 0xfffffff0LL || n_seg > 65535 /* a grid dimension */ || !j.d_row_idx) { st.reason = 7; return SNPM_OK; }
     int rc;
     int64_t maxlen = 0, kmax = 1;
     for (int64_t s = 0; s < n_seg; ++s) {

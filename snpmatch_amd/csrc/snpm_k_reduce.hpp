@@ -187,6 +187,7 @@ __device__ __forceinline__ double add_if(double acc, bool match, double w)
 // the plain form for the latency-bound sparse kernels (one lane per segment and column, per-lane weights),
 // where the fma form measured slower (k_strict_sparse_T: 0.53 vs 0.36 ms per re-evaluated accession at 50M SNPs)
 __device__ __forceinline__ double add_sel(double acc, bool match, double w) { return acc + (match ? w : 0.0); }
+constexpr int64_t STRICT_PAIRS_LANE_FORM = 2048;       // (pair, chunk) chains from which k_strict_pairs gives every chain a lane instead of a wave
 
 // genotype code of (row, accession) in either panel format: int8 -> the byte (negative = missing);
 // packed -> 2-bit field, 3 = missing (returned as -1)
@@ -319,6 +320,13 @@ __global__ void k_reduce_seg(const double *__restrict__ part_score, const uint32
 // of 64 rows in flight instead of one dependent gather per row.  (Round 3 gave every chunk ONE lane: a window of `cross` is a
 // single chunk, so a flagged (window, accession) pair walked its ~500 gathered rows on one lane -- 0.24 ms of a 0.06-ms pass.)
 //   grid.x walks the chunks of a segment, grid.y the flagged pairs (both bounded: no pair flagged = a launch of microseconds)
+//   Two forms in one launch, chosen by the number of (pair, chunk) chains the device finds flagged:
+//   few chains    a WAVE per chain (latency: a lone flagged pair should cost microseconds): 64 rows loaded side by side, their
+//                 three per-class contributions formed in parallel (the reference adds 0.0 where the class does not match,
+//                 add_sel), the chain of additions walked from broadcast values: 6 v_readlane + 3 v_add_f64 per row;
+//   many chains   a LANE per chain (throughput: every lane of the wave form executes the same additions, 64 pairs of a
+//   (>= 2048)     200-chunk sample kept the chip busy for 0.93 ms): a lane walks its own chunk, eight rows' loads in flight --
+//                 ~0.13 ms however many chains there are, up to tens of thousands.
 template <bool SKIP, bool GATHER>
 __global__ void __launch_bounds__(64)
 k_strict_pairs(const int8_t *__restrict__ db, int64_t pitch, int64_t packed, const int64_t *__restrict__ row_idx, int64_t row0,
@@ -328,6 +336,68 @@ k_strict_pairs(const int8_t *__restrict__ db, int64_t pitch, int64_t packed, con
 {
     const int np = *count < cap ? *count : cap;
     const int lane = threadIdx.x;
+    if ((int64_t)np * kmax >= STRICT_PAIRS_LANE_FORM) {
+        const int64_t n_items = (int64_t)np * kmax;
+        const int64_t n_waves = (int64_t)gridDim.x * gridDim.y;
+        for (int64_t it0 = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * WAVE; it0 < n_items; it0 += n_waves * WAVE) {
+            const int64_t it = it0 + lane;
+            if (it >= n_items) continue;
+            const int pr = (int)(it / kmax);
+            const int64_t k = it - (int64_t)pr * kmax;
+            const int64_t sg = pairs[2 * pr], col = pairs[2 * pr + 1];
+            const int64_t s0 = seg_off[sg], s1 = seg_off[sg + 1];
+            int64_t K = (s1 - s0 + chunk - 1) / chunk;
+            if (K < 1) K = 1;
+            if (k >= K) continue;
+            const int64_t r0 = s0 + k * chunk;
+            const int64_t r1 = (r0 + chunk < s1) ? r0 + chunk : s1;
+            // where this lane's column lies in a row, and how its code comes out of the byte there, settled ONCE: code_at decides
+            // the panel format per call, and eight loads behind eight branches were eight round trips, one after the other
+            // (codes are compared with 0, 1, 2 only: an int8 byte taken as 0..255 and a 2-bit field 0..3 answer alike)
+            int64_t base, stride;
+            int sh = 0, mask = 0xff;
+            if (packed) {
+                const int64_t bcol = col >> 2, tp = pk_tail_pitch(packed);
+                if (tp && bcol >= pitch) { base = pk_tail_off(packed) + (bcol - pitch); stride = tp; }
+                else { base = bcol; stride = pitch; }
+                sh = 2 * (int)(col & 3);
+                mask = 3;
+            } else {
+                base = col;
+                stride = pitch;
+            }
+            const uint8_t *cell = (const uint8_t *)db + base;
+            double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
+            int64_t r = r0;
+            for (; r + 8 <= r1; r += 8) {
+                int b[8];
+                double w0[8], w1[8], w2[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t prow = GATHER ? row_idx[r + u] : (row0 + r + u);
+                    b[u] = ((int)cell[prow * stride] >> sh) & mask;
+                    w0[u] = w[3 * (r + u) + 0];
+                    w1[u] = SKIP ? 0.0 : w[3 * (r + u) + 1];
+                    w2[u] = w[3 * (r + u) + 2];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    a_ref = add_sel(a_ref, b[u] == 0, w0[u]);
+                    if (!SKIP) a_het = add_sel(a_het, b[u] == 2, w1[u]);
+                    a_alt = add_sel(a_alt, b[u] == 1, w2[u]);
+                }
+            }
+            for (; r < r1; ++r) {
+                const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
+                const int bb = ((int)cell[prow * stride] >> sh) & mask;
+                a_ref = add_sel(a_ref, bb == 0, w[3 * r + 0]);
+                if (!SKIP) a_het = add_sel(a_het, bb == 2, w[3 * r + 1]);
+                a_alt = add_sel(a_alt, bb == 1, w[3 * r + 2]);
+            }
+            sums[(int64_t)pr * kmax + k] = ((0.0 + a_ref) + a_het) + a_alt;
+        }
+        return;
+    }
     for (int pr = blockIdx.y; pr < np; pr += gridDim.y) {
         const int64_t sg = pairs[2 * pr], col = pairs[2 * pr + 1];
         const int64_t s0 = seg_off[sg], s1 = seg_off[sg + 1];
@@ -337,23 +407,35 @@ k_strict_pairs(const int8_t *__restrict__ db, int64_t pitch, int64_t packed, con
             const int64_t r0 = s0 + k * chunk;
             const int64_t r1 = (r0 + chunk < s1) ? r0 + chunk : s1;
             double a_ref = 0.0, a_het = 0.0, a_alt = 0.0;
+            // the next 64 rows are requested before the current 64 are added
+            int bn = -1;
+            double wn0 = 0.0, wn1 = 0.0, wn2 = 0.0;
+            if (r0 + lane < r1) {
+                const int64_t r = r0 + lane;
+                const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
+                bn = code_at(db, pitch, prow, col, packed);
+                wn0 = w[3 * r + 0];
+                wn1 = w[3 * r + 1];
+                wn2 = w[3 * r + 2];
+            }
             for (int64_t rb = r0; rb < r1; rb += WAVE) {
-                const int64_t r = rb + lane;
-                int b = -1;
-                double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-                if (r < r1) {
+                // this lane's row: what the reference adds to each class sum (0.0 where the class does not match: add_sel)
+                const double c0 = bn == 0 ? wn0 : 0.0, c1 = bn == 2 ? wn1 : 0.0, c2 = bn == 1 ? wn2 : 0.0;
+                bn = -1;
+                wn0 = wn1 = wn2 = 0.0;
+                if (rb + WAVE + lane < r1) {
+                    const int64_t r = rb + WAVE + lane;
                     const int64_t prow = GATHER ? row_idx[r] : (row0 + r);
-                    b = code_at(db, pitch, prow, col, packed);
-                    w0 = w[3 * r + 0];
-                    w1 = w[3 * r + 1];
-                    w2 = w[3 * r + 2];
+                    bn = code_at(db, pitch, prow, col, packed);
+                    wn0 = w[3 * r + 0];
+                    wn1 = w[3 * r + 1];
+                    wn2 = w[3 * r + 2];
                 }
                 const int cnt = (int)((r1 - rb < WAVE) ? (r1 - rb) : WAVE);
                 for (int i = 0; i < cnt; ++i) {
-                    const int bi = __shfl(b, i);
-                    a_ref = add_sel(a_ref, bi == 0, __shfl(w0, i));
-                    if (!SKIP) a_het = add_sel(a_het, bi == 2, __shfl(w1, i));
-                    a_alt = add_sel(a_alt, bi == 1, __shfl(w2, i));
+                    a_ref = a_ref + __shfl(c0, i);
+                    if (!SKIP) a_het = a_het + __shfl(c1, i);
+                    a_alt = a_alt + __shfl(c2, i);
                 }
             }
             if (lane == 0) sums[(int64_t)pr * kmax + k] = ((0.0 + a_ref) + a_het) + a_alt;

@@ -335,27 +335,30 @@ def test_random_configurations_against_the_oracle(seed):
 
 def test_forced_pairs_and_the_reference_order_fallback_behind_the_contraction():
     """SNPM_DEBUG_REEVAL=k flags accessions 0..k-1 of every sample: the pair re-evaluation behind the shared-row pass returns the
-    reference's fp64 bits for them; with more flagged pairs than the sparse tier takes (700 x 60 > 32768) every sample goes
-    through the reference-order chain -- from the caller's device arrays, which the pass read in place"""
+    reference's fp64 bits for them -- in both forms of k_strict_pairs: a wave per (pair, chunk) chain while they are few (3 x 60
+    pairs x 3 chunks), a lane per chain from 2048 chains on (chunks of 50 rows; 40 flagged accessions per sample; packed panel and
+    skip_hets included); with more flagged pairs than the sparse tier takes (700 x 60 > 32768) every sample goes through the
+    reference-order chain -- from the caller's device arrays, which the pass read in place"""
     import torch
     rng = np.random.default_rng(77)
     n_snp, n_acc = 30_000, 800
     db = rand_db(rng, n_snp, n_acc)
     samples = chip_samples(rng, db, 60, 2500)
     off = np.concatenate([[0], np.cumsum([len(r) for r, _ in samples])]).astype(np.int64)
-    for reeval in (3, 700):
+    for reeval, chunk, packed, skip in ((3, 1000, False, False), (3, 50, False, False), (3, 37, True, True), (40, 1000, True, False),
+                                        (700, 1000, False, False)):
         ctx = make_ctx(SNPM_DEBUG_REEVAL=reeval)
-        panel = engine.Panel.from_host(ctx, db)
+        panel = engine.Panel.from_host(ctx, db, packed=packed)
         d_rows = torch.as_tensor(np.concatenate([r for r, _ in samples]), device="cuda:0")
         d_wei = torch.as_tensor(np.concatenate([w for _, w in samples]), device="cuda:0")
-        got = engine.score_batch(panel, None, 1000, False, engine.MODE_EXACT, device=(d_rows.data_ptr(), d_wei.data_ptr(), off))
+        got = engine.score_batch(panel, None, chunk, skip, engine.MODE_EXACT, device=(d_rows.data_ptr(), d_wei.data_ptr(), off))
         assert got["shared_rows"] and got["pairs_reeval"] >= reeval * 60
         assert got["strict_fallback"] == (reeval == 700)
         for b, (rows, wei) in enumerate(samples):
-            want_s, want_n = c_oracle.genotyper(db, rows, wei, 1000, False)
+            want_s, want_n = c_oracle.genotyper(db, rows, wei, chunk, skip)
             assert np.array_equal(got["ninfo"][b], want_n) and np.array_equal(got["score"][b].astype(np.int64), want_s.astype(np.int64)), b
             k = n_acc if reeval == 700 else reeval                     # these went through the reference-order kernels: its bits
-            assert np.array_equal(got["score"][b][:k].view(np.uint64), want_s[:k].view(np.uint64)), b
+            assert np.array_equal(got["score"][b][:k].view(np.uint64), want_s[:k].view(np.uint64)), (b, reeval, chunk, packed, skip)
         ctx.close()
 
 
