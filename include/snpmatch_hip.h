@@ -264,18 +264,20 @@ int snpm_score_batch_coded(snpm_panel *panel, int64_t n_samples, const int64_t *
    no rounding error, only the one-sided quantisation n_inexact 2^-F per sample; the certificate of SNPM_MODE_EXACT covers it and
    the unproven (sample, accession) pairs are re-scored in reference order as before: int(score) and ninfo stay bit-exact.
    Taken when every sample's row list is strictly increasing, all weights lie in [0, 1] and the panel holds no call code > 2;
-   otherwise (and in SNPM_MODE_STRICT) the per-sample pass runs.
+   otherwise (and in SNPM_MODE_STRICT) the per-sample pass runs.  The weights are vetted while they are converted, i.e. after
+   the pass was taken: a batch with a weight outside [0, 1] is scored AGAIN through the per-sample pass inside the same call
+   (results as if the shared-row pass had never run; stats [1] = 4, info[2] = 0).
      shared_rows  -1 (default; SNPM_BATCH_SHARED) automatic: batches whose inputs are already on the device (device_inputs != 0),
                   of at least 8 samples, with at least min_density calls per (sample, union row) slot;  0 never;
                   1 whenever the batch allows it (host batches are uploaded whole first)
      digits       3..7, or -1 (default; SNPM_SHARED_DIGITS=0): the fewest digits that keep a sample's quantisation below 2^-20 --
                   5 up to 262 144 matched SNPs per sample, 6 up to 2^26, else 7; 0 keeps the current value
-     min_density  threshold of the automatic choice (default 0.25; SNPM_SHARED_MIN_DENSITY); negative keeps the current value
+     min_density  threshold of the automatic choice (default 0.14 on int8, 0.28 on packed panels; SNPM_SHARED_MIN_DENSITY); negative keeps the current value
    snpm_score_batch[_coded] report in info[2] whether the shared-row pass scored the batch and in info[3] its union rows. */
 int snpm_batch_configure(snpm_ctx *ctx, int shared_rows, int digits, double min_density);
 /* stats int64 [8] of the context's last snpm_score_batch[_coded] call: [0] 1 = shared-row pass taken, [1] else why not (1 policy,
    2 too few samples or rows, 3 a row list not strictly increasing, 4 a weight outside [0, 1], 5 call codes > 2 in the panel,
-   6 overlap below min_density, 7 sizes beyond 32-bit indices, 8 a row index outside the panel), [2] union rows, [3] density * 1e6, [4] row tiles, [5] groups of
+   6 overlap below min_density, 7 sizes beyond 32-bit indices or more than 65 535 samples, 8 a row index outside the panel), [2] union rows, [3] density * 1e6, [4] row tiles, [5] groups of
    128 matrix rows, [6] passes over groups, [7] digits */
 int snpm_batch_last_stats(snpm_ctx *ctx, int64_t *stats);
 

@@ -95,7 +95,9 @@ struct snpm_ctx {
     // the automatic choice: calls per (sample, union row) slot from which the contraction is the cheaper pass -- measured on 64
     // samples x 200k SNPs x 1135 accessions: the contraction costs ~2.8 ns per union row, the per-sample pass 0.27 ns (int8) /
     // 0.16 ns (packed) per call
-    double shared_min_density_of(bool packed) const { return shared_min_density >= 0.0 ? shared_min_density : (packed ? 0.35 : 0.2); }
+    // break-even of the two passes at 64 samples x 200k markers on 1135 accessions (profiles/r05_shared_density.txt): int8 between 0.10 and
+    // 0.15 calls per (sample, union row) slot, packed between 0.2 and 0.3
+    double shared_min_density_of(bool packed) const { return shared_min_density >= 0.0 ? shared_min_density : (packed ? 0.28 : 0.14); }
     int64_t shared_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // snpm_batch_last_stats
     int64_t *h_desc = nullptr;          // pinned host image of ws_seg_desc
     size_t h_desc_cap = 0;
