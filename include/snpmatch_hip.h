@@ -268,11 +268,11 @@ int snpm_score_batch_coded(snpm_panel *panel, int64_t n_samples, const int64_t *
    the pass was taken: a batch with a weight outside [0, 1] is scored AGAIN through the per-sample pass inside the same call
    (results as if the shared-row pass had never run; stats [1] = 4, info[2] = 0).
      shared_rows  -1 (default; SNPM_BATCH_SHARED) automatic: batches whose inputs are already on the device (device_inputs != 0),
-                  of at least 8 samples, with at least min_density calls per (sample, union row) slot;  0 never;
+                  of at least 4 samples, with at least min_density calls per (sample, union row) slot;  0 never;
                   1 whenever the batch allows it (host batches are uploaded whole first)
      digits       3..7, or -1 (default; SNPM_SHARED_DIGITS=0): the fewest digits that keep a sample's quantisation below 2^-20 --
                   5 up to 262 144 matched SNPs per sample, 6 up to 2^26, else 7; 0 keeps the current value
-     min_density  threshold of the automatic choice (default 0.14 on int8, 0.28 on packed panels; SNPM_SHARED_MIN_DENSITY); negative keeps the current value
+     min_density  threshold of the automatic choice (default 0.14 on int8, 0.28 on packed panels, 0.5 for fewer than 8 samples; SNPM_SHARED_MIN_DENSITY); negative keeps the current value
    snpm_score_batch[_coded] report in info[2] whether the shared-row pass scored the batch and in info[3] its union rows. */
 int snpm_batch_configure(snpm_ctx *ctx, int shared_rows, int digits, double min_density);
 /* stats int64 [8] of the context's last snpm_score_batch[_coded] call: [0] 1 = shared-row pass taken, [1] else why not (1 policy,

@@ -82,7 +82,8 @@ struct snpm_ctx {
     Buf ws_sh_bitmap, ws_sh_wordbase, ws_sh_blocks, ws_sh_urows, ws_sh_meta, ws_sh_A, ws_sh_pos, ws_sh_partial;
     int batch_shared = -1;              // SNPM_BATCH_SHARED / snpm_batch_configure: -1 auto (batches whose inputs are on the device), 0 never, 1 whenever the batch allows it
     int shared_digits = 0;              // base-256 digits of the fixed-point weights (3..7: 2^-(8 (digits - 1) + 6) per matched SNP of quantisation); 0 = by the longest sample
-    int shared_min_samples = 8;         // auto: smaller batches keep the per-sample pass
+    int shared_min_samples = 4;         // auto: smaller batches keep the per-sample pass (2 / 3 / 4 / 6 samples of 194k SNPs on one marker set: 0.28 / 0.29 / 0.30 / 0.32 ms
+                                        // against 0.32 / 0.35 / 0.39 / 0.53: the gain below 4 is within what a lower overlap takes back)
     double shared_min_density = -1.0;   // auto threshold; negative: by panel format (shared_min_density_of)
     size_t shared_ws_bytes = size_t(2) << 30;   // SNPM_SHARED_WS_MB: digit matrix per pass over groups of samples
     int shared_force_tiles = 0;         // SNPM_SHARED_TILES: row tiles of k_sh_mfma (tests, experiments)
@@ -97,7 +98,12 @@ struct snpm_ctx {
     // 0.16 ns (packed) per call
     // break-even of the two passes at 64 samples x 200k markers on 1135 accessions (profiles/r05_shared_density.txt): int8 between 0.10 and
     // 0.15 calls per (sample, union row) slot, packed between 0.2 and 0.3
-    double shared_min_density_of(bool packed) const { return shared_min_density >= 0.0 ? shared_min_density : (packed ? 0.28 : 0.14); }
+    double shared_min_density_of(bool packed, int64_t n_samples) const
+    {
+        if (shared_min_density >= 0.0) return shared_min_density;
+        const double th = packed ? 0.28 : 0.14;
+        return n_samples < 8 ? (th > 0.5 ? th : 0.5) : th;      // a handful of samples: only when they really are on one marker set
+    }
     int64_t shared_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // snpm_batch_last_stats
     int64_t *h_desc = nullptr;          // pinned host image of ws_seg_desc
     size_t h_desc_cap = 0;

@@ -80,7 +80,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
             const double est = (double)n_probe / ((double)u_probe * (double)n_seg);
             st.union_rows = u_probe * 32;                       // an estimate
             st.density = est;
-            if (est < 0.8 * ctx->shared_min_density_of(p->packed != 0)) { st.reason = 6; return SNPM_OK; }
+            if (est < 0.8 * ctx->shared_min_density_of(p->packed != 0, n_seg)) { st.reason = 6; return SNPM_OK; }
         }
     }
     // (the pair counter is cleared by k_sh_scan: no memset of its own, and nothing but launches follows the host's wait for the union)
@@ -109,7 +109,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     if (bad & 1) { st.reason = 3; return SNPM_OK; }
     if (other) { st.reason = 5; return SNPM_OK; }
     if (U < 1) { st.reason = 2; return SNPM_OK; }
-    if (!forced && st.density < ctx->shared_min_density_of(p->packed != 0)) { st.reason = 6; return SNPM_OK; }
+    if (!forced && st.density < ctx->shared_min_density_of(p->packed != 0, n_seg)) { st.reason = 6; return SNPM_OK; }
 
     // ---- geometry
     // K steps of 8 union rows, padded to a multiple of SH_DEPTH with rows no sample has a call at (zero digits): the kernel's body is unconditional

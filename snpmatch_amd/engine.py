@@ -720,7 +720,7 @@ SHARED_WHY_NOT = {0: "", 1: "policy", 2: "too few samples or rows", 3: "a row li
 
 def batch_configure(ctx, shared_rows=-1, digits=0, min_density=-1.0):
     """Policy of score_batch for batches whose samples share DB rows (snpm_batch_configure): shared_rows -1 automatic (device
-    inputs, >= 8 samples, enough overlap), 0 never, 1 whenever the batch allows it; digits 3..7 base-256 digits of the fixed-point
+    inputs, >= 4 samples, enough overlap), 0 never, 1 whenever the batch allows it; digits 3..7 base-256 digits of the fixed-point
     weights (-1: chosen by the longest sample, 0: keep); min_density: threshold of the automatic choice (negative: keep)."""
     check(ctx.lib.snpm_batch_configure(ctx.h, int(shared_rows), int(digits), float(min_density)), ctx.h)
 
