@@ -402,9 +402,9 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
 
 // ---------------------------------------------------------------------------------------------------------------
 // one-hot B fragments of 4 accessions x 4 rows.  int8 panel: x[i] = the dword of row i (4 accessions as bytes): transpose, then
-// byte -> 1 << 8 (code & 3).  Packed panel: x[i] = one byte of row i (4 accessions as 2-bit fields).
+// byte -> 1 << 8 (code & 3).  Packed panel: x[i] = the aligned dword around the lane's byte of row i (4 accessions as 2-bit fields).
 template <bool PACKED>
-__device__ __forceinline__ void sh_onehot(const uint32_t (&x)[4], uint32_t one, sh_v4i (&b)[4])
+__device__ __forceinline__ void sh_onehot(const uint32_t (&x)[4], uint32_t one, uint32_t byte_shift, sh_v4i (&b)[4])
 {
     // every byte of y[i] = 8 * class of one accession of row i; the fragment dword of (accession j, row i) is then ONE shift whose
     // amount is byte j of y[i]: `one` is the constant 1 in a register the optimiser cannot see through and the amount keeps its
@@ -414,7 +414,8 @@ __device__ __forceinline__ void sh_onehot(const uint32_t (&x)[4], uint32_t one, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         if (PACKED) {
-            const uint32_t t = (x[i] << 3) | (x[i] << 9);        // field 0 at bits 3-4, field 1 at bits 11-12 (and junk)
+            const uint32_t xb = __builtin_amdgcn_ubfe(x[i], byte_shift, 8u);       // this lane's byte of the dword
+            const uint32_t t = (xb << 3) | (xb << 9);            // field 0 at bits 3-4, field 1 at bits 11-12 (and junk)
             y[i] = (t | (t << 12)) & 0x18181818u;                // fields 2 and 3 at bits 19-20 and 27-28
         } else {
             y[i] = (x[i] << 3) & 0x18181818u;                    // -1 (0xff) -> class 3
@@ -474,7 +475,12 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
         if (col_off > pitch - 4) col_off = pitch - 4;
         row_stride = pitch;
     }
-    const int8_t *base = db + mat_off + col_off;
+    // packed panels: the lane's byte of a row is read as the aligned dword around it and cut out when it is used (every packed pitch
+    // and matrix offset is a multiple of 4).  A byte load's value travels round the loop as an 8-bit quantity, and the compiler
+    // widened ALL sixteen of a round at the loop's head: one wait for the youngest load per round, the prefetch depth gone
+    // (SQ_WAIT_ANY 48M against 10M wave-quad-cycles on the int8 panel, 0.32 against 0.27 ms).
+    const uint32_t byte_shift = PACKED ? (uint32_t)(col_off & 3) * 8u : 0u;
+    const int8_t *base = db + mat_off + (PACKED ? (col_off & ~(int64_t)3) : col_off);
     const sh_v4i *Ag = A + (int64_t)g * steps_ld * 256 + lane;
 
     sh_v16i acc[4][4];
@@ -506,7 +512,7 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
 #define SH_LOAD_STAGE_AT(D, KS, P)                                                            \
     do {                                                                                      \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
-            x[D][i] = PACKED ? (uint32_t) * reinterpret_cast<const uint8_t *>((P)[i]) : *reinterpret_cast<const uint32_t *>((P)[i]); \
+            x[D][i] = *reinterpret_cast<const uint32_t *>((P)[i]);                            \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) a[D][t] = Ag[((KS) * 4 + t) * 64];      \
     } while (0)
 #define SH_LOAD_STAGE(D, KS)                                                                  \
@@ -536,12 +542,12 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
     sh_v4i b[2][4];
     uint32_t one = 1u;
     asm("" : "+v"(one));
-    sh_onehot<PACKED>(x[0], one, b[0]);
+    sh_onehot<PACKED>(x[0], one, byte_shift, b[0]);
     int64_t ks = k0;
     do {                                    // a tile is never empty
 #pragma unroll
         for (int d = 0; d < SH_DEPTH; ++d) {
-            sh_onehot<PACKED>(x[(d + 1) % SH_DEPTH], one, b[(d + 1) & 1]);       // stage 0 of the next round when d is the last stage
+            sh_onehot<PACKED>(x[(d + 1) % SH_DEPTH], one, byte_shift, b[(d + 1) & 1]);       // stage 0 of the next round when d is the last stage
             const int8_t *pn[4];
             SH_ROW_PTRS(d, pn);                                             // the addresses of this stage's next loads: VALU work for the MFMAs' shadow too
 #pragma unroll
