@@ -658,12 +658,14 @@ def pl_table(n=8192):
     return np.exp(np.arange(n, dtype=np.float64) / (-10))
 
 
-def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, likelihoods=True, device=None, table=None):
+def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, likelihoods=True, device=None, table=None, out=None):
     """Many samples against one resident panel in one call (snpm_score_batch).  ``samples``: list of
     (row_idx int64 [n_b], wei float64 [n_b, 3]) pairs.  With ``table`` (float64 [256]) the second element of a sample is
     uint16 codes [n_b, 3] instead, wei = table[codes] (snpm_score_batch_coded: 10 instead of 32 bytes per SNP over PCIe).  ``device`` = (d_row_idx, d_wei, offsets): the concatenated
     inputs already in device memory (raw pointers) instead.  Returns a dict with score / ninfo (and lik / lrt)
-    arrays [B, n_acc] and the re-evaluation counters."""
+    arrays [B, n_acc] and the re-evaluation counters.  ``out``: the dict of an earlier call of the same shape, whose arrays are
+    written again instead of new ones (a service that scores batch after batch: fresh arrays cost their page faults on every
+    call, 9 MB of them for 256 samples x 1135 accessions)."""
     if isinstance(panel, GroupPanel):
         return panel.score_batch(samples, chunk, skip_hets, mode, likelihoods, device, table)
     ctx = panel.ctx
@@ -693,10 +695,13 @@ def score_batch(panel, samples, chunk=1000, skip_hets=False, mode=MODE_EXACT, li
         off = np.ascontiguousarray(off, dtype=np.int64)
         p_rows, p_wei, dev_flag = C.c_void_p(int(d_rows)), C.c_void_p(int(d_wei)), 1
     nb, na = len(off) - 1, panel.n_acc
-    out = {"score": np.empty((nb, na), dtype=np.float64), "ninfo": np.empty((nb, na), dtype=np.int64)}
-    if likelihoods:
-        out["lik"] = np.empty((nb, na), dtype=np.float64)
-        out["lrt"] = np.empty((nb, na), dtype=np.float64)
+    reuse = out
+    out = {}
+    for key, dtype in (("score", np.float64), ("ninfo", np.int64)) + ((("lik", np.float64), ("lrt", np.float64)) if likelihoods else ()):
+        arr = reuse.get(key) if reuse is not None else None
+        if not (isinstance(arr, np.ndarray) and arr.shape == (nb, na) and arr.dtype == dtype and arr.flags.c_contiguous and arr.flags.writeable):
+            arr = np.empty((nb, na), dtype=dtype)
+        out[key] = arr
     info = np.zeros(4, dtype=np.int64)
     if table is not None:
         assert device is None, "coded weights come from host memory"

@@ -45,9 +45,10 @@ for policy, name in ((0, "per-sample pass"), (1, "shared-row scan")):
     out = engine.score_batch(panel, None, device=dev)
     ctx.synchronize()
     each = []
+    reuse = os.environ.get("TIME_SHARED_REUSE_OUTPUTS", "1") != "0"      # the result arrays of the previous call are written again (0: fresh arrays per call)
     for _ in range(reps):
         t0 = time.perf_counter()
-        out = engine.score_batch(panel, None, device=dev)
+        out = engine.score_batch(panel, None, device=dev, out=out if reuse else None)
         each.append(time.perf_counter() - t0)
     ctx.profile(True)
     ctx.profile_reset()
