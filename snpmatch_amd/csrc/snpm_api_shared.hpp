@@ -119,7 +119,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
     const int n_accgroups = (int)((p->n_acc + SH_WAVE_ACCS - 1) / SH_WAVE_ACCS);
     const int64_t ldn = (int64_t)n_accgroups * SH_WAVE_ACCS;
     const int64_t groups_total = (n_seg * rps + SH_GROUP_ROWS - 1) / SH_GROUP_ROWS;   // sample s owns matrix rows s * rps .. + rps - 1
-    const size_t bytes_per_group = (size_t)steps_ld * 4096;
+    const size_t bytes_per_group = (size_t)steps_ld * SH_A_STEP_BYTES;
     const size_t budget = ctx->shared_ws_bytes;
     int64_t groups_per_pass = std::max<int64_t>(1, std::min<int64_t>(groups_total, (int64_t)(budget / std::max<size_t>(bytes_per_group, 1))));
     // row tiles: blocks of one tile run on one XCD (n_cu / 8 CUs, one block each at a time); among T = 8 m tiles take the m with the
@@ -157,7 +157,7 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
         n_tiles = (int)((n_steps + steps_per_tile - 1) / steps_per_tile);
     }
     const int64_t samples_per_pass = std::max<int64_t>(1, groups_per_pass * SH_GROUP_ROWS / rps);
-    if ((rc = ensure(ctx, ctx->ws_sh_A, ((size_t)groups_per_pass * steps_ld + SH_PAD_STEPS) * 4096))) return rc;
+    if ((rc = ensure(ctx, ctx->ws_sh_A, ((size_t)groups_per_pass * steps_ld + SH_PAD_STEPS) * SH_A_STEP_BYTES))) return rc;
     if ((rc = ensure(ctx, ctx->ws_sh_pos, (size_t)std::min<int64_t>(samples_per_pass, n_seg) * ld_pos * 4))) return rc;
     if ((rc = ensure(ctx, ctx->ws_sh_partial, (size_t)n_tiles * groups_per_pass * SH_GROUP_ROWS * ldn * 4))) return rc;
     // ---- certificate: pair list (the per-sample reference-order bound is a closed form here: sh_eseg_of)

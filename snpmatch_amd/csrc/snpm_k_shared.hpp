@@ -36,9 +36,11 @@ namespace snpm {
 
 constexpr int SH_GROUP_ROWS = 128;      // matrix rows (sample digits) per wave tile
 constexpr int SH_WAVE_ACCS = 128;       // accessions per wave tile
-constexpr int SH_STEP_ROWS = 8;         // union rows per K step
-constexpr int SH_DEPTH = 4;             // K steps in flight per wave (even: the one-hot fragments of step d + 1 are built beside the MFMAs of step d in two alternating register sets)
-constexpr int SH_PAD_STEPS = 3 * SH_DEPTH;   // steps a wave may read (never score) past the last one: row list 3 x DEPTH - 2, A fragments 2 x DEPTH - 1
+constexpr int SH_STEP_ROWS = 8;         // union rows per STEP, the unit of the host's geometry (tiles, parts, pads)
+constexpr int SH_ROUND_ROWS = 32;       // a ROUND = 4 steps = 32 union rows: what a wave contracts with 3 x 16 MFMAs (K = 32 rows of ONE class each)
+constexpr int SH_DEPTH = 8;             // steps a tile is a multiple of: two rounds (the contraction's loop is unrolled over two)
+constexpr int SH_PAD_STEPS = 3 * SH_DEPTH;   // steps a wave may read (never score) past the last one: row list three rounds, panel rows two, A fragments one
+constexpr int SH_A_STEP_BYTES = 3072;   // bytes of A per group of 128 matrix rows and step: a round holds 3 classes x 4 tiles x 64 lanes x 16 B
 constexpr int SH_MAX_RPS = 8;           // matrix rows per sample: digits + the missing-count row
 
 typedef int sh_v4i __attribute__((ext_vector_type(4)));
@@ -308,17 +310,20 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
             int64_t step0, int64_t n_steps, int64_t steps_ld, sh_v4i *__restrict__ A, int *__restrict__ nonint /* of the pass's samples */,
             long long *__restrict__ meta)
 {
-    // K steps [step0, step0 + n_steps) of the pass (a launch per part: the contraction of a part starts when its digits are there).
-    // blockIdx.x = sample, blockIdx.y walks runs of 128 K steps = 1024 union rows.  A thread converts ONE union row at a time
-    // (consecutive lanes = consecutive rows: positions 4 B and weights 24 B per lane, a wave's loads cover 12 cache lines each) and
-    // leaves its six dwords in LDS, where four rows make the 16-B piece of a (step, lane half, digit row); the pieces then leave in
-    // the order they lie in A: the six digit rows of a sample are 96 contiguous bytes, so a wave's store covers ~16 cache lines.
+    // K steps [step0, step0 + n_steps) of the pass (a launch per part; both multiples of 8 = two rounds).
+    // blockIdx.x = sample, blockIdx.y walks runs of 128 K steps = 32 rounds = 1024 union rows.
+    //   phase 1  a thread converts ONE union row at a time (consecutive lanes = consecutive rows: positions 4 B and weights 24 B per
+    //            lane, a wave's loads cover 12 cache lines each) and leaves one dword per digit row -- the bytes (ref, alt, het, 0) --
+    //            in LDS, digit row major;
+    //   phase 2  a thread takes the four dwords of four consecutive rows of one digit row (one ds_read_b128), transposes them into one
+    //            dword per CLASS (rows 4q .. 4q+3 of that class: a quarter of a 16-B fragment piece) and stores the three where lane
+    //            (m, h) of tile t will load them: the six digit rows of a sample are 96 contiguous bytes of every class block.
     // (The first version gave a thread the four rows of a piece: every load and store instruction of a wave touched 48 - 64 lines,
-    // ~970 line visits per 256 rows against ~250 here, and the address path, not HBM, set its 0.22 ms.)
+    // and the address path, not HBM, set its 0.22 ms.)
     constexpr int RPS = DIGITS + 1;
-    constexpr int PIECES = 128 * 2 * RPS;                                      // of one run
-    __shared__ uint32_t stage[PIECES * 4];
+    __shared__ uint32_t stage[RPS * 1024];
     const int64_t s = blockIdx.x;
+    const int64_t rounds_ld = steps_ld >> 2;
     bool out_of_range = false, fractional = false;
     constexpr int frac_bits = 8 * (DIGITS - 1) + 6;
     const double scale = __builtin_ldexp(1.0, frac_bits);
@@ -360,8 +365,6 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
                 lo[c] = (uint32_t)Q;
                 hi[c] = (uint32_t)(Q >> 32);
             }
-            // piece (step, half) of the row and its place in it: dword index = (piece * RPS + j) * 4 + row-in-piece
-            uint32_t *dst = stage + (ul >> 2) * (RPS * 4) + (ul & 3);
 #pragma unroll
             for (int j = 0; j < DIGITS; ++j) {
                 const int p = DIGITS - 1 - j;                                  // byte position of digit j (j = 0: the top digit)
@@ -371,22 +374,37 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
                 const uint32_t t = __builtin_amdgcn_perm(src[1], src[0], 0x0c0c0000u | ((4u + b) << 8) | b);
                 uint32_t d = __builtin_amdgcn_perm(src[2], t, 0x0c000100u | ((4u + b) << 16));
                 if (j > 0) d ^= 0x00808080u;
-                dst[j * 4] = e[i] ? d : 0u;
+                stage[j * 1024 + ul] = e[i] ? d : 0u;
             }
-            dst[DIGITS * 4] = e[i] ? (skip_hets ? 0x01010000u : 0x01000000u) : 0u;
+            // the count row: 1 in every class that is an informative call (het is not when the DB's hets are skipped)
+            stage[DIGITS * 1024 + ul] = e[i] ? (skip_hets ? 0x00000101u : 0x00010101u) : 0u;
         }
         __syncthreads();
+        const int rounds_here = (int)(steps_here >> 2);
+        const int64_t round0 = (step0 + kb * 128) >> 2;
 #pragma unroll
-        for (int r = 0; r < (PIECES + 255) / 256; ++r) {
-            const int pc = r * 256 + (int)threadIdx.x;                         // piece = ((step * 2 + half) * RPS + digit row)
-            const int j = pc % RPS, kh = pc / RPS;
-            const int kk = kh >> 1, h = kh & 1;
-            if (pc < PIECES && kk < steps_here) {
+        for (int it = 0; it < RPS; ++it) {
+            const int item = it * 256 + (int)threadIdx.x;                      // (((round, half), digit row), quarter)
+            const int q = item & 3;
+            const int j = (item >> 2) % RPS;
+            const int rh = (item >> 2) / RPS;
+            const int h = rh & 1, rd = rh >> 1;
+            if (rd < rounds_here) {
+                const sh_v4i d = *reinterpret_cast<const sh_v4i *>(stage + j * 1024 + rd * 32 + h * 16 + q * 4);
+                const uint32_t lo01 = __builtin_amdgcn_perm((uint32_t)d.y, (uint32_t)d.x, 0x05010400u);       // (x.b0, y.b0, x.b1, y.b1)
+                const uint32_t hi01 = __builtin_amdgcn_perm((uint32_t)d.w, (uint32_t)d.z, 0x05010400u);
+                const uint32_t lo2 = __builtin_amdgcn_perm((uint32_t)d.y, (uint32_t)d.x, 0x0c0c0602u);        // (x.b2, y.b2, 0, 0)
+                const uint32_t hi2 = __builtin_amdgcn_perm((uint32_t)d.w, (uint32_t)d.z, 0x0c0c0602u);
+                const uint32_t o0 = __builtin_amdgcn_perm(hi01, lo01, 0x05040100u);                           // class 0 of rows 4q .. 4q+3
+                const uint32_t o1 = __builtin_amdgcn_perm(hi01, lo01, 0x07060302u);
+                const uint32_t o2 = __builtin_amdgcn_perm(hi2, lo2, 0x05040100u);
                 const int64_t M = s * RPS + j;
                 const int64_t g = M >> 7;
                 const int t = (int)((M >> 5) & 3), m = (int)(M & 31);
-                const sh_v4i v = *reinterpret_cast<const sh_v4i *>(stage + pc * 4);
-                A[((g * steps_ld + step0 + kb * 128 + kk) * 4 + t) * 64 + h * 32 + m] = v;
+                uint32_t *dst = reinterpret_cast<uint32_t *>(A + (((g * rounds_ld + round0 + rd) * 3) * 4 + t) * 64 + h * 32 + m) + q;
+                dst[0] = o0;
+                dst[4 * 64 * 4] = o1;                                          // the next class block: 4 tiles x 64 lanes x 4 dwords
+                dst[2 * 4 * 64 * 4] = o2;
             }
         }
         __syncthreads();                                                       // the next run refills the stage
@@ -401,39 +419,49 @@ k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__re
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// one-hot B fragments of 4 accessions x 4 rows.  int8 panel: x[i] = the dword of row i (4 accessions as bytes): transpose, then
-// byte -> 1 << 8 (code & 3).  Packed panel: x[i] = the aligned dword around the lane's byte of row i (4 accessions as 2-bit fields).
-template <bool PACKED>
-__device__ __forceinline__ void sh_onehot(const uint32_t (&x)[4], uint32_t one, uint32_t byte_shift, sh_v4i (&b)[4])
+// B fragments.  A lane holds 16 rows of a round (rows 16h .. 16h+15), one dword per row with the calls of its four accessions
+// (int8 panel: the bytes themselves, -1 = 0xff; packed panel: its byte of 2-bit fields spread to four bytes).  Only bits 0 and 1 of a
+// byte matter: 0 ref, 1 alt, 2 het, 3 missing.  sh_transpose turns them into V[j][q] = the codes of accession j at rows 4q .. 4q+3;
+// the fragment of class C for accession j is then the four dwords sh_ind<C>(V[j][q]): bytes 1 where the call is C -- one 3-input
+// boolean per dword (t = v >> 1 brings bit 1 of every byte to bit 0).
+template <int C>
+__device__ __forceinline__ uint32_t sh_ind(uint32_t v, uint32_t t)
 {
-    // every byte of y[i] = 8 * class of one accession of row i; the fragment dword of (accession j, row i) is then ONE shift whose
-    // amount is byte j of y[i]: `one` is the constant 1 in a register the optimiser cannot see through and the amount keeps its
-    // `& 0xff`, so that the SDWA peephole folds the byte extraction into the shift (v_lshlrev_b32_sdwa ... src0_sel:BYTE_j).  24 (int8)
-    // and 32 (packed) VALU instructions a step; the first version transposed the rows with v_perm and took 52.
-    uint32_t y[4];
+    return C == 0 ? (~(v | t) & 0x01010101u) : (C == 1 ? (v & ~t & 0x01010101u) : (~v & t & 0x01010101u));
+}
+
+template <bool PACKED>
+__device__ __forceinline__ void sh_transpose(const uint32_t (&x)[16], uint32_t byte_shift, uint32_t (&V)[4][4], uint32_t (&T)[4][4])
+{
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (PACKED) {
-            const uint32_t xb = __builtin_amdgcn_ubfe(x[i], byte_shift, 8u);       // this lane's byte of the dword
-            const uint32_t t = (xb << 3) | (xb << 9);            // field 0 at bits 3-4, field 1 at bits 11-12 (and junk)
-            y[i] = (t | (t << 12)) & 0x18181818u;                // fields 2 and 3 at bits 19-20 and 27-28
-        } else {
-            y[i] = (x[i] << 3) & 0x18181818u;                    // -1 (0xff) -> class 3
+    for (int q = 0; q < 4; ++q) {
+        uint32_t y[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (PACKED) {
+                const uint32_t xb = __builtin_amdgcn_ubfe(x[4 * q + i], byte_shift, 8u);      // this lane's byte of the dword
+                const uint32_t t1 = xb | (xb << 6);                                             // field k at bits 8k .. 8k+1 (junk elsewhere)
+                y[i] = t1 | (t1 << 12);
+            } else {
+                y[i] = x[4 * q + i];
+            }
         }
-        asm("" : "+v"(y[i]));
-    }
+        const uint32_t p0 = __builtin_amdgcn_perm(y[1], y[0], 0x05010400u);   // (y0.b0, y1.b0, y0.b1, y1.b1)
+        const uint32_t p1 = __builtin_amdgcn_perm(y[1], y[0], 0x07030602u);   // (y0.b2, y1.b2, y0.b3, y1.b3)
+        const uint32_t p2 = __builtin_amdgcn_perm(y[3], y[2], 0x05010400u);
+        const uint32_t p3 = __builtin_amdgcn_perm(y[3], y[2], 0x07030602u);
+        V[0][q] = __builtin_amdgcn_perm(p2, p0, 0x05040100u);                 // accession 0: rows 4q .. 4q+3
+        V[1][q] = __builtin_amdgcn_perm(p2, p0, 0x07060302u);
+        V[2][q] = __builtin_amdgcn_perm(p3, p1, 0x05040100u);
+        V[3][q] = __builtin_amdgcn_perm(p3, p1, 0x07060302u);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        b[j].x = (int)(one << ((y[0] >> (8 * j)) & 0xffu));
-        b[j].y = (int)(one << ((y[1] >> (8 * j)) & 0xffu));
-        b[j].z = (int)(one << ((y[2] >> (8 * j)) & 0xffu));
-        b[j].w = (int)(one << ((y[3] >> (8 * j)) & 0xffu));
+        for (int j = 0; j < 4; ++j) T[j][q] = V[j][q] >> 1;
     }
 }
 
 // k_sh_mfma: see the head of this file.  partial [n_tiles, ldn, n_groups * 128] int32 (accession-major), ldn = n_accgroups * 128: every
-// element is written by exactly one wave.  steps_per_tile K steps per row tile; union_rows carries SH_PAD_STEPS * 8 valid entries past the
-// last step and A SH_PAD_STEPS steps past the last group.
+// element is written by exactly one wave.  steps_per_tile K steps per row tile (a multiple of 8); union_rows carries SH_PAD_STEPS * 8
+// valid entries past the last step and A SH_PAD_STEPS steps past the last group.
 template <bool PACKED>
 __global__ void __launch_bounds__(256, 1)
 k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int32_t *__restrict__ union_rows,
@@ -443,9 +471,9 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
     // blocks of one row tile on ONE XCD: workgroups are dealt round-robin over the 8 XCDs in launch order.  This launch owns the
     // row tiles [tile0, n_tiles) it can reach: a pass is cut into parts of whole tiles, one launch each.
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, q = bid >> 3;
-    const int tile = tile0 + (q / blocks_per_tile) * 8 + xcd;
-    const int wb = q % blocks_per_tile;
+    const int xcd = bid & 7, q8 = bid >> 3;
+    const int tile = tile0 + (q8 / blocks_per_tile) * 8 + xcd;
+    const int wb = q8 % blocks_per_tile;
     if (tile >= n_tiles) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wt = wb * 4 + wave;
@@ -456,6 +484,7 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
     const int64_t k0 = (int64_t)tile * steps_per_tile;
     int64_t k1 = k0 + steps_per_tile;
     if (k1 > n_steps) k1 = n_steps;
+    const int64_t R0 = k0 >> 2, R1 = k1 >> 2;                   // rounds of this tile: an even number, never none
 
     // byte offset of this lane's accessions inside a row (and the matrix it lies in, for split packed panels)
     int64_t col_off, row_stride, mat_off = 0;
@@ -477,11 +506,10 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
     }
     // packed panels: the lane's byte of a row is read as the aligned dword around it and cut out when it is used (every packed pitch
     // and matrix offset is a multiple of 4).  A byte load's value travels round the loop as an 8-bit quantity, and the compiler
-    // widened ALL sixteen of a round at the loop's head: one wait for the youngest load per round, the prefetch depth gone
-    // (SQ_WAIT_ANY 48M against 10M wave-quad-cycles on the int8 panel, 0.32 against 0.27 ms).
+    // widened ALL of a round's at the loop's head: one wait for the youngest load per round, the prefetch depth gone.
     const uint32_t byte_shift = PACKED ? (uint32_t)(col_off & 3) * 8u : 0u;
     const int8_t *base = db + mat_off + (PACKED ? (col_off & ~(int64_t)3) : col_off);
-    const sh_v4i *Ag = A + (int64_t)g * steps_ld * 256 + lane;
+    const sh_v4i *Ag = A + (int64_t)g * (steps_ld >> 2) * 768 + lane;          // a round of a group: 3 x 4 x 64 fragments of 16 B
 
     sh_v16i acc[4][4];
 #pragma unroll
@@ -491,90 +519,104 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][j][r] = 0;
 
-    sh_v4i a[SH_DEPTH][4];
-    uint32_t x[SH_DEPTH][4];
-    int32_t rows_next[SH_DEPTH][4];          // union rows of the step this stage loads NEXT (one round ahead of the panel loads)
+    sh_v4i a[3][4];                          // A fragments of the round being contracted, one set per class: reloaded for the next round
+                                             // as soon as their sixteen MFMAs are issued
+    uint32_t xb[2][16];                      // panel dwords: round r lives in xb[r & 1], requested two rounds ahead
+    int32_t rn[16];                          // union rows of the round whose panel dwords are requested next
+    uint32_t V[4][4], T[4][4];               // codes of the current round by accession (and shifted by one bit)
+    sh_v4i bf[2][4];                         // B fragments of a class: built for the next class while this one's MFMAs run
 
-#define SH_LOAD_ROWS(D, KS)                                                                   \
-    do {                                                                                      \
-        const sh_v4i rr = *reinterpret_cast<const sh_v4i *>(union_rows + (KS) * SH_STEP_ROWS + 4 * h); \
-        rows_next[D][0] = rr.x; rows_next[D][1] = rr.y; rows_next[D][2] = rr.z; rows_next[D][3] = rr.w; \
-    } while (0)
     // row address = base + row * stride: rows are non-negative 32-bit numbers and a row stride is below 4 GiB, so ONE v_mad_u64_u32
-    // per row (the general 64 x 64-bit product took five instructions per row, 20 per step -- outside the MFMAs' shadow, where
-    // every VALU cycle is a cycle the matrix pipe idles)
     const uint32_t stride32 = (uint32_t)row_stride;
-#define SH_ROW_PTRS(D, P)                                                                     \
+#define SH_LOAD_RN(R)                                                                         \
     do {                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
-            (P)[i] = base + (uint64_t)(uint32_t)rows_next[D][i] * (uint64_t)stride32;         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+            const sh_v4i rr = *reinterpret_cast<const sh_v4i *>(union_rows + (R) * SH_ROUND_ROWS + 16 * h + 4 * i); \
+            rn[4 * i] = rr.x; rn[4 * i + 1] = rr.y; rn[4 * i + 2] = rr.z; rn[4 * i + 3] = rr.w; \
+        }                                                                                     \
     } while (0)
-#define SH_LOAD_STAGE_AT(D, KS, P)                                                            \
+#define SH_LOAD_X(BUF)                                                                        \
     do {                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                         \
-            x[D][i] = *reinterpret_cast<const uint32_t *>((P)[i]);                            \
-        _Pragma("unroll") for (int t = 0; t < 4; ++t) a[D][t] = Ag[((KS) * 4 + t) * 64];      \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i)                                        \
+            xb[BUF][i] = *reinterpret_cast<const uint32_t *>(base + (uint64_t)(uint32_t)rn[i] * (uint64_t)stride32); \
     } while (0)
-#define SH_LOAD_STAGE(D, KS)                                                                  \
+#define SH_LOAD_A(C, R)                                                                       \
     do {                                                                                      \
-        const int8_t *p_[4];                                                                  \
-        SH_ROW_PTRS(D, p_);                                                                   \
-        SH_LOAD_STAGE_AT(D, KS, p_);                                                          \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) a[C][t] = Ag[(((R) * 3 + (C)) * 4 + t) * 64]; \
+    } while (0)
+#define SH_IND(C, BUF)                                                                        \
+    do {                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                       \
+            bf[BUF][j].x = (int)sh_ind<C>(V[j][0], T[j][0]); bf[BUF][j].y = (int)sh_ind<C>(V[j][1], T[j][1]); \
+            bf[BUF][j].z = (int)sh_ind<C>(V[j][2], T[j][2]); bf[BUF][j].w = (int)sh_ind<C>(V[j][3], T[j][3]); \
+        }                                                                                     \
+    } while (0)
+#define SH_MFMA(C, BUF)                                                                       \
+    do {                                                                                      \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                     \
+                acc[t][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[C][t], bf[BUF][j], acc[t][j], 0, 0, 0); \
+    } while (0)
+    // sixteen MFMAs with NV vector instructions and NL loads between two of them; the fence keeps what belongs to a phase inside it
+    // (without it the scheduler sinks the loads to their uses a round later and waits with vmcnt(0))
+#define SH_PHASE_END(NV, NL)                                                                  \
+    do {                                                                                      \
+        _Pragma("unroll") for (int g16 = 0; g16 < 16; ++g16) {                                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                \
+            __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);                               \
+            __builtin_amdgcn_sched_group_barrier(0x020, NL, 0);                               \
+        }                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+    // One round = three phases of sixteen MFMAs (K = 32 rows of one class).  P / Q: the fragment buffers (class 0 of the round is in
+    // P when it starts and class 0 of the next round in Q when it ends: the roles swap every round, hence two rounds per loop body);
+    // XL: the buffer the panel dwords of round R + 2 go to (= the one round R came from), XT: the one holding round R + 1.
+#define SH_ROUND(R, P, Q, XL, XT)                                                             \
+    do {                                                                                      \
+        SH_IND(1, Q);                                                                         \
+        SH_MFMA(0, P);                                                                        \
+        SH_LOAD_X(XL);                      /* rn holds the rows of round R + 2 */            \
+        SH_LOAD_RN((R) + 3);                                                                  \
+        SH_LOAD_A(0, (R) + 1);                                                                \
+        SH_PHASE_END(2, 2);                                                                   \
+        SH_IND(2, P);                                                                         \
+        SH_MFMA(1, Q);                                                                        \
+        SH_LOAD_A(1, (R) + 1);                                                                \
+        SH_PHASE_END(2, 1);                                                                   \
+        sh_transpose<PACKED>(xb[XT], byte_shift, V, T);                                       \
+        SH_IND(0, Q);                                                                         \
+        SH_MFMA(2, P);                                                                        \
+        SH_LOAD_A(2, (R) + 1);                                                                \
+        SH_PHASE_END(7, 1);                                                                   \
     } while (0)
 
-    // prologue: rows of the first 2 * DEPTH steps, panel dwords and A fragments of the first DEPTH steps
-#pragma unroll
-    for (int d = 0; d < SH_DEPTH; ++d) SH_LOAD_ROWS(d, k0 + d);
-#pragma unroll
-    for (int d = 0; d < SH_DEPTH; ++d) {
-        SH_LOAD_STAGE(d, k0 + d);
-        SH_LOAD_ROWS(d, k0 + d + SH_DEPTH);
-    }
-    // the prologue's loads are drained here: the wait the compiler places at the loop head is the merge of "entered from the
-    // prologue" (its panel loads are the youngest in flight: vmcnt(0)) and "came round the loop" (vmcnt(18)), i.e. a full drain
-    // in EVERY iteration unless the first path arrives with nothing pending
+    // prologue: the panel dwords of the first two rounds, the rows of the third, the A fragments of the first; everything is waited
+    // for here (the wait the compiler places at the loop head is the merge of "entered from the prologue" and "came round the
+    // loop": a full drain in EVERY iteration unless the first path arrives with nothing pending)
+    SH_LOAD_RN(R0);
+    SH_LOAD_X(0);
+    SH_LOAD_RN(R0 + 1);
+    SH_LOAD_X(1);
+    SH_LOAD_RN(R0 + 2);
+    SH_LOAD_A(0, R0);
+    SH_LOAD_A(1, R0);
+    SH_LOAD_A(2, R0);
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0) expcnt(7) lgkmcnt(15)
-    // [k0, k1) holds a multiple of SH_DEPTH steps (the host pads the union with rows no sample has a call at: zero digits), so the
-    // body is straight-line code: the compiler counts the loads in flight exactly (s_waitcnt vmcnt(n) with n > 0)
-    // Software pipeline of the one-hot expansion: with one wave per SIMD nothing else feeds the matrix pipe while this wave runs
-    // its ~55 VALU instructions per step, so the fragments of step d + 1 are built BETWEEN the 16 MFMAs of step d (an MFMA holds
-    // the issue port for 8 of its 32 cycles; sched_group_barrier pins the pattern 1 MFMA : 4 VALU).
-    sh_v4i b[2][4];
-    uint32_t one = 1u;
-    asm("" : "+v"(one));
-    sh_onehot<PACKED>(x[0], one, byte_shift, b[0]);
-    int64_t ks = k0;
-    do {                                    // a tile is never empty
-#pragma unroll
-        for (int d = 0; d < SH_DEPTH; ++d) {
-            sh_onehot<PACKED>(x[(d + 1) % SH_DEPTH], one, byte_shift, b[(d + 1) & 1]);       // stage 0 of the next round when d is the last stage
-            const int8_t *pn[4];
-            SH_ROW_PTRS(d, pn);                                             // the addresses of this stage's next loads: VALU work for the MFMAs' shadow too
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[t][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[d][t], b[d & 1][j], acc[t][j], 0, 0, 0);
-            // the next round's step of this stage (unconditional: the pads make it readable), issued BETWEEN the MFMAs as well: nine
-            // loads behind a fence cost ~150 cycles a step in which the matrix pipe idled (SQ counters: MFMA busy 72 % of the
-            // wave's cycles).  The fence at the end of the stage stays: without it the scheduler sinks the loads to their uses a
-            // round later and waits with vmcnt(0).
-            SH_LOAD_STAGE_AT(d, ks + d + SH_DEPTH, pn);
-            SH_LOAD_ROWS(d, ks + d + 2 * SH_DEPTH);
-#pragma unroll
-            for (int g16 = 0; g16 < 16; ++g16) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);          // four VALU
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // one load (nine per stage: the last groups find none)
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        ks += SH_DEPTH;
-    } while (ks < k1);
-#undef SH_LOAD_ROWS
-#undef SH_LOAD_STAGE
-#undef SH_LOAD_STAGE_AT
-#undef SH_ROW_PTRS
+    sh_transpose<PACKED>(xb[0], byte_shift, V, T);
+    SH_IND(0, 0);
+    int64_t R = R0;
+    do {                                    // a tile is never empty and holds an even number of rounds
+        SH_ROUND(R, 0, 1, 0, 1);
+        SH_ROUND(R + 1, 1, 0, 1, 0);
+        R += 2;
+    } while (R < R1);
+#undef SH_ROUND
+#undef SH_PHASE_END
+#undef SH_MFMA
+#undef SH_IND
+#undef SH_LOAD_A
+#undef SH_LOAD_X
+#undef SH_LOAD_RN
 
     // C layout of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): registers 4 q .. 4 q + 3 of a
     // tile are four adjacent matrix rows of one accession.  The partial sums are kept accession-major ([.., accession, matrix
@@ -645,12 +687,12 @@ k_sh_finish(const int *__restrict__ partial, int n_tiles, int n_groups, int64_t 
     const int n_hi = digits < 3 ? digits : 3;
     const double v = __builtin_ldexp((double)hi, 8 * (digits - n_hi) - frac_bits) + __builtin_ldexp((double)lo, -frac_bits);
     const int64_t len = seg_off[sg + 1] - seg_off[sg];
-    long long missing = 0;
+    long long informative = 0;
 #pragma unroll
     for (int j = 0; j < SH_MAX_RPS; ++j)
-        if (j == digits) missing = dsum[j];
+        if (j == digits) informative = dsum[j];
     score[sg * ldo + a] = v;
-    ninfo[sg * ldo + a] = len - missing;
+    ninfo[sg * ldo + a] = informative;
     if (nonint) {
         const double E = sh_eseg_of(len, chunk, nonint[sg]) + 8.0 * 1.1102230246251565e-16 * (fabs(v) + 1.0);
         // quantisation, one-sided: every matched SNP may lose up to 2^-F (counted for all of them: an upward-only slack cannot
