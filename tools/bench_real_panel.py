@@ -236,12 +236,12 @@ def main():
             if st["taken"]:
                 leg["kernel"] = "k_sh_mfma<%s>" % ("packed" if packed else "int8")
                 u, rps = st["union_rows"], st["digits"] + 1
-                steps = -(-(-(-u // 8)) // 3) * 3
+                steps = -(-(-(-u // 8)) // 8) * 8                 # steps of 8 union rows, padded to two rounds of 32
                 m_rows = st["groups"] * 128
                 n_cols = -(-N_ACC // 128) * 128
-                macs = float(m_rows) * n_cols * steps * 32
+                macs = float(m_rows) * n_cols * steps * 24           # K = (row, class) over the three informative classes
                 # bytes that must come from HBM once: the union's panel rows, the samples' rows + weights, the digit matrix written and read
-                hbm = u * (row_bytes + 4.0) + n_entries * 32.0 + 2.0 * steps * 4096.0 * st["groups"]
+                hbm = u * (row_bytes + 4.0) + n_entries * 32.0 + 2.0 * steps * 3072.0 * st["groups"]
                 leg["algorithmic_bytes_per_call"] = hbm
                 leg["hbm_bytes_per_sample"] = hbm / B
                 leg["achieved_GBs"] = hbm / (leg["kernel_ms_per_call"] * 1e-3) / 1e9
