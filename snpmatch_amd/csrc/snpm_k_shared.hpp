@@ -12,22 +12,26 @@
 // fp64 arithmetic cannot use it (gfx950 runs v_mfma_f64 at the fp64 VALU rate, 3-4 x the flops of the LUT form), but the
 // EXACT mode only needs a fast pass with a rigorous error bound (DESIGN.md "Exactness contract"), so the weights are taken as
 // FIXED-POINT numbers: w in [0, 1] -> Q = floor(w * 2^F), written as L balanced base-256 digits d_0 .. d_{L-1} in [-128, 127],
-// w ~ sum_j d_j 256^(L-1-j) 2^-F, F = 8 (L - 1) + 6.  Digit j of every sample is one ROW of an int8 matrix A; the one-hot panel
-// expansion B is int8 {0, 1}; v_mfma_i32_32x32x32_i8 adds the products EXACTLY in int32.  One further row per sample holds
-// ones in the "missing" class: its product counts the sample's uninformative sites (ninfo).  The error of the pass is the
+// w ~ sum_j d_j 256^(L-1-j) 2^-F, F = 8 (L - 1) + 6.  Digit j of every sample is one ROW of an int8 matrix A; the panel's calls become
+// indicator bytes {0, 1} per class (B); v_mfma_i32_32x32x32_i8 adds the products EXACTLY in int32.  One further row per sample holds
+// a 1 in every informative class: its product counts the sample's informative sites (ninfo).  The error of the pass is the
 // quantisation alone, one-sided: fixed <= exact <= fixed + n 2^-F over a sample's n matched SNPs, and the certificate flags the few (sample, accession) pairs whose int() is not proven, as the fp64
 // fast pass does; those are re-scored in reference order by k_strict_pairs.
 //
 // Geometry of the contraction (k_sh_mfma):
-//   K step     = 8 union rows x 4 classes = the K = 32 of one MFMA; lane (c = lane & 31, h = lane >> 5) holds rows 4h .. 4h+3 of
-//                the step, one dword per row whose byte `class` belongs to k = (row, class)  [A and B use the same slots, so
-//                the hardware's k order inside a lane does not matter]
-//   A fragment = 32 matrix rows (sample digits) x one K step, 16 B per lane, stored in fragment order by k_sh_expand:
-//                A[group][step][tile t < 4][lane][16 B], group = 128 matrix rows
-//   B fragment = 32 accessions x one K step, built in registers: four row dwords (4 accessions each) are transposed with
-//                v_perm_b32 and every call code c becomes the dword 1 << 8 (c & 3): ref -> byte 0, alt -> 1, het -> 2, missing -> 3
+//   K          = (row, class) over the THREE informative classes (ref, alt, het): a missing call scores nothing and counts
+//                nothing, so it needs no K slot (the first version spent a quarter of its MFMAs on it).
+//   round      = 32 union rows = three K = 32 blocks, one per class; lane (c = lane & 31, h = lane >> 5) holds rows 16h .. 16h+15 of
+//                the round, byte i of a fragment = row 16h + i  [A and B use the same slots, so the hardware's k order inside a
+//                lane does not matter].  The host counts in STEPS of 8 rows; tiles and pads are multiples of 8 steps = two rounds.
+//   A fragment = 32 matrix rows (sample digits) x 32 rows of one class, 16 B per lane, stored in fragment order by k_sh_expand:
+//                A[group][round][class < 3][tile t < 4][lane][16 B], group = 128 matrix rows (3 KiB per group and step)
+//   B fragment = 32 accessions x 32 rows of one class, built in registers: the lane's sixteen row dwords (4 accessions each) are
+//                transposed with v_perm_b32 into the codes of each accession at four consecutive rows, and the indicator of a
+//                class is one 3-input boolean per dword (v_bitop3 on the code bits 0 and 1)
 //   wave tile  = 128 matrix rows x 128 accessions = 4 x 4 MFMA tiles, 256 accumulator registers, one wave per SIMD;
-//                a wave reads its A fragments and panel dwords straight into registers (no LDS, no barrier), three steps in flight
+//                a wave reads its A fragments and panel dwords straight into registers (no LDS, no barrier): panel dwords two
+//                rounds ahead, row indices three, the A fragments of a class reloaded for the next round right behind its MFMAs
 //   grid       = row tiles x (groups x accession groups / 4); blocks of one row tile are dealt to ONE XCD so that the L2 of that
 //                XCD serves the re-reads (A by every accession group, panel rows by every matrix-row group)
 #pragma once
@@ -41,7 +45,7 @@ constexpr int SH_ROUND_ROWS = 32;       // a ROUND = 4 steps = 32 union rows: wh
 constexpr int SH_DEPTH = 8;             // steps a tile is a multiple of: two rounds (the contraction's loop is unrolled over two)
 constexpr int SH_PAD_STEPS = 3 * SH_DEPTH;   // steps a wave may read (never score) past the last one: row list three rounds, panel rows two, A fragments one
 constexpr int SH_A_STEP_BYTES = 3072;   // bytes of A per group of 128 matrix rows and step: a round holds 3 classes x 4 tiles x 64 lanes x 16 B
-constexpr int SH_MAX_RPS = 8;           // matrix rows per sample: digits + the missing-count row
+constexpr int SH_MAX_RPS = 8;           // matrix rows per sample: digits + the count row
 
 typedef int sh_v4i __attribute__((ext_vector_type(4)));
 typedef int sh_v16i __attribute__((ext_vector_type(16)));
@@ -296,14 +300,14 @@ k_sh_pos(const int64_t *__restrict__ rows, const int64_t *__restrict__ seg_off, 
 
 // ---------------------------------------------------------------------------------------------------------------
 // k_sh_expand: the A matrix in fragment order.  Block = (sample s of the pass, run of 128 K steps); a thread converts the sample's
-// weights at ONE union row at a time to fixed point and splits them into balanced digits; four rows make the 16 B of a digit row
-// (and of the missing-count row) that lane (m, h) of tile t will load, assembled in LDS and stored in the order they lie in A.
+// weights at ONE union row at a time to fixed point and splits them into balanced digits; sixteen rows of one class make the 16 B
+// of a digit row (and of the count row) that lane (m, h) of tile t will load, assembled through LDS and stored in A's order.
 //   matrix row of (sample s, digit j): M = s * RPS + j, RPS = DIGITS + 1 (samples follow each other without gaps: a sample may
 //   lie across two groups of 128 rows); group M >> 7, tile (M >> 5) & 3, lane row M & 31
 //   balanced digits: Q' = floor(w 2^F) + sum_{p < DIGITS-1} 128 * 256^p; digit at position p < DIGITS-1 = byte p of Q' - 128
 //   (stored byte = byte ^ 0x80), top digit = Q' >> 8 (DIGITS - 1) (0 .. 65)
-//   byte order of a row dword: class 0 (ref) = W[:, 0], class 1 (alt) = W[:, 2], class 2 (het) = W[:, 1] (0 when skip_hets),
-//   class 3 (missing) = 0 in digit rows; the missing-count row holds 1 in class 3 (and in class 2 when skip_hets).
+//   class order: 0 (ref) = W[:, 0], 1 (alt) = W[:, 2], 2 (het) = W[:, 1] (0 when skip_hets); the count row holds 1 in every class
+//   that is an informative call (not in het when skip_hets): its product is ninfo.
 template <int DIGITS>
 __global__ void __launch_bounds__(256)
 k_sh_expand(const uint32_t *__restrict__ pos, int64_t ld_pos, const double *__restrict__ w, int64_t n_samples_pass, int skip_hets,
@@ -640,7 +644,7 @@ k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int3
 // k_sh_finish: block = accession a, four waves; lane = sample of the pass (the digit sums of one sample are adjacent in the
 // accession-major partial array, samples follow each other), wave w adds the row tiles w, w + 4, ... (int64), the waves' sums meet
 // in LDS.  Then the digits are put together and converted to fp64 (hi / lo parts: each conversion is exact or rounds once far
-// below the bound), ninfo = calls of the sample - missing count, and the certificate runs: the reference's score lies in
+// below the bound), ninfo = the count row (informative calls), and the certificate runs: the reference's score lies in
 // [v - E, v + E + Eq], E = eseg[s] (reference-order bound + the conversion), Eq = len[s] 2^-F (the quantisation, one-sided).
 __global__ void __launch_bounds__(256)
 k_sh_finish(const int *__restrict__ partial, int n_tiles, int n_groups, int64_t ldn, int digits, const int64_t *__restrict__ seg_off,
