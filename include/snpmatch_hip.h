@@ -272,7 +272,7 @@ int snpm_score_batch_coded(snpm_panel *panel, int64_t n_samples, const int64_t *
                   1 whenever the batch allows it (host batches are uploaded whole first)
      digits       3..7, or -1 (default; SNPM_SHARED_DIGITS=0): the fewest digits that keep a sample's quantisation below 2^-20 --
                   5 up to 262 144 matched SNPs per sample, 6 up to 2^26, else 7; 0 keeps the current value
-     min_density  threshold of the automatic choice (default 0.14 on int8, 0.28 on packed panels, 0.5 for fewer than 8 samples; SNPM_SHARED_MIN_DENSITY); negative keeps the current value
+     min_density  threshold of the automatic choice (default 0.11 on int8, 0.21 on packed panels, 0.5 for fewer than 8 samples; SNPM_SHARED_MIN_DENSITY); negative keeps the current value
    snpm_score_batch[_coded] report in info[2] whether the shared-row pass scored the batch and in info[3] its union rows. */
 int snpm_batch_configure(snpm_ctx *ctx, int shared_rows, int digits, double min_density);
 /* stats int64 [8] of the context's last snpm_score_batch[_coded] call: [0] 1 = shared-row pass taken, [1] else why not (1 policy,

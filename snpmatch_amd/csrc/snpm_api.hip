@@ -96,12 +96,12 @@ struct snpm_ctx {
     // the automatic choice: calls per (sample, union row) slot from which the contraction is the cheaper pass -- measured on 64
     // samples x 200k SNPs x 1135 accessions: the contraction costs ~2.8 ns per union row, the per-sample pass 0.27 ns (int8) /
     // 0.16 ns (packed) per call
-    // break-even of the two passes at 64 samples x 200k markers on 1135 accessions (profiles/r05_shared_density.txt): int8 between 0.10 and
-    // 0.15 calls per (sample, union row) slot, packed between 0.2 and 0.3
+    // break-even of the two passes at 64 samples x 200k markers on 1135 accessions (profiles/r05_shared_density.txt): int8 at 0.10
+    // calls per (sample, union row) slot, packed at 0.20
     double shared_min_density_of(bool packed, int64_t n_samples) const
     {
         if (shared_min_density >= 0.0) return shared_min_density;
-        const double th = packed ? 0.28 : 0.14;
+        const double th = packed ? 0.21 : 0.11;
         return n_samples < 8 ? (th > 0.5 ? th : 0.5) : th;      // a handful of samples: only when they really are on one marker set
     }
     int64_t shared_last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // snpm_batch_last_stats
