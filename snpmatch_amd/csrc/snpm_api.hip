@@ -87,6 +87,7 @@ struct snpm_ctx {
     double shared_min_density = -1.0;   // auto threshold; negative: by panel format (shared_min_density_of)
     size_t shared_ws_bytes = size_t(2) << 30;   // SNPM_SHARED_WS_MB: digit matrix per pass over groups of samples
     int shared_force_tiles = 0;         // SNPM_SHARED_TILES: row tiles of k_sh_mfma (tests, experiments)
+    int shared_fill = 1;                // SNPM_SHARED_FILL=0: no filler tiles on the CUs the XCD-aligned row tiles leave idle
     int shared_probe = 1;               // SNPM_SHARED_PROBE=0: the automatic policy decides after the full pass over the batch only
     int shared_parts = 1;               // SNPM_SHARED_PARTS=n: the pass in n parts, the digit layout of a part (auxiliary stream) beside the previous part's contraction.
                                         // Measured SLOWER (64 x 200k x 1135: 1.08 ms on one stream, 1.28 / 1.33 / 1.91 ms with 2 / 4 / 8 parts: the layout's waves take issue slots
@@ -520,6 +521,7 @@ try {
     if (const char *s = getenv("SNPM_BATCH_SHARED")) ctx->batch_shared = atoi(s) < 0 ? -1 : (atoi(s) ? 1 : 0);
     if (const char *s = getenv("SNPM_SHARED_DIGITS")) ctx->shared_digits = atoi(s) <= 0 ? 0 : std::min(7, std::max(3, atoi(s)));
     if (const char *s = getenv("SNPM_SHARED_MIN_DENSITY")) ctx->shared_min_density = atof(s);
+    if (const char *s = getenv("SNPM_SHARED_FILL")) ctx->shared_fill = atoi(s) != 0;
     if (const char *s = getenv("SNPM_SHARED_WS_MB")) ctx->shared_ws_bytes = (size_t)std::max(1, atoi(s)) << 20;
     if (const char *s = getenv("SNPM_SHARED_TILES")) ctx->shared_force_tiles = std::max(0, atoi(s));
     if (const char *s = getenv("SNPM_SHARED_PROBE")) ctx->shared_probe = atoi(s) != 0;

@@ -142,6 +142,14 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
             if (cost < best * 0.97) { best = cost; best_m = m; }
         }
         int64_t T = 8 * best_m;
+        {
+            // filler tiles: the CUs of an XCD that the last round of aligned tiles leaves idle take the blocks of further tiles
+            // (a filler tile then lies on two or three XCDs: 64 samples 27 x 32 -> 27 x 36 wave tiles on 1024 slots)
+            const int64_t rounds = ((int64_t)best_m * blocks_per_tile + cu_per_xcd - 1) / cu_per_xcd;
+            const int64_t idle = rounds * cu_per_xcd - (int64_t)best_m * blocks_per_tile;
+            const bool one_launch = !(ctx->shared_parts > 1 && ctx->aux_stream);
+            if (one_launch && ctx->shared_fill) T += 8 * idle / blocks_per_tile;
+        }
         if (T * 16 > n_steps) T = std::max<int64_t>(1, n_steps / 16);
         steps_per_tile = ((n_steps + T - 1) / T + SH_DEPTH - 1) / SH_DEPTH * SH_DEPTH;
         n_tiles = (int)((n_steps + steps_per_tile - 1) / steps_per_tile);
@@ -215,11 +223,13 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
             }
             {
                 ProfScope ps(ctx, PK_FAST);
-                const unsigned nblk = (unsigned)(8 * ((t1 - t0 + 7) / 8) * bpt);
+                const int aligned = ((t1 - t0) / 8) * 8;                             // dealt one per XCD in turn
+                const int fill_per_xcd = ((t1 - t0 - aligned) * bpt + 7) / 8;         // blocks of the remaining tiles, spread over the XCDs
+                const unsigned nblk = (unsigned)(8 * ((aligned / 8) * bpt + fill_per_xcd));
 #define LAUNCH_SH(PK)                                                                                                          \
     hipLaunchKernelGGL((k_sh_mfma<PK>), dim3(nblk), dim3(256), 0, ctx->stream, p->d, p->kpitch, p->desc, (const int32_t *)d_urows,     \
-                       (const sh_v4i *)ctx->ws_sh_A.p, n_steps, steps_ld, spt, t0, t1, (int)groups, n_accgroups, bpt,                   \
-                       (int *)ctx->ws_sh_partial.p, ldn)
+                       (const sh_v4i *)ctx->ws_sh_A.p, n_steps, steps_ld, spt, t0, t1, (int)groups, n_accgroups, bpt, aligned,          \
+                       fill_per_xcd, (int *)ctx->ws_sh_partial.p, ldn)
                 if (p->packed) LAUNCH_SH(true); else LAUNCH_SH(false);
 #undef LAUNCH_SH
                 HIPCHK(ctx, hipGetLastError());

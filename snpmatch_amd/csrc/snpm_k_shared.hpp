@@ -470,14 +470,25 @@ template <bool PACKED>
 __global__ void __launch_bounds__(256, 1)
 k_sh_mfma(const int8_t *__restrict__ db, int64_t pitch, int64_t desc, const int32_t *__restrict__ union_rows,
           const sh_v4i *__restrict__ A, int64_t n_steps, int64_t steps_ld, int64_t steps_per_tile, int tile0, int n_tiles, int n_groups,
-          int n_accgroups, int blocks_per_tile, int *__restrict__ partial, int64_t ldn)
+          int n_accgroups, int blocks_per_tile, int aligned_tiles, int fill_per_xcd, int *__restrict__ partial, int64_t ldn)
 {
     // blocks of one row tile on ONE XCD: workgroups are dealt round-robin over the 8 XCDs in launch order.  This launch owns the
-    // row tiles [tile0, n_tiles) it can reach: a pass is cut into parts of whole tiles, one launch each.
+    // row tiles [tile0, n_tiles): the first `aligned_tiles` (a multiple of 8) are dealt one per XCD in turn; the blocks of the
+    // remaining FILLER tiles take the compute units the aligned tiles leave idle -- `fill_per_xcd` per XCD, so a filler tile lies on
+    // two or three XCDs (the host plans the fillers so that every CU holds exactly one block: 27 wave tiles x 32 aligned row tiles
+    // fill 864 of 1024 wave slots, four filler tiles the rest).
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q8 = bid >> 3;
-    const int tile = tile0 + (q8 / blocks_per_tile) * 8 + xcd;
-    const int wb = q8 % blocks_per_tile;
+    const int aligned_blocks = (aligned_tiles >> 3) * blocks_per_tile;          // per XCD
+    int tile, wb;
+    if (q8 < aligned_blocks) {
+        tile = tile0 + (q8 / blocks_per_tile) * 8 + xcd;
+        wb = q8 % blocks_per_tile;
+    } else {
+        const int ex = xcd * fill_per_xcd + (q8 - aligned_blocks);
+        tile = tile0 + aligned_tiles + ex / blocks_per_tile;
+        wb = ex % blocks_per_tile;
+    }
     if (tile >= n_tiles) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wt = wb * 4 + wave;
