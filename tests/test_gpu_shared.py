@@ -309,7 +309,8 @@ def test_random_configurations_against_the_oracle(seed):
         packed = bool(rng.integers(0, 2))
         skip = bool(rng.integers(0, 2))
         digits = int(rng.choice([-1, 3, 4, 5, 6, 7]))
-        env = {"SNPM_SHARED_TILES": int(rng.choice([1, 2, 3, 7, 16])), "SNPM_SHARED_WS_MB": int(rng.choice([1, 2, 64]))}
+        # row tiles: fewer than 8 = filler tiles only, 16 = aligned only, 9 / 20 = aligned tiles + fillers spread over the XCDs
+        env = {"SNPM_SHARED_TILES": int(rng.choice([1, 2, 3, 7, 9, 16, 20])), "SNPM_SHARED_WS_MB": int(rng.choice([1, 2, 64]))}
         ctx = make_ctx(**env)
         db = rand_db(rng, n_snp, n_acc)
         panel = engine.Panel.from_host(ctx, db, packed=packed)
@@ -403,3 +404,28 @@ def test_samples_on_stretches_of_the_union_and_results_above_the_slab_limit():
     only_scores = engine.score_batch(panel, samples[:64], 1000, False, engine.MODE_EXACT, likelihoods=False)
     assert np.array_equal(only_scores["score"], seg["score"]) and np.array_equal(only_scores["ninfo"], seg["ninfo"])
     ctx.close()
+
+
+def test_result_arrays_of_an_earlier_call_are_written_again():
+    """engine.score_batch(out=previous): the same arrays come back with the new batch's results (a service reuses its buffers: fresh
+    arrays cost their page faults per call); a dict of another shape is ignored"""
+    ctx = make_ctx()
+    rng = np.random.default_rng(31)
+    db = rand_db(rng, 40_000, 600)
+    panel = engine.Panel.from_host(ctx, db)
+    first = chip_samples(rng, db, 12, 3000)
+    second = chip_samples(rng, db, 12, 3500)
+    engine.batch_configure(ctx, shared_rows=1)
+    a = engine.score_batch(panel, first, 1000, False, engine.MODE_EXACT)
+    keep = {k: a[k].copy() for k in ("score", "ninfo", "lik", "lrt")}
+    b = engine.score_batch(panel, second, 1000, False, engine.MODE_EXACT, out=a)
+    assert all(b[k] is a[k] for k in ("score", "ninfo", "lik", "lrt"))
+    check_against_oracle(db, second, b, False)
+    assert not np.array_equal(b["score"], keep["score"])
+    c = engine.score_batch(panel, first[:5], 1000, False, engine.MODE_EXACT, out=b)          # another shape: new arrays
+    assert c["score"].shape == (5, 600) and c["score"] is not b["score"]
+    check_against_oracle(db, first[:5], c, False)
+    d = engine.score_batch(panel, first, 1000, False, engine.MODE_EXACT, likelihoods=False, out=b)
+    assert d["score"] is b["score"] and "lik" not in d and np.array_equal(d["score"], keep["score"]) and np.array_equal(d["ninfo"], keep["ninfo"])
+    ctx.close()
+
