@@ -135,9 +135,9 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
             const size_t part_bytes = (size_t)T * groups * SH_GROUP_ROWS * ldn * 4;
             if (part_bytes > (size_t(192) << 20) && m > 1) break;
             const int64_t rounds = ((int64_t)m * blocks_per_tile + cu_per_xcd - 1) / cu_per_xcd;
-            // in units of one K step of one wave (~0.3 us): a round also pays for the waves' start and for their 64 KB of sums each,
-            // written in one burst when they all finish (~42k cycles, measured: profiles/r05_shared_tiles.txt), and k_sh_finish reads
-            // every tile's sums back
+            // in units of one K step of one wave (~0.25 us): a round also pays ~42k cycles per wave outside its steps (its start, the
+            // dispatch ramp, 64 KB of sums written when all waves finish together; fitted from two tile counts:
+            // profiles/r05_shared_tiles.txt), and k_sh_finish reads every tile's sums back
             const double cost = (double)rounds * ((double)((n_steps + T - 1) / T) + 100.0) + 1.1 * (double)part_bytes / 1048576.0;
             if (cost < best * 0.97) { best = cost; best_m = m; }
         }
@@ -186,9 +186,9 @@ static int shared_rows_try(snpm_ctx *ctx, SegJob &j, bool forced, SharedStats &s
         // (32 .. 512 blocks per sample: the same 38 us, it moves 250 MB)
         hipLaunchKernelGGL(k_sh_pos, dim3(gx, (unsigned)s_pass), dim3(256), 0, ctx->stream, j.d_row_idx, (const int64_t *)d_seg_off, s_base,
                            (const uint32_t *)d_bitmap, (const uint32_t *)d_wordbase, (uint32_t *)ctx->ws_sh_pos.p, ld_pos);
-        // The pass in parts of whole row tiles: the digits of part i + 1 are laid out (k_sh_expand, on the auxiliary stream: memory
-        // latency) while part i is contracted (k_sh_mfma, one wave per SIMD: the matrix cores); the expansion's waves fit beside
-        // the contraction's on every SIMD (368 + ~60 of 512 registers).  One part = everything on the main stream.
+        // The pass in parts of whole row tiles (SNPM_SHARED_PARTS > 1, an experiment that measured SLOWER and is off by default): the
+        // digits of part i + 1 are laid out (k_sh_expand, on the auxiliary stream: memory latency) while part i is contracted
+        // (k_sh_mfma, one wave per SIMD: the matrix cores).  One part = everything on the main stream.
         const int m_tiles = (tiles + 7) / 8;                                // tiles come in sets of 8 (one per XCD)
         const int n_parts = (ctx->shared_parts > 0 && ctx->aux_stream) ? std::max(1, std::min(ctx->shared_parts, m_tiles)) : 1;
         const bool overlap = n_parts > 1;
